@@ -1,0 +1,198 @@
+"""Oracle (TEST INFRASTRUCTURE): DDIM and DPM-Solver++(2M) restated from diffusers==0.27.0.
+
+The reference pipelines are scheduler-agnostic and only duck-type the scheduler
+(/root/reference/powerpaint/pipelines/pipeline_PowerPaint.py:906,993,1023,642;
+ pipeline_PowerPaint_Brushnet_CA.py:87-128,1391,1449,969).  The arithmetic lives in the
+un-vendored dependency diffusers==0.27.0 (requirements/requirements.txt:3):
+`DDIMScheduler`, `DPMSolverMultistepScheduler`.  SURVEY.md section 8a row a19 / Appendix B give
+the closed forms.  Torch classes below follow the diffusers call protocol in fp32; the
+`*_f64` functions are independent float64 NumPy re-derivations used to pin them.
+"""
+import math
+from typing import List, Optional
+
+import numpy as np
+import torch
+
+
+def sd_betas(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012) -> torch.Tensor:
+    """`scaled_linear` schedule, float32 exactly as diffusers builds it."""
+    return torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float32) ** 2
+
+
+class DDIMScheduler:
+    """eta=0, epsilon prediction, `leading` spacing, steps_offset=1, set_alpha_to_one=False, no clipping
+    (the `runwayml/stable-diffusion-inpainting` scheduler config applied to DDIM)."""
+    order = 1
+    init_noise_sigma = 1.0
+
+    def __init__(self, num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, steps_offset=1,
+                 set_alpha_to_one=False):
+        self.config = type("C", (), dict(num_train_timesteps=num_train_timesteps, steps_offset=steps_offset,
+                                         beta_start=beta_start, beta_end=beta_end))()
+        self.betas = sd_betas(num_train_timesteps, beta_start, beta_end)
+        self.alphas_cumprod = torch.cumprod(1.0 - self.betas, dim=0)
+        self.final_alpha_cumprod = torch.tensor(1.0) if set_alpha_to_one else self.alphas_cumprod[0]
+        self.num_inference_steps = None
+        self.timesteps = None
+
+    def set_timesteps(self, num_inference_steps: int, device=None):
+        self.num_inference_steps = num_inference_steps
+        step_ratio = self.config.num_train_timesteps // num_inference_steps
+        ts = (np.arange(0, num_inference_steps) * step_ratio).round()[::-1].copy().astype(np.int64)
+        ts += self.config.steps_offset
+        self.timesteps = torch.from_numpy(ts)
+
+    def scale_model_input(self, sample, timestep=None):
+        return sample
+
+    def step(self, model_output, timestep, sample, eta: float = 0.0, generator=None, return_dict=False):
+        assert eta == 0.0
+        t = int(timestep)
+        prev_t = t - self.config.num_train_timesteps // self.num_inference_steps
+        a_t = self.alphas_cumprod[t]
+        a_prev = self.alphas_cumprod[prev_t] if prev_t >= 0 else self.final_alpha_cumprod
+        beta_t = 1 - a_t
+        x0 = (sample - beta_t ** 0.5 * model_output) / a_t ** 0.5
+        direction = (1 - a_prev) ** 0.5 * model_output
+        prev = a_prev ** 0.5 * x0 + direction
+        return (prev,)
+
+    def add_noise(self, x0, noise, timesteps):
+        a = self.alphas_cumprod[timesteps].to(x0.dtype)
+        sa = (a ** 0.5).flatten()
+        s1 = ((1 - a) ** 0.5).flatten()
+        while sa.dim() < x0.dim():
+            sa, s1 = sa.unsqueeze(-1), s1.unsqueeze(-1)
+        return sa * x0 + s1 * noise
+
+
+class DPMSolverMultistepScheduler:
+    """dpmsolver++, order 2, midpoint, `linspace` spacing, final_sigmas_type='zero', lower_order_final."""
+    order = 1
+    init_noise_sigma = 1.0
+
+    def __init__(self, num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, solver_order=2):
+        self.config = type("C", (), dict(num_train_timesteps=num_train_timesteps, solver_order=solver_order,
+                                         steps_offset=0))()
+        self.betas = sd_betas(num_train_timesteps, beta_start, beta_end)
+        self.alphas_cumprod = torch.cumprod(1.0 - self.betas, dim=0)
+        self.timesteps = None
+
+    def set_timesteps(self, num_inference_steps: int, device=None):
+        T = self.config.num_train_timesteps
+        ts = np.linspace(0, T - 1, num_inference_steps + 1).round()[::-1][:-1].copy().astype(np.int64)
+        sig = np.array(((1 - self.alphas_cumprod) / self.alphas_cumprod) ** 0.5)
+        sig = np.interp(ts, np.arange(0, len(sig)), sig)
+        sig = np.concatenate([sig, [0.0]]).astype(np.float32)
+        self.sigmas = torch.from_numpy(sig)
+        self.timesteps = torch.from_numpy(ts)
+        self.num_inference_steps = num_inference_steps
+        self.model_outputs: List[Optional[torch.Tensor]] = [None] * self.config.solver_order
+        self.lower_order_nums = 0
+        self._step_index = None
+
+    def scale_model_input(self, sample, timestep=None):
+        return sample
+
+    @staticmethod
+    def _alpha_sigma(sigma):
+        alpha_t = 1 / ((sigma ** 2 + 1) ** 0.5)
+        return alpha_t, sigma * alpha_t
+
+    def step(self, model_output, timestep, sample, generator=None, return_dict=False):
+        if self._step_index is None:
+            idx = (self.timesteps == int(timestep)).nonzero()
+            self._step_index = int(idx[0])
+        i = self._step_index
+        n = len(self.timesteps)
+        lower_order_final = (i == n - 1)  # final_sigmas_type == "zero"
+        # convert_model_output: epsilon -> x0
+        alpha_t, sigma_t = self._alpha_sigma(self.sigmas[i])
+        x0 = (sample - sigma_t * model_output) / alpha_t
+        for k in range(self.config.solver_order - 1):
+            self.model_outputs[k] = self.model_outputs[k + 1]
+        self.model_outputs[-1] = x0
+
+        s_t, s_s0 = self.sigmas[i + 1], self.sigmas[i]
+        a_t, sg_t = self._alpha_sigma(s_t)
+        a_s0, sg_s0 = self._alpha_sigma(s_s0)
+        lam_t = torch.log(a_t) - torch.log(sg_t)
+        lam_s0 = torch.log(a_s0) - torch.log(sg_s0)
+        h = lam_t - lam_s0
+        if self.config.solver_order == 1 or self.lower_order_nums < 1 or lower_order_final:
+            prev = (sg_t / sg_s0) * sample - (a_t * (torch.exp(-h) - 1.0)) * x0
+        else:
+            s_s1 = self.sigmas[i - 1]
+            a_s1, sg_s1 = self._alpha_sigma(s_s1)
+            lam_s1 = torch.log(a_s1) - torch.log(sg_s1)
+            m0, m1 = self.model_outputs[-1], self.model_outputs[-2]
+            h_0 = lam_s0 - lam_s1
+            r0 = h_0 / h
+            D0, D1 = m0, (1.0 / r0) * (m0 - m1)
+            prev = ((sg_t / sg_s0) * sample - (a_t * (torch.exp(-h) - 1.0)) * D0
+                    - 0.5 * (a_t * (torch.exp(-h) - 1.0)) * D1)
+        if self.lower_order_nums < self.config.solver_order:
+            self.lower_order_nums += 1
+        self._step_index += 1
+        return (prev,)
+
+
+# ---------------------------------------------------------------------------------------
+# independent float64 closed forms (pins for the classes above and for the HIP step kernel)
+# ---------------------------------------------------------------------------------------
+def alphas_cumprod_f64(T=1000, beta_start=0.00085, beta_end=0.012) -> np.ndarray:
+    betas = np.linspace(beta_start ** 0.5, beta_end ** 0.5, T, dtype=np.float64) ** 2
+    return np.cumprod(1.0 - betas)
+
+
+def ddim_timesteps(N: int, T: int = 1000, offset: int = 1) -> np.ndarray:
+    return np.array([(N - 1 - i) * (T // N) + offset for i in range(N)], dtype=np.int64)
+
+
+def ddim_step_f64(x, eps, t: int, N: int, T: int = 1000):
+    ac = alphas_cumprod_f64(T)
+    prev_t = t - T // N
+    a_t = ac[t]
+    a_prev = ac[prev_t] if prev_t >= 0 else ac[0]
+    x0 = (x - math.sqrt(1 - a_t) * eps) / math.sqrt(a_t)
+    return math.sqrt(a_prev) * x0 + math.sqrt(1 - a_prev) * eps
+
+
+def dpm_timesteps(N: int, T: int = 1000) -> np.ndarray:
+    return np.linspace(0, T - 1, N + 1).round()[::-1][:-1].astype(np.int64)
+
+
+def dpm_sigmas_f64(N: int, T: int = 1000) -> np.ndarray:
+    ac = alphas_cumprod_f64(T)
+    sig = np.sqrt((1 - ac) / ac)
+    ts = dpm_timesteps(N, T)
+    return np.concatenate([np.interp(ts, np.arange(T), sig), [0.0]])
+
+
+def dpm_run_f64(x, eps_list, N: int):
+    """Run all N DPM-Solver++(2M) steps in float64 given the eps fed at every step."""
+    sig = dpm_sigmas_f64(N)
+    x = np.asarray(x, dtype=np.float64)
+    m1 = None
+    for i in range(N):
+        s0, st = sig[i], sig[i + 1]
+        a0, at = 1 / math.sqrt(s0 * s0 + 1), 1 / math.sqrt(st * st + 1)
+        g0, gt = s0 * a0, st * at
+        m0 = (x - g0 * np.asarray(eps_list[i], dtype=np.float64)) / a0
+        if st == 0.0:
+            x = m0            # sigma_t/sigma_s -> 0, alpha_t (e^{-h}-1) -> -1
+        else:
+            lam0, lamt = math.log(a0) - math.log(g0), math.log(at) - math.log(gt)
+            h = lamt - lam0
+            c = at * (math.exp(-h) - 1.0)
+            if i == 0:
+                x = (gt / g0) * x - c * m0
+            else:
+                sp = sig[i - 1]
+                ap = 1 / math.sqrt(sp * sp + 1)
+                lamp = math.log(ap) - math.log(sp * ap)
+                r0 = (lam0 - lamp) / h
+                x = (gt / g0) * x - c * m0 - 0.5 * c * (m0 - m1) / r0
+        m1 = m0
+    return x
