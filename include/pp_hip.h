@@ -1,0 +1,211 @@
+/*
+ * pp_hip.h -- C ABI of libpp_hip.so: the MI355X (gfx950) kernels of the PowerPaint denoising hot path.
+ *
+ * The reference (open-mmlab/PowerPaint) has NO FFI / plugin / custom-op interface for this path: it reaches the
+ * GPU only through torch/diffusers module calls.  Each entry point below therefore cites the
+ * reference *call site / module* whose device work it replaces.  Conventions for every entry:
+ *   - `extern "C"`, plain pointers + sizes, no torch types;
+ *   - all pointers are DEVICE pointers unless named `host_*`;
+ *   - activations are bf16 (raw uint16 storage) in NHWC / [rows][channels] layout, parameters as documented;
+ *   - the last argument is a `hipStream_t` (passed as void*; torch.cuda.current_stream().cuda_stream);
+ *   - returns PP_OK (0) or a negative PP_ERR_*; never throws, never allocates, never synchronises, keeps no
+ *     pointer after return, is re-entrant per stream; workspaces are caller-provided and sized by *_workspace_bytes.
+ */
+#ifndef PP_HIP_H_
+#define PP_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PP_OK 0
+#define PP_ERR_BAD_ARG (-1)      /* shape / alignment / enum outside the supported set            */
+#define PP_ERR_UNSUPPORTED (-2)  /* valid request the kernels do not implement (e.g. head_dim 24) */
+#define PP_ERR_LAUNCH (-3)       /* hipLaunchKernel / hipFuncSetAttribute failed                  */
+#define PP_ERR_WORKSPACE (-4)    /* workspace pointer null or too small                           */
+
+#define PP_ABI_VERSION 1
+int pp_abi_version(void);
+/* hipGetLastError() text of the last PP_ERR_LAUNCH on this thread (host pointer, static storage). */
+const char* pp_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * GEMM / implicit-GEMM 3x3 convolution on bf16 MFMA tiles.
+ *   out[m][n] = epilogue( sum_k X[m][k] * W[n][k] )
+ * Replaces: every nn.Conv2d(3x3) / nn.Conv2d(1x1) / nn.Linear on the path --
+ *   ResnetBlock2D.conv1/conv2/conv_shortcut, Downsample2D.conv, Upsample2D.conv (ctor sites
+ *   /root/reference/powerpaint/models/unet_2d_blocks.py:1274-1285,1319-1321,2542), Transformer2DModel.proj_in/out,
+ *   Attention.to_q/k/v/to_out, FeedForward GEGLU proj + out (unet_2d_blocks.py:1289-1300), BrushNet zero-convs
+ *   (/root/reference/powerpaint/models/BrushNet_CA.py:842-845,861,899-902) incl. `* conditioning_scale` (:930-934),
+ *   and the residual adds `hidden_states + *_add_samples.pop(0)` (unet_2d_blocks.py:1388-1398,2629-2638).
+ *
+ * X operand modes:
+ *   PP_X_PLAIN   : X[m][k] row-major; k <  c1 read from x1 (row stride ldx1), k >= c1 from x2 (row stride ldx2)
+ *                  -> channel-concat of two tensors without materialising it (up-block skip concat,
+ *                  unet_2d_blocks.py:2589,2732).  K = c1 + c2.
+ *   PP_X_CONV3X3 : X is the im2col view of an NHWC tensor [batch][hin][win][c1(+c2)]; pad 1; k = (ky*3+kx)*C + c;
+ *                  `stride` 1|2 (Downsample2D); `up`=1 fuses a nearest-2x upsample of the input (Upsample2D);
+ *                  M = batch*hout*wout, K = 9*(c1+c2).  c1, c2 multiples of 64.
+ * W operand: bf16 [N][K] row-major (conv weights pre-permuted to [Cout][ky][kx][Cin] by the host).
+ * Epilogue:  v = (acc + bias[n] + rowvec[m / rows_per_batch][n]) * scale + res1[m][n] + res2[m][n]
+ *            act = PP_ACT_GEGLU: columns come in interleaved groups of four (h0,h1,g0,g1); out[m][n/2+j] = h_j*gelu_erf(g_j)
+ *            (weights/bias pre-interleaved by the host), out has N/2 columns.
+ *            out_vt != NULL: columns >= vt_col0 are written TRANSPOSED per batch item to out_vt[b][n - vt_col0][row in batch]
+ *            (V^T for attention), the others to `out`.
+ */
+#define PP_X_PLAIN 0
+#define PP_X_CONV3X3 1
+#define PP_ACT_NONE 0
+#define PP_ACT_GEGLU 1
+#define PP_ACT_SILU 2
+
+typedef struct PPGemmArgs {
+  int32_t M, N, K;
+  int32_t x_mode;
+  const void* x1;
+  const void* x2;
+  int32_t c1, c2;
+  int32_t ldx1, ldx2;
+  int32_t batch, hin, win, hout, wout, stride, up;
+  const void* w;
+  const float* bias;
+  const float* rowvec;
+  int32_t ld_rowvec, rows_per_batch;
+  const void* res1;
+  int32_t ldres1;
+  const void* res2;
+  int32_t ldres2;
+  float scale;
+  int32_t act;
+  void* out;
+  int32_t ldo;
+  int32_t out_f32;
+  void* out_vt;
+  int32_t vt_col0;
+  int32_t vt_ld;      /* row stride of out_vt (>= rows_per_batch) */
+  int32_t splitk;     /* 0 = auto */
+  int32_t tile;       /* 0 = auto; else PP_TILE_* */
+  float* workspace;   /* split-K partials, pp_gemm_workspace_bytes() */
+  /* optional per-(batch,group) GroupNorm statistics of the OUTPUT accumulated in the epilogue (not yet used) */
+  int32_t reserved[4];
+} PPGemmArgs;
+
+#define PP_TILE_AUTO 0
+#define PP_TILE_128x160 1
+#define PP_TILE_64x160 2
+#define PP_TILE_256x160 3
+
+int pp_gemm_bf16(const PPGemmArgs* args, void* stream);
+size_t pp_gemm_workspace_bytes(const PPGemmArgs* args);
+
+/* Small-M ("skinny") linear in fp32 accumulate: out[b][n] = act_in(x[b][:]) . W[n][:] + bias[n], b < rows <= 16.
+ * Replaces TimestepEmbedding.linear_1/linear_2 and the 22 ResnetBlock2D.time_emb_proj (batched into one call by
+ * concatenating their weights along N) -- [diffusers-0.27.0]; reference call site unet_2d_condition.py:1155-1156.
+ * x fp32 [rows][K]; W bf16 [N][K]; bias fp32; out fp32 [rows][ldo]. act_in: 0 none, 2 silu. act_out likewise. */
+int pp_linear_skinny(const float* x, int rows, int K, const void* w, const float* bias, int N, float* out, int ldo,
+                     int act_in, int act_out, void* stream);
+
+/* Sinusoidal timestep embedding (Timesteps(dim, flip_sin_to_cos=True, freq_shift=0)), unet_2d_condition.py:914-938.
+ * out fp32 [rows][dim] = [cos(t f_k), sin(t f_k)], t read from device pointer (one value broadcast to all rows). */
+int pp_timestep_embedding(const float* t_dev, int rows, int dim, float* out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * GroupNorm (+ optional SiLU) on NHWC bf16, two launches: statistics, then apply.
+ * Replaces ResnetBlock2D.norm1/norm2 + nonlinearity, Transformer2DModel.norm, conv_norm_out + conv_act
+ * (unet_2d_condition.py:1351-1353) -- nn.GroupNorm(32, C, eps).
+ *   stats : x = concat(x1[c1], x2[c2]) per pixel; writes scale/shift fp32 [batch][C]:
+ *           scale = rstd*gamma, shift = beta - mean*rstd*gamma.   workspace: pp_groupnorm_workspace_bytes().
+ *   apply : y[b][p][c] = act(x*scale + shift) as bf16, y row stride = C.
+ */
+size_t pp_groupnorm_workspace_bytes(int batch, int hw, int C);
+int pp_groupnorm_stats(const void* x1, int c1, const void* x2, int c2, int batch, int hw, int groups, float eps,
+                       const float* gamma, const float* beta, float* scale_shift /* [batch][2][C] */,
+                       float* workspace, void* stream);
+int pp_groupnorm_apply(const void* x1, int c1, const void* x2, int c2, int batch, int hw,
+                       const float* scale_shift, int silu, void* y, void* stream);
+
+/* LayerNorm over the last dim, bf16 [rows][C] -> bf16 [rows][C]; BasicTransformerBlock.norm1/2/3 (eps 1e-5). */
+int pp_layernorm(const void* x, int rows, int C, const float* gamma, const float* beta, float eps, void* y,
+                 void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Fused attention forward  O = softmax(Q K^T * scale) V, non-causal, no mask (AttnProcessor2_0 /
+ * F.scaled_dot_product_attention) -- [diffusers-0.27.0] Attention used by Transformer2DModel.
+ *   q  : bf16, element (b, i, h, j) at q[(b*nq + i)*ldq + h*d + j]
+ *   k  : bf16, element (b, t, h, j) at k[(b*nk + t)*ldk + h*d + j]
+ *   vt : bf16 V TRANSPOSED, element (b, t, h, j) at vt[((b*heads + h)*d + j)*ldvt + t]   (ldvt >= nk, mult of 8)
+ *   o  : bf16, same indexing as q with ldo.
+ * head_dim d in {40, 80, 160}; nk arbitrary (keys >= nk masked).
+ */
+int pp_attention_fwd(const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt, void* o, int ldo,
+                     int batch, int heads, int nq, int nk, int d, float scale, void* stream);
+/* [rows = b*nk + t][cols] bf16 (row stride ld) -> vt[b][col][t] (row stride ldvt).  Used for the cross-attention V
+ * (computed once per call: encoder_hidden_states are step-invariant) and as the unfused fallback for self-attention. */
+int pp_transpose_v(const void* v, int ld, int batch, int nk, int cols, void* vt, int ldvt, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Direct 3x3 convolutions (pad 1) for MFMA-unfriendly channel counts:
+ *   pp_conv3x3_direct    : cout % 8 == 0, any cin, stride 1|2 -- conv_in (Cin 4/9 -> 320; BrushNet conv_in_condition,
+ *                          /root/reference/powerpaint/models/BrushNet_CA.py:223-228,822-823) and the
+ *                          ControlNetConditioningEmbedding convs (3->16->...->320, SiLU between).
+ *                          x: bf16 NHWC [batch][hin][win][cin]; w: bf16 [3][3][cin][cout] (cout contiguous);
+ *                          bias fp32; add: optional bf16 NHWC tensor added before the optional SiLU; out: bf16 NHWC.
+ *   pp_conv3x3_smallcout : cout == 4, cin % 8 == 0, stride 1 -- conv_out (unet_2d_condition.py:1354).
+ *                          x: bf16 NHWC; w: bf16 [cout][3][3][cin]; out: fp32 NCHW [batch][cout][h][w] (the UNet
+ *                          boundary layout, consumed directly by pp_cfg_sched_step).
+ */
+int pp_conv3x3_direct(const void* x, int batch, int hin, int win, int cin, const void* w, const float* bias,
+                      int cout, int stride, int silu_out, const void* add, void* out, void* stream);
+int pp_conv3x3_smallcout(const void* x, int batch, int h, int w_, int cin, const void* w, const float* bias, int cout,
+                         float* out_nchw, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Layout / assembly kernels at the module boundary (NCHW torch tensors <-> internal NHWC bf16).
+ * pp_nchw_to_nhwc : src fp32|bf16|f16 NCHW [batch][c][hw] -> dst bf16 [batch][hw][ldc] at channel offset c0.
+ *                   src_batch_mod > 0 reads batch item (b % src_batch_mod)  -> `torch.cat([latents]*2)`
+ *                   (pipeline_PowerPaint.py:990) without a copy.
+ * pp_nhwc_to_nchw : bf16 [batch][hw][c] -> fp32|bf16 NCHW.
+ * dtype codes: 0 fp32, 1 bf16, 2 fp16.
+ */
+int pp_nchw_to_nhwc(const void* src, int src_dtype, int batch, int c, int hw, int src_batch_mod, void* dst, int ldc,
+                    int c0, void* stream);
+int pp_nhwc_to_nchw(const void* src, int batch, int c, int hw, void* dst, int dst_dtype, void* stream);
+/* out = a + b on bf16 tensors of n elements (n % 8 == 0).  The residual adds that cannot ride a GEMM epilogue:
+ * ControlNet `down_block_res_sample + down_block_additional_residual` on the already-consumed skip tensors
+ * (/root/reference/powerpaint/models/unet_2d_condition.py:1263-1272,1296-1297). */
+int pp_add_bf16(const void* a, const void* b, void* out, long long n, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Fused classifier-free guidance + scheduler step on fp32 NCHW latents.
+ * Replaces pipeline_PowerPaint.py:1018-1023 / pipeline_PowerPaint_Brushnet_CA.py:1444-1449:
+ *     eps = eps_u + g * (eps_c - eps_u);  latents = scheduler.step(eps, t, latents)
+ * eps2 : fp32 [2*n] (uncond half first, pipeline_PowerPaint.py:516) when cfg != 0, else [n].
+ * The step is the linear form  x_next = cx * x + ce * eps_or_x0 + cm * m_prev  with per-step coefficients read from a
+ * DEVICE table coef[step][8] = {cx, c0, cm, a_inv, s_over_a, _, _, _} and a device step counter:
+ *     x0   = a_inv * x - s_over_a * eps          (DPM-Solver++ data prediction; DDIM: folded into cx/c0)
+ *     kind 0 (DDIM, eta=0): x_next = cx * x + c0 * eps
+ *     kind 1 (DPM-Solver++ 2M): x_next = cx * x + c0 * x0 + cm * m_prev ; m_prev <- x0
+ * `step_dev` (int32 on device) selects the row; it is NOT incremented here (pp_step_advance does).
+ */
+int pp_cfg_sched_step(const float* eps2, int cfg, float guidance, float* latents, float* m_prev, int n, int kind,
+                      const float* coef_table, const int32_t* step_dev, void* stream);
+/* t_out[0] = timesteps[step]; used at the top of a captured step.  advance: ++step. */
+int pp_step_select_t(const float* timesteps, const int32_t* step_dev, float* t_out, void* stream);
+int pp_step_advance(int32_t* step_dev, void* stream);
+
+/* Bit-exact mask prep (pipeline_PowerPaint.py:143-147,677-679; pipeline_PowerPaint_Brushnet_CA.py:1312,1342-1344):
+ *   mode 0: out = (mask >= 0.5) ? 1 : 0                                  fp32 [n]
+ *   mode 1: out = image * (mask < 0.5), mask broadcast over `c` channels  fp32 [batch][c][hw]
+ *   mode 2: nearest downsample of a [batch][1][h][w] mask to [batch][1][ho][wo]  (F.interpolate default)
+ *   mode 3: out = (sum_c rgb[b][c][p] < 0) ? 1 : 0                        (BrushNet original_mask)
+ */
+int pp_mask_prep(int mode, const float* a, const float* b, float* out, int batch, int c, int h, int w, int ho, int wo,
+                 void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PP_HIP_H_ */

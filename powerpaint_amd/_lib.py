@@ -1,0 +1,95 @@
+"""ctypes binding of libpp_hip.so (the C ABI declared in include/pp_hip.h).
+
+The product path has NO fallback: if the shared library is missing this module raises at import of the symbols
+(`lib()`), and every op raises on a non-zero return code.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpp_hip.so")
+
+PP_X_PLAIN, PP_X_CONV3X3 = 0, 1
+PP_ACT_NONE, PP_ACT_GEGLU, PP_ACT_SILU = 0, 1, 2
+PP_TILE_AUTO, PP_TILE_128x160, PP_TILE_64x160, PP_TILE_256x160 = 0, 1, 2, 3
+PP_ERR = {0: "PP_OK", -1: "PP_ERR_BAD_ARG", -2: "PP_ERR_UNSUPPORTED", -3: "PP_ERR_LAUNCH", -4: "PP_ERR_WORKSPACE"}
+
+vp, i32, f32, sz = C.c_void_p, C.c_int32, C.c_float, C.c_size_t
+
+
+class PPGemmArgs(C.Structure):
+    _fields_ = [
+        ("M", i32), ("N", i32), ("K", i32), ("x_mode", i32),
+        ("x1", vp), ("x2", vp),
+        ("c1", i32), ("c2", i32), ("ldx1", i32), ("ldx2", i32),
+        ("batch", i32), ("hin", i32), ("win", i32), ("hout", i32), ("wout", i32), ("stride", i32), ("up", i32),
+        ("w", vp), ("bias", vp), ("rowvec", vp),
+        ("ld_rowvec", i32), ("rows_per_batch", i32),
+        ("res1", vp), ("ldres1", i32),
+        ("res2", vp), ("ldres2", i32),
+        ("scale", f32), ("act", i32),
+        ("out", vp), ("ldo", i32), ("out_f32", i32),
+        ("out_vt", vp), ("vt_col0", i32), ("vt_ld", i32),
+        ("splitk", i32), ("tile", i32),
+        ("workspace", vp),
+        ("reserved", i32 * 4),
+    ]
+
+
+# name -> (restype, argtypes); must list every symbol of include/pp_hip.h (tests/test_abi.py checks the header)
+SIGNATURES = {
+    "pp_abi_version": (C.c_int, []),
+    "pp_last_error": (C.c_char_p, []),
+    "pp_gemm_bf16": (C.c_int, [C.POINTER(PPGemmArgs), vp]),
+    "pp_gemm_workspace_bytes": (sz, [C.POINTER(PPGemmArgs)]),
+    "pp_linear_skinny": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp]),
+    "pp_timestep_embedding": (C.c_int, [vp, C.c_int, C.c_int, vp, vp]),
+    "pp_groupnorm_workspace_bytes": (sz, [C.c_int, C.c_int, C.c_int]),
+    "pp_groupnorm_stats": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, f32, vp, vp, vp, vp, vp]),
+    "pp_groupnorm_apply": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp, vp]),
+    "pp_layernorm": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, f32, vp, vp]),
+    "pp_attention_fwd": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int,
+                                   C.c_int, C.c_int, f32, vp]),
+    "pp_transpose_v": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp]),
+    "pp_conv3x3_direct": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, vp,
+                                    vp, vp]),
+    "pp_conv3x3_smallcout": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, vp, vp]),
+    "pp_nchw_to_nhwc": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp]),
+    "pp_nhwc_to_nchw": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp]),
+    "pp_add_bf16": (C.c_int, [vp, vp, vp, C.c_longlong, vp]),
+    "pp_cfg_sched_step": (C.c_int, [vp, C.c_int, f32, vp, vp, C.c_int, C.c_int, vp, vp, vp]),
+    "pp_step_select_t": (C.c_int, [vp, vp, vp, vp]),
+    "pp_step_advance": (C.c_int, [vp, vp]),
+    "pp_mask_prep": (C.c_int, [C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+}
+
+_lib = None
+
+
+class PPError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libpp_hip.so (once).  Raises loudly if the HIP extension has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise PPError(
+                f"{LIB_PATH} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; "
+                f"g.build()'` (or `make -C powerpaint_amd/csrc`). There is no CPU/PyTorch fallback.")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        if l.pp_abi_version() != 1:
+            raise PPError("libpp_hip.so ABI version mismatch")
+        _lib = l
+    return _lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = lib().pp_last_error().decode() if rc == -3 else ""
+        raise PPError(f"{what} failed: {PP_ERR.get(rc, rc)} {msg}")

@@ -1,0 +1,415 @@
+// bf16 MFMA GEMM / implicit-GEMM 3x3 convolution for gfx950 (MI355X).
+//
+//   out[m][n] = epilogue( sum_k X[m][k] * W[n][k] )          X: activations (rows = pixels/tokens), W: weights
+//
+// Design (CDNA4-first, see DESIGN.md "GEMM core"):
+//   * block tile BM x 160 x 64 : every GEMM width in SD-1.5 is a multiple of 320 = 2*160, so BN = 160 wastes nothing
+//     (a 128/256-wide power-of-two tile would waste 17-37 % of the MFMA work of every 320-channel layer);
+//   * 4 (or 8) waves of 64 lanes, wave tile (MI*16) x 80, v_mfma_f32_16x16x32_bf16, fp32 accumulators in registers;
+//   * operands are SWAPPED at the MFMA (A-operand = W rows, B-operand = X rows) so each lane ends up with 4
+//     CONSECUTIVE output channels of one row -> 8-byte bf16 stores / residual loads along the contiguous axis and a
+//     per-lane GEGLU pair without any cross-lane traffic;
+//   * both operand tiles live in LDS as [rows][64] bf16 (128-B rows) with the 16-B slots XOR-swizzled by (row & 7):
+//     ds_write_b128 / ds_read_b128 are bank-conflict free;
+//   * global -> register -> LDS staging with the next tile's loads in flight during the MFMAs of the current one,
+//     double-buffered LDS, ONE barrier per 64-deep K step;
+//   * buffer loads with out-of-range offsets return 0: the 3x3 halo, nearest-2x upsample, stride-2 and the two-source
+//     channel concat of the up blocks are pure address arithmetic in the loader -- no im2col / concat / upsample
+//     tensor ever touches HBM;
+//   * workgroup id -> tile mapping is XCD-aware (8 XCDs, private 4 MiB L2 each): the blocks resident on one XCD walk
+//     consecutive N tiles of the same M panel, so the activation panel is fetched from HBM once per XCD.
+#include "pp_common.h"
+
+namespace {
+
+struct GemmDerived {
+  int tiles_m, tiles_n, kt_total, kt_per_split, ctiles;
+};
+
+template <int BN>
+PP_DEVINL void epilogue4(const PPGemmArgs& a, int m, int n, f32x4_t v) {
+  // v holds columns n..n+3 of row m (fp32 accumulators)
+  if (a.bias) {
+    const f32x4_t b = *reinterpret_cast<const f32x4_t*>(a.bias + n);
+    v += b;
+  }
+  int bidx = 0, rin = m;
+  if (a.rowvec || a.out_vt) {
+    bidx = m / a.rows_per_batch;
+    rin = m - bidx * a.rows_per_batch;
+  }
+  if (a.rowvec) {
+    const f32x4_t t = *reinterpret_cast<const f32x4_t*>(a.rowvec + (size_t)bidx * a.ld_rowvec + n);
+    v += t;
+  }
+  v *= a.scale;
+  if (a.res1) {
+    const u32x2_t r = *reinterpret_cast<const u32x2_t*>((const uint16_t*)a.res1 + (size_t)m * a.ldres1 + n);
+    v[0] += bflo(r[0]); v[1] += bfhi(r[0]); v[2] += bflo(r[1]); v[3] += bfhi(r[1]);
+  }
+  if (a.res2) {
+    const u32x2_t r = *reinterpret_cast<const u32x2_t*>((const uint16_t*)a.res2 + (size_t)m * a.ldres2 + n);
+    v[0] += bflo(r[0]); v[1] += bfhi(r[0]); v[2] += bflo(r[1]); v[3] += bfhi(r[1]);
+  }
+  if (a.act == PP_ACT_GEGLU) {
+    const float o0 = v[0] * gelu_erf_f(v[2]);
+    const float o1 = v[1] * gelu_erf_f(v[3]);
+    *reinterpret_cast<uint32_t*>((uint16_t*)a.out + (size_t)m * a.ldo + (n >> 1)) = pack2bf(o0, o1);
+    return;
+  }
+  if (a.act == PP_ACT_SILU) {
+    v[0] = silu_f(v[0]); v[1] = silu_f(v[1]); v[2] = silu_f(v[2]); v[3] = silu_f(v[3]);
+  }
+  if (a.out_vt && n >= a.vt_col0) {
+    const int ncols = a.N - a.vt_col0;
+    uint16_t* dst = (uint16_t*)a.out_vt + ((size_t)bidx * ncols + (n - a.vt_col0)) * a.vt_ld + rin;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dst[(size_t)j * a.vt_ld] = f2bf(v[j]);
+    return;
+  }
+  if (a.out_f32) {
+    *reinterpret_cast<f32x4_t*>((float*)a.out + (size_t)m * a.ldo + n) = v;
+  } else {
+    u32x2_t o;
+    o[0] = pack2bf(v[0], v[1]);
+    o[1] = pack2bf(v[2], v[3]);
+    *reinterpret_cast<u32x2_t*>((uint16_t*)a.out + (size_t)m * a.ldo + n) = o;
+  }
+}
+
+template <int BM, int BN, int WM, int WN, int XMODE>
+__global__ void __launch_bounds__(WM* WN * 64, 2) pp_gemm_kernel(const PPGemmArgs a, const GemmDerived d) {
+  constexpr int T = WM * WN * 64;
+  constexpr int MI = BM / WM / 16;
+  constexpr int NI = BN / WN / 16;
+  constexpr int RPP = T / 8;                      // tile rows covered per load pass
+  constexpr int XP = (BM + RPP - 1) / RPP;        // 16-B pieces per thread, X tile
+  constexpr int WP = (BN + RPP - 1) / RPP;        // 16-B pieces per thread, W tile
+  constexpr int XBYTES = BM * 128, WBYTES = BN * 128, BUFBYTES = XBYTES + WBYTES;
+  static_assert(BM % (WM * 16) == 0 && BN % (WN * 16) == 0, "tile/wave mismatch");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+
+  // ---- XCD-aware bijective block remap (block b runs on XCD b % 8)
+  int lid;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tile_m = lid / d.tiles_n;
+  const int tile_n = lid - tile_m * d.tiles_n;
+  const int m_blk = tile_m * BM, n_blk = tile_n * BN;
+  const int split = blockIdx.y;
+  const int kt_begin = split * d.kt_per_split;
+  int kt_end = kt_begin + d.kt_per_split;
+  if (kt_end > d.kt_total) kt_end = d.kt_total;
+
+  // ---- loader geometry
+  const int slot = tid & 7;
+  const int prow = tid >> 3;                                   // row within a pass
+  const int lds_piece = prow * 128 + ((slot ^ (prow & 7)) << 4);  // RPP % 8 == 0 -> same swizzle every pass
+
+  const int ctot = a.c1 + a.c2;
+  const __amdgpu_buffer_rsrc_t rs_x1 = make_rsrc(
+      a.x1, XMODE == PP_X_PLAIN ? (uint32_t)a.M * (uint32_t)a.ldx1 * 2u
+                                : (uint32_t)a.batch * (uint32_t)a.hin * (uint32_t)a.win * (uint32_t)a.c1 * 2u);
+  const __amdgpu_buffer_rsrc_t rs_x2 = make_rsrc(
+      a.x2 ? a.x2 : a.x1, !a.x2 ? 0u
+                          : (XMODE == PP_X_PLAIN ? (uint32_t)a.M * (uint32_t)a.ldx2 * 2u
+                                                 : (uint32_t)a.batch * (uint32_t)a.hin * (uint32_t)a.win * (uint32_t)a.c2 * 2u));
+  const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(a.w, (uint32_t)a.N * (uint32_t)a.K * 2u);
+
+  bool xvalid[XP];
+  int xa[XP], xb[XP], xc[XP];   // PLAIN: xa = m*ldx1, xb = m*ldx2 ; CONV: xa = b*hin*win, xb = oy*stride-1, xc = ox*stride-1
+#pragma unroll
+  for (int i = 0; i < XP; ++i) {
+    const int row = prow + i * RPP;
+    const int m = m_blk + row;
+    xvalid[i] = (row < BM) && (m < a.M);
+    if (XMODE == PP_X_PLAIN) {
+      xa[i] = m * a.ldx1;
+      xb[i] = m * a.ldx2;
+      xc[i] = 0;
+    } else {
+      const int hw = a.hout * a.wout;
+      const int b = m / hw;
+      const int rem = m - b * hw;
+      const int oy = rem / a.wout;
+      const int ox = rem - oy * a.wout;
+      xa[i] = b * a.hin * a.win;
+      xb[i] = oy * a.stride - 1;
+      xc[i] = ox * a.stride - 1;
+    }
+  }
+  bool wvalid[WP];
+  int wo[WP];
+#pragma unroll
+  for (int i = 0; i < WP; ++i) {
+    const int row = prow + i * RPP;
+    const int n = n_blk + row;
+    wvalid[i] = (row < BN) && (n < a.N);
+    wo[i] = n * a.K;
+  }
+
+  // conv tap bookkeeping (block-uniform)
+  int tap = 0, cc = 0;
+  if (XMODE == PP_X_CONV3X3) {
+    tap = kt_begin / d.ctiles;
+    cc = (kt_begin - tap * d.ctiles) * 64;
+  }
+  const int hv = a.up ? a.hin * 2 : a.hin;
+  const int wv = a.up ? a.win * 2 : a.win;
+
+  u32x4_t xr[XP], wr[WP];
+
+  auto load_tile = [&](int kt) {
+    const int k0 = kt * 64;
+    if (XMODE == PP_X_PLAIN) {
+      const bool first = k0 < a.c1;
+      const __amdgpu_buffer_rsrc_t rs = first ? rs_x1 : rs_x2;
+      const int kk = (first ? k0 : k0 - a.c1) + slot * 8;
+#pragma unroll
+      for (int i = 0; i < XP; ++i) {
+        const uint32_t off = xvalid[i] ? (uint32_t)((first ? xa[i] : xb[i]) + kk) * 2u : PP_OOB;
+        xr[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+      }
+    } else {
+      const int ky = tap / 3, kx = tap - ky * 3;
+      const bool first = cc < a.c1;
+      const __amdgpu_buffer_rsrc_t rs = first ? rs_x1 : rs_x2;
+      const int csrc = first ? a.c1 : a.c2;
+      const int kk = (first ? cc : cc - a.c1) + slot * 8;
+#pragma unroll
+      for (int i = 0; i < XP; ++i) {
+        const int iy = xb[i] + ky, ix = xc[i] + kx;
+        const bool ok = xvalid[i] && (unsigned)iy < (unsigned)hv && (unsigned)ix < (unsigned)wv;
+        const int sy = a.up ? (iy >> 1) : iy;
+        const int sx = a.up ? (ix >> 1) : ix;
+        const uint32_t off = ok ? (uint32_t)((xa[i] + sy * a.win + sx) * csrc + kk) * 2u : PP_OOB;
+        xr[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+      }
+      cc += 64;
+      if (cc == ctot) { cc = 0; ++tap; }
+    }
+#pragma unroll
+    for (int i = 0; i < WP; ++i) {
+      const uint32_t off = wvalid[i] ? (uint32_t)(wo[i] + k0 + slot * 8) * 2u : PP_OOB;
+      wr[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, off, 0, 0);
+    }
+  };
+  auto store_tile = [&](int buf) {
+    char* xs = smem + buf * BUFBYTES;
+    char* ws = xs + XBYTES;
+#pragma unroll
+    for (int i = 0; i < XP; ++i)
+      if ((XP * RPP == BM) || (prow + i * RPP < BM)) *reinterpret_cast<u32x4_t*>(xs + lds_piece + i * RPP * 128) = xr[i];
+#pragma unroll
+    for (int i = 0; i < WP; ++i)
+      if ((WP * RPP == BN) || (prow + i * RPP < BN)) *reinterpret_cast<u32x4_t*>(ws + lds_piece + i * RPP * 128) = wr[i];
+  };
+
+  f32x4_t acc[NI][MI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  // fragment read offsets: row = base + (lane & 15), k-slot = ks*4 + (lane >> 4), swizzled by row & 7
+  const int frow = lane & 15;
+  const int fk = lane >> 4;
+  const int xrow0 = wm * (MI * 16) + frow;
+  const int wrow0 = wn * (NI * 16) + frow;
+  // (row & 7) is invariant to +16*i, so the swizzle term is the same for every fragment of this lane
+  const int fsw = frow & 7;
+
+  if (kt_begin < kt_end) {
+    load_tile(kt_begin);
+    store_tile(0);
+  }
+  __syncthreads();
+
+  int cur = 0;
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
+    const bool more = (kt + 1 < kt_end);
+    if (more) load_tile(kt + 1);
+
+    const char* xs = smem + cur * BUFBYTES;
+    const char* ws = xs + XBYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int so = ((ks * 4 + fk) ^ fsw) << 4;
+      bf16x8_t xf[MI], wf[NI];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+        xf[mi] = *reinterpret_cast<const bf16x8_t*>(xs + (xrow0 + mi * 16) * 128 + so);
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+        wf[ni] = *reinterpret_cast<const bf16x8_t*>(ws + (wrow0 + ni * 16) * 128 + so);
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+          acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
+    }
+
+    if (more) store_tile(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // ---- epilogue: lane holds rows n = .. + 4*(lane>>4) + {0..3} (A-operand = W), col m = .. + (lane & 15)
+  const int m_base = m_blk + wm * (MI * 16) + (lane & 15);
+  const int n_base = n_blk + wn * (NI * 16) + 4 * (lane >> 4);
+  if (gridDim.y > 1) {
+    float* ws = a.workspace + (size_t)split * a.M * a.N;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      const int m = m_base + mi * 16;
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        const int n = n_base + ni * 16;
+        if (m < a.M && n < a.N) *reinterpret_cast<f32x4_t*>(ws + (size_t)m * a.N + n) = acc[ni][mi];
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    const int m = m_base + mi * 16;
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int n = n_base + ni * 16;
+      if (m < a.M && n < a.N) epilogue4<BN>(a, m, n, acc[ni][mi]);
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) pp_splitk_reduce_kernel(const PPGemmArgs a, int splits) {
+  const int n4 = a.N >> 2;
+  const long long total = (long long)a.M * n4;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int m = (int)(i / n4);
+    const int n = (int)(i - (long long)m * n4) * 4;
+    f32x4_t v = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < splits; ++s)
+      v += *reinterpret_cast<const f32x4_t*>(a.workspace + ((size_t)s * a.M + m) * a.N + n);
+    epilogue4<160>(a, m, n, v);
+  }
+}
+
+struct Choice {
+  int tile, splitk;
+};
+
+Choice choose(const PPGemmArgs& a) {
+  Choice c{a.tile, a.splitk};
+  const int tn = (a.N + 159) / 160;
+  auto blocks = [&](int bm) { return ((a.M + bm - 1) / bm) * tn; };
+  if (c.tile == PP_TILE_AUTO) c.tile = (blocks(128) >= 256) ? PP_TILE_128x160 : PP_TILE_64x160;
+  const int bm = c.tile == PP_TILE_128x160 ? 128 : c.tile == PP_TILE_64x160 ? 64 : 256;
+  if (c.splitk <= 0) {
+    const int nb = blocks(bm), kt = a.K / 64;
+    int sk = 1;
+    while (nb * sk < 224 && kt / (sk * 2) >= 12 && sk < 8) sk *= 2;
+    c.splitk = sk;
+  }
+  if (a.act == PP_ACT_GEGLU && false) c.splitk = 1;
+  return c;
+}
+
+template <int BM, int BN, int WM, int WN, int XMODE>
+int launch(const PPGemmArgs& a, int splitk, hipStream_t st) {
+  constexpr int T = WM * WN * 64;
+  constexpr int LDS = 2 * (BM + BN) * 128;
+  static bool attr_set = false;
+  auto kern = pp_gemm_kernel<BM, BN, WM, WN, XMODE>;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) !=
+        hipSuccess) {
+      pp_set_last_error("hipFuncSetAttribute(gemm)", hipGetLastError());
+      return PP_ERR_LAUNCH;
+    }
+    attr_set = true;
+  }
+  GemmDerived d;
+  d.tiles_m = (a.M + BM - 1) / BM;
+  d.tiles_n = (a.N + BN - 1) / BN;
+  d.kt_total = a.K / 64;
+  d.kt_per_split = (d.kt_total + splitk - 1) / splitk;
+  d.ctiles = (a.c1 + a.c2) / 64;
+  dim3 grid(d.tiles_m * d.tiles_n, splitk, 1);
+  hipLaunchKernelGGL(kern, grid, dim3(T), LDS, st, a, d);
+  PP_CHECK_LAUNCH("pp_gemm_kernel");
+  if (splitk > 1) {
+    const long long total = (long long)a.M * (a.N / 4);
+    int nb = (int)((total + 255) / 256);
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(pp_splitk_reduce_kernel, dim3(nb), dim3(256), 0, st, a, splitk);
+    PP_CHECK_LAUNCH("pp_splitk_reduce_kernel");
+  }
+  return PP_OK;
+}
+
+int validate(const PPGemmArgs& a) {
+  if (a.M <= 0 || a.N <= 0 || a.K <= 0) return PP_ERR_BAD_ARG;
+  if (a.K % 64 != 0 || a.N % 4 != 0) return PP_ERR_BAD_ARG;
+  if (!a.x1 || !a.w || !a.out) return PP_ERR_BAD_ARG;
+  if (a.x_mode == PP_X_PLAIN) {
+    if (a.c1 + a.c2 != a.K) return PP_ERR_BAD_ARG;
+    if (a.c2 > 0 && (!a.x2 || a.c1 % 64 != 0)) return PP_ERR_BAD_ARG;
+    if (a.ldx1 % 8 != 0 || (a.c2 > 0 && a.ldx2 % 8 != 0)) return PP_ERR_BAD_ARG;
+    if ((uint64_t)a.M * (uint64_t)a.ldx1 * 2u >= 0x80000000ull) return PP_ERR_UNSUPPORTED;
+  } else if (a.x_mode == PP_X_CONV3X3) {
+    if (a.c1 % 64 != 0 || a.c2 % 64 != 0 || a.c1 <= 0) return PP_ERR_BAD_ARG;
+    if (a.c2 > 0 && !a.x2) return PP_ERR_BAD_ARG;
+    if (a.K != 9 * (a.c1 + a.c2)) return PP_ERR_BAD_ARG;
+    if (a.stride != 1 && a.stride != 2) return PP_ERR_BAD_ARG;
+    if (a.M != a.batch * a.hout * a.wout) return PP_ERR_BAD_ARG;
+    const int hv = a.up ? 2 * a.hin : a.hin, wv = a.up ? 2 * a.win : a.win;
+    if (a.hout != (hv + 2 - 3) / a.stride + 1 || a.wout != (wv + 2 - 3) / a.stride + 1) return PP_ERR_BAD_ARG;
+    if ((uint64_t)a.batch * a.hin * a.win * (uint64_t)(a.c1 > a.c2 ? a.c1 : a.c2) * 2u >= 0x80000000ull)
+      return PP_ERR_UNSUPPORTED;
+  } else {
+    return PP_ERR_BAD_ARG;
+  }
+  if ((uint64_t)a.N * (uint64_t)a.K * 2u >= 0x80000000ull) return PP_ERR_UNSUPPORTED;
+  if ((a.rowvec || a.out_vt) && a.rows_per_batch <= 0) return PP_ERR_BAD_ARG;
+  if (a.act == PP_ACT_GEGLU && (a.out_f32 || a.out_vt)) return PP_ERR_BAD_ARG;
+  if (a.out_vt && a.vt_col0 % 4 != 0) return PP_ERR_BAD_ARG;
+  return PP_OK;
+}
+
+}  // namespace
+
+extern "C" size_t pp_gemm_workspace_bytes(const PPGemmArgs* args) {
+  if (!args || validate(*args) != PP_OK) return 0;
+  const Choice c = choose(*args);
+  return c.splitk > 1 ? (size_t)c.splitk * args->M * args->N * sizeof(float) : 0;
+}
+
+extern "C" int pp_gemm_bf16(const PPGemmArgs* args, void* stream) {
+  if (!args) return PP_ERR_BAD_ARG;
+  const PPGemmArgs& a = *args;
+  const int v = validate(a);
+  if (v != PP_OK) return v;
+  const Choice c = choose(a);
+  if (c.splitk > 1 && !a.workspace) return PP_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const bool conv = a.x_mode == PP_X_CONV3X3;
+  switch (c.tile) {
+    case PP_TILE_128x160:
+      return conv ? launch<128, 160, 2, 2, PP_X_CONV3X3>(a, c.splitk, st) : launch<128, 160, 2, 2, PP_X_PLAIN>(a, c.splitk, st);
+    case PP_TILE_64x160:
+      return conv ? launch<64, 160, 2, 2, PP_X_CONV3X3>(a, c.splitk, st) : launch<64, 160, 2, 2, PP_X_PLAIN>(a, c.splitk, st);
+    case PP_TILE_256x160:
+      return conv ? launch<256, 160, 4, 2, PP_X_CONV3X3>(a, c.splitk, st) : launch<256, 160, 4, 2, PP_X_PLAIN>(a, c.splitk, st);
+    default:
+      return PP_ERR_BAD_ARG;
+  }
+}

@@ -1,0 +1,258 @@
+// GroupNorm(32)(+SiLU) and LayerNorm on NHWC / [rows][C] bf16 -- HBM-bound wavefront-reduction kernels.
+//
+// GroupNorm on NHWC: the C/32 channels of a group are contiguous per pixel but strided across pixels, so a
+// one-block-per-group layout would read 20..160-byte fragments.  Instead every thread owns ONE fixed 16-byte channel
+// slot (8 channels) and walks pixels: all global reads are full-line coalesced, per-channel partial sums stay in
+// registers, and only the tiny per-block fold touches LDS.  Three launches:
+//   stats    : [batch][chunk] partial (sum, sumsq) per group  -> workspace           (reads x once)
+//   finalize : fold chunks (fp64), emit per-(batch,channel) scale/shift fp32
+//   apply    : y = act(x*scale + shift)                                               (reads x once, writes y once)
+// The fold order is fixed, so results are bit-reproducible run to run (no float atomics).
+#include "pp_common.h"
+
+namespace {
+
+constexpr int GN_MAX_T = 512;
+
+PP_DEVINL int gn_chunks(int hw) {
+  int c = hw / 64;
+  if (c < 1) c = 1;
+  if (c > 64) c = 64;
+  return c;
+}
+
+// grid (nchunk, batch); block = S*P threads, S = C/8 slots, P pixel lanes
+__global__ void __launch_bounds__(GN_MAX_T) gn_stats_kernel(const uint16_t* __restrict__ x1, int c1,
+                                                           const uint16_t* __restrict__ x2, int c2, int hw, int groups,
+                                                           int S, int P, float* __restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [P][C][2]
+  const int C = c1 + c2;
+  const int tid = threadIdx.x;
+  const int slot = tid % S, pl = tid / S;
+  const int b = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
+  const int per = (hw + nchunk - 1) / nchunk;
+  const int p0 = chunk * per;
+  int p1 = p0 + per;
+  if (p1 > hw) p1 = hw;
+  const int c = slot * 8;
+  const uint16_t* src;
+  int cs, cl;
+  if (c < c1) { src = x1; cs = c1; cl = c; } else { src = x2; cs = c2; cl = c - c1; }
+  float s[8], q[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { s[j] = 0.f; q[j] = 0.f; }
+  for (int p = p0 + pl; p < p1; p += P) {
+    const u32x4_t v = *reinterpret_cast<const u32x4_t*>(src + ((size_t)b * hw + p) * cs + cl);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float lo = bflo(v[j]), hi = bfhi(v[j]);
+      s[2 * j] += lo; q[2 * j] += lo * lo;
+      s[2 * j + 1] += hi; q[2 * j + 1] += hi * hi;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    red[(pl * C + c + j) * 2 + 0] = s[j];
+    red[(pl * C + c + j) * 2 + 1] = q[j];
+  }
+  __syncthreads();
+  if (tid < groups) {
+    const int cg = C / groups;
+    float ss = 0.f, qq = 0.f;
+    for (int l = 0; l < P; ++l)
+      for (int j = 0; j < cg; ++j) {
+        ss += red[(l * C + tid * cg + j) * 2 + 0];
+        qq += red[(l * C + tid * cg + j) * 2 + 1];
+      }
+    float* o = partial + (((size_t)b * nchunk + chunk) * groups + tid) * 2;
+    o[0] = ss;
+    o[1] = qq;
+  }
+}
+
+// grid (batch); block 256
+__global__ void __launch_bounds__(256) gn_finalize_kernel(const float* __restrict__ partial, int nchunk, int groups,
+                                                         int C, int hw, float eps, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, float* __restrict__ ss) {
+  __shared__ float mean_s[64], rstd_s[64];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  if (tid < groups) {
+    double s = 0.0, q = 0.0;
+    for (int k = 0; k < nchunk; ++k) {
+      const float* o = partial + (((size_t)b * nchunk + k) * groups + tid) * 2;
+      s += (double)o[0];
+      q += (double)o[1];
+    }
+    const double n = (double)hw * (double)(C / groups);
+    const double mean = s / n;
+    double var = q / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    mean_s[tid] = (float)mean;
+    rstd_s[tid] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+  __syncthreads();
+  const int cg = C / groups;
+  for (int c = tid; c < C; c += 256) {
+    const int g = c / cg;
+    const float sc = rstd_s[g] * gamma[c];
+    ss[((size_t)b * 2 + 0) * C + c] = sc;
+    ss[((size_t)b * 2 + 1) * C + c] = beta[c] - mean_s[g] * sc;
+  }
+}
+
+// grid (blocks, batch): flat over 16-B pieces of one batch item
+template <bool SILU>
+__global__ void __launch_bounds__(256) gn_apply_kernel(const uint16_t* __restrict__ x1, int c1,
+                                                      const uint16_t* __restrict__ x2, int c2, int hw,
+                                                      const float* __restrict__ ss, uint16_t* __restrict__ y) {
+  const int C = c1 + c2, S = C >> 3;
+  const int b = blockIdx.y;
+  const int total = hw * S;
+  const float* sc = ss + (size_t)b * 2 * C;
+  const float* sh = sc + C;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const int p = i / S;
+    const int c = (i - p * S) * 8;
+    const uint16_t* src = (c < c1) ? x1 + ((size_t)b * hw + p) * c1 + c : x2 + ((size_t)b * hw + p) * c2 + (c - c1);
+    const u32x4_t v = *reinterpret_cast<const u32x4_t*>(src);
+    const f32x4_t a0 = *reinterpret_cast<const f32x4_t*>(sc + c), a1 = *reinterpret_cast<const f32x4_t*>(sc + c + 4);
+    const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(sh + c), b1 = *reinterpret_cast<const f32x4_t*>(sh + c + 4);
+    float r[8];
+    r[0] = bflo(v[0]) * a0[0] + b0[0]; r[1] = bfhi(v[0]) * a0[1] + b0[1];
+    r[2] = bflo(v[1]) * a0[2] + b0[2]; r[3] = bfhi(v[1]) * a0[3] + b0[3];
+    r[4] = bflo(v[2]) * a1[0] + b1[0]; r[5] = bfhi(v[2]) * a1[1] + b1[1];
+    r[6] = bflo(v[3]) * a1[2] + b1[2]; r[7] = bfhi(v[3]) * a1[3] + b1[3];
+    if (SILU) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) r[j] = silu_f(r[j]);
+    }
+    u32x4_t o;
+    o[0] = pack2bf(r[0], r[1]); o[1] = pack2bf(r[2], r[3]); o[2] = pack2bf(r[4], r[5]); o[3] = pack2bf(r[6], r[7]);
+    *reinterpret_cast<u32x4_t*>(y + ((size_t)b * hw + p) * C + c) = o;
+  }
+}
+
+// LayerNorm: one wave per row, <= 4 16-B pieces per lane (C <= 2048), two-pass statistics in registers.
+template <int NP>
+__global__ void __launch_bounds__(256) layernorm_kernel(const uint16_t* __restrict__ x, int rows, int C,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       float eps, uint16_t* __restrict__ y) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int S = C >> 3;
+  float v[NP][8];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const int pc = lane + i * 64;
+    if (pc < S) {
+      const u32x4_t u = *reinterpret_cast<const u32x4_t*>(x + (size_t)row * C + pc * 8);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { v[i][2 * j] = bflo(u[j]); v[i][2 * j + 1] = bfhi(u[j]); }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[i][j] = 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sum += v[i][j];
+  }
+  const float mean = wave_sum(sum) / (float)C;
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const int pc = lane + i * 64;
+    if (pc < S) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float d = v[i][j] - mean; sq += d * d; }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(sq) / (float)C + eps);
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const int pc = lane + i * 64;
+    if (pc < S) {
+      const int c = pc * 8;
+      const f32x4_t g0 = *reinterpret_cast<const f32x4_t*>(gamma + c), g1 = *reinterpret_cast<const f32x4_t*>(gamma + c + 4);
+      const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(beta + c), b1 = *reinterpret_cast<const f32x4_t*>(beta + c + 4);
+      float r[8];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        r[j] = (v[i][j] - mean) * rstd * g0[j] + b0[j];
+        r[4 + j] = (v[i][4 + j] - mean) * rstd * g1[j] + b1[j];
+      }
+      u32x4_t o;
+      o[0] = pack2bf(r[0], r[1]); o[1] = pack2bf(r[2], r[3]); o[2] = pack2bf(r[4], r[5]); o[3] = pack2bf(r[6], r[7]);
+      *reinterpret_cast<u32x4_t*>(y + (size_t)row * C + c) = o;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" size_t pp_groupnorm_workspace_bytes(int batch, int hw, int C) {
+  (void)C;
+  return (size_t)batch * 64 * 64 * 2 * sizeof(float);  // [batch][<=64 chunks][<=64 groups][2]
+}
+
+extern "C" int pp_groupnorm_stats(const void* x1, int c1, const void* x2, int c2, int batch, int hw, int groups,
+                                  float eps, const float* gamma, const float* beta, float* scale_shift,
+                                  float* workspace, void* stream) {
+  const int C = c1 + c2;
+  if (!x1 || !gamma || !beta || !scale_shift) return PP_ERR_BAD_ARG;
+  if (!workspace) return PP_ERR_WORKSPACE;
+  if (c1 <= 0 || c1 % 8 || c2 % 8 || (c2 > 0 && !x2) || groups <= 0 || groups > 64 || C % groups) return PP_ERR_BAD_ARG;
+  const int S = C / 8;
+  if (S > GN_MAX_T) return PP_ERR_UNSUPPORTED;
+  int P = GN_MAX_T / S;
+  if (P > 16) P = 16;
+  const int nchunk = hw / 64 < 1 ? 1 : (hw / 64 > 64 ? 64 : hw / 64);
+  hipStream_t st = (hipStream_t)stream;
+  const size_t lds = (size_t)P * C * 2 * sizeof(float);
+  if (lds > 64 * 1024) return PP_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunk, batch), dim3(S * P), lds, st, (const uint16_t*)x1, c1,
+                     (const uint16_t*)x2, c2, hw, groups, S, P, workspace);
+  PP_CHECK_LAUNCH("gn_stats_kernel");
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(batch), dim3(256), 0, st, workspace, nchunk, groups, C, hw, eps, gamma,
+                     beta, scale_shift);
+  PP_CHECK_LAUNCH("gn_finalize_kernel");
+  return PP_OK;
+}
+
+extern "C" int pp_groupnorm_apply(const void* x1, int c1, const void* x2, int c2, int batch, int hw,
+                                  const float* scale_shift, int silu, void* y, void* stream) {
+  if (!x1 || !scale_shift || !y || c1 <= 0 || c1 % 8 || c2 % 8 || (c2 > 0 && !x2)) return PP_ERR_BAD_ARG;
+  const int C = c1 + c2;
+  const long long total = (long long)hw * (C / 8);
+  int nb = (int)((total + 255) / 256);
+  if (nb > 1024) nb = 1024;
+  hipStream_t st = (hipStream_t)stream;
+  if (silu)
+    hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(nb, batch), dim3(256), 0, st, (const uint16_t*)x1, c1,
+                       (const uint16_t*)x2, c2, hw, scale_shift, (uint16_t*)y);
+  else
+    hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(nb, batch), dim3(256), 0, st, (const uint16_t*)x1, c1,
+                       (const uint16_t*)x2, c2, hw, scale_shift, (uint16_t*)y);
+  PP_CHECK_LAUNCH("gn_apply_kernel");
+  return PP_OK;
+}
+
+extern "C" int pp_layernorm(const void* x, int rows, int C, const float* gamma, const float* beta, float eps, void* y,
+                            void* stream) {
+  if (!x || !y || !gamma || !beta || rows <= 0 || C <= 0 || C % 8) return PP_ERR_BAD_ARG;
+  const int S = C / 8;
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid((rows + 3) / 4), block(256);
+  if (S <= 64)
+    hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, st, (const uint16_t*)x, rows, C, gamma, beta, eps, (uint16_t*)y);
+  else if (S <= 128)
+    hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, st, (const uint16_t*)x, rows, C, gamma, beta, eps, (uint16_t*)y);
+  else if (S <= 192)
+    hipLaunchKernelGGL(layernorm_kernel<3>, grid, block, 0, st, (const uint16_t*)x, rows, C, gamma, beta, eps, (uint16_t*)y);
+  else if (S <= 256)
+    hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, st, (const uint16_t*)x, rows, C, gamma, beta, eps, (uint16_t*)y);
+  else
+    return PP_ERR_UNSUPPORTED;
+  PP_CHECK_LAUNCH("layernorm_kernel");
+  return PP_OK;
+}

@@ -1,0 +1,54 @@
+// Shared device helpers for the gfx950 kernels (wave = 64 lanes, bf16 MFMA, LDS 160 KiB/CU).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "pp_hip.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
+
+#define PP_DEVINL __device__ __forceinline__
+
+PP_DEVINL float bf2f(uint16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+PP_DEVINL uint16_t f2bf(float f) {
+  __bf16 b = (__bf16)f;  // round-to-nearest-even, v_cvt_pk_bf16_f32 on gfx950
+  return __builtin_bit_cast(uint16_t, b);
+}
+PP_DEVINL uint32_t pack2bf(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+PP_DEVINL float bflo(uint32_t u) { return __uint_as_float(u << 16); }
+PP_DEVINL float bfhi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
+
+PP_DEVINL float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+PP_DEVINL float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+// Buffer resource over [base, base+bytes): out-of-range voffset reads return 0 -> free zero padding for im2col.
+PP_DEVINL __amdgpu_buffer_rsrc_t make_rsrc(const void* base, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
+#define PP_OOB 0x80000000u
+
+PP_DEVINL float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+PP_DEVINL float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// Host-side error plumbing (pp_api.cpp)
+void pp_set_last_error(const char* what, hipError_t e);
+#define PP_CHECK_LAUNCH(what)                         \
+  do {                                                \
+    hipError_t e__ = hipGetLastError();               \
+    if (e__ != hipSuccess) {                          \
+      pp_set_last_error(what, e__);                   \
+      return PP_ERR_LAUNCH;                           \
+    }                                                 \
+  } while (0)

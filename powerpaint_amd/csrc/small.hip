@@ -1,0 +1,389 @@
+// HBM-/latency-bound helpers of the denoising step: timestep embedding, skinny linears, direct 3x3 convs for
+// MFMA-unfriendly channel counts, layout conversion at the NCHW module boundary, the fused CFG + scheduler step and the
+// bit-exact mask preparation.  All are coalesced / wave-reduction kernels; none allocates or synchronises.
+#include "pp_common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------ timestep embedding
+__global__ void timestep_embedding_kernel(const float* __restrict__ t_dev, int rows, int dim, float* __restrict__ out) {
+  const int half = dim >> 1;
+  const float t = t_dev[0];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < rows * half; i += gridDim.x * blockDim.x) {
+    const int r = i / half, k = i - r * half;
+    const float f = expf(-9.210340371976184f * (float)k / (float)half);  // ln(10000)
+    const float a = t * f;
+    out[(size_t)r * dim + k] = cosf(a);          // flip_sin_to_cos=True -> [cos | sin]
+    out[(size_t)r * dim + half + k] = sinf(a);
+  }
+}
+
+// ------------------------------------------------------------------------------------------ skinny linear (GEMV-like)
+template <int R>
+__global__ void __launch_bounds__(256) linear_skinny_kernel(const float* __restrict__ x, int rows, int K,
+                                                           const uint16_t* __restrict__ w, const float* __restrict__ bias,
+                                                           int N, float* __restrict__ out, int ldo, int act_in, int act_out) {
+  extern __shared__ __attribute__((aligned(16))) float xs[];  // [R][K]
+  for (int i = threadIdx.x; i < R * K; i += 256) {
+    const int r = i / K;
+    float v = (r < rows) ? x[(size_t)r * K + (i - r * K)] : 0.f;
+    if (act_in == PP_ACT_SILU) v = silu_f(v);
+    xs[i] = v;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int S = K >> 3;
+  for (int n = blockIdx.x * 4 + wave; n < N; n += gridDim.x * 4) {
+    float acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = 0.f;
+    for (int pc = lane; pc < S; pc += 64) {
+      const u32x4_t u = *reinterpret_cast<const u32x4_t*>(w + (size_t)n * K + pc * 8);
+      float wv[8];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { wv[2 * j] = bflo(u[j]); wv[2 * j + 1] = bfhi(u[j]); }
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const float* xp = xs + r * K + pc * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[r] = fmaf(wv[j], xp[j], acc[r]);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const float s = wave_sum(acc[r]);
+      if (lane == 0 && r < rows) {
+        float v = s + (bias ? bias[n] : 0.f);
+        if (act_out == PP_ACT_SILU) v = silu_f(v);
+        out[(size_t)r * ldo + n] = v;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ direct 3x3 conv, cout % 8 == 0
+// thread = (pixel, 8 consecutive output channels); weights [3][3][cin][cout] so the 8 weights of a tap are one 16-B load
+__global__ void __launch_bounds__(256) conv3x3_direct_kernel(const uint16_t* __restrict__ x, int batch, int hin, int win,
+                                                            int cin, const uint16_t* __restrict__ w,
+                                                            const float* __restrict__ bias, int cout, int stride,
+                                                            int hout, int wout, int silu_out,
+                                                            const uint16_t* __restrict__ add, uint16_t* __restrict__ out) {
+  const int S = cout >> 3;
+  const long long total = (long long)batch * hout * wout * S;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int sl = (int)(i % S);
+    const long long pix = i / S;
+    const int ox = (int)(pix % wout);
+    const int oy = (int)((pix / wout) % hout);
+    const int b = (int)(pix / ((long long)wout * hout));
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = bias ? bias[sl * 8 + j] : 0.f;
+    for (int ky = 0; ky < 3; ++ky) {
+      const int iy = oy * stride + ky - 1;
+      if ((unsigned)iy >= (unsigned)hin) continue;
+      for (int kx = 0; kx < 3; ++kx) {
+        const int ix = ox * stride + kx - 1;
+        if ((unsigned)ix >= (unsigned)win) continue;
+        const uint16_t* xp = x + (((size_t)b * hin + iy) * win + ix) * cin;
+        const uint16_t* wp = w + ((size_t)(ky * 3 + kx) * cin) * cout + sl * 8;
+        for (int ci = 0; ci < cin; ++ci) {
+          const float xv = bf2f(xp[ci]);
+          const u32x4_t u = *reinterpret_cast<const u32x4_t*>(wp + (size_t)ci * cout);
+          acc[0] = fmaf(xv, bflo(u[0]), acc[0]); acc[1] = fmaf(xv, bfhi(u[0]), acc[1]);
+          acc[2] = fmaf(xv, bflo(u[1]), acc[2]); acc[3] = fmaf(xv, bfhi(u[1]), acc[3]);
+          acc[4] = fmaf(xv, bflo(u[2]), acc[4]); acc[5] = fmaf(xv, bfhi(u[2]), acc[5]);
+          acc[6] = fmaf(xv, bflo(u[3]), acc[6]); acc[7] = fmaf(xv, bfhi(u[3]), acc[7]);
+        }
+      }
+    }
+    const size_t o = (size_t)pix * cout + sl * 8;
+    if (add) {
+      const u32x4_t r = *reinterpret_cast<const u32x4_t*>(add + o);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { acc[2 * j] += bflo(r[j]); acc[2 * j + 1] += bfhi(r[j]); }
+    }
+    if (silu_out) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] = silu_f(acc[j]);
+    }
+    u32x4_t ov;
+    ov[0] = pack2bf(acc[0], acc[1]); ov[1] = pack2bf(acc[2], acc[3]);
+    ov[2] = pack2bf(acc[4], acc[5]); ov[3] = pack2bf(acc[6], acc[7]);
+    *reinterpret_cast<u32x4_t*>(out + o) = ov;
+  }
+}
+
+// ------------------------------------------------------------------------------------------ 3x3 conv with tiny cout (conv_out)
+// one wave per output pixel; lanes split K = 9*cin (cin % 8 == 0); weights [cout][3][3][cin]; out fp32 NCHW
+template <int CO>
+__global__ void __launch_bounds__(256) conv3x3_smallcout_kernel(const uint16_t* __restrict__ x, int batch, int h, int w_,
+                                                               int cin, const uint16_t* __restrict__ w,
+                                                               const float* __restrict__ bias, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const long long pix = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long long npix = (long long)batch * h * w_;
+  if (pix >= npix) return;
+  const int ox = (int)(pix % w_), oy = (int)((pix / w_) % h), b = (int)(pix / ((long long)w_ * h));
+  const int S = cin >> 3;   // 16-B pieces per tap
+  float acc[CO];
+#pragma unroll
+  for (int c = 0; c < CO; ++c) acc[c] = 0.f;
+  for (int pc = lane; pc < 9 * S; pc += 64) {
+    const int tap = pc / S, sl = pc - tap * S;
+    const int ky = tap / 3, kx = tap - ky * 3;
+    const int iy = oy + ky - 1, ix = ox + kx - 1;
+    if ((unsigned)iy >= (unsigned)h || (unsigned)ix >= (unsigned)w_) continue;
+    const u32x4_t xv = *reinterpret_cast<const u32x4_t*>(x + (((size_t)b * h + iy) * w_ + ix) * cin + sl * 8);
+#pragma unroll
+    for (int c = 0; c < CO; ++c) {
+      const u32x4_t wv = *reinterpret_cast<const u32x4_t*>(w + ((size_t)c * 9 + tap) * cin + sl * 8);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc[c] = fmaf(bflo(xv[j]), bflo(wv[j]), acc[c]);
+        acc[c] = fmaf(bfhi(xv[j]), bfhi(wv[j]), acc[c]);
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < CO; ++c) {
+    const float s = wave_sum(acc[c]);
+    if (lane == 0) out[(((size_t)b * CO + c) * h + oy) * w_ + ox] = s + (bias ? bias[c] : 0.f);
+  }
+}
+
+// ------------------------------------------------------------------------------------------ layout
+PP_DEVINL float load_as_f32(const void* p, int dtype, size_t i) {
+  if (dtype == 0) return ((const float*)p)[i];
+  if (dtype == 1) return bf2f(((const uint16_t*)p)[i]);
+  return (float)(((const _Float16*)p)[i]);
+}
+
+__global__ void __launch_bounds__(256) nchw_to_nhwc_kernel(const void* __restrict__ src, int dtype, int batch, int c,
+                                                          int hw, int bmod, uint16_t* __restrict__ dst, int ldc, int c0) {
+  const long long total = (long long)batch * hw;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int b = (int)(i / hw), p = (int)(i - (long long)b * hw);
+    const int sb = bmod > 0 ? b % bmod : b;
+    for (int j = 0; j < c; ++j)
+      dst[(size_t)i * ldc + c0 + j] = f2bf(load_as_f32(src, dtype, ((size_t)sb * c + j) * hw + p));
+  }
+}
+
+__global__ void __launch_bounds__(256) nhwc_to_nchw_kernel(const uint16_t* __restrict__ src, int batch, int c, int hw,
+                                                          void* __restrict__ dst, int dtype) {
+  const long long total = (long long)batch * c * hw;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int p = (int)(i % hw);
+    const int ch = (int)((i / hw) % c);
+    const int b = (int)(i / ((long long)hw * c));
+    const uint16_t v = src[((size_t)b * hw + p) * c + ch];
+    if (dtype == 0) ((float*)dst)[i] = bf2f(v);
+    else ((uint16_t*)dst)[i] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------ elementwise add (bf16)
+__global__ void __launch_bounds__(256) add_bf16_kernel(const uint16_t* __restrict__ a, const uint16_t* __restrict__ b,
+                                                      uint16_t* __restrict__ out, long long n8) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
+    const u32x4_t x = *reinterpret_cast<const u32x4_t*>(a + i * 8);
+    const u32x4_t y = *reinterpret_cast<const u32x4_t*>(b + i * 8);
+    u32x4_t o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = pack2bf(bflo(x[j]) + bflo(y[j]), bfhi(x[j]) + bfhi(y[j]));
+    *reinterpret_cast<u32x4_t*>(out + i * 8) = o;
+  }
+}
+
+// ------------------------------------------------------------------------------------------ CFG + scheduler step
+__global__ void __launch_bounds__(256) cfg_sched_step_kernel(const float* __restrict__ eps2, int cfg, float g,
+                                                            float* __restrict__ x, float* __restrict__ m_prev, int n,
+                                                            int kind, const float* __restrict__ coef,
+                                                            const int32_t* __restrict__ step_dev) {
+  const float* c = coef + (size_t)step_dev[0] * 8;
+  const float c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3], c4 = c[4], c5 = c[5];
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    float e;
+    if (cfg) {
+      const float eu = eps2[i], ec = eps2[n + i];
+      e = eu + g * (ec - eu);                      // pipeline_PowerPaint.py:1019-1020
+    } else {
+      e = eps2[i];
+    }
+    const float xv = x[i];
+    if (kind == 0) {
+      // DDIM eta=0: c0 = sqrt(1-a_t), c1 = sqrt(a_t), c2 = sqrt(a_prev), c3 = sqrt(1-a_prev)
+      const float x0 = (xv - c0 * e) / c1;
+      x[i] = c2 * x0 + c3 * e;
+    } else {
+      // DPM-Solver++(2M): c0 = sigma_t(cur), c1 = alpha_t(cur), c2 = sigma_next/sigma_cur, c3 = alpha_next*(exp(-h)-1),
+      //                   c4 = 0.5*c3 (0 on first-order steps), c5 = 1/r0
+      const float x0 = (xv - c0 * e) / c1;
+      const float d1 = c5 * (x0 - m_prev[i]);
+      x[i] = c2 * xv - c3 * x0 - c4 * d1;
+      m_prev[i] = x0;
+    }
+  }
+}
+
+__global__ void step_select_t_kernel(const float* __restrict__ ts, const int32_t* __restrict__ step, float* __restrict__ t) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) t[0] = ts[step[0]];
+}
+__global__ void step_advance_kernel(int32_t* __restrict__ step) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) step[0] += 1;
+}
+
+// ------------------------------------------------------------------------------------------ bit-exact mask prep
+__global__ void __launch_bounds__(256) mask_prep_kernel(int mode, const float* __restrict__ a, const float* __restrict__ b,
+                                                       float* __restrict__ out, int batch, int c, int h, int w, int ho,
+                                                       int wo) {
+  const long long hw = (long long)h * w;
+  long long total;
+  if (mode == 0) total = (long long)batch * c * hw;
+  else if (mode == 1) total = (long long)batch * c * hw;
+  else if (mode == 2) total = (long long)batch * ho * wo;
+  else total = (long long)batch * hw;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    if (mode == 0) {
+      out[i] = a[i] >= 0.5f ? 1.0f : 0.0f;                 // mask[mask<0.5]=0; mask[mask>=0.5]=1
+    } else if (mode == 1) {
+      const long long bi = i / (c * hw), p = i % hw;
+      out[i] = b[bi * hw + p] < 0.5f ? a[i] : a[i] * 0.0f;  // image * (mask < 0.5)  (keeps -0.0 / NaN semantics)
+    } else if (mode == 2) {
+      const int x = (int)(i % wo), y = (int)((i / wo) % ho);
+      const long long bi = i / ((long long)wo * ho);
+      // torch nearest: src = floor(dst * (in/out)) with float scale
+      int sy = (int)floorf((float)y * ((float)h / (float)ho));
+      int sx = (int)floorf((float)x * ((float)w / (float)wo));
+      if (sy > h - 1) sy = h - 1;
+      if (sx > w - 1) sx = w - 1;
+      out[i] = a[bi * hw + (long long)sy * w + sx];
+    } else {
+      const long long bi = i / hw, p = i % hw;
+      float s = 0.f;
+      for (int j = 0; j < c; ++j) s += a[(bi * c + j) * hw + p];   // sequential fp32 sum over channels like .sum(1)
+      out[i] = s < 0.f ? 1.0f : 0.0f;
+    }
+  }
+}
+
+}  // namespace
+
+static int grid_for_host(long long total) {
+  long long nb = (total + 255) / 256;
+  return (int)(nb > 4096 ? 4096 : (nb < 1 ? 1 : nb));
+}
+
+extern "C" int pp_timestep_embedding(const float* t_dev, int rows, int dim, float* out, void* stream) {
+  if (!t_dev || !out || rows <= 0 || dim <= 0 || dim % 2) return PP_ERR_BAD_ARG;
+  hipLaunchKernelGGL(timestep_embedding_kernel, dim3((rows * dim / 2 + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                     t_dev, rows, dim, out);
+  PP_CHECK_LAUNCH("timestep_embedding_kernel");
+  return PP_OK;
+}
+
+extern "C" int pp_linear_skinny(const float* x, int rows, int K, const void* w, const float* bias, int N, float* out,
+                                int ldo, int act_in, int act_out, void* stream) {
+  if (!x || !w || !out || rows <= 0 || rows > 16 || K <= 0 || K % 8 || N <= 0) return PP_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  int nb = (N + 3) / 4;
+  if (nb > 2048) nb = 2048;
+  if (rows == 1) {
+    hipLaunchKernelGGL(linear_skinny_kernel<1>, dim3(nb), dim3(256), (size_t)K * 4, st, x, rows, K, (const uint16_t*)w,
+                       bias, N, out, ldo, act_in, act_out);
+  } else {
+    const size_t lds = (size_t)16 * K * 4;
+    if (lds > 64 * 1024) return PP_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(linear_skinny_kernel<16>, dim3(nb), dim3(256), lds, st, x, rows, K, (const uint16_t*)w, bias, N,
+                       out, ldo, act_in, act_out);
+  }
+  PP_CHECK_LAUNCH("linear_skinny_kernel");
+  return PP_OK;
+}
+
+extern "C" int pp_conv3x3_direct(const void* x, int batch, int hin, int win, int cin, const void* w, const float* bias,
+                                 int cout, int stride, int silu_out, const void* add, void* out, void* stream) {
+  if (!x || !w || !out || batch <= 0 || hin <= 0 || win <= 0 || cin <= 0 || cout <= 0 || cout % 8) return PP_ERR_BAD_ARG;
+  if (stride != 1 && stride != 2) return PP_ERR_BAD_ARG;
+  const int hout = (hin + 2 - 3) / stride + 1, wout = (win + 2 - 3) / stride + 1;
+  const long long total = (long long)batch * hout * wout * (cout / 8);
+  hipLaunchKernelGGL(conv3x3_direct_kernel, dim3(grid_for_host(total)), dim3(256), 0, (hipStream_t)stream,
+                     (const uint16_t*)x, batch, hin, win, cin, (const uint16_t*)w, bias, cout, stride, hout, wout,
+                     silu_out, (const uint16_t*)add, (uint16_t*)out);
+  PP_CHECK_LAUNCH("conv3x3_direct_kernel");
+  return PP_OK;
+}
+
+extern "C" int pp_conv3x3_smallcout(const void* x, int batch, int h, int w_, int cin, const void* w, const float* bias,
+                                    int cout, float* out_nchw, void* stream) {
+  if (!x || !w || !out_nchw || batch <= 0 || h <= 0 || w_ <= 0 || cin <= 0 || cin % 8) return PP_ERR_BAD_ARG;
+  if (cout != 4) return PP_ERR_UNSUPPORTED;
+  const long long npix = (long long)batch * h * w_;
+  hipLaunchKernelGGL(conv3x3_smallcout_kernel<4>, dim3((unsigned)((npix + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                     (const uint16_t*)x, batch, h, w_, cin, (const uint16_t*)w, bias, out_nchw);
+  PP_CHECK_LAUNCH("conv3x3_smallcout_kernel");
+  return PP_OK;
+}
+
+extern "C" int pp_nchw_to_nhwc(const void* src, int src_dtype, int batch, int c, int hw, int src_batch_mod, void* dst,
+                               int ldc, int c0, void* stream) {
+  if (!src || !dst || batch <= 0 || c <= 0 || hw <= 0 || src_dtype < 0 || src_dtype > 2 || c0 < 0 || c0 + c > ldc)
+    return PP_ERR_BAD_ARG;
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for_host((long long)batch * hw)), dim3(256), 0, (hipStream_t)stream,
+                     src, src_dtype, batch, c, hw, src_batch_mod, (uint16_t*)dst, ldc, c0);
+  PP_CHECK_LAUNCH("nchw_to_nhwc_kernel");
+  return PP_OK;
+}
+
+extern "C" int pp_nhwc_to_nchw(const void* src, int batch, int c, int hw, void* dst, int dst_dtype, void* stream) {
+  if (!src || !dst || batch <= 0 || c <= 0 || hw <= 0 || (dst_dtype != 0 && dst_dtype != 1)) return PP_ERR_BAD_ARG;
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_for_host((long long)batch * c * hw)), dim3(256), 0,
+                     (hipStream_t)stream, (const uint16_t*)src, batch, c, hw, dst, dst_dtype);
+  PP_CHECK_LAUNCH("nhwc_to_nchw_kernel");
+  return PP_OK;
+}
+
+extern "C" int pp_add_bf16(const void* a, const void* b, void* out, long long n, void* stream) {
+  if (!a || !b || !out || n <= 0 || n % 8) return PP_ERR_BAD_ARG;
+  hipLaunchKernelGGL(add_bf16_kernel, dim3(grid_for_host(n / 8)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)a,
+                     (const uint16_t*)b, (uint16_t*)out, n / 8);
+  PP_CHECK_LAUNCH("add_bf16_kernel");
+  return PP_OK;
+}
+
+extern "C" int pp_cfg_sched_step(const float* eps2, int cfg, float guidance, float* latents, float* m_prev, int n,
+                                 int kind, const float* coef_table, const int32_t* step_dev, void* stream) {
+  if (!eps2 || !latents || !coef_table || !step_dev || n <= 0 || (kind != 0 && kind != 1)) return PP_ERR_BAD_ARG;
+  if (kind == 1 && !m_prev) return PP_ERR_BAD_ARG;
+  hipLaunchKernelGGL(cfg_sched_step_kernel, dim3(grid_for_host(n)), dim3(256), 0, (hipStream_t)stream, eps2, cfg,
+                     guidance, latents, m_prev, n, kind, coef_table, step_dev);
+  PP_CHECK_LAUNCH("cfg_sched_step_kernel");
+  return PP_OK;
+}
+
+extern "C" int pp_step_select_t(const float* timesteps, const int32_t* step_dev, float* t_out, void* stream) {
+  if (!timesteps || !step_dev || !t_out) return PP_ERR_BAD_ARG;
+  hipLaunchKernelGGL(step_select_t_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, timesteps, step_dev, t_out);
+  PP_CHECK_LAUNCH("step_select_t_kernel");
+  return PP_OK;
+}
+
+extern "C" int pp_step_advance(int32_t* step_dev, void* stream) {
+  if (!step_dev) return PP_ERR_BAD_ARG;
+  hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, step_dev);
+  PP_CHECK_LAUNCH("step_advance_kernel");
+  return PP_OK;
+}
+
+extern "C" int pp_mask_prep(int mode, const float* a, const float* b, float* out, int batch, int c, int h, int w,
+                            int ho, int wo, void* stream) {
+  if (!a || !out || mode < 0 || mode > 3 || batch <= 0 || c <= 0 || h <= 0 || w <= 0) return PP_ERR_BAD_ARG;
+  if (mode == 1 && !b) return PP_ERR_BAD_ARG;
+  if (mode == 2 && (ho <= 0 || wo <= 0)) return PP_ERR_BAD_ARG;
+  long long total = mode == 2 ? (long long)batch * ho * wo : mode == 3 ? (long long)batch * h * w : (long long)batch * c * h * w;
+  hipLaunchKernelGGL(mask_prep_kernel, dim3(grid_for_host(total)), dim3(256), 0, (hipStream_t)stream, mode, a, b, out,
+                     batch, c, h, w, ho, wo);
+  PP_CHECK_LAUNCH("mask_prep_kernel");
+  return PP_OK;
+}

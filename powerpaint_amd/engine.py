@@ -1,0 +1,719 @@
+"""Host-side execution engine for the MI355X denoising hot path.
+
+Design (MI355X-first):
+  * parameters live in ONE contiguous device buffer per network (`ParamPack`) in kernel-ready layouts
+    ([Cout][ky][kx][Cin] bf16 conv weights, fused QKV / KV matrices, GEGLU-interleaved FF weights, fp32 biases and
+    norm affine) -> a single RCCL broadcast moves a whole network over xGMI;
+  * activations are NHWC bf16 inside one static `Arena` (stack-scoped bump allocator: temporaries of a resnet /
+    transformer block are released at block exit so consecutive blocks reuse the same, Infinity-Cache-hot addresses);
+  * a forward pass is compiled ONCE per (shape, wiring) into a `Plan` -- a flat list of C-ABI launches with baked
+    pointers -- which is replayed eagerly (ctypes, ~2 us / launch) or captured into a hipGraph;
+  * everything that varies per denoising step is read from device memory by the kernels (timestep, scheduler
+    coefficients, step counter), so a captured step replays with zero host->device traffic.
+"""
+import ctypes as C
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib as L
+
+ALIGN = 256
+
+
+def _align(x: int, a: int = ALIGN) -> int:
+    return (x + a - 1) // a * a
+
+
+# ------------------------------------------------------------------------------------------------------------------
+class Arena:
+    """Stack-scoped bump allocator over one device buffer (or a dry counting arena when device is None)."""
+
+    def __init__(self, nbytes: int = 0, device=None):
+        self.dry = device is None
+        self.size = nbytes
+        if not self.dry:
+            self.buf = torch.zeros(max(nbytes, ALIGN) + ALIGN, dtype=torch.uint8, device=device)
+            skew = (-self.buf.data_ptr()) % ALIGN
+            self.buf = self.buf[skew:skew + max(nbytes, ALIGN)]
+            self.base = self.buf.data_ptr()
+        else:
+            self.buf = None
+            self.base = 1 << 20  # fake non-null base for dry runs
+        self.off = 0
+        self.peak = 0
+
+    def alloc(self, nbytes: int) -> int:
+        off = _align(self.off)
+        self.off = off + nbytes
+        self.peak = max(self.peak, self.off)
+        if not self.dry and self.off > self.size:
+            raise L.PPError(f"arena overflow: need {self.off} > {self.size}")
+        return self.base + off
+
+    def mark(self) -> int:
+        return self.off
+
+    def release(self, m: int):
+        self.off = m
+
+    def view(self, ptr: int, shape: Sequence[int], dtype: torch.dtype, strides: Optional[Sequence[int]] = None):
+        """torch view of arena memory (element strides)."""
+        esize = torch.empty((), dtype=dtype).element_size()
+        off = ptr - self.base
+        assert off % esize == 0
+        typed = self.buf.view(dtype)
+        if strides is None:
+            n = 1
+            for s in shape:
+                n *= s
+            return typed[off // esize: off // esize + n].view(*shape)
+        return torch.as_strided(typed, tuple(shape), tuple(strides), off // esize)
+
+
+class ParamPack:
+    """All parameters of one network in one contiguous device buffer (single-collective broadcast unit)."""
+
+    def __init__(self):
+        self.items: List[Tuple[str, torch.Tensor]] = []
+        self.offsets: Dict[str, int] = {}
+        self.shapes: Dict[str, Tuple[torch.Size, torch.dtype]] = {}
+        self.total = 0
+        self.buf = None
+        self.ptr: Dict[str, int] = {}
+
+    def add(self, name: str, t: torch.Tensor, dtype: torch.dtype):
+        assert name not in self.offsets, name
+        t = t.detach().to(dtype).contiguous()
+        off = _align(self.total)
+        self.offsets[name] = off
+        self.shapes[name] = (t.shape, dtype)
+        self.total = off + t.numel() * t.element_size()
+        self.items.append((name, t))
+
+    def to_device(self, device, materialize: bool = True):
+        self.buf = torch.zeros(_align(self.total) + ALIGN, dtype=torch.uint8, device=device)
+        skew = (-self.buf.data_ptr()) % ALIGN
+        self.buf = self.buf[skew:skew + _align(self.total)]
+        base = self.buf.data_ptr()
+        for name, t in self.items:
+            off = self.offsets[name]
+            if materialize and t.device.type != "meta":
+                nb = t.numel() * t.element_size()
+                self.buf[off:off + nb].copy_(t.view(-1).view(torch.uint8))
+            self.ptr[name] = base + off
+        self.items = []  # drop host copies
+        return self
+
+    def tensor(self, name: str) -> torch.Tensor:
+        shape, dtype = self.shapes[name]
+        off = self.offsets[name]
+        n = 1
+        for s in shape:
+            n *= s
+        es = torch.empty((), dtype=dtype).element_size()
+        return self.buf[off:off + n * es].view(dtype).view(shape)
+
+
+@dataclass
+class Act:
+    """NHWC bf16 activation [B][H][W][C] living in an arena."""
+    ptr: int
+    B: int
+    H: int
+    W: int
+    C: int
+
+    @property
+    def rows(self) -> int:
+        return self.B * self.H * self.W
+
+    @property
+    def nbytes(self) -> int:
+        return self.rows * self.C * 2
+
+
+class Plan:
+    """Flat list of C-ABI launches with baked arguments."""
+
+    def __init__(self):
+        self.calls: List[Tuple] = []     # (fn, args_tuple, name)
+        self.keep: List = []             # keep ctypes structs alive
+        self.flops = 0.0                 # algorithmic FLOPs (2*MAC of conv/linear/attention matmuls)
+        self.flops_by_kind: Dict[str, float] = {}
+
+    def add(self, name: str, fn, *args):
+        self.calls.append((fn, args, name))
+
+    def count(self, kind: str, flops: float):
+        self.flops += flops
+        self.flops_by_kind[kind] = self.flops_by_kind.get(kind, 0.0) + flops
+
+    def run(self, stream: int):
+        for fn, args, name in self.calls:
+            rc = fn(*args, stream)
+            if rc != 0:
+                L.check(rc, name)
+
+    def run_timed(self, stream_obj) -> Dict[str, float]:
+        """Eager replay with a HIP event pair around every launch (on the launch stream); ms per kernel name."""
+        evs = []
+        s = stream_obj.cuda_stream
+        for fn, args, name in self.calls:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record(stream_obj)
+            rc = fn(*args, s)
+            e1.record(stream_obj)
+            if rc != 0:
+                L.check(rc, name)
+            evs.append((name, e0, e1))
+        stream_obj.synchronize()
+        out: Dict[str, float] = {}
+        for name, e0, e1 in evs:
+            out[name] = out.get(name, 0.0) + e0.elapsed_time(e1)
+        return out
+
+
+class Builder:
+    """Appends launches to a Plan, allocating outputs / workspaces from an Arena."""
+
+    def __init__(self, arena: Arena, plan: Optional[Plan] = None):
+        self.arena = arena
+        self.plan = plan or Plan()
+        self.lib = L.lib()
+        self.gemm_tile = 0       # tuning overrides (0 = auto)
+        self.gemm_splitk = 0
+
+    # -- memory
+    def alloc(self, nbytes: int) -> int:
+        return self.arena.alloc(nbytes)
+
+    def new_act(self, B, H, W, Cc) -> Act:
+        return Act(self.alloc(B * H * W * Cc * 2), B, H, W, Cc)
+
+    def mark(self):
+        return self.arena.mark()
+
+    def release(self, m):
+        self.arena.release(m)
+
+    # -- ops
+    def _gemm(self, a: L.PPGemmArgs, name: str):
+        if a.tile == 0:
+            a.tile = self.gemm_tile
+        if a.splitk == 0:
+            a.splitk = self.gemm_splitk
+        ws = self.lib.pp_gemm_workspace_bytes(C.byref(a))
+        if ws:
+            a.workspace = self.alloc(ws)
+        self.plan.keep.append(a)
+        self.plan.add(name, self.lib.pp_gemm_bf16, C.byref(a))
+        self.plan.count(name, 2.0 * a.M * a.N * a.K)
+
+    def linear(self, x: int, rows: int, K: int, w: int, N: int, bias: int = 0, ldx: Optional[int] = None,
+               x2: int = 0, K2: int = 0, ldx2: int = 0, res1: int = 0, ldres1: int = 0, res2: int = 0,
+               ldres2: int = 0, scale: float = 1.0, act: int = 0, out: int = 0, ldo: Optional[int] = None,
+               rowvec: int = 0, ld_rowvec: int = 0, rows_per_batch: int = 0, out_vt: int = 0, vt_col0: int = 0,
+               vt_ld: int = 0, out_f32: bool = False, name: str = "gemm") -> int:
+        """out[rows][N] = epilogue(X[rows][K(+K2)] @ W[N][K+K2]^T).  Returns the output pointer."""
+        n_out = N // 2 if act == L.PP_ACT_GEGLU else (vt_col0 if out_vt else N)
+        if ldo is None:
+            ldo = n_out
+        if not out:
+            out = self.alloc(rows * ldo * (4 if out_f32 else 2))
+        m = self.mark()
+        a = L.PPGemmArgs()
+        a.M, a.N, a.K, a.x_mode = rows, N, K + K2, L.PP_X_PLAIN
+        a.x1, a.x2, a.c1, a.c2 = x, x2 or None, K, K2
+        a.ldx1, a.ldx2 = (ldx if ldx is not None else K), (ldx2 or K2)
+        a.w, a.bias = w, bias or None
+        a.rowvec, a.ld_rowvec, a.rows_per_batch = rowvec or None, ld_rowvec, rows_per_batch
+        a.res1, a.ldres1 = res1 or None, ldres1 or N
+        a.res2, a.ldres2 = res2 or None, ldres2 or N
+        a.scale, a.act = scale, act
+        a.out, a.ldo, a.out_f32 = out, ldo, int(out_f32)
+        a.out_vt, a.vt_col0, a.vt_ld = out_vt or None, vt_col0, vt_ld
+        self._gemm(a, name)
+        self.release(m)
+        return out
+
+    def conv3x3(self, x: Act, w: int, cout: int, bias: int = 0, stride: int = 1, up: bool = False,
+                x2: Optional[Act] = None, rowvec: int = 0, res1: int = 0, res2: int = 0, scale: float = 1.0,
+                out: Optional[Act] = None, name: str = "conv3x3") -> Act:
+        hv, wv = (x.H * 2, x.W * 2) if up else (x.H, x.W)
+        ho, wo = (hv + 2 - 3) // stride + 1, (wv + 2 - 3) // stride + 1
+        if out is None:
+            out = self.new_act(x.B, ho, wo, cout)
+        m = self.mark()
+        a = L.PPGemmArgs()
+        c2 = x2.C if x2 is not None else 0
+        a.M, a.N, a.K, a.x_mode = x.B * ho * wo, cout, 9 * (x.C + c2), L.PP_X_CONV3X3
+        a.x1, a.x2, a.c1, a.c2 = x.ptr, (x2.ptr if x2 is not None else None), x.C, c2
+        a.batch, a.hin, a.win, a.hout, a.wout, a.stride, a.up = x.B, x.H, x.W, ho, wo, stride, int(up)
+        a.w, a.bias = w, bias or None
+        a.rowvec, a.ld_rowvec, a.rows_per_batch = rowvec or None, 0, ho * wo
+        a.res1, a.ldres1, a.res2, a.ldres2 = res1 or None, cout, res2 or None, cout
+        a.scale, a.act = scale, 0
+        a.out, a.ldo, a.out_f32 = out.ptr, cout, 0
+        self._gemm(a, name)
+        self.release(m)
+        return out
+
+    def groupnorm(self, x: Act, gamma: int, beta: int, eps: float, silu: bool, x2: Optional[Act] = None,
+                  groups: int = 32, out: Optional[Act] = None) -> Act:
+        c2 = x2.C if x2 is not None else 0
+        Ct = x.C + c2
+        hw = x.H * x.W
+        if out is None:
+            out = self.new_act(x.B, x.H, x.W, Ct)
+        m = self.mark()
+        ss = self.alloc(x.B * 2 * Ct * 4)
+        ws = self.alloc(self.lib.pp_groupnorm_workspace_bytes(x.B, hw, Ct))
+        x2p = x2.ptr if x2 is not None else None
+        self.plan.add("groupnorm_stats", self.lib.pp_groupnorm_stats, x.ptr, x.C, x2p, c2, x.B, hw, groups, eps,
+                      gamma, beta, ss, ws)
+        self.plan.add("groupnorm_apply", self.lib.pp_groupnorm_apply, x.ptr, x.C, x2p, c2, x.B, hw, ss, int(silu),
+                      out.ptr)
+        self.release(m)
+        return out
+
+    def layernorm(self, x: int, rows: int, Cc: int, gamma: int, beta: int, eps: float = 1e-5) -> int:
+        out = self.alloc(rows * Cc * 2)
+        self.plan.add("layernorm", self.lib.pp_layernorm, x, rows, Cc, gamma, beta, eps, out)
+        return out
+
+    def attention(self, q: int, ldq: int, k: int, ldk: int, vt: int, ldvt: int, B: int, heads: int, nq: int,
+                  nk: int, d: int, out: int = 0, ldo: int = 0) -> int:
+        Cc = heads * d
+        if not out:
+            out, ldo = self.alloc(B * nq * Cc * 2), Cc
+        self.plan.add("attention", self.lib.pp_attention_fwd, q, ldq, k, ldk, vt, ldvt, out, ldo, B, heads, nq, nk,
+                      d, float(d) ** -0.5)
+        self.plan.count("attention", 4.0 * B * heads * nq * nk * d)
+        return out
+
+    def add(self, a: int, b: int, out: int, n: int):
+        self.plan.add("add", self.lib.pp_add_bf16, a, b, out, n)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# parameter preparation (diffusers state-dict keys -> kernel layouts)
+# ------------------------------------------------------------------------------------------------------------------
+def _conv_igemm(w: torch.Tensor) -> torch.Tensor:
+    """[Cout,Cin,3,3] -> [Cout, 9*Cin] with k = (ky*3+kx)*Cin + ci."""
+    return w.permute(0, 2, 3, 1).reshape(w.shape[0], -1)
+
+
+def _conv_direct(w: torch.Tensor) -> torch.Tensor:
+    """[Cout,Cin,3,3] -> [3,3,Cin,Cout]."""
+    return w.permute(2, 3, 1, 0)
+
+
+def _geglu_interleave(w: torch.Tensor) -> torch.Tensor:
+    """GEGLU proj rows [h(0..F) ; g(0..F)] -> groups of four rows (h_{2q}, h_{2q+1}, g_{2q}, g_{2q+1})."""
+    F2 = w.shape[0]
+    F = F2 // 2
+    h, g = w[:F], w[F:]
+    rest = w.shape[1:]
+    h = h.reshape(F // 2, 2, *rest)
+    g = g.reshape(F // 2, 2, *rest)
+    return torch.cat([h, g], dim=1).reshape(F2, *rest)
+
+
+class SDNet:
+    """One network of the SD-1.5 family ("unet" | "brushnet" | "controlnet") compiled to HIP launch plans.
+
+    Mirrors the wiring of /root/reference/powerpaint/models/unet_2d_condition.py:1040-1363 (UNet incl. the fork's
+    *_add_samples), /root/reference/powerpaint/models/BrushNet_CA.py:690-952 (BrushNet) and the diffusers-0.27.0
+    ControlNetModel used at /root/reference/powerpaint/pipelines/pipeline_PowerPaint_ControlNet.py:1686-1694.
+    """
+
+    def __init__(self, kind: str, in_channels: int, block_out_channels=(320, 640, 1280, 1280), layers_per_block=2,
+                 heads=8, cross_attention_dim=768, groups=32, eps=1e-5,
+                 down_block_types=("CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "DownBlock2D"),
+                 up_block_types=("UpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D"),
+                 conditioning_channels: int = 0, cond_embed_channels=(16, 32, 96, 256), out_channels: int = 4):
+        assert kind in ("unet", "brushnet", "controlnet")
+        self.kind = kind
+        self.in_channels = in_channels
+        self.conditioning_channels = conditioning_channels
+        self.boc = tuple(block_out_channels)
+        self.L = layers_per_block
+        self.heads = heads
+        self.ctx_dim = cross_attention_dim
+        self.groups, self.eps = groups, eps
+        self.down_types, self.up_types = tuple(down_block_types), tuple(up_block_types)
+        self.cond_embed_channels = tuple(cond_embed_channels)
+        self.out_channels = out_channels
+        self.params: Optional[ParamPack] = None
+        self.P: Dict[str, int] = {}
+        self.temb_off: Dict[str, int] = {}
+        self.temb_total = 0
+        for c in self.boc:
+            if c % 64 or (c // heads) not in (40, 80, 160):
+                raise L.PPError(f"unsupported channel width {c} (need multiple of 64 and head_dim in 40/80/160)")
+
+    # ---------------------------------------------------------------- structure walk (shared by params and plans)
+    def _resnet_specs(self) -> List[Tuple[str, int, int]]:
+        """(prefix, cin, cout) of every ResnetBlock2D in execution order."""
+        out = []
+        boc, Lp = self.boc, self.L
+        oc = boc[0]
+        for i in range(len(boc)):
+            ic, oc = oc, boc[i]
+            for j in range(Lp):
+                out.append((f"down_blocks.{i}.resnets.{j}", ic if j == 0 else oc, oc))
+        out.append(("mid_block.resnets.0", boc[-1], boc[-1]))
+        out.append(("mid_block.resnets.1", boc[-1], boc[-1]))
+        if self.kind != "controlnet":
+            rev = list(reversed(boc))
+            oc = rev[0]
+            for i in range(len(boc)):
+                prev, oc = oc, rev[i]
+                ic = rev[min(i + 1, len(boc) - 1)]
+                for j in range(Lp + 1):
+                    skip = ic if j == Lp else oc
+                    rin = prev if j == 0 else oc
+                    out.append((f"up_blocks.{i}.resnets.{j}", rin + skip, oc))
+        return out
+
+    def _attn_specs(self) -> List[Tuple[str, int]]:
+        out = []
+        for i, t in enumerate(self.down_types):
+            if t == "CrossAttnDownBlock2D":
+                out += [(f"down_blocks.{i}.attentions.{j}", self.boc[i]) for j in range(self.L)]
+        out.append(("mid_block.attentions.0", self.boc[-1]))
+        if self.kind != "controlnet":
+            rev = list(reversed(self.boc))
+            for i, t in enumerate(self.up_types):
+                if t == "CrossAttnUpBlock2D":
+                    out += [(f"up_blocks.{i}.attentions.{j}", rev[i]) for j in range(self.L + 1)]
+        return out
+
+    def _zero_conv_specs(self) -> List[Tuple[str, int]]:
+        """(state-dict prefix, channels) of the 1x1 output convs (BrushNet 12+1+15, ControlNet 12+1)."""
+        if self.kind == "unet":
+            return []
+        nm = "brushnet" if self.kind == "brushnet" else "controlnet"
+        out = [(f"{nm}_down_blocks.0", self.boc[0])]
+        k = 1
+        for i, c in enumerate(self.boc):
+            for _ in range(self.L):
+                out.append((f"{nm}_down_blocks.{k}", c)); k += 1
+            if i != len(self.boc) - 1:
+                out.append((f"{nm}_down_blocks.{k}", c)); k += 1
+        out.append((f"{nm}_mid_block", self.boc[-1]))
+        if self.kind == "brushnet":
+            k = 0
+            for i, c in enumerate(reversed(self.boc)):
+                for _ in range(self.L + 1):
+                    out.append((f"brushnet_up_blocks.{k}", c)); k += 1
+                if i != len(self.boc) - 1:
+                    out.append((f"brushnet_up_blocks.{k}", c)); k += 1
+        return out
+
+    # ---------------------------------------------------------------- parameters
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], device, materialize: bool = True):
+        """sd: diffusers-format state dict (fp32/any float, CPU or meta).  Packs into kernel layouts on `device`."""
+        pk = ParamPack()
+        bf, f32 = torch.bfloat16, torch.float32
+
+        def W(k):
+            return sd[k].float() if sd[k].device.type != "meta" else sd[k]
+
+        conv_in = "conv_in_condition" if self.kind == "brushnet" else "conv_in"
+        pk.add("conv_in.weight", _conv_direct(W(conv_in + ".weight")), bf)
+        pk.add("conv_in.bias", W(conv_in + ".bias"), f32)
+        for n in ("linear_1", "linear_2"):
+            pk.add(f"time_embedding.{n}.weight", W(f"time_embedding.{n}.weight"), bf)
+            pk.add(f"time_embedding.{n}.bias", W(f"time_embedding.{n}.bias"), f32)
+        # resnets
+        tw, tb, off = [], [], 0
+        for pre, cin, cout in self._resnet_specs():
+            for nrm in ("norm1", "norm2"):
+                pk.add(f"{pre}.{nrm}.weight", W(f"{pre}.{nrm}.weight"), f32)
+                pk.add(f"{pre}.{nrm}.bias", W(f"{pre}.{nrm}.bias"), f32)
+            for cv in ("conv1", "conv2"):
+                pk.add(f"{pre}.{cv}.weight", _conv_igemm(W(f"{pre}.{cv}.weight")), bf)
+                pk.add(f"{pre}.{cv}.bias", W(f"{pre}.{cv}.bias"), f32)
+            if cin != cout:
+                pk.add(f"{pre}.conv_shortcut.weight", W(f"{pre}.conv_shortcut.weight").reshape(cout, cin), bf)
+                pk.add(f"{pre}.conv_shortcut.bias", W(f"{pre}.conv_shortcut.bias"), f32)
+            tw.append(W(f"{pre}.time_emb_proj.weight"))
+            tb.append(W(f"{pre}.time_emb_proj.bias"))
+            self.temb_off[pre] = off
+            off += cout
+        self.temb_total = off
+        pk.add("temb_all.weight", torch.cat(tw, 0), bf)
+        pk.add("temb_all.bias", torch.cat(tb, 0), f32)
+        # samplers
+        for i in range(len(self.boc) - 1):
+            pre = f"down_blocks.{i}.downsamplers.0.conv"
+            pk.add(pre + ".weight", _conv_igemm(W(pre + ".weight")), bf)
+            pk.add(pre + ".bias", W(pre + ".bias"), f32)
+            if self.kind != "controlnet":
+                pre = f"up_blocks.{i}.upsamplers.0.conv"
+                pk.add(pre + ".weight", _conv_igemm(W(pre + ".weight")), bf)
+                pk.add(pre + ".bias", W(pre + ".bias"), f32)
+        # transformers
+        for pre, c in self._attn_specs():
+            pk.add(f"{pre}.norm.weight", W(f"{pre}.norm.weight"), f32)
+            pk.add(f"{pre}.norm.bias", W(f"{pre}.norm.bias"), f32)
+            for pj in ("proj_in", "proj_out"):
+                pk.add(f"{pre}.{pj}.weight", W(f"{pre}.{pj}.weight").reshape(c, c), bf)
+                pk.add(f"{pre}.{pj}.bias", W(f"{pre}.{pj}.bias"), f32)
+            tb_ = f"{pre}.transformer_blocks.0"
+            for nrm in ("norm1", "norm2", "norm3"):
+                pk.add(f"{tb_}.{nrm}.weight", W(f"{tb_}.{nrm}.weight"), f32)
+                pk.add(f"{tb_}.{nrm}.bias", W(f"{tb_}.{nrm}.bias"), f32)
+            pk.add(f"{tb_}.attn1.qkv.weight", torch.cat([W(f"{tb_}.attn1.to_q.weight"), W(f"{tb_}.attn1.to_k.weight"),
+                                                         W(f"{tb_}.attn1.to_v.weight")], 0), bf)
+            pk.add(f"{tb_}.attn1.to_out.weight", W(f"{tb_}.attn1.to_out.0.weight"), bf)
+            pk.add(f"{tb_}.attn1.to_out.bias", W(f"{tb_}.attn1.to_out.0.bias"), f32)
+            pk.add(f"{tb_}.attn2.to_q.weight", W(f"{tb_}.attn2.to_q.weight"), bf)
+            pk.add(f"{tb_}.attn2.kv.weight", torch.cat([W(f"{tb_}.attn2.to_k.weight"), W(f"{tb_}.attn2.to_v.weight")], 0), bf)
+            pk.add(f"{tb_}.attn2.to_out.weight", W(f"{tb_}.attn2.to_out.0.weight"), bf)
+            pk.add(f"{tb_}.attn2.to_out.bias", W(f"{tb_}.attn2.to_out.0.bias"), f32)
+            pk.add(f"{tb_}.ff1.weight", _geglu_interleave(W(f"{tb_}.ff.net.0.proj.weight")), bf)
+            pk.add(f"{tb_}.ff1.bias", _geglu_interleave(W(f"{tb_}.ff.net.0.proj.bias")), f32)
+            pk.add(f"{tb_}.ff2.weight", W(f"{tb_}.ff.net.2.weight"), bf)
+            pk.add(f"{tb_}.ff2.bias", W(f"{tb_}.ff.net.2.bias"), f32)
+        if self.kind == "unet":
+            pk.add("conv_norm_out.weight", W("conv_norm_out.weight"), f32)
+            pk.add("conv_norm_out.bias", W("conv_norm_out.bias"), f32)
+            pk.add("conv_out.weight", _conv_igemm(W("conv_out.weight")), bf)
+            pk.add("conv_out.bias", W("conv_out.bias"), f32)
+        for pre, c in self._zero_conv_specs():
+            pk.add(pre + ".weight", W(pre + ".weight").reshape(c, c), bf)
+            pk.add(pre + ".bias", W(pre + ".bias"), f32)
+        if self.kind == "controlnet":
+            ce = "controlnet_cond_embedding"
+            names = ["conv_in"] + [f"blocks.{i}" for i in range(2 * (len(self.cond_embed_channels) - 1))] + ["conv_out"]
+            for n in names:
+                pk.add(f"{ce}.{n}.weight", _conv_direct(W(f"{ce}.{n}.weight")), bf)
+                pk.add(f"{ce}.{n}.bias", W(f"{ce}.{n}.bias"), f32)
+        pk.to_device(device, materialize)
+        self.params, self.P = pk, pk.ptr
+        return self
+
+    # ---------------------------------------------------------------- plan pieces
+    def _resnet(self, pb: Builder, pre: str, x: Act, cout: int, temb_all: int, x2: Optional[Act] = None,
+                res2: int = 0) -> Act:
+        P = self.P
+        cin = x.C + (x2.C if x2 is not None else 0)
+        out = pb.new_act(x.B, x.H, x.W, cout)
+        m = pb.mark()
+        h = pb.groupnorm(x, P[f"{pre}.norm1.weight"], P[f"{pre}.norm1.bias"], self.eps, True, x2=x2, groups=self.groups)
+        h = pb.conv3x3(h, P[f"{pre}.conv1.weight"], cout, P[f"{pre}.conv1.bias"],
+                       rowvec=temb_all + 4 * self.temb_off[pre], name="conv3x3")
+        h = pb.groupnorm(h, P[f"{pre}.norm2.weight"], P[f"{pre}.norm2.bias"], self.eps, True, groups=self.groups)
+        if cin != cout:
+            sc = pb.linear(x.ptr, x.rows, x.C, P[f"{pre}.conv_shortcut.weight"], cout, P[f"{pre}.conv_shortcut.bias"],
+                           x2=(x2.ptr if x2 is not None else 0), K2=(x2.C if x2 is not None else 0), name="conv1x1")
+        else:
+            assert x2 is None
+            sc = x.ptr
+        pb.conv3x3(h, P[f"{pre}.conv2.weight"], cout, P[f"{pre}.conv2.bias"], res1=sc, res2=res2, out=out,
+                   name="conv3x3")
+        pb.release(m)
+        return out
+
+    def _transformer(self, pb: Builder, pre: str, x: Act, kv: Tuple[int, int, int, int], res2: int = 0) -> Act:
+        """kv = (k_ptr, ldk, vt_ptr, ldvt) of the hoisted cross-attention K / V^T; nk = ctx tokens in self._nctx."""
+        P = self.P
+        Cc, rows, hw = x.C, x.rows, x.H * x.W
+        d = Cc // self.heads
+        tb = f"{pre}.transformer_blocks.0"
+        out = pb.new_act(x.B, x.H, x.W, Cc)
+        m = pb.mark()
+        n = pb.groupnorm(x, P[f"{pre}.norm.weight"], P[f"{pre}.norm.bias"], 1e-6, False, groups=self.groups)
+        hs = pb.linear(n.ptr, rows, Cc, P[f"{pre}.proj_in.weight"], Cc, P[f"{pre}.proj_in.bias"], name="conv1x1")
+        # self-attention: fused QKV GEMM, V written transposed by the epilogue
+        ln = pb.layernorm(hs, rows, Cc, P[f"{tb}.norm1.weight"], P[f"{tb}.norm1.bias"])
+        vt = pb.alloc(x.B * Cc * hw * 2)
+        qk = pb.linear(ln, rows, Cc, P[f"{tb}.attn1.qkv.weight"], 3 * Cc, out_vt=vt, vt_col0=2 * Cc, vt_ld=hw,
+                       rows_per_batch=hw, name="linear")
+        a = pb.attention(qk, 2 * Cc, qk + 2 * Cc, 2 * Cc, vt, hw, x.B, self.heads, hw, hw, d)
+        hs = pb.linear(a, rows, Cc, P[f"{tb}.attn1.to_out.weight"], Cc, P[f"{tb}.attn1.to_out.bias"], res1=hs,
+                       name="linear")
+        # cross-attention (K / V^T hoisted out of the step: encoder_hidden_states are step-invariant)
+        ln = pb.layernorm(hs, rows, Cc, P[f"{tb}.norm2.weight"], P[f"{tb}.norm2.bias"])
+        q = pb.linear(ln, rows, Cc, P[f"{tb}.attn2.to_q.weight"], Cc, name="linear")
+        a = pb.attention(q, Cc, kv[0], kv[1], kv[2], kv[3], x.B, self.heads, hw, self._nctx, d)
+        hs = pb.linear(a, rows, Cc, P[f"{tb}.attn2.to_out.weight"], Cc, P[f"{tb}.attn2.to_out.bias"], res1=hs,
+                       name="linear")
+        # feed-forward: GEGLU fused into the first GEMM's epilogue
+        ln = pb.layernorm(hs, rows, Cc, P[f"{tb}.norm3.weight"], P[f"{tb}.norm3.bias"])
+        g = pb.linear(ln, rows, Cc, P[f"{tb}.ff1.weight"], 8 * Cc, P[f"{tb}.ff1.bias"], act=L.PP_ACT_GEGLU,
+                      name="linear_geglu")
+        hs = pb.linear(g, rows, 4 * Cc, P[f"{tb}.ff2.weight"], Cc, P[f"{tb}.ff2.bias"], res1=hs, name="linear")
+        pb.linear(hs, rows, Cc, P[f"{pre}.proj_out.weight"], Cc, P[f"{pre}.proj_out.bias"], res1=x.ptr, res2=res2,
+                  out=out.ptr, name="conv1x1")
+        pb.release(m)
+        return out
+
+    # ---------------------------------------------------------------- setup plan: step-invariant work
+    def build_setup(self, pb: Builder, B: int, nctx: int, ehs: int, cond: Optional[Act] = None):
+        """Cross-attention K and V^T for every transformer from encoder_hidden_states (bf16 [B*nctx][ctx_dim] at
+        `ehs`); for ControlNet also the conditioning embedding of `cond` (NHWC bf16 image)."""
+        self._nctx = nctx
+        ldvt = _align(nctx, 8)
+        self.kv: Dict[str, Tuple[int, int, int, int]] = {}
+        for pre, c in self._attn_specs():
+            tb = f"{pre}.transformer_blocks.0"
+            vt = pb.alloc(B * c * ldvt * 2)
+            k = pb.linear(ehs, B * nctx, self.ctx_dim, self.P[f"{tb}.attn2.kv.weight"], 2 * c, out_vt=vt,
+                          vt_col0=c, vt_ld=ldvt, rows_per_batch=nctx, name="linear")
+            self.kv[pre] = (k, c, vt, ldvt)
+        self.cond_emb = None
+        if self.kind == "controlnet":
+            assert cond is not None
+            ce = "controlnet_cond_embedding"
+            chans = self.cond_embed_channels
+            lib = pb.lib
+
+            def dconv(x: Act, name: str, cout: int, stride: int, silu: int) -> Act:
+                ho, wo = (x.H - 1) // stride + 1, (x.W - 1) // stride + 1
+                o = pb.new_act(x.B, ho, wo, cout)
+                pb.plan.add("conv3x3_direct", lib.pp_conv3x3_direct, x.ptr, x.B, x.H, x.W, x.C,
+                            self.P[f"{ce}.{name}.weight"], self.P[f"{ce}.{name}.bias"], cout, stride, silu, None, o.ptr)
+                return o
+
+            e = dconv(cond, "conv_in", chans[0], 1, 1)
+            for i in range(len(chans) - 1):
+                e = dconv(e, f"blocks.{2 * i}", chans[i], 1, 1)
+                e = dconv(e, f"blocks.{2 * i + 1}", chans[i + 1], 2, 1)
+            self.cond_emb = dconv(e, "conv_out", self.boc[0], 1, 0)
+
+    # ---------------------------------------------------------------- step plan
+    def build_step(self, pb: Builder, x_in: Act, t_dev: int, add_down: Optional[List[int]] = None,
+                   add_mid: int = 0, add_up: Optional[List[int]] = None, ctrl_down: Optional[List[int]] = None,
+                   ctrl_mid: int = 0, scale: float = 1.0) -> Dict[str, object]:
+        """Append one forward pass.  x_in: NHWC bf16 input (already channel-concatenated).  Returns outputs:
+        unet -> {"eps": ptr fp32 NCHW}; brushnet -> {"down": [Act], "mid": Act, "up": [Act]}; controlnet likewise."""
+        P, lib = self.P, pb.lib
+        B, H, W = x_in.B, x_in.H, x_in.W
+        boc = self.boc
+        brush = add_down is not None
+        add_down = list(add_down) if brush else None
+        add_up = list(add_up) if brush else None
+
+        def pop(lst):
+            return lst.pop(0) if lst is not None else 0
+
+        # 1. time embedding (identical for every batch row: timesteps.expand(B))
+        tsin = pb.alloc(boc[0] * 4)
+        t1 = pb.alloc(boc[0] * 4 * 4)
+        temb = pb.alloc(boc[0] * 4 * 4)
+        temb_all = pb.alloc(self.temb_total * 4)
+        te = boc[0] * 4
+        pb.plan.add("timestep_embedding", lib.pp_timestep_embedding, t_dev, 1, boc[0], tsin)
+        pb.plan.add("linear_skinny", lib.pp_linear_skinny, tsin, 1, boc[0], P["time_embedding.linear_1.weight"],
+                    P["time_embedding.linear_1.bias"], te, t1, te, 0, L.PP_ACT_SILU)
+        pb.plan.add("linear_skinny", lib.pp_linear_skinny, t1, 1, te, P["time_embedding.linear_2.weight"],
+                    P["time_embedding.linear_2.bias"], te, temb, te, 0, 0)
+        pb.plan.add("linear_skinny", lib.pp_linear_skinny, temb, 1, te, P["temb_all.weight"], P["temb_all.bias"],
+                    self.temb_total, temb_all, self.temb_total, L.PP_ACT_SILU, 0)
+
+        # 2. conv_in
+        def conv_in(add_ptr) -> Act:
+            o = pb.new_act(B, H, W, boc[0])
+            pb.plan.add("conv3x3_direct", lib.pp_conv3x3_direct, x_in.ptr, B, H, W, x_in.C, P["conv_in.weight"],
+                        P["conv_in.bias"], boc[0], 1, 0, add_ptr, o.ptr)
+            pb.plan.count("conv_in", 2.0 * B * H * W * boc[0] * 9 * x_in.C)
+            return o
+
+        if self.kind == "controlnet":
+            s = conv_in(self.cond_emb.ptr)
+            skips = [s]
+        else:
+            s = conv_in(None)
+            skips = [s]                       # captured BEFORE the BrushNet add (unet_2d_condition.py:1220-1223)
+            if brush:
+                s = conv_in(pop(add_down))
+
+        # 3. down
+        for i, typ in enumerate(self.down_types):
+            for j in range(self.L):
+                pre = f"down_blocks.{i}.resnets.{j}"
+                has_attn = typ == "CrossAttnDownBlock2D"
+                r2 = pop(add_down)
+                s = self._resnet(pb, pre, s, boc[i], temb_all, res2=0 if has_attn else r2)
+                if has_attn:
+                    ap = f"down_blocks.{i}.attentions.{j}"
+                    s = self._transformer(pb, ap, s, self.kv[ap], res2=r2)
+                skips.append(s)
+            if i != len(boc) - 1:
+                pre = f"down_blocks.{i}.downsamplers.0.conv"
+                s = pb.conv3x3(s, P[pre + ".weight"], boc[i], P[pre + ".bias"], stride=2, res2=pop(add_down),
+                               name="conv3x3")
+                skips.append(s)
+
+        # 4. mid
+        s = self._resnet(pb, "mid_block.resnets.0", s, boc[-1], temb_all)
+        s = self._transformer(pb, "mid_block.attentions.0", s, self.kv["mid_block.attentions.0"])
+        mid_res = add_mid if brush else (ctrl_mid if ctrl_down is not None else 0)
+        s = self._resnet(pb, "mid_block.resnets.1", s, boc[-1], temb_all, res2=mid_res)
+
+        if self.kind == "controlnet":
+            feats = skips + [s]
+            outs = []
+            for (pre, c), f in zip(self._zero_conv_specs(), feats):
+                o = pb.new_act(f.B, f.H, f.W, c)
+                pb.linear(f.ptr, f.rows, c, P[pre + ".weight"], c, P[pre + ".bias"], scale=scale, out=o.ptr,
+                          name="zero_conv")
+                outs.append(o)
+            return {"down": outs[:-1], "mid": outs[-1]}
+
+        if ctrl_down is not None:  # stock-UNet ControlNet residuals on the skip tensors (unet_2d_condition.py:1263-1272)
+            new = []
+            for sk, cp in zip(skips, ctrl_down):
+                o = pb.new_act(sk.B, sk.H, sk.W, sk.C)
+                pb.add(sk.ptr, cp, o.ptr, sk.rows * sk.C)
+                new.append(o)
+            skips = new
+
+        brush_down = list(skips)
+        brush_mid = s
+        brush_up: List[Act] = []
+
+        # 5. up
+        rev = list(reversed(boc))
+        for i, typ in enumerate(self.up_types):
+            has_attn = typ == "CrossAttnUpBlock2D"
+            for j in range(self.L + 1):
+                sk = skips.pop()
+                assert sk.H == s.H and sk.W == s.W, "skip / hidden size mismatch (odd latent size?)"
+                r2 = pop(add_up)
+                s = self._resnet(pb, f"up_blocks.{i}.resnets.{j}", s, rev[i], temb_all, x2=sk,
+                                 res2=0 if has_attn else r2)
+                if has_attn:
+                    ap = f"up_blocks.{i}.attentions.{j}"
+                    s = self._transformer(pb, ap, s, self.kv[ap], res2=r2)
+                brush_up.append(s)
+            if i != len(boc) - 1:
+                pre = f"up_blocks.{i}.upsamplers.0.conv"
+                s = pb.conv3x3(s, P[pre + ".weight"], rev[i], P[pre + ".bias"], up=True, res2=pop(add_up),
+                               name="conv3x3")
+                brush_up.append(s)
+
+        if self.kind == "brushnet":
+            feats = brush_down + [brush_mid] + brush_up
+            outs = []
+            for (pre, c), f in zip(self._zero_conv_specs(), feats):
+                o = pb.new_act(f.B, f.H, f.W, c)
+                pb.linear(f.ptr, f.rows, c, P[pre + ".weight"], c, P[pre + ".bias"], scale=scale, out=o.ptr,
+                          name="zero_conv")
+                outs.append(o)
+            nd = len(brush_down)
+            return {"down": outs[:nd], "mid": outs[nd], "up": outs[nd + 1:]}
+
+        # 6. out
+        h = pb.groupnorm(s, P["conv_norm_out.weight"], P["conv_norm_out.bias"], self.eps, True, groups=self.groups)
+        eps = pb.alloc(B * self.out_channels * H * W * 4)
+        pb.plan.add("conv_out", lib.pp_conv3x3_smallcout, h.ptr, B, H, W, boc[0], P["conv_out.weight"],
+                    P["conv_out.bias"], self.out_channels, eps)
+        pb.plan.count("conv_out", 2.0 * B * H * W * self.out_channels * 9 * boc[0])
+        return {"eps": eps}

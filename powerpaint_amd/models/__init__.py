@@ -1,0 +1,5 @@
+from .BrushNet_CA import BrushNetModel
+from .controlnet import ControlNetModel
+from .unet_2d_condition import UNet2DConditionModel
+
+__all__ = ["BrushNetModel", "UNet2DConditionModel", "ControlNetModel"]

@@ -1,0 +1,74 @@
+"""ControlNetModel (SD-1.5 canny/depth/hed/openpose) on the MI355X HIP path.
+
+The reference uses the stock diffusers-0.27.0 class (built at /root/reference/app.py:121-123, called at
+/root/reference/powerpaint/pipelines/pipeline_PowerPaint_ControlNet.py:1686-1694).  Returns `(list[12], Tensor)`.
+The conditioning embedding of `controlnet_cond` is step-invariant and is computed once per distinct tensor.
+"""
+from types import SimpleNamespace
+from typing import Union
+
+import torch
+
+from ._base import SD15_DOWN, Output, _HipModel
+
+
+class ControlNetModel(_HipModel):
+    kind = "controlnet"
+
+    def __init__(self, in_channels: int = 4, conditioning_channels: int = 3, down_block_types=SD15_DOWN,
+                 block_out_channels=(320, 640, 1280, 1280), layers_per_block: int = 2, norm_num_groups: int = 32,
+                 norm_eps: float = 1e-5, cross_attention_dim: int = 768, attention_head_dim: int = 8,
+                 conditioning_embedding_out_channels=(16, 32, 96, 256), device="cuda", dtype=torch.bfloat16, **unused):
+        super().__init__(in_channels, block_out_channels, layers_per_block, attention_head_dim, cross_attention_dim,
+                         norm_num_groups, norm_eps, down_block_types, (), device, dtype,
+                         conditioning_channels=conditioning_channels,
+                         cond_embed_channels=conditioning_embedding_out_channels)
+        self.config = SimpleNamespace(
+            in_channels=in_channels, conditioning_channels=conditioning_channels,
+            down_block_types=tuple(down_block_types), block_out_channels=tuple(block_out_channels),
+            layers_per_block=layers_per_block, norm_num_groups=norm_num_groups, norm_eps=norm_eps,
+            cross_attention_dim=cross_attention_dim, attention_head_dim=attention_head_dim,
+            conditioning_embedding_out_channels=tuple(conditioning_embedding_out_channels),
+            global_pool_conditions=False)
+
+    def prepare(self, sample_shape, encoder_hidden_states, controlnet_cond, conditioning_scale=1.0,
+                guess_mode: bool = False):
+        B, Cin, H, W = sample_shape
+        scale = conditioning_scale
+        if guess_mode and not self.config.global_pool_conditions:
+            n = len(self.net._zero_conv_specs())
+            scale = [float(s) * conditioning_scale for s in torch.logspace(-1, 0, n)]
+        self.rt.ensure(B, H, W, self._nctx(encoder_hidden_states), Cin, ("plain",),
+                       cond_hw=tuple(controlnet_cond.shape[-2:]), scale=scale)
+        self.rt.set_cond(controlnet_cond)
+        self.rt.set_context(encoder_hidden_states)
+        return self.rt
+
+    def outputs(self):
+        o = self.rt.outputs
+        v = self.rt.act_as_nchw
+        return [v(a) for a in o["down"]], v(o["mid"])
+
+    @torch.no_grad()
+    def forward(self, sample: torch.FloatTensor, timestep: Union[torch.Tensor, float, int],
+                encoder_hidden_states: torch.Tensor, controlnet_cond: torch.FloatTensor,
+                conditioning_scale: float = 1.0, class_labels=None, timestep_cond=None, attention_mask=None,
+                added_cond_kwargs=None, cross_attention_kwargs=None, guess_mode: bool = False,
+                return_dict: bool = True):
+        for name, v in (("class_labels", class_labels), ("timestep_cond", timestep_cond),
+                        ("attention_mask", attention_mask)):
+            if v is not None:
+                raise NotImplementedError(f"{name} is outside the PowerPaint hot path")
+        if isinstance(conditioning_scale, (list, tuple)):
+            conditioning_scale = conditioning_scale[0]
+        rt = self.prepare(tuple(sample.shape), encoder_hidden_states, controlnet_cond, float(conditioning_scale),
+                          guess_mode)
+        rt.load_input([(sample, 0)])
+        rt.set_timestep(timestep)
+        rt.run_step()
+        down, mid = self.outputs()
+        if not return_dict:
+            return (down, mid)
+        return Output(down_block_res_samples=down, mid_block_res_sample=mid)
+
+    __call__ = forward

@@ -1,0 +1,140 @@
+"""The fused denoising loop: one launch program per step, replayed eagerly or as a hipGraph.
+
+Per step (reference: /root/reference/powerpaint/pipelines/pipeline_PowerPaint.py:988-1041,
+pipeline_PowerPaint_Brushnet_CA.py:1384-1466, pipeline_PowerPaint_ControlNet.py:1663-1741):
+    t            <- timesteps[step]                                   (device table, pp_step_select_t)
+    x_in[:, 0:4] <- cat([latents] * 2)                                (pp_nchw_to_nhwc with batch wrap, no copy of the cat)
+    [BrushNet | ControlNet forward]                                   (own launch plan, residuals stay in HBM as NHWC)
+    eps          <- UNet(x_in, t, ctx, residuals)
+    latents      <- scheduler.step(eps_u + g (eps_c - eps_u), t, latents)   (pp_cfg_sched_step, fp32)
+    step         <- step + 1                                          (pp_step_advance)
+No host->device traffic and no host synchronisation inside the loop.
+"""
+from typing import Callable, List, Optional
+
+import torch
+
+from .. import _lib as L
+from ..engine import Plan
+from ..schedulers import _SchedulerBase
+
+
+class DenoiseLoop:
+    def __init__(self, unet, scheduler, side=None, side_kind: Optional[str] = None):
+        if not isinstance(scheduler, _SchedulerBase):
+            raise TypeError(
+                "the HIP denoising loop needs powerpaint_amd.schedulers.{DDIMScheduler,DPMSolverMultistepScheduler}; "
+                f"got {type(scheduler).__name__}")
+        self.unet, self.scheduler, self.side, self.side_kind = unet, scheduler, side, side_kind
+        self.lib = L.lib()
+        self.program: Optional[Plan] = None
+        self.graph = None
+        self._key = None
+        self.latents: Optional[torch.Tensor] = None
+
+    # ------------------------------------------------------------------
+    def bind(self, latents_shape, do_cfg: bool, guidance_scale: float, prompt_embeds, prompt_embeds_side=None,
+             static_inputs=(), side_static_inputs=(), controlnet_cond=None, side_scale: float = 1.0):
+        """Compile the per-step program.  latents_shape = (B, 4, h, w) of the *un-duplicated* latents."""
+        dev = self.unet.device
+        B, Cl, h, w = latents_shape
+        Be = 2 * B if do_cfg else B
+        sch = self.scheduler
+        if self.latents is None or tuple(self.latents.shape) != tuple(latents_shape):
+            self.latents = torch.zeros(latents_shape, dtype=torch.float32, device=dev)
+        lat = self.latents
+        prog = Plan()
+        lib = self.lib
+        cin = self.unet.config.in_channels
+        side_rt = None
+        wiring_kw = {}
+        if self.side is not None:
+            if self.side_kind == "brushnet":
+                side_rt = self.side.prepare((Be, Cl, h, w), prompt_embeds_side, side_scale, False)
+                d, m, u = self.side.outputs()
+                wiring_kw = dict(down_block_add_samples=d, mid_block_add_sample=m, up_block_add_samples=u)
+            else:
+                side_rt = self.side.prepare((Be, Cl, h, w), prompt_embeds_side, controlnet_cond, side_scale, False)
+                d, m = self.side.outputs()
+                wiring_kw = dict(down_block_additional_residuals=d, mid_block_additional_residual=m)
+        rt = self.unet.prepare((Be, cin, h, w), prompt_embeds, **wiring_kw)
+        # one-time (per call) static channels of the UNet / side inputs
+        rt.load_input(list(static_inputs))
+        if side_rt is not None and side_static_inputs:
+            side_rt.load_input(list(side_static_inputs))
+
+        ts, step = sch.timesteps_f32(), sch.step_counter()
+        mp = sch.m_prev(lat) if sch.kind == 1 else None
+        key = (tuple(latents_shape), bool(do_cfg), float(guidance_scale), id(rt.step_plan),
+               id(side_rt.step_plan) if side_rt is not None else None, sch.kind, ts.data_ptr(), step.data_ptr(),
+               sch.coef_table().data_ptr(), mp.data_ptr() if mp is not None else 0, lat.data_ptr())
+        if key == self._key and self.program is not None:
+            return self
+        self._key = key
+        hw = h * w
+        mod = B if do_cfg else 0
+        for r in ([side_rt] if side_rt is not None else []) + [rt]:
+            prog.add("step_select_t", lib.pp_step_select_t, ts.data_ptr(), step.data_ptr(), r.lay["t_dev"])
+            x = r.lay["x_in"]
+            prog.add("nchw_to_nhwc", lib.pp_nchw_to_nhwc, lat.data_ptr(), 0, Be, Cl, hw, mod, x.ptr, x.C, 0)
+        if side_rt is not None:
+            prog.calls += side_rt.step_plan.calls
+            prog.flops += side_rt.step_plan.flops
+        prog.calls += rt.step_plan.calls
+        prog.flops += rt.step_plan.flops
+        prog.add("cfg_sched_step", lib.pp_cfg_sched_step, rt.outputs["eps"], int(do_cfg), float(guidance_scale),
+                 lat.data_ptr(), mp.data_ptr() if mp is not None else None, lat.numel(), sch.kind,
+                 sch.coef_table().data_ptr(), step.data_ptr())
+        prog.add("step_advance", lib.pp_step_advance, step.data_ptr())
+        self.program = prog
+        self.rt, self.side_rt = rt, side_rt
+        self.graph = None
+        self._keep = (ts, step, mp, lat)
+        return self
+
+    def capture(self):
+        """Capture one step into a hipGraph (torch.cuda.CUDAGraph).  The captured launches read the step counter from
+        device memory, so the same graph serves every step."""
+        torch.cuda.synchronize()
+        step = self.scheduler.step_counter()
+        saved_step = step.clone()
+        saved_lat = self.latents.clone()
+        saved_m = self._keep[2].clone() if self._keep[2] is not None else None
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            self.program.run(s.cuda_stream)        # warm-up outside capture (func attributes, lazy module load)
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self.program.run(torch.cuda.current_stream().cuda_stream)
+        # undo the warm-up's side effects
+        step.copy_(saved_step)
+        self.latents.copy_(saved_lat)
+        if saved_m is not None:
+            self._keep[2].copy_(saved_m)
+        torch.cuda.synchronize()
+        self.graph = g
+
+    def run(self, latents: torch.Tensor, num_steps: int, use_graph: bool = True,
+            callback: Optional[Callable] = None, timesteps=None, scale_schedule: Optional[List[float]] = None):
+        """Runs `num_steps` steps starting from step counter 0.  Returns the fp32 latents tensor (owned by the loop)."""
+        self.scheduler.reset()
+        if self.scheduler.kind == 1:
+            self._keep[2].zero_()
+        self.latents.copy_(latents.to(self.latents.device, torch.float32))
+        varying = scale_schedule is not None and len(set(scale_schedule)) > 1
+        if use_graph and not varying and self.graph is None:
+            self.capture()
+        stream = torch.cuda.current_stream().cuda_stream
+        for i in range(num_steps):
+            if varying and self.side_rt is not None:
+                self.side_rt._patch_scale(scale_schedule[i])
+            if use_graph and not varying:
+                self.graph.replay()
+            else:
+                self.program.run(stream)
+            if callback is not None:
+                callback(i, timesteps[i] if timesteps is not None else None, self.latents)
+        return self.latents

@@ -1,0 +1,219 @@
+"""Per-network runtime: static arena, compiled launch plans, step-invariant setup, optional hipGraph replay."""
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib as L
+from .engine import Act, Arena, Builder, Plan, SDNet, _align
+
+_DT = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+class NetRuntime:
+    """Owns the device state of one SDNet for one (batch, latent size, wiring)."""
+
+    def __init__(self, net: SDNet, device):
+        self.net = net
+        self.device = torch.device(device)
+        self.key = None
+        self.arena: Optional[Arena] = None
+        self.step_plan: Optional[Plan] = None
+        self.setup_plan: Optional[Plan] = None
+        self.outputs: Dict[str, object] = {}
+        self._ctx_id = None
+        self._cond_id = None
+        self.graph = None
+        self.lib = L.lib()
+        self.gemm_tile = 0
+        self.gemm_splitk = 0
+
+    # ------------------------------------------------------------------ build
+    def _build(self, arena: Arena, B, H, W, nctx, cin_total, wiring, cond_hw, scale):
+        net = self.net
+        pb_setup = Builder(arena)
+        pb_setup.gemm_tile, pb_setup.gemm_splitk = self.gemm_tile, self.gemm_splitk
+        lay = {}
+        lay["t_dev"] = arena.alloc(256)
+        lay["x_in"] = Act(arena.alloc(B * H * W * cin_total * 2), B, H, W, cin_total)
+        lay["ehs"] = arena.alloc(B * nctx * net.ctx_dim * 2)
+        cond = None
+        if net.kind == "controlnet":
+            ch, cw = cond_hw
+            cond = Act(arena.alloc(B * ch * cw * net.conditioning_channels * 2), B, ch, cw, net.conditioning_channels)
+            lay["cond"] = cond
+        # slots for foreign residual tensors (copied in at forward time)
+        kind, n_down, n_up = wiring[0], 0, 0
+        slots: Dict[str, List[Act]] = {}
+        if kind in ("brushnet", "controlnet") and net.kind == "unet":
+            shapes = self._residual_shapes(B, H, W, with_up=(kind == "brushnet"))
+            slots = {k: [Act(arena.alloc(b * h * w * c * 2), b, h, w, c) for (b, c, h, w) in v]
+                     for k, v in shapes.items()}
+        lay["slots"] = slots
+        net.build_setup(pb_setup, B, nctx, lay["ehs"], cond)
+        pb = Builder(arena)
+        pb.gemm_tile, pb.gemm_splitk = self.gemm_tile, self.gemm_splitk
+        kw = {}
+        if net.kind == "unet" and kind == "brushnet":
+            ptrs = wiring[1]
+            dn = [p if p else s.ptr for p, s in zip(ptrs["down"], slots["down"])]
+            up = [p if p else s.ptr for p, s in zip(ptrs["up"], slots["up"])]
+            md = ptrs["mid"][0] if ptrs["mid"][0] else slots["mid"][0].ptr
+            kw = dict(add_down=dn, add_mid=md, add_up=up)
+        elif net.kind == "unet" and kind == "controlnet":
+            ptrs = wiring[1]
+            dn = [p if p else s.ptr for p, s in zip(ptrs["down"], slots["down"])]
+            md = ptrs["mid"][0] if ptrs["mid"][0] else slots["mid"][0].ptr
+            kw = dict(ctrl_down=dn, ctrl_mid=md)
+        outs = net.build_step(pb, lay["x_in"], lay["t_dev"], scale=1.0, **kw)
+        return lay, pb_setup.plan, pb.plan, outs
+
+    def _residual_shapes(self, B, H, W, with_up: bool):
+        """(batch, C, h, w) of the residual tensors the UNet accepts, in reference order."""
+        net = self.net
+        boc = net.boc
+        down = [(B, boc[0], H, W)]
+        h, w = H, W
+        for i, c in enumerate(boc):
+            for _ in range(net.L):
+                down.append((B, c, h, w))
+            if i != len(boc) - 1:
+                h, w = h // 2, w // 2
+                down.append((B, c, h, w))
+        out = {"down": down, "mid": [(B, boc[-1], h, w)]}
+        if with_up:
+            up = []
+            for i, c in enumerate(reversed(boc)):
+                for _ in range(net.L + 1):
+                    up.append((B, c, h, w))
+                if i != len(boc) - 1:
+                    h, w = h * 2, w * 2
+                    up.append((B, c, h, w))
+            out["up"] = up
+        return out
+
+    def ensure(self, B: int, H: int, W: int, nctx: int, cin_total: int, wiring=("plain",), cond_hw=None,
+               scale: float = 1.0):
+        def freeze(w):
+            if len(w) == 1:
+                return w
+            return (w[0], tuple((k, tuple(v)) for k, v in sorted(w[1].items())))
+
+        key = (B, H, W, nctx, cin_total, freeze(wiring), cond_hw, self.gemm_tile, self.gemm_splitk)
+        if key == self.key:
+            if scale != self._scale:
+                self._patch_scale(scale)
+            return
+        if H % (2 ** (len(self.net.boc) - 1)) or W % (2 ** (len(self.net.boc) - 1)):
+            raise L.PPError(f"latent size {H}x{W} must be divisible by {2 ** (len(self.net.boc) - 1)}")
+        dry = Arena()
+        self._build(dry, B, H, W, nctx, cin_total, wiring, cond_hw, scale)
+        self.arena = Arena(_align(dry.peak, 4096), self.device)
+        self.lay, self.setup_plan, self.step_plan, self.outputs = self._build(
+            self.arena, B, H, W, nctx, cin_total, wiring, cond_hw, scale)
+        self.key = key
+        self._scale = 1.0
+        if scale != 1.0:
+            self._patch_scale(scale)
+        self._ctx_id = None
+        self._cond_id = None
+        self.graph = None
+        self.B, self.H, self.W, self.nctx = B, H, W, nctx
+
+    def _patch_scale(self, scale):
+        """conditioning_scale is baked into the zero-conv GEMM launches; patch it in place (float or per-output list)."""
+        zc = [args[0]._obj for fn, args, name in self.step_plan.calls if name == "zero_conv"]
+        vals = list(scale) if isinstance(scale, (list, tuple)) else [scale] * len(zc)
+        for a, v in zip(zc, vals):
+            a.scale = float(v)
+        self._scale = scale
+        self.graph = None
+
+    # ------------------------------------------------------------------ inputs
+    def set_timestep(self, t):
+        tv = self.arena.view(self.lay["t_dev"], (1,), torch.float32)
+        if torch.is_tensor(t):
+            tv.copy_(t.reshape(-1)[:1].to(torch.float32), non_blocking=True)
+        else:
+            tv.fill_(float(t))
+
+    def set_context(self, ehs: torch.Tensor, force: bool = False):
+        """encoder_hidden_states [B, nctx, ctx_dim]; recomputes the hoisted cross-attention K/V^T only on change."""
+        ident = (ehs.data_ptr(), ehs._version, tuple(ehs.shape))
+        if not force and ident == self._ctx_id:
+            return
+        dst = self.arena.view(self.lay["ehs"], (self.B, self.nctx, self.net.ctx_dim), torch.bfloat16)
+        dst.copy_(ehs.to(self.device))
+        if self.net.kind != "controlnet" or self._cond_id is not None:
+            self.setup_plan.run(_stream())
+        self._ctx_id = ident
+
+    def set_cond(self, cond: torch.Tensor):
+        """ControlNet conditioning image [B,3,8H,8W] (NCHW, any float dtype)."""
+        ident = (cond.data_ptr(), cond._version, tuple(cond.shape))
+        if ident == self._cond_id:
+            return
+        c = self.lay["cond"]
+        self.load_nchw(cond, c.ptr, c.C, 0, c.H * c.W)
+        self._cond_id = ident
+        if self._ctx_id is not None:
+            self.setup_plan.run(_stream())
+
+    def load_nchw(self, src: torch.Tensor, dst_ptr: int, ldc: int, c0: int, hw: int, batch: Optional[int] = None,
+                  batch_mod: int = 0):
+        src = src.to(self.device)
+        if src.dtype not in _DT:
+            src = src.float()
+        src = src.contiguous()
+        nb = batch if batch is not None else src.shape[0]
+        L.check(self.lib.pp_nchw_to_nhwc(src.data_ptr(), _DT[src.dtype], nb, src.shape[1], hw, batch_mod, dst_ptr, ldc,
+                                         c0, _stream()), "pp_nchw_to_nhwc")
+
+    def load_input(self, parts: Sequence[Tuple[torch.Tensor, int]]):
+        """parts: (NCHW tensor, channel offset); a tensor with half the batch is CFG-duplicated."""
+        x = self.lay["x_in"]
+        for t, c0 in parts:
+            mod = t.shape[0] if t.shape[0] != x.B else 0
+            self.load_nchw(t, x.ptr, x.C, c0, x.H * x.W, batch=x.B, batch_mod=mod)
+
+    def load_residual(self, group: str, idx: int, t: torch.Tensor):
+        s = self.lay["slots"][group][idx]
+        if tuple(t.shape) != (s.B, s.C, s.H, s.W):
+            raise L.PPError(f"residual {group}[{idx}] has shape {tuple(t.shape)}, expected {(s.B, s.C, s.H, s.W)}")
+        self.load_nchw(t, s.ptr, s.C, 0, s.H * s.W)
+
+    # ------------------------------------------------------------------ run
+    def run_step(self, use_graph: bool = False):
+        if use_graph:
+            if self.graph is None:
+                self.capture()
+            self.graph.replay()
+        else:
+            self.step_plan.run(_stream())
+
+    def capture(self):
+        torch.cuda.synchronize()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            self.step_plan.run(s.cuda_stream)      # warm-up (sets func attributes outside capture)
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self.step_plan.run(_stream())
+        self.graph = g
+
+    # ------------------------------------------------------------------ outputs
+    def act_as_nchw(self, a: Act) -> torch.Tensor:
+        """Zero-copy NCHW-logical (channels_last strides) bf16 torch view of an arena activation."""
+        t = self.arena.view(a.ptr, (a.B, a.C, a.H, a.W), torch.bfloat16,
+                            strides=(a.H * a.W * a.C, 1, a.W * a.C, a.C))
+        t._pp_nhwc_ptr = a.ptr
+        return t
+
+    def eps_tensor(self) -> torch.Tensor:
+        return self.arena.view(self.outputs["eps"], (self.B, self.net.out_channels, self.H, self.W), torch.float32)

@@ -1,0 +1,194 @@
+"""Schedulers of the hot path with the diffusers duck-type the reference pipelines rely on
+(/root/reference/powerpaint/pipelines/pipeline_PowerPaint.py:536-551,906,993,1023,642;
+ pipeline_PowerPaint_Brushnet_CA.py:87-128,1391,1449,969): `.set_timesteps`, `.timesteps`, `.order`,
+`.init_noise_sigma`, `.scale_model_input`, `.step(..., return_dict=False)[0]`, `.add_noise`, `.config.steps_offset`.
+
+The arithmetic restates diffusers==0.27.0 `DDIMScheduler` / `DPMSolverMultistepScheduler` (pinned at
+/root/reference/requirements/requirements.txt:3, not vendored).  Per-step coefficients are computed on the host in
+fp32 torch exactly in the library's operation order and uploaded as a device table `coef[step][8]`; the tensor math
+(CFG combine + step) runs in the fused HIP kernel `pp_cfg_sched_step` on fp32 latents.  `.step()` itself launches
+that kernel, so a foreign loop calling `scheduler.step` still runs on the HIP path.
+"""
+from types import SimpleNamespace
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+
+def _betas(T, beta_start, beta_end):
+    return torch.linspace(beta_start ** 0.5, beta_end ** 0.5, T, dtype=torch.float32) ** 2
+
+
+class _SchedulerBase:
+    order = 1
+    init_noise_sigma = 1.0
+    kind = -1
+
+    def __init__(self, num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, **cfg):
+        self.config = SimpleNamespace(num_train_timesteps=num_train_timesteps, beta_start=beta_start,
+                                      beta_end=beta_end, **cfg)
+        self.betas = _betas(num_train_timesteps, beta_start, beta_end)
+        self.alphas_cumprod = torch.cumprod(1.0 - self.betas, dim=0)
+        self.timesteps = None
+        self.num_inference_steps = None
+        self._coef_dev = None
+        self._ts_dev = None
+        self._step_dev = None
+        self._m_prev = None
+        self._device = None
+
+    # -- device state for the fused kernel
+    def scale_model_input(self, sample, timestep=None):
+        return sample
+
+    def _upload(self, device):
+        self._device = torch.device(device) if device is not None else None
+        if self._device is not None and self._device.type == "cuda":
+            same = (self._coef_dev is not None and self._coef_dev.shape == self._coef.shape
+                    and self._coef_dev.device == self._device)
+            if same:   # keep device addresses stable across calls so captured graphs stay valid
+                self._coef_dev.copy_(self._coef)
+                self._ts_dev.copy_(self.timesteps.to(torch.float32))
+                self._step_dev.zero_()
+            else:
+                self._coef_dev = self._coef.to(self._device).contiguous()
+                self._ts_dev = self.timesteps.to(self._device, torch.float32).contiguous()
+                self._step_dev = torch.zeros(1, dtype=torch.int32, device=self._device)
+            self.timesteps = self.timesteps.to(self._device)
+        if self._m_prev is not None:
+            self._m_prev.zero_()
+
+    def coef_table(self) -> torch.Tensor:
+        return self._coef_dev
+
+    def timesteps_f32(self) -> torch.Tensor:
+        return self._ts_dev
+
+    def step_counter(self) -> torch.Tensor:
+        return self._step_dev
+
+    def m_prev(self, like: torch.Tensor) -> torch.Tensor:
+        if self._m_prev is None or self._m_prev.shape != like.shape:
+            self._m_prev = torch.zeros_like(like, dtype=torch.float32)
+        return self._m_prev
+
+    def reset(self):
+        if self._step_dev is not None:
+            self._step_dev.zero_()
+        if self._m_prev is not None:
+            self._m_prev.zero_()
+
+    def _index_of(self, timestep) -> int:
+        t = int(timestep)
+        idx = (self._ts_host == t).nonzero()
+        if len(idx) == 0:
+            raise ValueError(f"timestep {t} is not in the schedule")
+        return int(idx[0])
+
+    def step(self, model_output, timestep, sample, eta: float = 0.0, generator=None, return_dict: bool = True, **kw):
+        """x_t -> x_{t-1} on the HIP kernel (fp32 math).  Returns a NEW tensor in sample's dtype."""
+        if eta != 0.0:
+            raise NotImplementedError("eta != 0 (stochastic DDIM) is outside the hot path")
+        if not sample.is_cuda:
+            raise L.PPError("scheduler.step needs CUDA tensors: the step runs in the HIP kernel, no CPU fallback")
+        i = self._index_of(timestep)
+        x = sample.detach().to(torch.float32).contiguous().clone()
+        e = model_output.detach().to(torch.float32).contiguous()
+        step = torch.full((1,), i, dtype=torch.int32, device=x.device)
+        mp = self.m_prev(x) if self.kind == 1 else None
+        L.check(L.lib().pp_cfg_sched_step(e.data_ptr(), 0, 0.0, x.data_ptr(), mp.data_ptr() if mp is not None else None,
+                                           x.numel(), self.kind, self._coef_dev.data_ptr(), step.data_ptr(),
+                                           torch.cuda.current_stream().cuda_stream), "pp_cfg_sched_step")
+        out = x.to(sample.dtype)
+        if not return_dict:
+            return (out,)
+        return SimpleNamespace(prev_sample=out)
+
+    def add_noise(self, original_samples, noise, timesteps):
+        a = self.alphas_cumprod.to(original_samples.device)[timesteps.to(original_samples.device).long()]
+        sa = (a ** 0.5).flatten().to(original_samples.dtype)
+        s1 = ((1 - a) ** 0.5).flatten().to(original_samples.dtype)
+        while sa.dim() < original_samples.dim():
+            sa, s1 = sa.unsqueeze(-1), s1.unsqueeze(-1)
+        return sa * original_samples + s1 * noise
+
+
+class DDIMScheduler(_SchedulerBase):
+    """eta = 0, epsilon prediction, `leading` spacing, steps_offset = 1, set_alpha_to_one = False, no clipping."""
+    kind = 0
+
+    def __init__(self, num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, steps_offset=1,
+                 set_alpha_to_one=False, **kw):
+        super().__init__(num_train_timesteps, beta_start, beta_end, steps_offset=steps_offset,
+                         set_alpha_to_one=set_alpha_to_one, timestep_spacing="leading", prediction_type="epsilon")
+        self.final_alpha_cumprod = torch.tensor(1.0) if set_alpha_to_one else self.alphas_cumprod[0]
+
+    def set_timesteps(self, num_inference_steps: int, device=None):
+        T = self.config.num_train_timesteps
+        self.num_inference_steps = num_inference_steps
+        ratio = T // num_inference_steps
+        ts = (np.arange(0, num_inference_steps) * ratio).round()[::-1].copy().astype(np.int64) + self.config.steps_offset
+        self._ts_host = torch.from_numpy(ts)
+        self.timesteps = self._ts_host.clone()
+        coef = torch.zeros(num_inference_steps, 8, dtype=torch.float32)
+        for i, t in enumerate(ts.tolist()):
+            prev = t - ratio
+            a_t = self.alphas_cumprod[t]
+            a_p = self.alphas_cumprod[prev] if prev >= 0 else self.final_alpha_cumprod
+            coef[i, 0] = (1 - a_t) ** 0.5
+            coef[i, 1] = a_t ** 0.5
+            coef[i, 2] = a_p ** 0.5
+            coef[i, 3] = (1 - a_p) ** 0.5
+        self._coef = coef
+        self._upload(device)
+
+
+class DPMSolverMultistepScheduler(_SchedulerBase):
+    """dpmsolver++ (2M), midpoint, `linspace` spacing, final_sigmas_type = "zero", lower_order_final."""
+    kind = 1
+
+    def __init__(self, num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, solver_order=2, **kw):
+        super().__init__(num_train_timesteps, beta_start, beta_end, solver_order=solver_order, steps_offset=0,
+                         algorithm_type="dpmsolver++", solver_type="midpoint", final_sigmas_type="zero",
+                         timestep_spacing="linspace", prediction_type="epsilon")
+        if solver_order != 2:
+            raise NotImplementedError("only the 2M solver is on the hot path")
+
+    @staticmethod
+    def _alpha_sigma(sigma):
+        alpha_t = 1 / ((sigma ** 2 + 1) ** 0.5)
+        return alpha_t, sigma * alpha_t
+
+    def set_timesteps(self, num_inference_steps: int, device=None):
+        T = self.config.num_train_timesteps
+        self.num_inference_steps = num_inference_steps
+        ts = np.linspace(0, T - 1, num_inference_steps + 1).round()[::-1][:-1].copy().astype(np.int64)
+        sig = np.array(((1 - self.alphas_cumprod) / self.alphas_cumprod) ** 0.5)
+        sig = np.interp(ts, np.arange(0, len(sig)), sig)
+        self.sigmas = torch.from_numpy(np.concatenate([sig, [0.0]]).astype(np.float32))
+        self._ts_host = torch.from_numpy(ts)
+        self.timesteps = self._ts_host.clone()
+        n = num_inference_steps
+        coef = torch.zeros(n, 8, dtype=torch.float32)
+        for i in range(n):
+            a_cur, s_cur = self._alpha_sigma(self.sigmas[i])
+            a_t, sg_t = self._alpha_sigma(self.sigmas[i + 1])
+            lam_t = torch.log(a_t) - torch.log(sg_t)
+            lam_s0 = torch.log(a_cur) - torch.log(s_cur)
+            h = lam_t - lam_s0
+            c3 = a_t * (torch.exp(-h) - 1.0)
+            coef[i, 0], coef[i, 1] = s_cur, a_cur
+            coef[i, 2] = sg_t / s_cur
+            coef[i, 3] = c3
+            first_order = (i == 0) or (i == n - 1)       # lower_order_nums < 1, lower_order_final (sigma_last = 0)
+            if not first_order:
+                a_s1, sg_s1 = self._alpha_sigma(self.sigmas[i - 1])
+                lam_s1 = torch.log(a_s1) - torch.log(sg_s1)
+                r0 = (lam_s0 - lam_s1) / h
+                coef[i, 4] = 0.5 * c3
+                coef[i, 5] = 1.0 / r0
+        self._coef = coef
+        self._upload(device)
