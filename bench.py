@@ -1,0 +1,229 @@
+#!/usr/bin/env python
+"""Headline benchmark of the denoising hot path (BASELINE.json config 2).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is ONE pass of the hot path over one batch: a full 50-step DDIM, CFG-7.5 denoise of 4 synthetic 512x512
+images (latents 4x64x64, 9-channel UNet input) per GPU, `output_type="latent"` (VAE / CLIP excluded, as the metric
+says).  Inputs are resident in HBM before the timed region.  Weak scaling: every rank denoises its own 4 images; the
+only collective is the start-up RCCL broadcast of the packed UNet parameters from rank 0.
+
+Prints ONE JSON line on rank 0 (fields: see the driver contract; plus `roofline` and `cpu_baseline`).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from powerpaint_amd import dist as ppdist  # noqa: E402
+
+MFMA_PEAK_TFLOPS = 2500.0        # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md (2495 TF measured)
+# algorithmic GFLOP per sample per forward at 64x64 latents (2*MAC of conv/linear/attention)
+GFLOP_PER_SAMPLE = {"unet9": 803.4, "unet4": 803.3, "brushnet": 826.2, "controlnet": 283.3}
+
+
+def build_pipeline(cfg, device, rank, world):
+    from powerpaint_amd import models as PM, pipelines as PP, schedulers as PS
+    unet = PM.UNet2DConditionModel(in_channels=9 if cfg != "v2" else 4, device=device)
+    side = None
+    nets = [unet]
+    if cfg == "v2":
+        side = PM.BrushNetModel(in_channels=4, conditioning_channels=5, device=device)
+        nets.append(side)
+    elif cfg == "controlnet":
+        side = PM.ControlNetModel(in_channels=4, device=device)
+        nets.append(side)
+    for i, m in enumerate(nets):
+        if rank == 0:
+            sd = m.net.synthetic_state_dict(device=device, seed=i)       # random init directly in HBM
+            m.load_state_dict(sd)
+            del sd
+        else:
+            m.load_state_dict(m.net.synthetic_state_dict(meta=True), materialize=False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ppdist.broadcast_params([m.param_buffer() for m in nets], src=0)     # the ONE collective (RCCL over xGMI)
+    torch.cuda.synchronize()
+    bcast_s = time.perf_counter() - t0
+    if cfg == "v1":
+        pipe = PP.StableDiffusionInpaintPipeline(unet=unet, scheduler=PS.DDIMScheduler())
+    elif cfg == "v2":
+        pipe = PP.StableDiffusionPowerPaintBrushNetPipeline(unet=unet, brushnet=side,
+                                                            scheduler=PS.DPMSolverMultistepScheduler())
+    else:
+        pipe = PP.StableDiffusionControlNetInpaintPipeline(unet=unet, controlnet=side, scheduler=PS.DDIMScheduler())
+    return pipe, nets, bcast_s
+
+
+def synthetic_inputs(cfg, device, rank, per_gpu, lat_hw):
+    """SURVEY.md section 8d seeds: generator keyed by the GLOBAL image index, generated on CPU in fp32."""
+    h = w = lat_hw
+    lat, mil, pos, neg, posU, negU, ctrl = [], [], [], [], [], [], []
+    for j in range(per_gpu):
+        g = ppdist.image_generator(rank * per_gpu + j)
+        lat.append(torch.randn(1, 4, h, w, generator=g))
+        mil.append(torch.randn(1, 4, h, w, generator=g) * 0.5)
+        neg.append(torch.randn(1, 77, 768, generator=g))
+        pos.append(torch.randn(1, 77, 768, generator=g))
+        negU.append(torch.randn(1, 77, 768, generator=g))
+        posU.append(torch.randn(1, 77, 768, generator=g))
+        if cfg == "controlnet":
+            ctrl.append(torch.rand(1, 3, h * 8, w * 8, generator=g))
+    mask = torch.zeros(per_gpu, 1, h, w)
+    mask[:, :, h // 4: 3 * h // 4, w // 4: 3 * w // 4] = 1.0
+    cat = lambda l: torch.cat(l).to(device)  # noqa: E731
+    kw = dict(prompt_embeds=cat(pos), negative_prompt_embeds=cat(neg), latents=cat(lat), guidance_scale=7.5,
+              num_inference_steps=50, output_type="latent", return_dict=False)
+    if cfg in ("v1", "controlnet"):
+        kw.update(mask_latents=mask.to(device), masked_image_latents=cat(mil), height=h * 8, width=w * 8)
+        if cfg == "controlnet":
+            kw.update(control_image=cat(ctrl), controlnet_conditioning_scale=0.5)
+    else:
+        kw.update(conditioning_latents=torch.cat([cat(mil), mask.to(device)], 1), prompt_embedsU=cat(posU),
+                  negative_prompt_embedsU=cat(negU))
+    return kw
+
+
+def roofline_pass(pipe):
+    """Instrumented eager replay of one denoising step: HIP events around every launch on the launch stream."""
+    loop = pipe._loop
+    loop.scheduler.reset()
+    st = torch.cuda.current_stream()
+    loop.program.run(st.cuda_stream)               # warm
+    loop.scheduler.reset()
+    per = {}
+    reps = 3
+    for _ in range(reps):
+        loop.scheduler.reset()
+        for k, v in loop.program.run_timed(st).items():
+            per[k] = per.get(k, 0.0) + v / reps
+    flops = {}
+    for plan in ([loop.side_rt.step_plan] if loop.side_rt is not None else []) + [loop.rt.step_plan]:
+        for k, v in plan.flops_by_kind.items():
+            flops[k] = flops.get(k, 0.0) + v
+    counts = {}
+    for _, _, name in loop.program.calls:
+        counts[name] = counts.get(name, 0) + 1
+    return per, flops, counts
+
+
+def cpu_baseline(sample_steps=1):
+    """The CPU oracle (kind 'port': plain-PyTorch fp32 restatement of the reference's diffusers path) timed on this
+    box's host cores on a bounded sample: one image (CFG batch 2) x `sample_steps` UNet forwards at 64x64 latents,
+    extrapolated to 50 steps."""
+    from oracle import sd_modules as OM
+    torch.set_num_threads(os.cpu_count())
+    with torch.device("meta"):
+        o = OM.UNet2DConditionModel(in_channels=9)
+    o = o.to_empty(device="cpu")
+    g = torch.Generator("cpu").manual_seed(0)
+    with torch.no_grad():
+        for p in o.parameters():
+            if p.dim() == 1:
+                p.zero_()
+            else:
+                p.normal_(0, (1.0 / p[0].numel()) ** 0.5, generator=g)
+        for n, p in o.named_parameters():
+            if n.endswith("norm.weight") or ".norm1.weight" in n or ".norm2.weight" in n or ".norm3.weight" in n \
+                    or n == "conv_norm_out.weight":
+                p.fill_(1.0)
+        x = torch.randn(2, 9, 64, 64, generator=g)
+        e = torch.randn(2, 77, 768, generator=g)
+        o(x[:, :, :16, :16], 500, e)                  # touch weights / warm threads
+        t0 = time.perf_counter()
+        for _ in range(sample_steps):
+            o(x, 500, e)
+        dt = (time.perf_counter() - t0) / sample_steps
+    return {"value": 1.0 / (dt * 50), "unit": "images/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"{sample_steps} UNet forward(s) of 1 image (CFG batch 2) at 64x64 latents, fp32 torch CPU oracle, "
+                      f"{dt:.2f} s/forward, extrapolated x50 steps"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="v1", choices=["v1", "v2", "controlnet"])
+    ap.add_argument("--per-gpu", type=int, default=4)
+    ap.add_argument("--latent", type=int, default=64)
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    rank, world, local = ppdist.init_from_env()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N > 1")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+
+    pipe, nets, bcast_s = build_pipeline(args.config, device, rank, world)
+    pipe.use_graph = not args.no_graph
+    kw = synthetic_inputs(args.config, device, rank, args.per_gpu, args.latent)
+
+    for _ in range(args.warmup):
+        pipe(**kw)
+    ppdist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = pipe(**kw)[0]
+    torch.cuda.synchronize()
+    ppdist.barrier()
+    dt = ppdist.max_over_ranks(time.perf_counter() - t0, device)
+    assert torch.isfinite(out).all()
+
+    if rank == 0:
+        images = args.per_gpu * world * args.steps
+        ms_per_step = dt / args.steps * 1e3
+        unet_steps = 50
+        gf = {"v1": GFLOP_PER_SAMPLE["unet9"], "v2": GFLOP_PER_SAMPLE["unet4"] + GFLOP_PER_SAMPLE["brushnet"],
+              "controlnet": GFLOP_PER_SAMPLE["unet9"] + GFLOP_PER_SAMPLE["controlnet"]}[args.config]
+        scale_hw = (args.latent / 64.0) ** 2 if args.latent != 64 else 1.0
+        tflop_step = gf * 2 * args.per_gpu * scale_hw / 1e3         # CFG doubles the batch
+        ms_denoise_step = ms_per_step / unet_steps
+        res = {
+            "metric": "inpainted images/sec @512x512, 50-step DDIM CFG, batch4/GPU",
+            "value": images / dt, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": {"v1": "ppt-v1 SD1.5-inpaint UNet (9-ch in), 512x512, 50-step DDIM, CFG=7.5, batch=4/GPU",
+                                    "v2": "ppt-v2 BrushNet + SD1.5 UNet, 512x512, 50-step DPMSolver++, CFG=7.5, batch=4/GPU",
+                                    "controlnet": "ppt-v1 + ControlNet, 512x512, 50-step DDIM, CFG=7.5, batch=4/GPU"}[args.config],
+                       "global_batch": args.per_gpu * world, "latent": [4, args.latent, args.latent],
+                       "denoise_steps": unet_steps, "parallelism": f"dp{world} (image shards, no step collectives)",
+                       "hipgraph": not args.no_graph, "weights": "random init (no checkpoints offline)",
+                       "weight_broadcast_s": round(bcast_s, 4)},
+            "ms_per_denoise_step": ms_denoise_step,
+            "unet_step_mfma_util": tflop_step / (ms_denoise_step * 1e-3) / MFMA_PEAK_TFLOPS,
+        }
+        if not args.no_roofline:
+            per, flops, counts = roofline_pass(pipe)
+            # dominant kernel = the implicit-GEMM 3x3 convolution launches of pp_gemm_kernel
+            k = "conv3x3"
+            ach = flops[k] / 1e12 / (per[k] * 1e-3)
+            res["roofline"] = {"bound": "mfma", "kernel": "pp_gemm_kernel<...,CONV3X3> (implicit-GEMM 3x3 conv)",
+                               "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": ach / MFMA_PEAK_TFLOPS, "traffic": None,
+                               "launches_per_step": counts[k], "avg_launch_ms": per[k] / counts[k],
+                               "alg_flop_per_launch": flops[k] / counts[k]}
+            res["per_kernel_ms_per_denoise_step"] = {n: round(v, 4) for n, v in sorted(per.items(), key=lambda kv: -kv[1])}
+            res["per_kernel_tflops"] = {n: round(flops[n] / 1e12 / (per[n] * 1e-3), 1) for n in flops if per.get(n)}
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(res), flush=True)
+    ppdist.barrier()
+
+
+if __name__ == "__main__":
+    main()

@@ -415,6 +415,84 @@ class SDNet:
         return out
 
     # ---------------------------------------------------------------- parameters
+    def state_dict_spec(self) -> Dict[str, Tuple[int, ...]]:
+        """diffusers-format parameter names -> shapes for this architecture (SURVEY.md section 8b "Weight naming")."""
+        sp: Dict[str, Tuple[int, ...]] = {}
+        boc, te = self.boc, self.boc[0] * 4
+
+        def conv(name, cout, cin, k):
+            sp[name + ".weight"] = (cout, cin, k, k)
+            sp[name + ".bias"] = (cout,)
+
+        def lin(name, cout, cin, bias=True):
+            sp[name + ".weight"] = (cout, cin)
+            if bias:
+                sp[name + ".bias"] = (cout,)
+
+        def norm(name, c):
+            sp[name + ".weight"] = (c,)
+            sp[name + ".bias"] = (c,)
+
+        cin0 = self.in_channels + (self.conditioning_channels if self.kind == "brushnet" else 0)
+        conv("conv_in_condition" if self.kind == "brushnet" else "conv_in", boc[0], cin0, 3)
+        lin("time_embedding.linear_1", te, boc[0])
+        lin("time_embedding.linear_2", te, te)
+        for pre, cin, cout in self._resnet_specs():
+            norm(pre + ".norm1", cin); conv(pre + ".conv1", cout, cin, 3); lin(pre + ".time_emb_proj", cout, te)
+            norm(pre + ".norm2", cout); conv(pre + ".conv2", cout, cout, 3)
+            if cin != cout:
+                conv(pre + ".conv_shortcut", cout, cin, 1)
+        for i in range(len(boc) - 1):
+            conv(f"down_blocks.{i}.downsamplers.0.conv", boc[i], boc[i], 3)
+            if self.kind != "controlnet":
+                c = list(reversed(boc))[i]
+                conv(f"up_blocks.{i}.upsamplers.0.conv", c, c, 3)
+        for pre, c in self._attn_specs():
+            norm(pre + ".norm", c); conv(pre + ".proj_in", c, c, 1); conv(pre + ".proj_out", c, c, 1)
+            tb = pre + ".transformer_blocks.0"
+            for n in ("norm1", "norm2", "norm3"):
+                norm(f"{tb}.{n}", c)
+            for a, kd in (("attn1", c), ("attn2", self.ctx_dim)):
+                lin(f"{tb}.{a}.to_q", c, c, False); lin(f"{tb}.{a}.to_k", c, kd, False); lin(f"{tb}.{a}.to_v", c, kd, False)
+                lin(f"{tb}.{a}.to_out.0", c, c)
+            lin(f"{tb}.ff.net.0.proj", 8 * c, c); lin(f"{tb}.ff.net.2", c, 4 * c)
+        if self.kind == "unet":
+            norm("conv_norm_out", boc[0]); conv("conv_out", self.out_channels, boc[0], 3)
+        for pre, c in self._zero_conv_specs():
+            conv(pre, c, c, 1)
+        if self.kind == "controlnet":
+            ce, ch = "controlnet_cond_embedding", self.cond_embed_channels
+            conv(f"{ce}.conv_in", ch[0], self.conditioning_channels, 3)
+            for i in range(len(ch) - 1):
+                conv(f"{ce}.blocks.{2 * i}", ch[i], ch[i], 3)
+                conv(f"{ce}.blocks.{2 * i + 1}", ch[i + 1], ch[i], 3)
+            conv(f"{ce}.conv_out", boc[0], ch[-1], 3)
+        return sp
+
+    def synthetic_state_dict(self, device="cpu", seed: int = 0, meta: bool = False) -> Dict[str, torch.Tensor]:
+        """Random-init weights of this architecture (there is no network for checkpoints): fan-in scaled normal for
+        matrices, (1, 0) for norm affine, N(0, 0.02) for the zero-convs so that routing bugs cannot hide."""
+        sp = self.state_dict_spec()
+        if meta:
+            return {k: torch.empty(v, device="meta") for k, v in sp.items()}
+        g = torch.Generator(device=device).manual_seed(seed)
+        zc = tuple(p for p, _ in self._zero_conv_specs()) + ("controlnet_cond_embedding.conv_out",)
+        sd = {}
+        for k, shp in sp.items():
+            if k.endswith(".weight") and len(shp) == 1:
+                sd[k] = torch.ones(shp, device=device)
+            elif len(shp) == 1:
+                sd[k] = torch.randn(shp, generator=g, device=device) * 0.02
+                if ".norm" in k or k.startswith("conv_norm_out"):
+                    sd[k] = torch.zeros(shp, device=device)
+            else:
+                fan_in = 1
+                for d in shp[1:]:
+                    fan_in *= d
+                std = 0.02 if k.startswith(zc) else (1.0 / fan_in) ** 0.5
+                sd[k] = torch.randn(shp, generator=g, device=device) * std
+        return sd
+
     def load_state_dict(self, sd: Dict[str, torch.Tensor], device, materialize: bool = True):
         """sd: diffusers-format state dict (fp32/any float, CPU or meta).  Packs into kernel layouts on `device`."""
         pk = ParamPack()

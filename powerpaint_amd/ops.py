@@ -1,0 +1,186 @@
+"""Tensor-level convenience wrappers over the C ABI (one call = one kernel launch family).
+
+These take/return torch CUDA tensors (bf16 NHWC / row-major activations) and exist for tests, micro-benchmarks and
+users who want a single op; the networks themselves go through `engine.Builder`, which bakes raw pointers into plans.
+Every wrapper raises `PPError` on a non-zero return code -- there is no fallback.
+"""
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib as L
+
+_DT = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
+
+
+def _s():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]):
+    return t.data_ptr() if t is not None else None
+
+
+def gemm(x: torch.Tensor, w: torch.Tensor, bias=None, x2=None, res1=None, res2=None, scale: float = 1.0, act: int = 0,
+         rowvec=None, rows_per_batch: int = 0, out_f32: bool = False, vt_col0: int = 0, tile: int = 0,
+         splitk: int = 0):
+    """x [M,K1] (+ x2 [M,K2]) bf16, w [N,K1+K2] bf16 -> out [M,N] (or [M,N/2] for GEGLU; (out, vt) when vt_col0)."""
+    lib = L.lib()
+    M, K1 = x.shape
+    K2 = x2.shape[1] if x2 is not None else 0
+    N = w.shape[0]
+    a = L.PPGemmArgs()
+    a.M, a.N, a.K, a.x_mode = M, N, K1 + K2, L.PP_X_PLAIN
+    a.x1, a.x2, a.c1, a.c2, a.ldx1, a.ldx2 = _p(x), _p(x2), K1, K2, x.stride(0), (x2.stride(0) if x2 is not None else 0)
+    a.w, a.bias = _p(w), _p(bias)
+    a.rowvec = _p(rowvec)
+    a.ld_rowvec = rowvec.stride(0) if (rowvec is not None and rowvec.dim() == 2 and rowvec.shape[0] > 1) else 0
+    a.rows_per_batch = rows_per_batch
+    a.res1, a.ldres1 = _p(res1), (res1.stride(0) if res1 is not None else N)
+    a.res2, a.ldres2 = _p(res2), (res2.stride(0) if res2 is not None else N)
+    a.scale, a.act = scale, act
+    n_out = N // 2 if act == L.PP_ACT_GEGLU else (vt_col0 if vt_col0 else N)
+    out = torch.empty(M, n_out, dtype=torch.float32 if out_f32 else torch.bfloat16, device=x.device)
+    a.out, a.ldo, a.out_f32 = _p(out), n_out, int(out_f32)
+    vt = None
+    if vt_col0:
+        nb = M // rows_per_batch
+        vt = torch.zeros(nb, N - vt_col0, rows_per_batch, dtype=torch.bfloat16, device=x.device)
+        a.out_vt, a.vt_col0, a.vt_ld = _p(vt), vt_col0, rows_per_batch
+    a.tile, a.splitk = tile, splitk
+    ws = lib.pp_gemm_workspace_bytes(C.byref(a))
+    wsb = torch.empty(max(ws, 4) // 4, dtype=torch.float32, device=x.device) if ws else None
+    a.workspace = _p(wsb)
+    L.check(lib.pp_gemm_bf16(C.byref(a), _s()), "pp_gemm_bf16")
+    return (out, vt) if vt_col0 else out
+
+
+def conv3x3(x: torch.Tensor, w: torch.Tensor, bias=None, stride: int = 1, up: bool = False, x2=None, rowvec=None,
+            res1=None, res2=None, scale: float = 1.0, tile: int = 0, splitk: int = 0):
+    """x NHWC bf16 [B,H,W,C1] (+x2 [B,H,W,C2]); w bf16 [Cout, 9*(C1+C2)] (k = (ky*3+kx)*C + c) -> NHWC bf16."""
+    lib = L.lib()
+    B, H, W, C1 = x.shape
+    C2 = x2.shape[3] if x2 is not None else 0
+    cout = w.shape[0]
+    hv, wv = (2 * H, 2 * W) if up else (H, W)
+    ho, wo = (hv - 1) // stride + 1, (wv - 1) // stride + 1
+    out = torch.empty(B, ho, wo, cout, dtype=torch.bfloat16, device=x.device)
+    a = L.PPGemmArgs()
+    a.M, a.N, a.K, a.x_mode = B * ho * wo, cout, 9 * (C1 + C2), L.PP_X_CONV3X3
+    a.x1, a.x2, a.c1, a.c2 = _p(x), _p(x2), C1, C2
+    a.batch, a.hin, a.win, a.hout, a.wout, a.stride, a.up = B, H, W, ho, wo, stride, int(up)
+    a.w, a.bias, a.rowvec, a.ld_rowvec, a.rows_per_batch = _p(w), _p(bias), _p(rowvec), 0, ho * wo
+    if rowvec is not None and rowvec.dim() == 2 and rowvec.shape[0] > 1:
+        a.ld_rowvec = rowvec.stride(0)
+    a.res1, a.ldres1, a.res2, a.ldres2 = _p(res1), cout, _p(res2), cout
+    a.scale, a.act, a.out, a.ldo = scale, 0, _p(out), cout
+    a.tile, a.splitk = tile, splitk
+    ws = lib.pp_gemm_workspace_bytes(C.byref(a))
+    wsb = torch.empty(max(ws, 4) // 4, dtype=torch.float32, device=x.device) if ws else None
+    a.workspace = _p(wsb)
+    L.check(lib.pp_gemm_bf16(C.byref(a), _s()), "pp_gemm_bf16(conv)")
+    return out
+
+
+def groupnorm(x: torch.Tensor, gamma, beta, eps: float, silu: bool, groups: int = 32, x2=None):
+    """x NHWC bf16 [B,H,W,C1] (+x2) -> NHWC bf16 [B,H,W,C1+C2]; gamma/beta fp32."""
+    lib = L.lib()
+    B, H, W, C1 = x.shape
+    C2 = x2.shape[3] if x2 is not None else 0
+    Ct = C1 + C2
+    ss = torch.empty(B, 2, Ct, dtype=torch.float32, device=x.device)
+    ws = torch.empty(lib.pp_groupnorm_workspace_bytes(B, H * W, Ct) // 4, dtype=torch.float32, device=x.device)
+    y = torch.empty(B, H, W, Ct, dtype=torch.bfloat16, device=x.device)
+    L.check(lib.pp_groupnorm_stats(_p(x), C1, _p(x2), C2, B, H * W, groups, eps, _p(gamma), _p(beta), _p(ss), _p(ws),
+                                   _s()), "pp_groupnorm_stats")
+    L.check(lib.pp_groupnorm_apply(_p(x), C1, _p(x2), C2, B, H * W, _p(ss), int(silu), _p(y), _s()),
+            "pp_groupnorm_apply")
+    return y
+
+
+def layernorm(x: torch.Tensor, gamma, beta, eps: float = 1e-5):
+    rows, Cc = x.shape
+    y = torch.empty_like(x)
+    L.check(L.lib().pp_layernorm(_p(x), rows, Cc, _p(gamma), _p(beta), eps, _p(y), _s()), "pp_layernorm")
+    return y
+
+
+def transpose_v(v: torch.Tensor, batch: int, nk: int, ldvt: Optional[int] = None):
+    """v [batch*nk, cols] (row stride v.stride(0)) -> vt [batch, cols, ldvt]."""
+    cols = v.shape[1]
+    ldvt = ldvt or (nk + 7) // 8 * 8
+    vt = torch.empty(batch, cols, ldvt, dtype=torch.bfloat16, device=v.device)
+    L.check(L.lib().pp_transpose_v(_p(v), v.stride(0), batch, nk, cols, _p(vt), ldvt, _s()), "pp_transpose_v")
+    return vt
+
+
+def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, batch: int, heads: int, nq: int, nk: int, d: int,
+              scale: Optional[float] = None):
+    """q [batch*nq, >=heads*d] / k [batch*nk, ...] row-major bf16 (row strides taken from the tensors);
+    vt [batch, heads*d, ldvt].  Returns o [batch*nq, heads*d]."""
+    o = torch.empty(batch * nq, heads * d, dtype=torch.bfloat16, device=q.device)
+    L.check(L.lib().pp_attention_fwd(_p(q), q.stride(0), _p(k), k.stride(0), _p(vt), vt.stride(1), _p(o), heads * d,
+                                     batch, heads, nq, nk, d, scale if scale is not None else d ** -0.5, _s()),
+            "pp_attention_fwd")
+    return o
+
+
+def conv3x3_direct(x, w, bias, stride: int = 1, silu: bool = False, add=None):
+    """x NHWC bf16 [B,H,W,Cin]; w bf16 [3,3,Cin,Cout]."""
+    B, H, W, Cin = x.shape
+    cout = w.shape[3]
+    ho, wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    out = torch.empty(B, ho, wo, cout, dtype=torch.bfloat16, device=x.device)
+    L.check(L.lib().pp_conv3x3_direct(_p(x), B, H, W, Cin, _p(w), _p(bias), cout, stride, int(silu), _p(add), _p(out),
+                                      _s()), "pp_conv3x3_direct")
+    return out
+
+
+def conv3x3_smallcout(x, w, bias):
+    """x NHWC bf16 [B,H,W,Cin]; w bf16 [4, 9*Cin] -> fp32 NCHW [B,4,H,W]."""
+    B, H, W, Cin = x.shape
+    out = torch.empty(B, w.shape[0], H, W, dtype=torch.float32, device=x.device)
+    L.check(L.lib().pp_conv3x3_smallcout(_p(x), B, H, W, Cin, _p(w), _p(bias), w.shape[0], _p(out), _s()),
+            "pp_conv3x3_smallcout")
+    return out
+
+
+def nchw_to_nhwc(src: torch.Tensor, batch: Optional[int] = None, ldc: Optional[int] = None, c0: int = 0, dst=None):
+    B, Cc, H, W = src.shape
+    nb = batch or B
+    ldc = ldc or Cc
+    if dst is None:
+        dst = torch.zeros(nb, H, W, ldc, dtype=torch.bfloat16, device=src.device)
+    src = src.contiguous()
+    L.check(L.lib().pp_nchw_to_nhwc(_p(src), _DT[src.dtype], nb, Cc, H * W, B if nb != B else 0, _p(dst), ldc, c0,
+                                    _s()), "pp_nchw_to_nhwc")
+    return dst
+
+
+def nhwc_to_nchw(src: torch.Tensor, dtype=torch.float32):
+    B, H, W, Cc = src.shape
+    dst = torch.empty(B, Cc, H, W, dtype=dtype, device=src.device)
+    L.check(L.lib().pp_nhwc_to_nchw(_p(src), B, Cc, H * W, _p(dst), _DT[dtype], _s()), "pp_nhwc_to_nchw")
+    return dst
+
+
+def add(a: torch.Tensor, b: torch.Tensor):
+    out = torch.empty_like(a)
+    L.check(L.lib().pp_add_bf16(_p(a), _p(b), _p(out), a.numel(), _s()), "pp_add_bf16")
+    return out
+
+
+def timestep_embedding(t: torch.Tensor, rows: int, dim: int):
+    out = torch.empty(rows, dim, dtype=torch.float32, device=t.device)
+    L.check(L.lib().pp_timestep_embedding(_p(t), rows, dim, _p(out), _s()), "pp_timestep_embedding")
+    return out
+
+
+def linear_skinny(x: torch.Tensor, w: torch.Tensor, bias=None, act_in: int = 0, act_out: int = 0):
+    rows, K = x.shape
+    N = w.shape[0]
+    out = torch.empty(rows, N, dtype=torch.float32, device=x.device)
+    L.check(L.lib().pp_linear_skinny(_p(x), rows, K, _p(w), _p(bias), N, _p(out), N, act_in, act_out, _s()),
+            "pp_linear_skinny")
+    return out

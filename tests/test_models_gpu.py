@@ -1,0 +1,213 @@
+"""-m gpu: network-level and loop-level parity of the HIP path against the CPU fp32 oracle on identical weights/inputs.
+
+Tolerances (bf16 compute with fp32 accumulate vs an fp32 oracle, SURVEY.md section 8d "Parity gates"):
+  UNet / BrushNet / ControlNet forward : cosine >= 0.999 and max-abs <= 3e-2 * max(1, max|ref|)
+  teacher-forced loop                  : the same per step
+  free-running short loop              : cosine >= 0.995 on the final latents (error compounds; informational bound)
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import loops as OL  # noqa: E402
+from oracle import schedulers as OS  # noqa: E402
+from oracle import sd_modules as OM  # noqa: E402
+from powerpaint_amd import models as PM  # noqa: E402
+from powerpaint_amd import pipelines as PP  # noqa: E402
+from powerpaint_amd import schedulers as PS  # noqa: E402
+
+DEV = "cuda"
+TINY = dict(block_out_channels=(320, 640), layers_per_block=1,
+            down_block_types=("CrossAttnDownBlock2D", "DownBlock2D"), up_block_types=("UpBlock2D", "CrossAttnUpBlock2D"))
+
+
+def gen(*shape, seed=0, scale=1.0):
+    return torch.randn(*shape, generator=torch.Generator("cpu").manual_seed(seed)) * scale
+
+
+def bf16_weights_(m):
+    """Round the oracle's matrix weights to bf16 (the HIP path stores them in bf16): isolates kernel error from
+    weight-quantisation error.  Biases / norm affine stay fp32 on both sides."""
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if p.dim() >= 2:
+                p.copy_(p.to(torch.bfloat16).float())
+    return m
+
+
+def close(out, ref, what, cos_min=0.999, rel=3e-2):
+    out, ref = out.float().cpu(), ref.float().cpu()
+    assert out.shape == ref.shape, (what, out.shape, ref.shape)
+    assert torch.isfinite(out).all(), f"{what}: non-finite"
+    cos = torch.nn.functional.cosine_similarity(out.flatten(), ref.flatten(), dim=0).item()
+    err = (out - ref).abs().max().item()
+    bound = rel * max(1.0, ref.abs().max().item())
+    assert cos >= cos_min and err <= bound, f"{what}: cosine {cos:.6f}, max-abs {err:.4g} (bound {bound:.4g})"
+    return cos, err
+
+
+def make_tiny(kind, seed=0, **extra):
+    torch.manual_seed(seed)
+    if kind == "unet":
+        o = OM.UNet2DConditionModel(in_channels=extra.pop("in_channels", 9), **TINY)
+        h = PM.UNet2DConditionModel(in_channels=o.config.in_channels, device=DEV, **TINY)
+    elif kind == "brushnet":
+        o = OM.randomize_zero_convs(OM.BrushNetModel(in_channels=4, conditioning_channels=5, **TINY))
+        h = PM.BrushNetModel(in_channels=4, conditioning_channels=5, device=DEV, **TINY)
+    else:
+        o = OM.randomize_zero_convs(OM.ControlNetModel(in_channels=4, **{k: v for k, v in TINY.items() if k != "up_block_types"}))
+        h = PM.ControlNetModel(in_channels=4, device=DEV, **{k: v for k, v in TINY.items() if k != "up_block_types"})
+    bf16_weights_(o).eval()
+    h.load_state_dict(o.state_dict())
+    return o, h
+
+
+@pytest.mark.parametrize("cin", [9, 4])
+def test_unet_tiny_forward(cin):
+    o, h = make_tiny("unet", in_channels=cin)
+    x, e = gen(2, cin, 16, 16, seed=1), gen(2, 77, 768, seed=2)
+    with torch.no_grad():
+        ref = o(x, 500, e)[0]
+    out = h(x.to(DEV), 500, e.to(DEV), return_dict=False)[0]
+    close(out, ref, "unet tiny")
+    out2 = h(x.to(DEV), torch.tensor(500, device=DEV), e.to(DEV)).sample     # tensor timestep, cached context
+    assert torch.equal(out, out2)
+
+
+def test_brushnet_into_unet_tiny():
+    ob, hb = make_tiny("brushnet")
+    ou, hu = make_tiny("unet", seed=1, in_channels=4)
+    x, e, eu, cond = gen(2, 4, 16, 16, seed=1), gen(2, 77, 768, seed=2), gen(2, 77, 768, seed=3), gen(2, 5, 16, 16, seed=4)
+    with torch.no_grad():
+        dn, md, up = ob(x, 321, e, cond, conditioning_scale=0.8)
+        ref = ou(x, 321, eu, down_block_add_samples=list(dn), mid_block_add_sample=md, up_block_add_samples=list(up))[0]
+    hdn, hmd, hup = hb(x.to(DEV), 321, e.to(DEV), cond.to(DEV), conditioning_scale=0.8, return_dict=False)
+    assert len(hdn) == len(dn) and len(hup) == len(up)
+    for i, (a, b) in enumerate(zip(hdn + [hmd] + hup, list(dn) + [md] + list(up))):
+        close(a, b, f"brushnet residual {i}", cos_min=0.998)
+    # zero-copy hand-off (tensors carry their NHWC pointer) ...
+    lst_d, lst_u = list(hdn), list(hup)
+    out = hu(x.to(DEV), 321, eu.to(DEV), down_block_add_samples=lst_d, mid_block_add_sample=hmd,
+             up_block_add_samples=lst_u, return_dict=False)[0]
+    assert lst_d == [] and lst_u == []          # consumed destructively like the reference
+    close(out, ref, "unet(+brushnet) zero-copy")
+    # ... and foreign NCHW fp32 tensors (copied into the residual slots)
+    out2 = hu(x.to(DEV), 321, eu.to(DEV), down_block_add_samples=[t.to(DEV) for t in dn], mid_block_add_sample=md.to(DEV),
+              up_block_add_samples=[t.to(DEV) for t in up], return_dict=False)[0]
+    close(out2, ref, "unet(+brushnet) foreign tensors")
+
+
+def test_controlnet_into_unet_tiny():
+    oc, hc = make_tiny("controlnet")
+    ou, hu = make_tiny("unet", seed=1, in_channels=9)
+    x4, x9 = gen(2, 4, 16, 16, seed=1), gen(2, 9, 16, 16, seed=5)
+    e, img = gen(2, 77, 768, seed=2), torch.rand(2, 3, 128, 128, generator=torch.Generator("cpu").manual_seed(3))
+    with torch.no_grad():
+        dn, md = oc(x4, 700, e, img, conditioning_scale=0.5)
+        ref = ou(x9, 700, e, down_block_additional_residuals=dn, mid_block_additional_residual=md)[0]
+    hdn, hmd = hc(x4.to(DEV), 700, e.to(DEV), img.to(DEV), conditioning_scale=0.5, return_dict=False)
+    for i, (a, b) in enumerate(zip(hdn + [hmd], list(dn) + [md])):
+        close(a, b, f"controlnet residual {i}", cos_min=0.998)
+    out = hu(x9.to(DEV), 700, e.to(DEV), down_block_additional_residuals=hdn, mid_block_additional_residual=hmd,
+             return_dict=False)[0]
+    close(out, ref, "unet(+controlnet)")
+
+
+def test_unet_full_sd15_32x32():
+    """The real SD-1.5 inpainting architecture (859.5 M parameters, random init) at 32x32 latents, CFG batch 2."""
+    torch.manual_seed(0)
+    o = bf16_weights_(OM.UNet2DConditionModel(in_channels=9)).eval()
+    h = PM.UNet2DConditionModel(in_channels=9, device=DEV).load_state_dict(o.state_dict())
+    x, e = gen(2, 9, 32, 32, seed=1), gen(2, 77, 768, seed=2)
+    with torch.no_grad():
+        ref = o(x, 981, e)[0]
+    out = h(x.to(DEV), 981, e.to(DEV), return_dict=False)[0]
+    close(out, ref, "SD-1.5 UNet 32x32")
+
+
+def _v1_inputs(B, h, w, seed=0):
+    lat = gen(B, 4, h, w, seed=seed)
+    mask = torch.zeros(B, 1, h, w)
+    mask[:, :, h // 4: 3 * h // 4, w // 4: 3 * w // 4] = 1.0
+    mil = gen(B, 4, h, w, seed=seed + 1, scale=0.5)
+    pe = gen(2 * B, 77, 768, seed=seed + 2)
+    return lat, mask, mil, pe
+
+
+@pytest.mark.parametrize("kind,N", [("ddim", 4), ("dpm", 5)])
+def test_pipeline_v1_loop(kind, N):
+    o, h = make_tiny("unet", in_channels=9)
+    B, hh = 2, 16
+    lat, mask, mil, pe = _v1_inputs(B, hh, hh)
+    osch = OS.DDIMScheduler() if kind == "ddim" else OS.DPMSolverMultistepScheduler()
+    hsch = PS.DDIMScheduler() if kind == "ddim" else PS.DPMSolverMultistepScheduler()
+    rec = []
+    ref = OL.loop_v1(o, osch, lat, torch.cat([mask] * 2), torch.cat([mil] * 2), pe, N, 7.5,
+                     eps_hook=lambda i, t, l, e: rec.append((l.clone(), e.clone())))
+    pipe = PP.StableDiffusionInpaintPipeline(unet=h, scheduler=hsch)
+    kw = dict(prompt_embeds=pe[B:].to(DEV), negative_prompt_embeds=pe[:B].to(DEV), height=hh * 8, width=hh * 8,
+              num_inference_steps=N, guidance_scale=7.5, latents=lat.to(DEV), mask_latents=mask.to(DEV),
+              masked_image_latents=mil.to(DEV), output_type="latent", return_dict=False)
+    pipe.use_graph = False
+    seen = []
+    out_eager = pipe(callback=lambda i, t, l: seen.append((i, int(t), l.clone())), **kw)[0]
+    assert [s[0] for s in seen] == list(range(N)) and [s[1] for s in seen] == [int(t) for t in osch.timesteps]
+    close(out_eager, ref, f"v1 {kind} free-running", cos_min=0.995, rel=0.1)
+    pipe.use_graph = True
+    out_graph = pipe(**kw)[0]
+    assert torch.equal(out_eager, out_graph), "hipGraph replay differs from eager replay"
+    out_graph2 = pipe(**kw)[0]                                  # cached program / graph
+    assert torch.equal(out_graph, out_graph2)
+    # teacher-forced per-step epsilon parity through the model boundary
+    for i, (l_in, e_ref) in enumerate(rec):
+        x = torch.cat([torch.cat([l_in] * 2), torch.cat([mask] * 2), torch.cat([mil] * 2)], 1)
+        e = h(x.to(DEV), osch.timesteps[i], pe.to(DEV), return_dict=False)[0]
+        close(e, e_ref, f"teacher-forced eps step {i}")
+
+
+def test_pipeline_v2_brushnet_loop():
+    ob, hb = make_tiny("brushnet")
+    ou, hu = make_tiny("unet", seed=1, in_channels=4)
+    B, hh, N = 2, 16, 4
+    lat = gen(B, 4, hh, hh, seed=0)
+    mask = torch.zeros(B, 1, hh, hh); mask[:, :, 4:12, 4:12] = 1.0
+    cl = torch.cat([gen(B, 4, hh, hh, seed=1, scale=0.5), mask], 1)
+    pe, peU = gen(2 * B, 77, 768, seed=2), gen(2 * B, 77, 768, seed=3)
+    ref = OL.loop_v2(ou, ob, OS.DPMSolverMultistepScheduler(), lat, torch.cat([cl] * 2), pe, peU, N, 7.5, 1.0)
+    pipe = PP.StableDiffusionPowerPaintBrushNetPipeline(unet=hu, brushnet=hb, scheduler=PS.DPMSolverMultistepScheduler())
+    kw = dict(prompt_embeds=pe[B:].to(DEV), negative_prompt_embeds=pe[:B].to(DEV), prompt_embedsU=peU[B:].to(DEV),
+              negative_prompt_embedsU=peU[:B].to(DEV), conditioning_latents=cl.to(DEV), num_inference_steps=N,
+              guidance_scale=7.5, latents=lat.to(DEV), output_type="latent", return_dict=False)
+    out = pipe(**kw)[0]
+    close(out, ref, "v2 free-running", cos_min=0.995, rel=0.1)
+    pipe.use_graph = False
+    assert torch.equal(out, pipe(**kw)[0])
+    # control_guidance_end < 1 switches BrushNet off for the tail steps (scale patched per step, eager replay)
+    ref2 = OL.loop_v2(ou, ob, OS.DPMSolverMultistepScheduler(), lat, torch.cat([cl] * 2), pe, peU, N, 7.5, 1.0,
+                      control_guidance_end=0.5)
+    out2 = pipe(control_guidance_end=0.5, **kw)[0]
+    close(out2, ref2, "v2 guidance window", cos_min=0.995, rel=0.1)
+
+
+def test_pipeline_controlnet_loop():
+    oc, hc = make_tiny("controlnet")
+    ou, hu = make_tiny("unet", seed=1, in_channels=9)
+    B, hh, N = 2, 16, 3
+    lat, mask, mil, pe = _v1_inputs(B, hh, hh)
+    img = torch.rand(B, 3, hh * 8, hh * 8, generator=torch.Generator("cpu").manual_seed(9))
+    ref = OL.loop_v1(ou, OS.DDIMScheduler(), lat, torch.cat([mask] * 2), torch.cat([mil] * 2), pe, N, 7.5,
+                     controlnet=oc, control_image=torch.cat([img] * 2), controlnet_conditioning_scale=0.5)
+    pipe = PP.StableDiffusionControlNetInpaintPipeline(unet=hu, controlnet=hc, scheduler=PS.DDIMScheduler())
+    out = pipe(prompt_embeds=pe[B:].to(DEV), negative_prompt_embeds=pe[:B].to(DEV), control_image=img.to(DEV),
+               height=hh * 8, width=hh * 8, num_inference_steps=N, guidance_scale=7.5, latents=lat.to(DEV),
+               mask_latents=mask.to(DEV), masked_image_latents=mil.to(DEV), output_type="latent", return_dict=False)[0]
+    close(out, ref, "controlnet free-running", cos_min=0.995, rel=0.1)
+
+
+def test_product_fails_loudly_without_extension(monkeypatch):
+    from powerpaint_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libpp_hip.so")
+    with pytest.raises(_lib.PPError):
+        _lib.lib()

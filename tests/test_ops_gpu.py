@@ -1,0 +1,318 @@
+"""-m gpu: every HIP kernel, called through the C ABI, against a plain PyTorch fp32 reference of the same op.
+
+Inputs are rounded to bf16 first so the reference sees exactly the bits the kernel sees; the reference itself runs in
+fp32 (on the GPU via torch, which is only the checker here).  Tolerances are stated per test: bf16 output rounding is
+2^-9 relative, fp32 accumulation order differences are ~1e-6 * sqrt(K).
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from powerpaint_amd import _lib as L  # noqa: E402
+from powerpaint_amd import ops  # noqa: E402
+
+DEV = "cuda"
+
+
+def bf(t):
+    return t.to(torch.bfloat16)
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator("cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(DEV)
+
+
+def check(out, ref, atol, rtol, what=""):
+    out, ref = out.float(), ref.float()
+    assert out.shape == ref.shape, (what, out.shape, ref.shape)
+    assert torch.isfinite(out).all(), f"{what}: non-finite output"
+    err = (out - ref).abs()
+    tol = atol + rtol * ref.abs()
+    bad = (err > tol)
+    assert not bad.any(), (f"{what}: {int(bad.sum())}/{bad.numel()} off; max abs err {float(err.max()):.4g} "
+                           f"(ref max {float(ref.abs().max()):.4g}) at {np.unravel_index(int(err.argmax()), err.shape)}")
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("tile", [1, 2, 3])
+@pytest.mark.parametrize("M,N,K", [(256, 320, 320), (616, 640, 768), (1024, 960, 320), (2048, 320, 1280)])
+def test_gemm_plain(tile, M, N, K):
+    x, w = bf(rnd(M, K, seed=1)), bf(rnd(N, K, seed=2, scale=K ** -0.5))
+    bias = rnd(N, seed=3)
+    res = bf(rnd(M, N, seed=4))
+    out = ops.gemm(x, w, bias=bias, res1=res, tile=tile, splitk=1)
+    ref = x.float() @ w.float().t() + bias + res.float()
+    check(out, ref, 2e-2, 1e-2, f"gemm tile{tile}")
+
+
+def test_gemm_transpose_detect():
+    """A = I check with asymmetric W (guide rule: a symmetric B hides a row<->col swap)."""
+    K = 320
+    x = bf(torch.eye(K, device=DEV))
+    w = bf(rnd(640, K, seed=5))
+    out = ops.gemm(x, w, tile=1, splitk=1)
+    check(out, w.float().t(), 0, 0, "gemm identity")
+
+
+@pytest.mark.parametrize("splitk", [2, 4])
+def test_gemm_splitk(splitk):
+    M, N, K = 512, 1280, 2560
+    x, w = bf(rnd(M, K, seed=1)), bf(rnd(N, K, seed=2, scale=K ** -0.5))
+    bias, res = rnd(N, seed=3), bf(rnd(M, N, seed=4))
+    out = ops.gemm(x, w, bias=bias, res1=res, res2=res, scale=0.5, tile=2, splitk=splitk)
+    ref = (x.float() @ w.float().t() + bias) * 0.5 + 2 * res.float()
+    check(out, ref, 2e-2, 1e-2, "gemm splitk")
+
+
+def test_gemm_concat_and_rowvec():
+    M, K1, K2, N = 512, 640, 320, 320
+    x1, x2 = bf(rnd(M, K1, seed=1)), bf(rnd(M, K2, seed=2))
+    w = bf(rnd(N, K1 + K2, seed=3, scale=(K1 + K2) ** -0.5))
+    rv = rnd(2, N, seed=4)
+    out = ops.gemm(x1, w, x2=x2, rowvec=rv, rows_per_batch=256, out_f32=True)
+    ref = torch.cat([x1, x2], 1).float() @ w.float().t() + rv.repeat_interleave(256, 0)
+    check(out, ref, 2e-3, 1e-3, "gemm concat+rowvec")
+
+
+def test_gemm_geglu():
+    from powerpaint_amd.engine import _geglu_interleave
+    M, C = 512, 320
+    x = bf(rnd(M, C, seed=1))
+    w = bf(rnd(8 * C, C, seed=2, scale=C ** -0.5))
+    b = rnd(8 * C, seed=3)
+    out = ops.gemm(x, _geglu_interleave(w).contiguous(), bias=_geglu_interleave(b).contiguous(), act=L.PP_ACT_GEGLU)
+    y = x.float() @ w.float().t() + b
+    h, g = y.chunk(2, -1)
+    check(out, h * F.gelu(g), 2e-2, 1e-2, "gemm geglu")
+
+
+def test_gemm_vt_epilogue():
+    B, hw, C = 2, 256, 320
+    x = bf(rnd(B * hw, C, seed=1))
+    w = bf(rnd(3 * C, C, seed=2, scale=C ** -0.5))
+    out, vt = ops.gemm(x, w, vt_col0=2 * C, rows_per_batch=hw)
+    y = x.float() @ w.float().t()
+    check(out, y[:, :2 * C], 2e-2, 1e-2, "qk part")
+    check(vt, y[:, 2 * C:].reshape(B, hw, C).transpose(1, 2), 2e-2, 1e-2, "v^T part")
+
+
+# ------------------------------------------------------------------------------------------------ conv3x3 (implicit GEMM)
+def conv_ref(x_nhwc, w_igemm, bias, stride=1, up=False):
+    B, H, W, Cin = x_nhwc.shape
+    cout = w_igemm.shape[0]
+    w = w_igemm.float().reshape(cout, 3, 3, Cin).permute(0, 3, 1, 2)
+    x = x_nhwc.float().permute(0, 3, 1, 2)
+    if up:
+        x = F.interpolate(x, scale_factor=2.0, mode="nearest")
+    y = F.conv2d(x, w, bias, stride=stride, padding=1)
+    return y.permute(0, 2, 3, 1)
+
+
+@pytest.mark.parametrize("tile", [1, 2, 3])
+@pytest.mark.parametrize("stride,up", [(1, False), (2, False), (1, True)])
+def test_conv3x3(tile, stride, up):
+    B, H, W, Cin, Cout = 2, 16, 16, 320, 320
+    x = bf(rnd(B, H, W, Cin, seed=1))
+    w = bf(rnd(Cout, 9 * Cin, seed=2, scale=(9 * Cin) ** -0.5))
+    bias = rnd(Cout, seed=3)
+    out = ops.conv3x3(x, w, bias, stride=stride, up=up, tile=tile, splitk=1)
+    check(out, conv_ref(x, w, bias, stride, up), 2e-2, 1e-2, f"conv s{stride} up{up} tile{tile}")
+
+
+def test_conv3x3_concat_temb_res_splitk():
+    B, H, W, C1, C2, Cout = 2, 8, 8, 640, 320, 640
+    x1, x2 = bf(rnd(B, H, W, C1, seed=1)), bf(rnd(B, H, W, C2, seed=2))
+    w = bf(rnd(Cout, 9 * (C1 + C2), seed=3, scale=(9 * (C1 + C2)) ** -0.5))
+    bias, temb = rnd(Cout, seed=4), rnd(1, Cout, seed=5)
+    r1, r2 = bf(rnd(B, H, W, Cout, seed=6)), bf(rnd(B, H, W, Cout, seed=7))
+    for sk in (1, 4):
+        out = ops.conv3x3(x1, w, bias, x2=x2, rowvec=temb, res1=r1, res2=r2, tile=2, splitk=sk)
+        ref = conv_ref(torch.cat([x1, x2], -1), w, bias) + temb.view(1, 1, 1, -1) + r1.float() + r2.float()
+        check(out, ref, 3e-2, 1e-2, f"conv concat splitk{sk}")
+
+
+def test_conv3x3_halo_exact():
+    """All-ones input/weights: every output equals the number of valid taps * Cin (catches halo / tap-order bugs)."""
+    B, H, W, Cin, Cout = 1, 8, 8, 64, 320
+    x = torch.ones(B, H, W, Cin, dtype=torch.bfloat16, device=DEV)
+    w = torch.ones(Cout, 9 * Cin, dtype=torch.bfloat16, device=DEV) / 64
+    out = ops.conv3x3(x, w, None, tile=2, splitk=1).float()
+    cnt = F.conv2d(torch.ones(1, 1, H, W, device=DEV), torch.ones(1, 1, 3, 3, device=DEV), padding=1)[0, 0]
+    assert torch.equal(out[0, :, :, 0], cnt), (out[0, :, :, 0], cnt)
+    assert torch.equal(out[0, :, :, 319], cnt)
+
+
+# ------------------------------------------------------------------------------------------------ norms
+@pytest.mark.parametrize("C1,C2,H", [(320, 0, 16), (640, 320, 8), (1280, 1280, 8), (1920, 0, 4), (320, 0, 64)])
+@pytest.mark.parametrize("silu", [True, False])
+def test_groupnorm(C1, C2, H, silu):
+    B = 2
+    x1 = bf(rnd(B, H, H, C1, seed=1) * 2 + 0.5)
+    x2 = bf(rnd(B, H, H, C2, seed=2)) if C2 else None
+    C = C1 + C2
+    g, b = rnd(C, seed=3), rnd(C, seed=4)
+    eps = 1e-5 if silu else 1e-6
+    out = ops.groupnorm(x1, g, b, eps, silu, x2=x2)
+    x = torch.cat([x1, x2], -1) if C2 else x1
+    ref = F.group_norm(x.float().permute(0, 3, 1, 2), 32, g, b, eps)
+    if silu:
+        ref = F.silu(ref)
+    check(out, ref.permute(0, 2, 3, 1), 2e-2, 1e-2, "groupnorm")
+
+
+@pytest.mark.parametrize("C", [320, 640, 1280])
+def test_layernorm(C):
+    x = bf(rnd(1000, C, seed=1) * 3 + 1)
+    g, b = rnd(C, seed=2), rnd(C, seed=3)
+    check(ops.layernorm(x, g, b), F.layer_norm(x.float(), (C,), g, b, 1e-5), 2e-2, 1e-2, "layernorm")
+
+
+# ------------------------------------------------------------------------------------------------ attention
+@pytest.mark.parametrize("d,nq,nk", [(40, 256, 256), (80, 256, 256), (160, 64, 64), (40, 1024, 77), (80, 200, 77),
+                                     (160, 256, 77), (40, 4096, 4096)])
+def test_attention(d, nq, nk):
+    B, Hh = 2, 8
+    C = Hh * d
+    q, k, v = bf(rnd(B * nq, C, seed=1)), bf(rnd(B * nk, C, seed=2)), bf(rnd(B * nk, C, seed=3))
+    vt = ops.transpose_v(v, B, nk)
+    out = ops.attention(q, k, vt, B, Hh, nq, nk, d)
+    qh = q.float().view(B, nq, Hh, d).transpose(1, 2)
+    kh = k.float().view(B, nk, Hh, d).transpose(1, 2)
+    vh = v.float().view(B, nk, Hh, d).transpose(1, 2)
+    ref = F.scaled_dot_product_attention(qh, kh, vh).transpose(1, 2).reshape(B * nq, C)
+    check(out, ref, 2e-2, 2e-2, f"attention d{d}")
+
+
+def test_attention_strided_qkv_and_spike():
+    """q/k taken as column slices of a fused [M, 2C] buffer; one huge score forces the online-softmax rescale path."""
+    B, Hh, d, n = 1, 8, 40, 512
+    C = Hh * d
+    qk = bf(rnd(B * n, 2 * C, seed=1))
+    qk[300, C:C + d] = 30.0          # key 300 of head 0 dominates for queries aligned with it
+    qk[5, :d] = 4.0
+    v = bf(rnd(B * n, C, seed=3))
+    vt = ops.transpose_v(v, B, n)
+    out = ops.attention(qk[:, :C], qk[:, C:], vt, B, Hh, n, n, d)
+    qh = qk[:, :C].float().view(B, n, Hh, d).transpose(1, 2)
+    kh = qk[:, C:].float().view(B, n, Hh, d).transpose(1, 2)
+    vh = v.float().view(B, n, Hh, d).transpose(1, 2)
+    ref = F.scaled_dot_product_attention(qh, kh, vh).transpose(1, 2).reshape(B * n, C)
+    check(out, ref, 2e-2, 2e-2, "attention strided+spike")
+
+
+def test_transpose_v():
+    B, nk, cols = 2, 77, 320
+    v = bf(rnd(B * nk, cols, seed=1))
+    vt = ops.transpose_v(v, B, nk)
+    assert vt.shape == (B, cols, 80)
+    assert torch.equal(vt[:, :, :nk], v.view(B, nk, cols).transpose(1, 2))
+    assert torch.count_nonzero(vt[:, :, nk:]) == 0
+
+
+# ------------------------------------------------------------------------------------------------ small kernels
+def test_timestep_embedding_and_skinny():
+    t = torch.tensor([981.0], device=DEV)
+    e = ops.timestep_embedding(t, 1, 320)
+    k = torch.arange(160, device=DEV, dtype=torch.float32)
+    f = torch.exp(-math.log(10000.0) * k / 160)
+    ref = torch.cat([torch.cos(t * f), torch.sin(t * f)])[None]
+    check(e, ref, 2e-4, 0, "timestep embedding")
+    w, b = bf(rnd(1280, 320, seed=1, scale=320 ** -0.5)), rnd(1280, seed=2)
+    y = ops.linear_skinny(e, w, b, act_out=L.PP_ACT_SILU)
+    check(y, F.silu(e @ w.float().t() + b), 1e-4, 1e-4, "skinny 1")
+    x8 = rnd(8, 1280, seed=3)
+    w2 = bf(rnd(333, 1280, seed=4, scale=1280 ** -0.5))
+    y2 = ops.linear_skinny(x8, w2, None, act_in=L.PP_ACT_SILU)
+    check(y2, F.silu(x8) @ w2.float().t(), 1e-4, 1e-4, "skinny 8 rows")
+
+
+@pytest.mark.parametrize("cin,cout,stride", [(9, 320, 1), (4, 320, 1), (3, 16, 1), (16, 32, 2), (256, 320, 1)])
+def test_conv_direct(cin, cout, stride):
+    B, H = 2, 16
+    x = bf(rnd(B, H, H, cin, seed=1))
+    w = bf(rnd(cout, cin, 3, 3, seed=2, scale=(9 * cin) ** -0.5))
+    b = rnd(cout, seed=3)
+    add = bf(rnd(B, (H - 1) // stride + 1, (H - 1) // stride + 1, cout, seed=4))
+    out = ops.conv3x3_direct(x, w.permute(2, 3, 1, 0).contiguous(), b, stride, True, add)
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), w.float(), b, stride=stride, padding=1).permute(0, 2, 3, 1)
+    check(out, F.silu(ref + add.float()), 2e-2, 1e-2, "conv direct")
+
+
+def test_conv_smallcout():
+    B, H, cin = 2, 16, 320
+    x = bf(rnd(B, H, H, cin, seed=1))
+    w = bf(rnd(4, cin, 3, 3, seed=2, scale=(9 * cin) ** -0.5))
+    b = rnd(4, seed=3)
+    out = ops.conv3x3_smallcout(x, w.permute(0, 2, 3, 1).reshape(4, -1).contiguous(), b)
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), w.float(), b, padding=1)
+    check(out, ref, 1e-3, 1e-3, "conv_out")
+
+
+def test_layout_and_add():
+    x = rnd(2, 4, 8, 8, seed=1)
+    y = ops.nchw_to_nhwc(x, batch=4, ldc=9, c0=0)
+    assert torch.equal(y[:2, :, :, :4], bf(x).permute(0, 2, 3, 1)) and torch.equal(y[2:, :, :, :4], y[:2, :, :, :4])
+    assert torch.count_nonzero(y[..., 4:]) == 0
+    z = bf(rnd(2, 8, 8, 320, seed=2))
+    assert torch.equal(ops.nhwc_to_nchw(z), z.float().permute(0, 3, 1, 2))
+    a, b = bf(rnd(4096, seed=3)), bf(rnd(4096, seed=4))
+    assert torch.equal(ops.add(a, b), bf(a.float() + b.float()))
+
+
+def test_mask_prep_bit_exact():
+    from powerpaint_amd.pipelines._base import hip_mask_prep
+    g = torch.Generator("cpu").manual_seed(0)
+    mask = torch.rand(2, 1, 64, 64, generator=g)
+    mask[0, 0, 0, :8] = torch.tensor([0.5, 0.49999997, 0.50000006, 0.0, 1.0, 0.25, 0.75, 0.5])
+    img = torch.rand(2, 3, 64, 64, generator=g) * 2 - 1
+    m = mask.clone(); m[m < 0.5] = 0; m[m >= 0.5] = 1
+    out = hip_mask_prep(0, mask.to(DEV), None, mask.shape, 2, 1, 64, 64)
+    assert torch.equal(out.cpu(), m)
+    mi = hip_mask_prep(1, img.to(DEV), out, img.shape, 2, 3, 64, 64)
+    assert torch.equal(mi.cpu(), img * (m < 0.5))
+    dn = hip_mask_prep(2, out, None, (2, 1, 8, 8), 2, 1, 64, 64, 8, 8)
+    assert torch.equal(dn.cpu(), F.interpolate(m, size=(8, 8)))
+    dn2 = hip_mask_prep(2, out, None, (2, 1, 24, 40), 2, 1, 64, 64, 24, 40)
+    assert torch.equal(dn2.cpu(), F.interpolate(m, size=(24, 40)))
+    rgb = torch.rand(2, 3, 64, 64, generator=g) * 2 - 1
+    om = hip_mask_prep(3, rgb.to(DEV), None, (2, 1, 64, 64), 2, 3, 64, 64)
+    assert torch.equal(om.cpu(), (rgb.sum(1)[:, None] < 0).float())
+
+
+@pytest.mark.parametrize("kind", ["ddim", "dpm"])
+@pytest.mark.parametrize("N", [10, 50])
+def test_scheduler_step_kernel(kind, N):
+    """Fused CFG + step kernel over a whole schedule vs the float64 closed form (oracle)."""
+    from oracle import schedulers as OS
+    from powerpaint_amd import schedulers as PS
+    sch = (PS.DDIMScheduler if kind == "ddim" else PS.DPMSolverMultistepScheduler)()
+    sch.set_timesteps(N, device=DEV)
+    g = torch.Generator("cpu").manual_seed(0)
+    x0 = torch.randn(2, 4, 8, 8, generator=g)
+    eps = [torch.randn(4, 4, 8, 8, generator=g) for _ in range(N)]
+    gs = 7.5
+    x = x0.to(DEV).clone()
+    mp = torch.zeros_like(x)
+    lib = L.lib()
+    sch.reset()
+    for i in range(N):
+        e = eps[i].to(DEV)
+        L.check(lib.pp_cfg_sched_step(e.data_ptr(), 1, gs, x.data_ptr(), mp.data_ptr(), x.numel(), sch.kind,
+                                      sch.coef_table().data_ptr(), sch.step_counter().data_ptr(),
+                                      torch.cuda.current_stream().cuda_stream), "step")
+        L.check(lib.pp_step_advance(sch.step_counter().data_ptr(), torch.cuda.current_stream().cuda_stream), "adv")
+    comb = [(e[:2] + gs * (e[2:] - e[:2])).double().numpy() for e in eps]
+    if kind == "ddim":
+        ref = x0.double().numpy()
+        for i, t in enumerate(OS.ddim_timesteps(N)):
+            ref = OS.ddim_step_f64(ref, comb[i], int(t), N)
+    else:
+        ref = OS.dpm_run_f64(x0.double().numpy(), comb, N)
+    check(x.cpu(), torch.from_numpy(ref).float(), 2e-3, 2e-3, f"{kind} {N} steps")
+    assert int(sch.step_counter()) == N

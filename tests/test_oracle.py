@@ -1,0 +1,137 @@
+"""CPU: pins for the oracle itself (it has no reference golden vectors to lean on -- see oracle/__init__.py)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import loops as OL
+from oracle import schedulers as OS
+from oracle import sd_modules as OM
+
+
+def test_parameter_counts_match_sd15():
+    """UNet 859.5 M is the well-known SD-1.5 figure; BrushNet_CA / ControlNet from the constructor loops."""
+    with torch.device("meta"):
+        assert OM.count_params(OM.UNet2DConditionModel(in_channels=4)) == 859_520_964
+        assert OM.count_params(OM.UNet2DConditionModel(in_channels=9)) == 859_535_364
+        assert round(OM.count_params(OM.BrushNetModel()) / 1e6, 1) == 886.1
+        assert round(OM.count_params(OM.ControlNetModel()) / 1e6, 1) == 361.3
+
+
+def test_state_dict_keys_follow_diffusers_naming():
+    with torch.device("meta"):
+        sd = OM.BrushNetModel().state_dict()
+    for k in ["conv_in_condition.weight", "time_embedding.linear_1.weight", "down_blocks.0.resnets.0.norm1.weight",
+              "down_blocks.0.attentions.1.transformer_blocks.0.attn2.to_k.weight",
+              "down_blocks.0.attentions.0.transformer_blocks.0.ff.net.0.proj.weight",
+              "down_blocks.2.downsamplers.0.conv.weight", "mid_block.attentions.0.proj_out.bias",
+              "up_blocks.1.resnets.2.conv_shortcut.weight", "up_blocks.2.upsamplers.0.conv.bias",
+              "brushnet_down_blocks.11.weight", "brushnet_mid_block.bias", "brushnet_up_blocks.14.weight"]:
+        assert k in sd, k
+    assert "down_blocks.3.downsamplers.0.conv.weight" not in sd and "up_blocks.3.upsamplers.0.conv.weight" not in sd
+
+
+def test_timestep_arrays():
+    d = OS.DDIMScheduler(); d.set_timesteps(50)
+    assert d.timesteps[:3].tolist() == [981, 961, 941] and d.timesteps[-1].item() == 1
+    assert np.array_equal(d.timesteps.numpy(), OS.ddim_timesteps(50))
+    p = OS.DPMSolverMultistepScheduler(); p.set_timesteps(50)
+    assert p.timesteps[:3].tolist() == [999, 979, 959] and p.timesteps[-1].item() == 20
+    p.set_timesteps(30)
+    assert np.array_equal(p.timesteps.numpy(), OS.dpm_timesteps(30))
+
+
+@pytest.mark.parametrize("N", [10, 30, 50])
+def test_ddim_torch_vs_float64_closed_form(N):
+    s = OS.DDIMScheduler(); s.set_timesteps(N)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 4, 8, 8, generator=g)
+    ref = x.double().numpy()
+    for t in s.timesteps:
+        e = torch.randn(2, 4, 8, 8, generator=g)
+        x = s.step(e, t, x)[0]
+        ref = OS.ddim_step_f64(ref, e.double().numpy(), int(t), N)
+    assert np.allclose(x.numpy(), ref, rtol=2e-4, atol=2e-4)
+
+
+@pytest.mark.parametrize("N", [10, 30, 50])
+def test_dpm_torch_vs_float64_closed_form(N):
+    s = OS.DPMSolverMultistepScheduler(); s.set_timesteps(N)
+    g = torch.Generator().manual_seed(0)
+    x0 = torch.randn(2, 4, 8, 8, generator=g)
+    eps = [torch.randn(2, 4, 8, 8, generator=g) for _ in range(N)]
+    x = x0
+    for t, e in zip(s.timesteps, eps):
+        x = s.step(e, t, x)[0]
+    ref = OS.dpm_run_f64(x0.double().numpy(), [e.double().numpy() for e in eps], N)
+    assert np.allclose(x.numpy(), ref, rtol=5e-4, atol=5e-4)
+    # DPM-Solver++ is exact for a constant data prediction: x0 fixed -> final latent == x0
+    s.set_timesteps(N)
+    x, target = x0, torch.randn(2, 4, 8, 8, generator=g)
+    for i, t in enumerate(s.timesteps):
+        a, sg = s._alpha_sigma(s.sigmas[i])
+        x = s.step((x - a * target) / sg, t, x)[0]
+    assert torch.allclose(x, target, atol=1e-4)
+
+
+def test_leaf_modules_against_functional():
+    torch.manual_seed(0)
+    a = OM.Attention(320, 768, 8, 40)
+    x, c = torch.randn(2, 64, 320), torch.randn(2, 77, 768)
+    q = a.to_q(x).view(2, 64, 8, 40).transpose(1, 2)
+    k = a.to_k(c).view(2, 77, 8, 40).transpose(1, 2)
+    v = a.to_v(c).view(2, 77, 8, 40).transpose(1, 2)
+    ref = a.to_out[0](F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(2, 64, 320))
+    assert torch.allclose(a(x, c), ref, atol=1e-5)
+    e = OM.timestep_embedding(torch.tensor([981]), 320)
+    f = torch.exp(-math.log(10000) * torch.arange(160) / 160)
+    assert torch.allclose(e[0, :160], torch.cos(981 * f), atol=1e-6) and torch.allclose(e[0, 160:], torch.sin(981 * f), atol=1e-6)
+    ff = OM.FeedForward(320)
+    y = ff.net[0].proj(x)
+    assert torch.allclose(ff(x), ff.net[2](y[..., :1280] * F.gelu(y[..., 1280:])), atol=1e-6)
+
+
+TINY = dict(block_out_channels=(320, 640), layers_per_block=1,
+            down_block_types=("CrossAttnDownBlock2D", "DownBlock2D"), up_block_types=("UpBlock2D", "CrossAttnUpBlock2D"))
+
+
+def test_brushnet_routing_properties():
+    torch.manual_seed(0)
+    u = OM.UNet2DConditionModel(in_channels=4, **TINY).eval()
+    b = OM.BrushNetModel.from_unet(u).eval()
+    x, e, cond = torch.randn(1, 4, 16, 16), torch.randn(1, 77, 768), torch.randn(1, 5, 16, 16)
+    with torch.no_grad():
+        dn, md, up = b(x, 10, e, cond)
+        assert len(dn) == 4 and len(up) == 5
+        assert all(float(t.abs().max()) == 0 for t in dn + [md] + up)           # zero-convs: exact zeros (:955-958)
+        base = u(x, 10, e)[0]
+        same = u(x, 10, e, down_block_add_samples=list(dn), mid_block_add_sample=md, up_block_add_samples=list(up))[0]
+        assert torch.equal(base, same)
+        # from_unet copies conv_in into channels 0-3 and 4-7, zero for channel 8 (BrushNet_CA.py:525-540)
+        w = b.conv_in_condition.weight
+        assert torch.equal(w[:, :4], u.conv_in.weight) and torch.equal(w[:, 4:8], u.conv_in.weight)
+        assert float(w[:, 8].abs().max()) == 0
+        # the residual list is consumed destructively and completely
+        OM.randomize_zero_convs(b)
+        dn, md, up = b(x, 10, e, cond, conditioning_scale=2.0)
+        d2, _, _ = b(x, 10, e, cond, conditioning_scale=1.0)
+        assert torch.allclose(dn[1], 2 * d2[1], atol=1e-6)
+        ld, lu = list(dn), list(up)
+        u(x, 10, e, down_block_add_samples=ld, mid_block_add_sample=md, up_block_add_samples=lu)
+        assert ld == [] and lu == []
+
+
+def test_bit_exact_prep_and_cfg_order():
+    g = torch.Generator().manual_seed(0)
+    m = torch.rand(2, 1, 16, 16, generator=g)
+    mb = OL.binarize_mask(m)
+    assert set(mb.unique().tolist()) <= {0.0, 1.0} and torch.equal(mb, (m >= 0.5).float())
+    img = torch.rand(2, 3, 16, 16, generator=g) * 2 - 1
+    assert torch.equal(OL.masked_image(img, mb), img * (1 - mb))
+    assert torch.equal(OL.mask_to_latent(mb, 2, 2), mb[:, :, ::8, ::8])
+    rgb = torch.stack([-torch.ones(16, 16), -torch.ones(16, 16), -torch.ones(16, 16)])[None]
+    assert OL.brushnet_original_mask(rgb).min() == 1.0 and OL.brushnet_original_mask(-rgb).max() == 0.0
+    a, b = torch.randn(1, 77, 768, generator=g), torch.randn(1, 77, 768, generator=g)
+    assert torch.equal(OL.blend_prompt_embeds(a, b, 1.0), a * 1.0 + 0.0 * b)
