@@ -82,7 +82,7 @@ class DPMSolverMultistepScheduler:
     def set_timesteps(self, num_inference_steps: int, device=None):
         T = self.config.num_train_timesteps
         ts = np.linspace(0, T - 1, num_inference_steps + 1).round()[::-1][:-1].copy().astype(np.int64)
-        sig = np.array(((1 - self.alphas_cumprod) / self.alphas_cumprod) ** 0.5)
+        sig = (((1 - self.alphas_cumprod) / self.alphas_cumprod) ** 0.5).numpy()
         sig = np.interp(ts, np.arange(0, len(sig)), sig)
         sig = np.concatenate([sig, [0.0]]).astype(np.float32)
         self.sigmas = torch.from_numpy(sig)

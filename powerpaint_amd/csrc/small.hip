@@ -289,15 +289,27 @@ extern "C" int pp_linear_skinny(const float* x, int rows, int K, const void* w, 
   hipStream_t st = (hipStream_t)stream;
   int nb = (N + 3) / 4;
   if (nb > 2048) nb = 2048;
-  if (rows == 1) {
-    hipLaunchKernelGGL(linear_skinny_kernel<1>, dim3(nb), dim3(256), (size_t)K * 4, st, x, rows, K, (const uint16_t*)w,
-                       bias, N, out, ldo, act_in, act_out);
-  } else {
-    const size_t lds = (size_t)16 * K * 4;
-    if (lds > 64 * 1024) return PP_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(linear_skinny_kernel<16>, dim3(nb), dim3(256), lds, st, x, rows, K, (const uint16_t*)w, bias, N,
-                       out, ldo, act_in, act_out);
-  }
+#define PP_SKINNY(R)                                                                                              \
+  do {                                                                                                            \
+    const size_t lds = (size_t)(R) * K * 4;                                                                       \
+    if (lds > 160 * 1024) return PP_ERR_UNSUPPORTED;                                                              \
+    static size_t attr_lds = 0;                                                                                   \
+    if (lds > 64 * 1024 && lds > attr_lds) {                                                                      \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(linear_skinny_kernel<R>),                             \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {              \
+        pp_set_last_error("hipFuncSetAttribute(linear_skinny)", hipGetLastError());                               \
+        return PP_ERR_LAUNCH;                                                                                     \
+      }                                                                                                           \
+      attr_lds = lds;                                                                                             \
+    }                                                                                                             \
+    hipLaunchKernelGGL(linear_skinny_kernel<R>, dim3(nb), dim3(256), lds, st, x, rows, K, (const uint16_t*)w, bias, \
+                       N, out, ldo, act_in, act_out);                                                             \
+  } while (0)
+  if (rows == 1) PP_SKINNY(1);
+  else if (rows <= 4) PP_SKINNY(4);
+  else if (rows <= 8) PP_SKINNY(8);
+  else PP_SKINNY(16);
+#undef PP_SKINNY
   PP_CHECK_LAUNCH("linear_skinny_kernel");
   return PP_OK;
 }

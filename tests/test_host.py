@@ -1,0 +1,173 @@
+"""CPU: host logic of the product (plan compilation, parameter packing, schedulers' coefficient tables, sharding and
+the world-size-2 weight broadcast over gloo).  No kernel is launched here."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from oracle import schedulers as OS
+from oracle import sd_modules as OM
+from powerpaint_amd import dist as ppdist
+from powerpaint_amd import schedulers as PS
+from powerpaint_amd.engine import SDNet, _geglu_interleave
+from powerpaint_amd.runtime import NetRuntime
+
+TINY = dict(block_out_channels=(320, 640), layers_per_block=1,
+            down_block_types=("CrossAttnDownBlock2D", "DownBlock2D"), up_block_types=("UpBlock2D", "CrossAttnUpBlock2D"))
+
+
+def test_state_dict_spec_matches_oracle_architecture():
+    for kind, cls, kw, nk in (("unet", OM.UNet2DConditionModel, dict(in_channels=9), {}),
+                              ("brushnet", OM.BrushNetModel, {}, dict(conditioning_channels=5)),
+                              ("controlnet", OM.ControlNetModel, {}, dict(conditioning_channels=3))):
+        with torch.device("meta"):
+            ref = {k: tuple(v.shape) for k, v in cls(**kw).state_dict().items()}
+        assert SDNet(kind, kw.get("in_channels", 4), **nk).state_dict_spec() == ref
+
+
+def test_full_size_plans_and_flop_accounting():
+    """Launch plans of the real SD-1.5 shapes compile on the host; algorithmic FLOPs match SURVEY.md section 8d
+    (minus the cross-attention K/V projections hoisted out of the step)."""
+    exp = {"unet": (803.4, 400), "brushnet": (826.2, 425), "controlnet": (283.3 - 16.1, 188)}
+    for kind, cin, tot, nk in (("unet", 9, 9, {}), ("brushnet", 4, 9, dict(conditioning_channels=5)),
+                               ("controlnet", 4, 4, dict(conditioning_channels=3))):
+        net = SDNet(kind, cin, **nk)
+        net.load_state_dict(net.synthetic_state_dict(meta=True), "cpu", materialize=False)
+        rt = NetRuntime(net, "cpu")
+        rt.ensure(8, 64, 64, 77, tot, ("plain",), cond_hw=(512, 512))
+        gf = rt.step_plan.flops / 8 / 1e9
+        assert abs(gf - exp[kind][0]) / exp[kind][0] < 0.01, (kind, gf)
+        assert len(rt.step_plan.calls) == exp[kind][1]
+        assert len(rt.setup_plan.calls) >= 15
+
+
+def test_brushnet_wiring_changes_the_unet_plan():
+    net = SDNet("unet", 4, **TINY)
+    net.load_state_dict(net.synthetic_state_dict(meta=True), "cpu", materialize=False)
+    rt = NetRuntime(net, "cpu")
+    rt.ensure(2, 16, 16, 77, 4, ("plain",))
+    n_plain = len(rt.step_plan.calls)
+    shapes = rt._residual_shapes(2, 16, 16, True)
+    assert [len(shapes[k]) for k in ("down", "mid", "up")] == [4, 1, 5]
+    wiring = ("brushnet", {k: [0] * len(v) for k, v in shapes.items()})
+    rt.ensure(2, 16, 16, 77, 4, wiring)
+    assert len(rt.step_plan.calls) == n_plain + 1          # the second conv_in launch (skip captured before the add)
+    res2 = [a for a in rt.step_plan.keep if a.res2]
+    assert len(res2) == 4 + 1 + 5 - 1                      # every residual except conv_in's rides a GEMM epilogue
+    slots = {s.ptr for g in rt.lay["slots"].values() for s in g}
+    assert {a.res2 for a in res2} <= slots
+
+
+def test_geglu_interleave_is_a_row_permutation():
+    w = torch.arange(16 * 3, dtype=torch.float32).reshape(16, 3)
+    p = _geglu_interleave(w)
+    assert torch.equal(p[0], w[0]) and torch.equal(p[1], w[1]) and torch.equal(p[2], w[8]) and torch.equal(p[3], w[9])
+    assert torch.equal(p[4], w[2]) and torch.equal(p[6], w[10])
+    assert sorted(p[:, 0].tolist()) == sorted(w[:, 0].tolist())
+
+
+def test_param_pack_roundtrip_and_single_buffer():
+    torch.manual_seed(0)
+    o = OM.UNet2DConditionModel(in_channels=9, **TINY)
+    net = SDNet("unet", 9, **TINY).load_state_dict(o.state_dict(), "cpu")
+    pk = net.params
+    w = o.down_blocks[0].resnets[0].conv1.weight
+    got = pk.tensor("down_blocks.0.resnets.0.conv1.weight")
+    assert got.shape == (320, 9 * 320) and got.dtype == torch.bfloat16
+    assert torch.equal(got, w.permute(0, 2, 3, 1).reshape(320, -1).to(torch.bfloat16))
+    qkv = pk.tensor("down_blocks.0.attentions.0.transformer_blocks.0.attn1.qkv.weight")
+    a = o.down_blocks[0].attentions[0].transformer_blocks[0].attn1
+    assert torch.equal(qkv[640:], a.to_v.weight.to(torch.bfloat16))
+    assert pk.tensor("temb_all.weight").shape == (net.temb_total, 1280)
+    lo, hi = min(pk.ptr.values()), max(pk.ptr.values())
+    assert pk.buf.data_ptr() <= lo and hi < pk.buf.data_ptr() + pk.buf.numel()      # everything in ONE buffer
+
+
+@pytest.mark.parametrize("N", [10, 50])
+def test_product_scheduler_tables_reproduce_the_oracle(N):
+    """Emulate pp_cfg_sched_step on the host with the product's coefficient tables; compare with the oracle classes."""
+    g = torch.Generator().manual_seed(0)
+    x0 = torch.randn(1, 4, 8, 8, generator=g)
+    eps = [torch.randn(1, 4, 8, 8, generator=g) for _ in range(N)]
+    for P, O in ((PS.DDIMScheduler, OS.DDIMScheduler), (PS.DPMSolverMultistepScheduler, OS.DPMSolverMultistepScheduler)):
+        p, o = P(), O()
+        p.set_timesteps(N)
+        o.set_timesteps(N)
+        assert torch.equal(p.timesteps, o.timesteps)
+        x, ref, m = x0.clone(), x0.clone(), torch.zeros_like(x0)
+        for i, t in enumerate(o.timesteps):
+            c = p._coef[i]
+            if p.kind == 0:
+                x = c[2] * ((x - c[0] * eps[i]) / c[1]) + c[3] * eps[i]
+            else:
+                pred = (x - c[0] * eps[i]) / c[1]
+                x = c[2] * x - c[3] * pred - c[4] * (c[5] * (pred - m))
+                m = pred
+            ref = o.step(eps[i], t, ref)[0]
+        assert torch.allclose(x, ref, rtol=1e-5, atol=1e-5), (P.__name__, (x - ref).abs().max())
+
+
+def test_scheduler_duck_type_surface():
+    s = PS.DDIMScheduler()
+    s.set_timesteps(50)
+    assert s.order == 1 and s.init_noise_sigma == 1.0 and s.config.steps_offset == 1
+    assert s.timesteps[0] == 981 and len(s.timesteps) == 50
+    x = torch.randn(2, 4, 8, 8)
+    assert s.scale_model_input(x, s.timesteps[0]) is x
+    import inspect
+    assert {"eta", "generator"} <= set(inspect.signature(s.step).parameters)
+    with pytest.raises(Exception):
+        s.step(x, 981, x)           # CPU tensors: the step only exists as a HIP kernel -> loud failure, no fallback
+
+
+def test_shard_ranges_cover_the_batch_once():
+    for gb, world in ((32, 8), (16, 8), (5, 2), (4, 1), (3, 4)):
+        seen = []
+        for r in range(world):
+            seen += list(ppdist.shard_range(gb, r, world))
+        assert seen == list(range(gb))
+    g1, g2 = ppdist.image_generator(7), ppdist.image_generator(7)
+    assert torch.equal(torch.randn(4, generator=g1), torch.randn(4, generator=g2))
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r, w, _ = ppdist.init_from_env("gloo")
+    net = SDNet("unet", 9, **TINY)
+    if r == 0:
+        net.load_state_dict(net.synthetic_state_dict(seed=3), "cpu")
+    else:
+        net.load_state_dict(net.synthetic_state_dict(meta=True), "cpu", materialize=False)
+        assert int(net.params.buf.count_nonzero()) == 0
+    ppdist.broadcast_params([net.params.buf], src=0)                   # the one collective of the path
+    chk = float(net.params.buf.view(torch.int16).double().sum())
+    # image shards: rank-count-invariant inputs, gather back in global order
+    idx = list(ppdist.shard_range(4, r, w))
+    local = torch.stack([torch.randn(4, 2, 2, generator=ppdist.image_generator(i)) for i in idx])
+    allv = ppdist.gather_latents(local, 4)
+    t = ppdist.max_over_ranks(float(r + 1), "cpu")
+    ppdist.barrier()
+    q.put((r, chk, allv, t))
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_broadcast_and_sharding_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda x: x[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res[0][1] == res[1][1] != 0.0                                 # identical parameter bytes on both ranks
+    ref = torch.stack([torch.randn(4, 2, 2, generator=ppdist.image_generator(i)) for i in range(4)])
+    assert torch.equal(res[0][2], ref) and torch.equal(res[1][2], ref)  # global order, independent of rank count
+    assert res[0][3] == res[1][3] == 2.0

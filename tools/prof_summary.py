@@ -1,0 +1,21 @@
+#!/usr/bin/env python
+"""Turn a rocprofv3 (--kernel-trace --stats) rocpd SQLite database into a text kernel summary for profiles/."""
+import sqlite3
+import sys
+
+
+def main(db, out, title=""):
+    c = sqlite3.connect(db)
+    rows = list(c.execute("select name, total_calls, total_duration, average, percentage from top_kernels"))
+    with open(out, "w") as f:
+        f.write(f"# rocprofv3 --kernel-trace --stats summary  {title}\n# source: {db}\n")
+        f.write(f"# {'calls':>7} {'total_ms':>11} {'avg_us':>10} {'pct':>6}  kernel\n")
+        for name, calls, tot, avg, pct in rows:
+            if len(name) > 150:
+                name = name[:147] + "..."
+            f.write(f"  {calls:7d} {tot / 1e3:11.3f} {avg:10.2f} {pct:6.2f}  {name}\n")
+    print(open(out).read()[:3000])
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2], " ".join(sys.argv[3:]))
