@@ -290,6 +290,337 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) pp_gemm_kernel(const PPGemmArg
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// v2: multi-stage LDS-direct pipeline + LDS-staged coalesced epilogue.
+//   * operand tiles go HBM/L2 -> LDS with `buffer_load_dwordx4 ... lds` (no VGPR staging, no ds_write pass); the LDS
+//     image of a wave-instruction is lane-linear (8 rows x 128 B), so the XOR swizzle is applied to the per-lane SOURCE
+//     k-slot and undone by the same XOR on the fragment read;
+//   * NS stages: the loads of tiles t+1 .. t+NS-1 stay in flight across the (raw) barrier while tile t is consumed;
+//     counted `s_waitcnt vmcnt(P*(NS-2))`, ONE s_barrier per 64-deep K step;
+//   * addressing: per-lane byte offsets are computed once per (3x3 tap, source tensor) -- NOT per K tile; the walk
+//     along K is a wave-uniform SGPR offset.  Invalid lanes (halo, row tail) carry an out-of-range voffset and dead
+//     tiles a zero-sized descriptor: both make the DMA write zeros, and every wave always issues exactly P loads per
+//     tile so the vmcnt arithmetic is uniform;
+//   * epilogue: accumulators are staged through LDS (fp32, 64-row passes, row stride padded by 16 B => conflict-free
+//     ds_write_b128) and read back row-major, so bias / residual loads and the output stores are 16 B per lane along
+//     the contiguous axis: 320-byte full-row segments instead of 8-byte pieces scattered over 16 rows.
+template <int BM, int BN, int WM, int WN, int XMODE, int NS>
+__global__ void __launch_bounds__(WM* WN * 64, 1) pp_gemm_kernel_v2(const PPGemmArgs a, const GemmDerived d) {
+  constexpr int T = WM * WN * 64;
+  constexpr int MI = BM / WM / 16;
+  constexpr int NI = BN / WN / 16;
+  constexpr int RPP = T / 8;
+  constexpr int XP = BM / RPP;
+  constexpr int WP = (BN + RPP - 1) / RPP;
+  constexpr int P = XP + WP;
+  constexpr int XBYTES = BM * 128, WBYTES = BN * 128, STAGE = XBYTES + WBYTES;
+  constexpr int EPI_ROWS = 64;                    // rows per epilogue pass
+  constexpr int EPI_LD = BN * 4 + 16;             // fp32 row stride in bytes (+16: bank spread for ds_write_b128)
+  static_assert(BM % RPP == 0, "X tile must be whole passes");
+  static_assert(P * (NS - 1) < 64, "vmcnt field");
+  static_assert(EPI_ROWS * EPI_LD <= NS * STAGE, "epilogue staging must fit in the pipeline stages");
+  static_assert(MI * 16 <= EPI_ROWS && EPI_ROWS % (MI * 16) == 0, "wave rows vs epilogue pass");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+
+  int lid;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tile_m = lid / d.tiles_n;
+  const int tile_n = lid - tile_m * d.tiles_n;
+  const int m_blk = tile_m * BM, n_blk = tile_n * BN;
+  const int split = blockIdx.y;
+  const int kt_begin = split * d.kt_per_split;
+  int kt_end = kt_begin + d.kt_per_split;
+  if (kt_end > d.kt_total) kt_end = d.kt_total;
+  const int nkt = kt_end - kt_begin;
+  const int dbg = a.reserved[0];   // ablation switches (tools/gemm_ablate.py): 1 no refill, 2 no MFMA, 4 no epilogue
+
+  // lane -> (row within the wave's 8-row strip, k-slot it must FETCH so that its lane-linear LDS position is swizzled)
+  const int lrow = lane >> 3;
+  const int kslot = (lane & 7) ^ lrow;          // (row & 7) == lrow because every strip starts at a multiple of 8
+  const int prow = wave * 8 + lrow;             // tile row of pass 0
+
+  const int ctot = a.c1 + a.c2;
+  const uint32_t xbytes1 = XMODE == PP_X_PLAIN ? (uint32_t)a.M * (uint32_t)a.ldx1 * 2u
+                                               : (uint32_t)a.batch * (uint32_t)a.hin * (uint32_t)a.win * (uint32_t)a.c1 * 2u;
+  const uint32_t xbytes2 = !a.x2 ? 0u
+                           : (XMODE == PP_X_PLAIN ? (uint32_t)a.M * (uint32_t)a.ldx2 * 2u
+                                                  : (uint32_t)a.batch * (uint32_t)a.hin * (uint32_t)a.win * (uint32_t)a.c2 * 2u);
+  const uint32_t wbytes = (uint32_t)a.N * (uint32_t)a.K * 2u;
+
+  // ---- per-lane offsets.  PLAIN: vx1/vx2 = byte offset of (row m, k-slot) in source 1 / 2 (OOB if m >= M), fixed.
+  //      CONV : pixel coordinates kept in (xa, xb, xc); vx1 recomputed when the (tap, source) pair changes.
+  int vx1[XP], vx2[XP];   // (int: the LDS-DMA builtin takes a signed voffset)
+  int xa[XP], xb[XP], xc[XP];
+#pragma unroll
+  for (int i = 0; i < XP; ++i) {
+    const int m = m_blk + prow + i * RPP;
+    const bool ok = m < a.M;
+    if (XMODE == PP_X_PLAIN) {
+      vx1[i] = ok ? (m * a.ldx1 + kslot * 8) * 2 : (int)PP_OOB;
+      vx2[i] = ok ? (m * a.ldx2 + kslot * 8) * 2 : (int)PP_OOB;
+      xa[i] = xb[i] = xc[i] = 0;
+    } else {
+      const int hw = a.hout * a.wout;
+      const int b = m / hw;
+      const int rem = m - b * hw;
+      const int oy = rem / a.wout;
+      const int ox = rem - oy * a.wout;
+      xa[i] = ok ? b * a.hin * a.win : -1;      // -1 marks a dead row
+      xb[i] = oy * a.stride - 1;
+      xc[i] = ox * a.stride - 1;
+      vx1[i] = (int)PP_OOB;
+      vx2[i] = (int)PP_OOB;
+    }
+  }
+  int vw[WP];
+  int wlds[WP];   // wave-uniform LDS byte offset of the strip inside the W tile
+#pragma unroll
+  for (int i = 0; i < WP; ++i) {
+    // a wave whose strip falls beyond BN in the last pass re-issues its previous strip (identical bytes to the
+    // identical LDS address) so that every wave has exactly WP loads in flight per tile
+    const int strip = (wave * 8 + i * RPP < BN) ? i : i - 1;
+    const int n = n_blk + prow + strip * RPP;
+    vw[i] = (n < a.N) ? (n * a.K + kslot * 8) * 2 : (int)PP_OOB;
+    wlds[i] = (wave * 8 + strip * RPP) * 128;
+  }
+
+  int tap = 0, cc = 0;
+  bool retap = true;
+  if (XMODE == PP_X_CONV3X3) {
+    tap = kt_begin / d.ctiles;
+    cc = (kt_begin - tap * d.ctiles) * 64;
+  }
+  const int hv = a.up ? a.hin * 2 : a.hin;
+  const int wv = a.up ? a.win * 2 : a.win;
+
+  auto issue = [&](int kt, int stage) {
+    char* xs = smem + stage * STAGE;
+    char* ws = xs + XBYTES;
+    const bool live = kt < kt_end;
+    const int k0 = kt * 64;
+    if (XMODE == PP_X_PLAIN) {
+      const bool first = k0 < a.c1;
+      const __amdgpu_buffer_rsrc_t rs = make_rsrc(first ? a.x1 : a.x2, live ? (first ? xbytes1 : xbytes2) : 0u);
+      const int so = (first ? k0 : k0 - a.c1) * 2;
+#pragma unroll
+      for (int i = 0; i < XP; ++i) {
+        const int vo = first ? vx1[i] : vx2[i];   // (local copy: passing the captured array element straight to the
+                                                  //  builtin makes clang drop the HOST stub of this kernel)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(xs + (wave * 8 + i * RPP) * 128), 16, vo, so, 0, 0);
+      }
+    } else {
+      const bool first = cc < a.c1;
+      if (live && (retap || cc == 0 || cc == a.c1)) {      // (tap, source) changed: refresh the per-lane offsets
+        const int ky = tap / 3, kx = tap - ky * 3;
+        const int csrc = first ? a.c1 : a.c2;
+#pragma unroll
+        for (int i = 0; i < XP; ++i) {
+          const int iy = xb[i] + ky, ix = xc[i] + kx;
+          const bool ok = xa[i] >= 0 && (unsigned)iy < (unsigned)hv && (unsigned)ix < (unsigned)wv;
+          const int sy = a.up ? (iy >> 1) : iy;
+          const int sx = a.up ? (ix >> 1) : ix;
+          vx1[i] = ok ? ((xa[i] + sy * a.win + sx) * csrc + kslot * 8) * 2 : (int)PP_OOB;
+        }
+        retap = false;
+      }
+      const __amdgpu_buffer_rsrc_t rs = make_rsrc(first ? a.x1 : a.x2, live ? (first ? xbytes1 : xbytes2) : 0u);
+      const int so = (first ? cc : cc - a.c1) * 2;
+#pragma unroll
+      for (int i = 0; i < XP; ++i) {
+        const int vo = vx1[i];
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(xs + (wave * 8 + i * RPP) * 128), 16, vo, so, 0, 0);
+      }
+      if (live) {
+        cc += 64;
+        if (cc == ctot) { cc = 0; ++tap; }
+      }
+    }
+    const __amdgpu_buffer_rsrc_t rsw = make_rsrc(a.w, live ? wbytes : 0u);
+#pragma unroll
+    for (int i = 0; i < WP; ++i) {
+      const int vo = vw[i], lo = wlds[i];
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr_t)(ws + lo), 16, vo, k0 * 2, 0, 0);
+    }
+  };
+
+  f32x4_t acc[NI][MI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int frow = lane & 15;
+  const int fk = lane >> 4;
+  const int xrow0 = wm * (MI * 16) + frow;
+  const int wrow0 = wn * (NI * 16) + frow;
+  const int fsw = frow & 7;
+
+#pragma unroll
+  for (int s = 0; s < NS - 1; ++s) issue(kt_begin + s, s);
+
+  int stage = 0;
+  for (int t = 0; t < nkt; ++t) {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P * (NS - 2)) : "memory");   // this wave's loads of tile t have landed
+    asm volatile("s_barrier" ::: "memory");                               // everyone's have; everyone left tile t-1
+    int nstage = stage + (NS - 1);
+    if (nstage >= NS) nstage -= NS;
+    issue((dbg & 1) ? kt_end : kt_begin + t + NS - 1, nstage);            // refill the stage consumed last iteration
+
+    const char* xs = smem + stage * STAGE;
+    const char* ws = xs + XBYTES;
+    if (!(dbg & 2))
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int so = ((ks * 4 + fk) ^ fsw) << 4;
+      bf16x8_t xf[MI], wf[NI];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+        xf[mi] = *reinterpret_cast<const bf16x8_t*>(xs + (xrow0 + mi * 16) * 128 + so);
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+        wf[ni] = *reinterpret_cast<const bf16x8_t*>(ws + (wrow0 + ni * 16) * 128 + so);
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+          acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
+    }
+    stage = stage + 1 == NS ? 0 : stage + 1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the (zero-sized) tail prefetches before LDS is reused
+  if (dbg & 4) {
+    if (acc[0][0][0] == 123.456f) ((float*)a.out)[0] = 1.f;   // keep the accumulators live
+    return;
+  }
+
+  // ================= epilogue: 64-row passes through LDS =================
+  const bool splitk = gridDim.y > 1;
+  const bool vt_blk = !splitk && a.out_vt && n_blk >= a.vt_col0;
+  const bool geglu = !splitk && a.act == PP_ACT_GEGLU;
+  const int my_pass = (wm * (MI * 16)) / EPI_ROWS;
+  const int my_row0 = (wm * (MI * 16)) % EPI_ROWS;
+#pragma unroll 1
+  for (int pass = 0; pass < BM / EPI_ROWS; ++pass) {
+    asm volatile("s_barrier" ::: "memory");            // LDS free: main loop (pass 0) / previous read-out finished
+    if (my_pass == pass) {
+      // lane holds rows n = wn*NI*16 + ni*16 + 4*(lane>>4) + {0..3} of column m = my_row0 + mi*16 + (lane & 15)
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+          *reinterpret_cast<f32x4_t*>(smem + (my_row0 + mi * 16 + (lane & 15)) * EPI_LD +
+                                      (wn * (NI * 16) + ni * 16 + 4 * (lane >> 4)) * 4) = acc[ni][mi];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    const int m0 = m_blk + pass * EPI_ROWS;
+    if (vt_blk) {
+      // transposed (V^T) output: thread = (column n, 8 consecutive rows)
+      const int ncols = a.N - a.vt_col0;
+      for (int q = tid; q < BN * (EPI_ROWS / 8); q += T) {
+        const int col = q % BN, rg = q / BN;
+        const int n = n_blk + col, m = m0 + rg * 8;
+        if (n >= a.N || m >= a.M) continue;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const float*>(smem + (rg * 8 + j) * EPI_LD + col * 4);
+        const float bsv = a.bias ? a.bias[n] : 0.f;
+        const int bidx = m / a.rows_per_batch, rin = m - bidx * a.rows_per_batch;
+        uint16_t* dst = (uint16_t*)a.out_vt + ((size_t)bidx * ncols + (n - a.vt_col0)) * a.vt_ld;
+        if ((a.rows_per_batch & 7) == 0 && (a.vt_ld & 7) == 0 && m + 8 <= a.M) {
+          u32x4_t o;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] = pack2bf((v[2 * j] + bsv) * a.scale, (v[2 * j + 1] + bsv) * a.scale);
+          *reinterpret_cast<u32x4_t*>(dst + rin) = o;
+        } else {
+          for (int j = 0; j < 8 && m + j < a.M; ++j) {
+            const int bj = (m + j) / a.rows_per_batch, rj = (m + j) - bj * a.rows_per_batch;
+            ((uint16_t*)a.out_vt)[((size_t)bj * ncols + (n - a.vt_col0)) * a.vt_ld + rj] = f2bf((v[j] + bsv) * a.scale);
+          }
+        }
+      }
+    } else if (geglu) {
+      // 16 tile columns = 4 x (h0,h1,g0,g1) -> 8 outputs = one 16-B store
+      for (int q = tid; q < EPI_ROWS * (BN / 16); q += T) {
+        const int row = q / (BN / 16), c16 = q - row * (BN / 16);
+        const int m = m0 + row, n = n_blk + c16 * 16;
+        if (m >= a.M || n >= a.N) continue;
+        float o[8];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          f32x4_t v = *reinterpret_cast<const f32x4_t*>(smem + row * EPI_LD + (c16 * 16 + g * 4) * 4);
+          if (a.bias) v += *reinterpret_cast<const f32x4_t*>(a.bias + n + g * 4);
+          o[2 * g] = v[0] * gelu_erf_f(v[2]);
+          o[2 * g + 1] = v[1] * gelu_erf_f(v[3]);
+        }
+        u32x4_t w;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w[j] = pack2bf(o[2 * j], o[2 * j + 1]);
+        *reinterpret_cast<u32x4_t*>((uint16_t*)a.out + (size_t)m * a.ldo + (n >> 1)) = w;
+      }
+    } else {
+      for (int q = tid; q < EPI_ROWS * (BN / 8); q += T) {
+        const int row = q / (BN / 8), c8 = q - row * (BN / 8);
+        const int m = m0 + row, n = n_blk + c8 * 8;
+        if (m >= a.M || n >= a.N) continue;
+        f32x4_t v0 = *reinterpret_cast<const f32x4_t*>(smem + row * EPI_LD + c8 * 32);
+        f32x4_t v1 = *reinterpret_cast<const f32x4_t*>(smem + row * EPI_LD + c8 * 32 + 16);
+        if (splitk) {
+          float* wsp = a.workspace + ((size_t)split * a.M + m) * a.N + n;
+          *reinterpret_cast<f32x4_t*>(wsp) = v0;
+          *reinterpret_cast<f32x4_t*>(wsp + 4) = v1;
+          continue;
+        }
+        if (a.bias) {
+          v0 += *reinterpret_cast<const f32x4_t*>(a.bias + n);
+          v1 += *reinterpret_cast<const f32x4_t*>(a.bias + n + 4);
+        }
+        if (a.rowvec) {
+          const float* rv = a.rowvec + (size_t)(m / a.rows_per_batch) * a.ld_rowvec + n;
+          v0 += *reinterpret_cast<const f32x4_t*>(rv);
+          v1 += *reinterpret_cast<const f32x4_t*>(rv + 4);
+        }
+        v0 *= a.scale;
+        v1 *= a.scale;
+        if (a.res1) {
+          const u32x4_t r = *reinterpret_cast<const u32x4_t*>((const uint16_t*)a.res1 + (size_t)m * a.ldres1 + n);
+          v0[0] += bflo(r[0]); v0[1] += bfhi(r[0]); v0[2] += bflo(r[1]); v0[3] += bfhi(r[1]);
+          v1[0] += bflo(r[2]); v1[1] += bfhi(r[2]); v1[2] += bflo(r[3]); v1[3] += bfhi(r[3]);
+        }
+        if (a.res2) {
+          const u32x4_t r = *reinterpret_cast<const u32x4_t*>((const uint16_t*)a.res2 + (size_t)m * a.ldres2 + n);
+          v0[0] += bflo(r[0]); v0[1] += bfhi(r[0]); v0[2] += bflo(r[1]); v0[3] += bfhi(r[1]);
+          v1[0] += bflo(r[2]); v1[1] += bfhi(r[2]); v1[2] += bflo(r[3]); v1[3] += bfhi(r[3]);
+        }
+        if (a.act == PP_ACT_SILU) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { v0[j] = silu_f(v0[j]); v1[j] = silu_f(v1[j]); }
+        }
+        if (a.out_f32) {
+          float* op = (float*)a.out + (size_t)m * a.ldo + n;
+          *reinterpret_cast<f32x4_t*>(op) = v0;
+          *reinterpret_cast<f32x4_t*>(op + 4) = v1;
+        } else {
+          u32x4_t o;
+          o[0] = pack2bf(v0[0], v0[1]); o[1] = pack2bf(v0[2], v0[3]);
+          o[2] = pack2bf(v1[0], v1[1]); o[3] = pack2bf(v1[2], v1[3]);
+          *reinterpret_cast<u32x4_t*>((uint16_t*)a.out + (size_t)m * a.ldo + n) = o;
+        }
+      }
+    }
+  }
+}
+
 __global__ void __launch_bounds__(256) pp_splitk_reduce_kernel(const PPGemmArgs a, int splits) {
   const int n4 = a.N >> 2;
   const long long total = (long long)a.M * n4;
@@ -307,19 +638,40 @@ struct Choice {
   int tile, splitk;
 };
 
+// v2 (LDS-direct pipeline + staged 16-byte epilogue) needs 16-byte aligned rows on every tensor the epilogue touches
+bool v2_ok(const PPGemmArgs& a) {
+  if (a.N % 8) return false;
+  if (a.act == PP_ACT_GEGLU && (a.N % 16 || a.ldo % 8)) return false;
+  if (a.out_f32 ? (a.ldo % 4) : (a.ldo % 8)) return false;
+  if (a.res1 && a.ldres1 % 8) return false;
+  if (a.res2 && a.ldres2 % 8) return false;
+  if (a.out_vt && (a.vt_col0 % 160 || a.res1 || a.res2 || a.rowvec)) return false;
+  return true;
+}
+
 Choice choose(const PPGemmArgs& a) {
+  // Heuristic distilled from tools/gemm_sweep.py on MI355X (profiles/r01_gemm_sweep.txt):
+  //   * long-K implicit-GEMM convs: 256x160 tile, 8 waves, 3-stage LDS-direct pipeline; split-K until ~one block per CU;
+  //   * short-K linears: 128x160 (>= 2 blocks per CU) else 64x160, 2-stage (two co-resident blocks per CU);
+  //   * tensors the 16-byte staged epilogue cannot address fall back to the register-staged v1 kernel.
   Choice c{a.tile, a.splitk};
   const int tn = (a.N + 159) / 160;
   auto blocks = [&](int bm) { return ((a.M + bm - 1) / bm) * tn; };
-  if (c.tile == PP_TILE_AUTO) c.tile = (blocks(128) >= 256) ? PP_TILE_128x160 : PP_TILE_64x160;
-  const int bm = c.tile == PP_TILE_128x160 ? 128 : c.tile == PP_TILE_64x160 ? 64 : 256;
+  const bool conv = a.x_mode == PP_X_CONV3X3;
+  if (c.tile == PP_TILE_AUTO) {
+    if (!v2_ok(a)) c.tile = (blocks(128) >= 256) ? PP_TILE_128x160 : PP_TILE_64x160;
+    else if (conv) c.tile = 33;
+    else c.tile = (blocks(128) >= 512) ? 21 : 22;
+  }
+  const int tb = c.tile % 10;
+  const int bm = tb == PP_TILE_128x160 ? 128 : tb == PP_TILE_64x160 ? 64 : 256;
   if (c.splitk <= 0) {
     const int nb = blocks(bm), kt = a.K / 64;
+    const int want = conv ? 192 : 128, min_kt = conv ? 20 : 16;
     int sk = 1;
-    while (nb * sk < 224 && kt / (sk * 2) >= 12 && sk < 8) sk *= 2;
+    while (nb * sk < want && kt / (sk * 2) >= min_kt && sk < 8) sk *= 2;
     c.splitk = sk;
   }
-  if (a.act == PP_ACT_GEGLU && false) c.splitk = 1;
   return c;
 }
 
@@ -346,6 +698,40 @@ int launch(const PPGemmArgs& a, int splitk, hipStream_t st) {
   dim3 grid(d.tiles_m * d.tiles_n, splitk, 1);
   hipLaunchKernelGGL(kern, grid, dim3(T), LDS, st, a, d);
   PP_CHECK_LAUNCH("pp_gemm_kernel");
+  if (splitk > 1) {
+    const long long total = (long long)a.M * (a.N / 4);
+    int nb = (int)((total + 255) / 256);
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(pp_splitk_reduce_kernel, dim3(nb), dim3(256), 0, st, a, splitk);
+    PP_CHECK_LAUNCH("pp_splitk_reduce_kernel");
+  }
+  return PP_OK;
+}
+
+template <int BM, int BN, int WM, int WN, int XMODE, int NS>
+int launch2(const PPGemmArgs& a, int splitk, hipStream_t st) {
+  constexpr int T = WM * WN * 64;
+  constexpr int LDS = NS * (BM + BN) * 128;
+  static_assert(LDS <= 160 * 1024, "LDS budget");
+  static bool attr_set = false;
+  auto kern = pp_gemm_kernel_v2<BM, BN, WM, WN, XMODE, NS>;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) !=
+        hipSuccess) {
+      pp_set_last_error("hipFuncSetAttribute(gemm v2)", hipGetLastError());
+      return PP_ERR_LAUNCH;
+    }
+    attr_set = true;
+  }
+  GemmDerived d;
+  d.tiles_m = (a.M + BM - 1) / BM;
+  d.tiles_n = (a.N + BN - 1) / BN;
+  d.kt_total = a.K / 64;
+  d.kt_per_split = (d.kt_total + splitk - 1) / splitk;
+  d.ctiles = (a.c1 + a.c2) / 64;
+  dim3 grid(d.tiles_m * d.tiles_n, splitk, 1);
+  hipLaunchKernelGGL(kern, grid, dim3(T), LDS, st, a, d);
+  PP_CHECK_LAUNCH("pp_gemm_kernel_v2");
   if (splitk > 1) {
     const long long total = (long long)a.M * (a.N / 4);
     int nb = (int)((total + 255) / 256);
@@ -400,6 +786,7 @@ extern "C" int pp_gemm_bf16(const PPGemmArgs* args, void* stream) {
   if (v != PP_OK) return v;
   const Choice c = choose(a);
   if (c.splitk > 1 && !a.workspace) return PP_ERR_WORKSPACE;
+  if (c.tile > 10 && !v2_ok(a)) return PP_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)stream;
   const bool conv = a.x_mode == PP_X_CONV3X3;
   switch (c.tile) {
@@ -409,6 +796,18 @@ extern "C" int pp_gemm_bf16(const PPGemmArgs* args, void* stream) {
       return conv ? launch<64, 160, 2, 2, PP_X_CONV3X3>(a, c.splitk, st) : launch<64, 160, 2, 2, PP_X_PLAIN>(a, c.splitk, st);
     case PP_TILE_256x160:
       return conv ? launch<256, 160, 4, 2, PP_X_CONV3X3>(a, c.splitk, st) : launch<256, 160, 4, 2, PP_X_PLAIN>(a, c.splitk, st);
+#define PP_V2(ID, BM_, WM_, NS_)                                                                          \
+    case ID:                                                                                             \
+      return conv ? launch2<BM_, 160, WM_, 2, PP_X_CONV3X3, NS_>(a, c.splitk, st)                        \
+                  : launch2<BM_, 160, WM_, 2, PP_X_PLAIN, NS_>(a, c.splitk, st);
+      PP_V2(21, 128, 2, 2)
+      PP_V2(31, 128, 2, 3)
+      PP_V2(22, 64, 2, 2)
+      PP_V2(32, 64, 2, 3)
+      PP_V2(42, 64, 2, 4)
+      PP_V2(23, 256, 4, 2)
+      PP_V2(33, 256, 4, 3)
+#undef PP_V2
     default:
       return PP_ERR_BAD_ARG;
   }

@@ -40,7 +40,10 @@ def check(out, ref, atol, rtol, what=""):
 
 
 # ------------------------------------------------------------------------------------------------ GEMM
-@pytest.mark.parametrize("tile", [1, 2, 3])
+ALL_TILES = [1, 2, 3, 21, 31, 22, 32, 42, 23, 33]
+
+
+@pytest.mark.parametrize("tile", ALL_TILES)
 @pytest.mark.parametrize("M,N,K", [(256, 320, 320), (616, 640, 768), (1024, 960, 320), (2048, 320, 1280)])
 def test_gemm_plain(tile, M, N, K):
     x, w = bf(rnd(M, K, seed=1)), bf(rnd(N, K, seed=2, scale=K ** -0.5))
@@ -60,12 +63,13 @@ def test_gemm_transpose_detect():
     check(out, w.float().t(), 0, 0, "gemm identity")
 
 
-@pytest.mark.parametrize("splitk", [2, 4])
-def test_gemm_splitk(splitk):
+@pytest.mark.parametrize("tile", [2, 22, 42, 31])
+@pytest.mark.parametrize("splitk", [2, 4, 3])
+def test_gemm_splitk(splitk, tile):
     M, N, K = 512, 1280, 2560
     x, w = bf(rnd(M, K, seed=1)), bf(rnd(N, K, seed=2, scale=K ** -0.5))
     bias, res = rnd(N, seed=3), bf(rnd(M, N, seed=4))
-    out = ops.gemm(x, w, bias=bias, res1=res, res2=res, scale=0.5, tile=2, splitk=splitk)
+    out = ops.gemm(x, w, bias=bias, res1=res, res2=res, scale=0.5, tile=tile, splitk=splitk)
     ref = (x.float() @ w.float().t() + bias) * 0.5 + 2 * res.float()
     check(out, ref, 2e-2, 1e-2, "gemm splitk")
 
@@ -114,7 +118,7 @@ def conv_ref(x_nhwc, w_igemm, bias, stride=1, up=False):
     return y.permute(0, 2, 3, 1)
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3])
+@pytest.mark.parametrize("tile", ALL_TILES)
 @pytest.mark.parametrize("stride,up", [(1, False), (2, False), (1, True)])
 def test_conv3x3(tile, stride, up):
     B, H, W, Cin, Cout = 2, 16, 16, 320, 320
@@ -131,10 +135,11 @@ def test_conv3x3_concat_temb_res_splitk():
     w = bf(rnd(Cout, 9 * (C1 + C2), seed=3, scale=(9 * (C1 + C2)) ** -0.5))
     bias, temb = rnd(Cout, seed=4), rnd(1, Cout, seed=5)
     r1, r2 = bf(rnd(B, H, W, Cout, seed=6)), bf(rnd(B, H, W, Cout, seed=7))
-    for sk in (1, 4):
-        out = ops.conv3x3(x1, w, bias, x2=x2, rowvec=temb, res1=r1, res2=r2, tile=2, splitk=sk)
-        ref = conv_ref(torch.cat([x1, x2], -1), w, bias) + temb.view(1, 1, 1, -1) + r1.float() + r2.float()
-        check(out, ref, 3e-2, 1e-2, f"conv concat splitk{sk}")
+    ref = conv_ref(torch.cat([x1, x2], -1), w, bias) + temb.view(1, 1, 1, -1) + r1.float() + r2.float()
+    for tile in (2, 32, 31, 33):
+        for sk in (1, 4):
+            out = ops.conv3x3(x1, w, bias, x2=x2, rowvec=temb, res1=r1, res2=r2, tile=tile, splitk=sk)
+            check(out, ref, 3e-2, 1e-2, f"conv concat tile{tile} splitk{sk}")
 
 
 def test_conv3x3_halo_exact():
@@ -142,10 +147,11 @@ def test_conv3x3_halo_exact():
     B, H, W, Cin, Cout = 1, 8, 8, 64, 320
     x = torch.ones(B, H, W, Cin, dtype=torch.bfloat16, device=DEV)
     w = torch.ones(Cout, 9 * Cin, dtype=torch.bfloat16, device=DEV) / 64
-    out = ops.conv3x3(x, w, None, tile=2, splitk=1).float()
     cnt = F.conv2d(torch.ones(1, 1, H, W, device=DEV), torch.ones(1, 1, 3, 3, device=DEV), padding=1)[0, 0]
-    assert torch.equal(out[0, :, :, 0], cnt), (out[0, :, :, 0], cnt)
-    assert torch.equal(out[0, :, :, 319], cnt)
+    for tile in (2, 22, 21, 33):
+        out = ops.conv3x3(x, w, None, tile=tile, splitk=1).float()
+        assert torch.equal(out[0, :, :, 0], cnt), (tile, out[0, :, :, 0], cnt)
+        assert torch.equal(out[0, :, :, 319], cnt)
 
 
 # ------------------------------------------------------------------------------------------------ norms
