@@ -116,36 +116,34 @@ def roofline_pass(pipe):
     return per, flops, counts
 
 
-def cpu_baseline(sample_steps=1):
+def cpu_baseline():
     """The CPU oracle (kind 'port': plain-PyTorch fp32 restatement of the reference's diffusers path) timed on this
-    box's host cores on a bounded sample: one image (CFG batch 2) x `sample_steps` UNet forwards at 64x64 latents,
-    extrapolated to 50 steps."""
+    box's host cores on a BOUNDED sample of the same workload: ONE UNet forward of one image with CFG (batch 2) at
+    32x32 latents (256x256 px, BASELINE config 1's shape; 0.360 TFLOP), scaled to the 64x64-latent forward by the
+    algorithmic FLOP ratio (803.4 / 180.1 GFLOP per sample) and to 50 steps."""
     from oracle import sd_modules as OM
-    torch.set_num_threads(os.cpu_count())
+    cores = min(os.cpu_count() or 1, 64)        # more threads only add contention for these conv sizes
+    torch.set_num_threads(cores)
     with torch.device("meta"):
         o = OM.UNet2DConditionModel(in_channels=9)
     o = o.to_empty(device="cpu")
     g = torch.Generator("cpu").manual_seed(0)
     with torch.no_grad():
-        for p in o.parameters():
+        for n, p in o.named_parameters():
             if p.dim() == 1:
-                p.zero_()
+                p.fill_(1.0) if ("norm" in n and n.endswith("weight")) else p.zero_()
             else:
                 p.normal_(0, (1.0 / p[0].numel()) ** 0.5, generator=g)
-        for n, p in o.named_parameters():
-            if n.endswith("norm.weight") or ".norm1.weight" in n or ".norm2.weight" in n or ".norm3.weight" in n \
-                    or n == "conv_norm_out.weight":
-                p.fill_(1.0)
-        x = torch.randn(2, 9, 64, 64, generator=g)
+        x = torch.randn(2, 9, 32, 32, generator=g)
         e = torch.randn(2, 77, 768, generator=g)
-        o(x[:, :, :16, :16], 500, e)                  # touch weights / warm threads
+        o(x[:, :, :8, :8], 500, e)                    # touch weights / warm the thread pool
         t0 = time.perf_counter()
-        for _ in range(sample_steps):
-            o(x, 500, e)
-        dt = (time.perf_counter() - t0) / sample_steps
-    return {"value": 1.0 / (dt * 50), "unit": "images/s", "cores": os.cpu_count(), "kind": "port",
-            "sample": f"{sample_steps} UNet forward(s) of 1 image (CFG batch 2) at 64x64 latents, fp32 torch CPU oracle, "
-                      f"{dt:.2f} s/forward, extrapolated x50 steps"}
+        o(x, 500, e)
+        dt = time.perf_counter() - t0
+    scale = 803.4 / 180.1
+    return {"value": 1.0 / (dt * scale * 50), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"1 UNet forward, 1 image with CFG (batch 2), 32x32 latents, fp32 torch CPU oracle: {dt:.2f} s; "
+                      f"scaled x{scale:.2f} (FLOP ratio to 64x64 latents) x50 steps"}
 
 
 def main():

@@ -12,10 +12,12 @@
 //     permutation (the contraction index may be permuted freely) -- no permlane / LDS round trip for P;
 //   * V arrives already TRANSPOSED from the producing GEMM's epilogue (vt[b][h*d+j][key]), so both K and V^T tiles
 //     are staged with full-line 16-byte loads and no in-kernel transpose;
-//   * K tile rows are padded to an odd number of 16-B slots, V^T rows to an odd number of 8-B slots: the
-//     ds_read_b128 (K) and ds_read_b64 (V^T) fragment reads are bank-conflict free;
+//   * K and V^T tile rows are padded to an odd number of 16-B slots and the keys of a V^T row are permuted inside
+//     each 16-key block so that every MFMA operand fragment is ONE conflict-free ds_read_b128;
 //   * next K/V tile is prefetched into registers while the current one is consumed (global latency hidden behind
 //     the MFMAs), exp2 with the softmax scale folded into one FMA.
+#include <type_traits>
+
 #include "pp_common.h"
 
 namespace {
@@ -30,7 +32,7 @@ struct Cfg {
   static constexpr int DS = DP / 16;              // MFMA k-steps for QK^T
   static constexpr int DT = (D + 31) / 32;        // 32-wide output tiles of O^T
   static constexpr int KS = DP * 2 + 16;          // K tile row stride in bytes (odd number of 16-B slots)
-  static constexpr int VS = KB * 2 + 8;           // V^T tile row stride in bytes (odd number of 8-B slots)
+  static constexpr int VS = KB * 2 + 16;          // V^T tile row stride in bytes (odd number of 16-B slots)
   static constexpr int KBYTES = KB * KS;
   static constexpr int VROWS = DT * 32;
   static constexpr int VBYTES = VROWS * VS;
@@ -40,24 +42,35 @@ struct Cfg {
   static constexpr int VPT = (VPIECES + 255) / 256;
 };
 
+constexpr float RESCALE_THR = 8.0f;   // defer the O rescale while the running max grows by < 2^8 (log2 domain)
+
 template <int D>
-__global__ void __launch_bounds__(256, 1)
+__global__ void __launch_bounds__(256, (D <= 80 ? 2 : 1))
 attn_fwd_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __restrict__ k, int ldk,
                 const uint16_t* __restrict__ vt, int ldvt, uint16_t* __restrict__ o, int ldo, int heads, int nq, int nk,
                 float scale_log2e) {
   using C = Cfg<D>;
-  __shared__ __attribute__((aligned(16))) char smem[C::KBYTES + C::VBYTES];
-  char* ks = smem;
-  char* vs = smem + C::KBYTES;
+  constexpr int BUF = C::KBYTES + C::VBYTES;
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x (K tile | V^T tile)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = blockIdx.y, b = blockIdx.z;
   const int q0 = blockIdx.x * (QW * NW) + wave * QW;
   const int qi = lane & 31, half = lane >> 5;
 
-  // zero the V^T rows >= D once (they only feed output rows that are never stored, but must stay finite)
-  for (int i = tid; i < (C::VROWS - D) * (C::VS / 8); i += 256)
-    *reinterpret_cast<u32x2_t*>(vs + D * C::VS + i * 8) = u32x2_t{0u, 0u};
+  // zero the V^T rows >= D of both buffers once (they only feed output rows that are never stored, but must stay finite)
+  // Padding rows of the V^T tile (both buffers), written once: row D is ALL ONES, so the P.V MFMAs also produce the
+  // softmax denominator sum_k P[k][q] as output row D (no VALU adds; it is rescaled together with O for free).
+  // The remaining padding rows are zero (they feed output rows that are never stored, but must stay finite).
+  constexpr bool MFMA_SUM = C::VROWS > D;
+  if constexpr (MFMA_SUM) {
+    constexpr int PADP = (C::VROWS - D) * (C::VS / 8);   // 8-B pieces of padding rows per buffer
+    for (int i = tid; i < 2 * PADP; i += 256) {
+      const int bufi = i / PADP, r = i - bufi * PADP;
+      const uint32_t v = (r < C::VS / 8) ? 0x3F803F80u : 0u;   // bf16 1.0 pairs for row D
+      *reinterpret_cast<u32x2_t*>(smem + bufi * BUF + C::KBYTES + D * C::VS + r * 8) = u32x2_t{v, v};
+    }
+  }
 
   // ---- Q fragments (B operand): lane = query qi, k-slot = 8*half + jj  ->  Q[q0+qi][16 s + 8 half + jj]
   bf16x8_t qf[C::DS];
@@ -98,7 +111,9 @@ attn_fwd_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __restr
       vreg[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_v, off, 0, 0);
     }
   };
-  auto store_tile = [&]() {
+  auto store_tile = [&](int bufi) {
+    char* ks = smem + bufi * BUF;
+    char* vs = ks + C::KBYTES;
 #pragma unroll
     for (int i = 0; i < C::KPT; ++i) {
       const int pc = tid + i * 256;
@@ -112,9 +127,12 @@ attn_fwd_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __restr
       const int pc = tid + i * 256;
       if (pc < C::VPIECES) {
         const int row = pc >> 3, sl = pc & 7;
-        char* dst = vs + row * C::VS + sl * 16;   // 8-B aligned only (VS = 136)
-        *reinterpret_cast<u32x2_t*>(dst) = u32x2_t{vreg[i][0], vreg[i][1]};
-        *reinterpret_cast<u32x2_t*>(dst + 8) = u32x2_t{vreg[i][2], vreg[i][3]};
+        // keys are permuted inside every 16-key block to [0-3, 8-11 | 4-7, 12-15] so that the 8 keys one lane half
+        // contracts over (it owns S^T rows 4h..4h+3 and 8+4h..8+4h+3) are ONE contiguous 16-byte fragment
+        char* blk = vs + row * C::VS + (sl >> 1) * 32;
+        const int pos = (sl & 1) * 8;                       // 8-key piece: even -> keys 0-7, odd -> keys 8-15
+        *reinterpret_cast<u32x2_t*>(blk + pos) = u32x2_t{vreg[i][0], vreg[i][1]};        // keys +0..3
+        *reinterpret_cast<u32x2_t*>(blk + 16 + pos) = u32x2_t{vreg[i][2], vreg[i][3]};   // keys +4..7
       }
     }
   };
@@ -124,56 +142,71 @@ attn_fwd_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __restr
   for (int t = 0; t < C::DT; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) oacc[t][r] = 0.f;
-  float m_run = -1.0e30f, l_run = 0.f;
+  float m_run = -1.0e30f, l_run = 0.f;   // m_run in the log2 domain (raw score * scale * log2 e)
 
-  const int ntiles = (nk + KB - 1) / KB;
-  load_tile(0);
-  store_tile();
-  __syncthreads();
-
-  for (int t = 0; t < ntiles; ++t) {
-    const int t0 = t * KB;
-    if (t + 1 < ntiles) load_tile(t0 + KB);
-
-    // ---- S^T = K Q^T : two 32-key sub-tiles
+  // one 64-key tile: S^T = K Q^T, online softmax (per-lane row state), O^T += V^T P^T
+  auto tile = [&](const char* ks, const char* vs, int t0, auto tail_tag) {
+    constexpr bool TAIL = decltype(tail_tag)::value;
     f32x16_t sacc[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) sacc[j][r] = 0.f;
+      const f32x16_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int s = 0; s < C::DS; ++s) {
         const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(ks + (32 * j + qi) * C::KS + (16 * s + 8 * half) * 2);
-        sacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sacc[j], 0, 0, 0);
+        sacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], s == 0 ? zero : sacc[j], 0, 0, 0);
       }
     }
-    // ---- mask keys >= nk (last tile only), tile max
+    // V^T fragments of the whole tile are fetched NOW (D = 40), so their LDS latency hides behind the softmax VALU
+    // block instead of serialising with the P.V MFMAs
+    constexpr bool PREF = (C::DT <= 2);   // d = 40 (d = 80 would spill at 2 waves/SIMD)
+    bf16x8_t vpre[2][2][PREF ? C::DT : 1];
+    if constexpr (PREF) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int dt = 0; dt < C::DT; ++dt)
+            vpre[j][u][dt] = *reinterpret_cast<const bf16x8_t*>(vs + (dt * 32 + qi) * C::VS + (2 * j + u) * 32 + half * 16);
+    }
     float tmax = -1.0e30f;
-    const bool tail = (t0 + KB > nk);
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        if (tail) {
+        if (TAIL) {   // keys >= nk exist only in the last tile
           const int key = t0 + 32 * j + (r & 3) + 8 * (r >> 2) + 4 * half;
           if (key >= nk) sacc[j][r] = -1.0e30f;
         }
         tmax = fmaxf(tmax, sacc[j][r]);
       }
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-    const float m_new = fmaxf(m_run, tmax);
-    const float alpha = exp2f((m_run - m_new) * scale_log2e);
-    const float mc = m_new * scale_log2e;
-    m_run = m_new;
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64)) * scale_log2e;
+    // deferred rescale: keep the stale max while it is within 2^RESCALE_THR of the true one (P stays <= 2^THR; the
+    // decision precedes every exponentiation of this tile and all of the previous tile's P.V is already in O)
+    if (!__all(tmax - m_run <= RESCALE_THR)) {
+      const float m_new = fmaxf(m_run, tmax);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      m_run = m_new;
+      if constexpr (!MFMA_SUM) l_run *= alpha;
+#pragma unroll
+      for (int dt = 0; dt < C::DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+    }
     float psum = 0.f;
     bf16x8_t pf[2][2];
+    const f32x2_t c2 = {scale_log2e, scale_log2e}, nm2 = {-m_run, -m_run};
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       float p[16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        p[r] = exp2f(fmaf(sacc[j][r], scale_log2e, -mc));
-        psum += p[r];
+      for (int r = 0; r < 16; r += 2) {
+        const f32x2_t s2 = {sacc[j][r], sacc[j][r + 1]};
+        const f32x2_t e2 = __builtin_elementwise_fma(s2, c2, nm2);        // v_pk_fma_f32: two scores per VALU op
+        p[r] = __builtin_amdgcn_exp2f(e2[0]);
+        p[r + 1] = __builtin_amdgcn_exp2f(e2[1]);
+        if constexpr (!MFMA_SUM) psum += p[r] + p[r + 1];
       }
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
@@ -185,37 +218,48 @@ attn_fwd_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __restr
         pf[j][u] = __builtin_bit_cast(bf16x8_t, w);
       }
     }
-    l_run = l_run * alpha + psum;
-#pragma unroll
-    for (int dt = 0; dt < C::DT; ++dt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
-
-    // ---- O^T += V^T P^T : key slot (half, jj) <-> key 16u + 4 half + jj (jj<4) | 16u + 8 + 4 half + jj-4
+    if constexpr (!MFMA_SUM) l_run += psum;
+    // O^T += V^T P^T : key slot (half, jj) <-> key 16u + 4 half + jj (jj<4) | 16u + 8 + 4 half + jj-4
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int koff = (32 * j + 16 * u + 4 * half) * 2;
+      for (int u = 0; u < 2; ++u)
 #pragma unroll
         for (int dt = 0; dt < C::DT; ++dt) {
-          const char* vp = vs + (dt * 32 + qi) * C::VS + koff;
-          const u32x2_t lo = *reinterpret_cast<const u32x2_t*>(vp);
-          const u32x2_t hi = *reinterpret_cast<const u32x2_t*>(vp + 16);
-          const u32x4_t w = {lo[0], lo[1], hi[0], hi[1]};
-          oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, w), pf[j][u], oacc[dt], 0, 0, 0);
+          bf16x8_t vf;
+          if constexpr (PREF) vf = vpre[j][u][dt];
+          else vf = *reinterpret_cast<const bf16x8_t*>(vs + (dt * 32 + qi) * C::VS + (2 * j + u) * 32 + half * 16);
+          oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[j][u], oacc[dt], 0, 0, 0);
         }
-      }
+  };
 
-    __syncthreads();                       // everyone done reading this tile
-    if (t + 1 < ntiles) {
-      store_tile();
-      __syncthreads();                     // next tile visible
-    }
+  const int ntiles = (nk + KB - 1) / KB;
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+
+  for (int t = 0; t < ntiles; ++t) {
+    const int t0 = t * KB;
+    const bool more = t + 1 < ntiles;
+    if (more) load_tile(t0 + KB);                       // global -> registers, in flight during the MFMAs below
+    const char* ks = smem + (t & 1) * BUF;
+    if (t0 + KB > nk) tile(ks, ks + C::KBYTES, t0, std::true_type{});
+    else tile(ks, ks + C::KBYTES, t0, std::false_type{});
+    if (more) store_tile((t + 1) & 1);                  // the other buffer: last read two barriers ago
+    __syncthreads();
   }
 
   // ---- epilogue: lane = query qi; rows (dcols) = dt*32 + (r&3) + 8 (r>>2) + 4 half
-  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  float l_tot;
+  if constexpr (MFMA_SUM) {
+    // output row D of O^T: tile D/32, row D%32 = 8*(r>>2) + (r&3) + 4*half  ->  held by the half-0 lanes
+    constexpr int LR = D % 32;
+    static_assert((LR & 7) < 4, "row D must live in lane half 0");
+    const float l0 = oacc[D / 32][4 * (LR >> 3) + (LR & 3)];
+    l_tot = __shfl(l0, qi, 64);
+  } else {
+    l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  }
   const float inv = 1.0f / l_tot;
   const int qrow = q0 + qi;
   if (qrow < nq) {
@@ -255,31 +299,38 @@ __global__ void __launch_bounds__(256) transpose_v_kernel(const uint16_t* __rest
 
 }  // namespace
 
+template <int D>
+static int launch_attn(const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt, void* o, int ldo,
+                       int batch, int heads, int nq, int nk, float sl2, hipStream_t st) {
+  constexpr int LDS = 2 * (Cfg<D>::KBYTES + Cfg<D>::VBYTES);
+  static bool attr_set = false;
+  if (!attr_set && LDS > 64 * 1024) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<D>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
+      pp_set_last_error("hipFuncSetAttribute(attention)", hipGetLastError());
+      return PP_ERR_LAUNCH;
+    }
+    attr_set = true;
+  }
+  const dim3 grid((nq + QW * NW - 1) / (QW * NW), heads, batch), block(256);
+  hipLaunchKernelGGL(attn_fwd_kernel<D>, grid, block, LDS, st, (const uint16_t*)q, ldq, (const uint16_t*)k, ldk,
+                     (const uint16_t*)vt, ldvt, (uint16_t*)o, ldo, heads, nq, nk, sl2);
+  PP_CHECK_LAUNCH("attn_fwd_kernel");
+  return PP_OK;
+}
+
 extern "C" int pp_attention_fwd(const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt, void* o,
                                 int ldo, int batch, int heads, int nq, int nk, int d, float scale, void* stream) {
   if (!q || !k || !vt || !o || batch <= 0 || heads <= 0 || nq <= 0 || nk <= 0) return PP_ERR_BAD_ARG;
   if (ldq % 8 || ldk % 8 || ldvt % 8 || ldo % 4 || ldvt < nk) return PP_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)stream;
-  const dim3 grid((nq + QW * NW - 1) / (QW * NW), heads, batch), block(256);
   const float sl2 = scale * 1.4426950408889634f;
   switch (d) {
-    case 40:
-      hipLaunchKernelGGL(attn_fwd_kernel<40>, grid, block, 0, st, (const uint16_t*)q, ldq, (const uint16_t*)k, ldk,
-                         (const uint16_t*)vt, ldvt, (uint16_t*)o, ldo, heads, nq, nk, sl2);
-      break;
-    case 80:
-      hipLaunchKernelGGL(attn_fwd_kernel<80>, grid, block, 0, st, (const uint16_t*)q, ldq, (const uint16_t*)k, ldk,
-                         (const uint16_t*)vt, ldvt, (uint16_t*)o, ldo, heads, nq, nk, sl2);
-      break;
-    case 160:
-      hipLaunchKernelGGL(attn_fwd_kernel<160>, grid, block, 0, st, (const uint16_t*)q, ldq, (const uint16_t*)k, ldk,
-                         (const uint16_t*)vt, ldvt, (uint16_t*)o, ldo, heads, nq, nk, sl2);
-      break;
-    default:
-      return PP_ERR_UNSUPPORTED;
+    case 40: return launch_attn<40>(q, ldq, k, ldk, vt, ldvt, o, ldo, batch, heads, nq, nk, sl2, st);
+    case 80: return launch_attn<80>(q, ldq, k, ldk, vt, ldvt, o, ldo, batch, heads, nq, nk, sl2, st);
+    case 160: return launch_attn<160>(q, ldq, k, ldk, vt, ldvt, o, ldo, batch, heads, nq, nk, sl2, st);
+    default: return PP_ERR_UNSUPPORTED;
   }
-  PP_CHECK_LAUNCH("attn_fwd_kernel");
-  return PP_OK;
 }
 
 extern "C" int pp_transpose_v(const void* v, int ld, int batch, int nk, int cols, void* vt, int ldvt, void* stream) {

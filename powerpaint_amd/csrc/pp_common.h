@@ -18,7 +18,12 @@ PP_DEVINL uint16_t f2bf(float f) {
   __bf16 b = (__bf16)f;  // round-to-nearest-even, v_cvt_pk_bf16_f32 on gfx950
   return __builtin_bit_cast(uint16_t, b);
 }
-PP_DEVINL uint32_t pack2bf(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+PP_DEVINL uint32_t pack2bf(float lo, float hi) {   // one v_cvt_pk_bf16_f32
+  const f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+}
 PP_DEVINL float bflo(uint32_t u) { return __uint_as_float(u << 16); }
 PP_DEVINL float bfhi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
 
