@@ -157,6 +157,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--dump-launches", default=None, help="write per-launch HIP-event timings of one step (JSON)")
     args = ap.parse_args()
 
     rank, world, local = ppdist.init_from_env()
@@ -217,6 +218,10 @@ def main():
                                "alg_flop_per_launch": flops[k] / counts[k]}
             res["per_kernel_ms_per_denoise_step"] = {n: round(v, 4) for n, v in sorted(per.items(), key=lambda kv: -kv[1])}
             res["per_kernel_tflops"] = {n: round(flops[n] / 1e12 / (per[n] * 1e-3), 1) for n in flops if per.get(n)}
+            if args.dump_launches:
+                prog = pipe._loop.program
+                json.dump([{"i": i, "what": prog.describe(i), "ms": prog.last_launch_ms[i]}
+                           for i in range(len(prog.calls))], open(args.dump_launches, "w"))
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res), flush=True)

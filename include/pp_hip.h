@@ -116,16 +116,17 @@ int pp_timestep_embedding(const float* t_dev, int rows, int dim, float* out, voi
  * GroupNorm (+ optional SiLU) on NHWC bf16, two launches: statistics, then apply.
  * Replaces ResnetBlock2D.norm1/norm2 + nonlinearity, Transformer2DModel.norm, conv_norm_out + conv_act
  * (unet_2d_condition.py:1351-1353) -- nn.GroupNorm(32, C, eps).
- *   stats : x = concat(x1[c1], x2[c2]) per pixel; writes scale/shift fp32 [batch][C]:
- *           scale = rstd*gamma, shift = beta - mean*rstd*gamma.   workspace: pp_groupnorm_workspace_bytes().
- *   apply : y[b][p][c] = act(x*scale + shift) as bf16, y row stride = C.
+ *   stats : x = concat(x1[c1], x2[c2]) per pixel; per-chunk partial (sum, sum of squares) per group -> workspace
+ *           (pp_groupnorm_workspace_bytes()).
+ *   apply : folds the partials (fp64, fixed order), then y[b][p][c] = act((x - mean) * rstd * gamma + beta) as bf16,
+ *           y row stride = c1 + c2.  `workspace` is the buffer the stats call wrote (same batch / hw / channels).
  */
 size_t pp_groupnorm_workspace_bytes(int batch, int hw, int C);
-int pp_groupnorm_stats(const void* x1, int c1, const void* x2, int c2, int batch, int hw, int groups, float eps,
-                       const float* gamma, const float* beta, float* scale_shift /* [batch][2][C] */,
+int pp_groupnorm_stats(const void* x1, int c1, const void* x2, int c2, int batch, int hw, int groups,
                        float* workspace, void* stream);
-int pp_groupnorm_apply(const void* x1, int c1, const void* x2, int c2, int batch, int hw,
-                       const float* scale_shift, int silu, void* y, void* stream);
+int pp_groupnorm_apply(const void* x1, int c1, const void* x2, int c2, int batch, int hw, int groups, float eps,
+                       const float* gamma, const float* beta, const float* workspace, int silu, void* y,
+                       void* stream);
 
 /* LayerNorm over the last dim, bf16 [rows][C] -> bf16 [rows][C]; BasicTransformerBlock.norm1/2/3 (eps 1e-5). */
 int pp_layernorm(const void* x, int rows, int C, const float* gamma, const float* beta, float eps, void* y,

@@ -45,8 +45,9 @@ SIGNATURES = {
     "pp_linear_skinny": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp]),
     "pp_timestep_embedding": (C.c_int, [vp, C.c_int, C.c_int, vp, vp]),
     "pp_groupnorm_workspace_bytes": (sz, [C.c_int, C.c_int, C.c_int]),
-    "pp_groupnorm_stats": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, f32, vp, vp, vp, vp, vp]),
-    "pp_groupnorm_apply": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp, vp]),
+    "pp_groupnorm_stats": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
+    "pp_groupnorm_apply": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, f32, vp, vp, vp, C.c_int, vp,
+                                     vp]),
     "pp_layernorm": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, f32, vp, vp]),
     "pp_attention_fwd": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_int, C.c_int, f32, vp]),

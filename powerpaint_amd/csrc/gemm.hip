@@ -479,22 +479,28 @@ __global__ void __launch_bounds__(WM* WN * 64, 1) pp_gemm_kernel_v2(const PPGemm
 
     const char* xs = smem + stage * STAGE;
     const char* ws = xs + XBYTES;
-    if (!(dbg & 2))
+    if (!(dbg & 2)) {
+      // all 2*(MI+NI) fragment reads of the tile are issued up front (the LDS latency of k-step 1 hides behind the MFMAs
+      // of k-step 0 instead of serialising read -> wait -> 4 MFMAs -> read ...), then 2*MI*NI MFMAs back to back
+      bf16x8_t xf[2][MI], wf[2][NI];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int so = ((ks * 4 + fk) ^ fsw) << 4;
-      bf16x8_t xf[MI], wf[NI];
+      for (int ks = 0; ks < 2; ++ks) {
+        const int so = ((ks * 4 + fk) ^ fsw) << 4;
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi)
-        xf[mi] = *reinterpret_cast<const bf16x8_t*>(xs + (xrow0 + mi * 16) * 128 + so);
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni)
-        wf[ni] = *reinterpret_cast<const bf16x8_t*>(ws + (wrow0 + ni * 16) * 128 + so);
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni)
+        for (int ni = 0; ni < NI; ++ni)
+          wf[ks][ni] = *reinterpret_cast<const bf16x8_t*>(ws + (wrow0 + ni * 16) * 128 + so);
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
-          acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
+          xf[ks][mi] = *reinterpret_cast<const bf16x8_t*>(xs + (xrow0 + mi * 16) * 128 + so);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+            acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][ni], xf[ks][mi], acc[ni][mi], 0, 0, 0);
     }
     stage = stage + 1 == NS ? 0 : stage + 1;
   }
@@ -650,26 +656,40 @@ bool v2_ok(const PPGemmArgs& a) {
 }
 
 Choice choose(const PPGemmArgs& a) {
-  // Heuristic distilled from tools/gemm_sweep.py on MI355X (profiles/r01_gemm_sweep.txt):
-  //   * long-K implicit-GEMM convs: 256x160 tile, 8 waves, 3-stage LDS-direct pipeline; split-K until ~one block per CU;
-  //   * short-K linears: 128x160 (>= 2 blocks per CU) else 64x160, 2-stage (two co-resident blocks per CU);
-  //   * tensors the 16-byte staged epilogue cannot address fall back to the register-staged v1 kernel.
+  // Heuristic distilled from tools/gemm_sweep.py on MI355X (profiles/r01_gemm_sweep*.txt).  The unit is "blocks per
+  // CU" of the 256-CU chip: two co-resident 128x160 / 64x160 blocks (NS = 2) hide each other's barrier and LDS latency;
+  // below that, one block per CU with a 3-stage pipeline, and split-K once even 64-row tiles cannot fill the chip.
+  // Tensors the 16-byte staged epilogue cannot address fall back to the register-staged v1 kernel.
   Choice c{a.tile, a.splitk};
   const int tn = (a.N + 159) / 160;
   auto blocks = [&](int bm) { return ((a.M + bm - 1) / bm) * tn; };
   const bool conv = a.x_mode == PP_X_CONV3X3;
+  const int nb128 = blocks(128), nb64 = blocks(64), kt = a.K / 64;
   if (c.tile == PP_TILE_AUTO) {
-    if (!v2_ok(a)) c.tile = (blocks(128) >= 256) ? PP_TILE_128x160 : PP_TILE_64x160;
-    else if (conv) c.tile = 33;
-    else c.tile = (blocks(128) >= 512) ? 21 : 22;
-  }
-  const int tb = c.tile % 10;
-  const int bm = tb == PP_TILE_128x160 ? 128 : tb == PP_TILE_64x160 ? 64 : 256;
-  if (c.splitk <= 0) {
-    const int nb = blocks(bm), kt = a.K / 64;
-    const int want = conv ? 192 : 128, min_kt = conv ? 20 : 16;
     int sk = 1;
-    while (nb * sk < want && kt / (sk * 2) >= min_kt && sk < 8) sk *= 2;
+    if (!v2_ok(a)) {
+      c.tile = (nb128 >= 256) ? PP_TILE_128x160 : PP_TILE_64x160;
+      while (blocks(c.tile == PP_TILE_128x160 ? 128 : 64) * sk < 224 && kt / (sk * 2) >= 12 && sk < 8) sk *= 2;
+    } else if (nb128 >= 512) {
+      c.tile = 21;
+    } else if (nb64 >= 512) {
+      if (conv && a.K > 8640) { c.tile = 21; sk = 2; }
+      else c.tile = 22;
+    } else if (a.K <= 2880) {
+      c.tile = 32;
+      while (nb64 * sk < 128 && kt / (sk * 2) >= 16 && sk < 8) sk *= 2;
+    } else {
+      c.tile = 21;
+      while (nb128 * sk < 384 && kt / (sk * 2) >= 16 && sk < 8) sk *= 2;
+      if (!conv && sk == 1) c.tile = 32;
+    }
+    if (c.splitk <= 0) c.splitk = sk;
+  }
+  if (c.splitk <= 0) {
+    const int tb = c.tile % 10;
+    const int bm = tb == PP_TILE_128x160 ? 128 : tb == PP_TILE_64x160 ? 64 : 256;
+    int sk = 1;
+    while (blocks(bm) * sk < 192 && kt / (sk * 2) >= 16 && sk < 8) sk *= 2;
     c.splitk = sk;
   }
   return c;

@@ -3,23 +3,16 @@
 // GroupNorm on NHWC: the C/32 channels of a group are contiguous per pixel but strided across pixels, so a
 // one-block-per-group layout would read 20..160-byte fragments.  Instead every thread owns ONE fixed 16-byte channel
 // slot (8 channels) and walks pixels: all global reads are full-line coalesced, per-channel partial sums stay in
-// registers, and only the tiny per-block fold touches LDS.  Three launches:
-//   stats    : [batch][chunk] partial (sum, sumsq) per group  -> workspace           (reads x once)
-//   finalize : fold chunks (fp64), emit per-(batch,channel) scale/shift fp32
-//   apply    : y = act(x*scale + shift)                                               (reads x once, writes y once)
-// The fold order is fixed, so results are bit-reproducible run to run (no float atomics).
+// registers, and only the tiny per-block fold touches LDS.  Two launches:
+//   stats : [batch][chunk] partial (sum, sumsq) per group -> workspace                (reads x once)
+//   apply : every block first folds the chunk partials (fp64, fixed order) into per-channel scale / shift in LDS,
+//           then y = act(x*scale + shift)                                             (reads x once, writes y once)
+// Two launches per norm; the fold order is fixed, so results are bit-reproducible run to run (no float atomics).
 #include "pp_common.h"
 
 namespace {
 
 constexpr int GN_MAX_T = 512;
-
-PP_DEVINL int gn_chunks(int hw) {
-  int c = hw / 64;
-  if (c < 1) c = 1;
-  if (c > 64) c = 64;
-  return c;
-}
 
 // grid (nchunk, batch); block = S*P threads, S = C/8 slots, P pixel lanes
 __global__ void __launch_bounds__(GN_MAX_T) gn_stats_kernel(const uint16_t* __restrict__ x1, int c1,
@@ -38,18 +31,27 @@ __global__ void __launch_bounds__(GN_MAX_T) gn_stats_kernel(const uint16_t* __re
   const uint16_t* src;
   int cs, cl;
   if (c < c1) { src = x1; cs = c1; cl = c; } else { src = x2; cs = c2; cl = c - c1; }
+  src += (size_t)b * hw * cs + cl;
   float s[8], q[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) { s[j] = 0.f; q[j] = 0.f; }
-  for (int p = p0 + pl; p < p1; p += P) {
-    const u32x4_t v = *reinterpret_cast<const u32x4_t*>(src + ((size_t)b * hw + p) * cs + cl);
+  auto acc8 = [&](const u32x4_t v) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const float lo = bflo(v[j]), hi = bfhi(v[j]);
       s[2 * j] += lo; q[2 * j] += lo * lo;
       s[2 * j + 1] += hi; q[2 * j + 1] += hi * hi;
     }
+  };
+  int p = p0 + pl;
+  for (; p + 3 * P < p1; p += 4 * P) {      // four independent 16-B loads in flight per lane
+    const u32x4_t v0 = *reinterpret_cast<const u32x4_t*>(src + (size_t)p * cs);
+    const u32x4_t v1 = *reinterpret_cast<const u32x4_t*>(src + (size_t)(p + P) * cs);
+    const u32x4_t v2 = *reinterpret_cast<const u32x4_t*>(src + (size_t)(p + 2 * P) * cs);
+    const u32x4_t v3 = *reinterpret_cast<const u32x4_t*>(src + (size_t)(p + 3 * P) * cs);
+    acc8(v0); acc8(v1); acc8(v2); acc8(v3);
   }
+  for (; p < p1; p += P) acc8(*reinterpret_cast<const u32x4_t*>(src + (size_t)p * cs));
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     red[(pl * C + c + j) * 2 + 0] = s[j];
@@ -70,46 +72,61 @@ __global__ void __launch_bounds__(GN_MAX_T) gn_stats_kernel(const uint16_t* __re
   }
 }
 
-// grid (batch); block 256
-__global__ void __launch_bounds__(256) gn_finalize_kernel(const float* __restrict__ partial, int nchunk, int groups,
-                                                         int C, int hw, float eps, const float* __restrict__ gamma,
-                                                         const float* __restrict__ beta, float* __restrict__ ss) {
-  __shared__ float mean_s[64], rstd_s[64];
-  const int b = blockIdx.x, tid = threadIdx.x;
-  if (tid < groups) {
+// Fold of the per-chunk partials (fixed order => deterministic) into per-channel scale / shift, executed in the
+// prologue of EVERY apply block (a few KB of L2-resident reads) instead of a separate launch.
+//   ss_out (optional, block 0 of each batch item): [batch][2][C] for callers that want the affine form.
+PP_DEVINL void gn_fold(const float* __restrict__ partial, int nchunk, int groups, int C, int hw, float eps,
+                       const float* __restrict__ gamma, const float* __restrict__ beta, int b, float* mean_s,
+                       float* rstd_s, float* sc_s, float* sh_s) {
+  const int tid = threadIdx.x;
+  // 8 lanes per group, each folds a strided subset of the chunks; combined in fixed lane order
+  const int g = tid >> 3, sub = tid & 7;
+  if (g < groups) {
     double s = 0.0, q = 0.0;
-    for (int k = 0; k < nchunk; ++k) {
-      const float* o = partial + (((size_t)b * nchunk + k) * groups + tid) * 2;
+    for (int k = sub; k < nchunk; k += 8) {
+      const float* o = partial + (((size_t)b * nchunk + k) * groups + g) * 2;
       s += (double)o[0];
       q += (double)o[1];
     }
-    const double n = (double)hw * (double)(C / groups);
-    const double mean = s / n;
-    double var = q / n - mean * mean;
-    if (var < 0.0) var = 0.0;
-    mean_s[tid] = (float)mean;
-    rstd_s[tid] = (float)(1.0 / sqrt(var + (double)eps));
+#pragma unroll
+    for (int off = 4; off > 0; off >>= 1) {
+      s += __shfl_down(s, off, 8);
+      q += __shfl_down(q, off, 8);
+    }
+    if (sub == 0) {
+      const double n = (double)hw * (double)(C / groups);
+      const double mean = s / n;
+      double var = q / n - mean * mean;
+      if (var < 0.0) var = 0.0;
+      mean_s[g] = (float)mean;
+      rstd_s[g] = (float)(1.0 / sqrt(var + (double)eps));
+    }
   }
   __syncthreads();
   const int cg = C / groups;
-  for (int c = tid; c < C; c += 256) {
-    const int g = c / cg;
-    const float sc = rstd_s[g] * gamma[c];
-    ss[((size_t)b * 2 + 0) * C + c] = sc;
-    ss[((size_t)b * 2 + 1) * C + c] = beta[c] - mean_s[g] * sc;
+  for (int c = tid; c < C; c += blockDim.x) {
+    const int gg = c / cg;
+    const float sc = rstd_s[gg] * gamma[c];
+    sc_s[c] = sc;
+    sh_s[c] = beta[c] - mean_s[gg] * sc;
   }
+  __syncthreads();
 }
 
 // grid (blocks, batch): flat over 16-B pieces of one batch item
 template <bool SILU>
 __global__ void __launch_bounds__(256) gn_apply_kernel(const uint16_t* __restrict__ x1, int c1,
                                                       const uint16_t* __restrict__ x2, int c2, int hw,
-                                                      const float* __restrict__ ss, uint16_t* __restrict__ y) {
+                                                      const float* __restrict__ partial, int nchunk, int groups,
+                                                      float eps, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, uint16_t* __restrict__ y) {
+  extern __shared__ __attribute__((aligned(16))) float tab[];   // [2][C] scale | shift, then 2 x 64 group stats
   const int C = c1 + c2, S = C >> 3;
   const int b = blockIdx.y;
+  float* sc = tab;
+  float* sh = tab + C;
+  gn_fold(partial, nchunk, groups, C, hw, eps, gamma, beta, b, tab + 2 * C, tab + 2 * C + 64, sc, sh);
   const int total = hw * S;
-  const float* sc = ss + (size_t)b * 2 * C;
-  const float* sh = sc + C;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
     const int p = i / S;
     const int c = (i - p * S) * 8;
@@ -190,49 +207,56 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const uint16_t* __restri
 
 }  // namespace
 
+static int gn_nchunk(int hw) {
+  int c = hw / 16;
+  if (c < 1) c = 1;
+  if (c > 128) c = 128;
+  return c;
+}
+
 extern "C" size_t pp_groupnorm_workspace_bytes(int batch, int hw, int C) {
   (void)C;
-  return (size_t)batch * 64 * 64 * 2 * sizeof(float);  // [batch][<=64 chunks][<=64 groups][2]
+  (void)hw;
+  return (size_t)batch * 128 * 64 * 2 * sizeof(float);  // [batch][<=128 chunks][<=64 groups][2]
 }
 
 extern "C" int pp_groupnorm_stats(const void* x1, int c1, const void* x2, int c2, int batch, int hw, int groups,
-                                  float eps, const float* gamma, const float* beta, float* scale_shift,
                                   float* workspace, void* stream) {
   const int C = c1 + c2;
-  if (!x1 || !gamma || !beta || !scale_shift) return PP_ERR_BAD_ARG;
+  if (!x1) return PP_ERR_BAD_ARG;
   if (!workspace) return PP_ERR_WORKSPACE;
-  if (c1 <= 0 || c1 % 8 || c2 % 8 || (c2 > 0 && !x2) || groups <= 0 || groups > 64 || C % groups) return PP_ERR_BAD_ARG;
+  if (c1 <= 0 || c1 % 8 || c2 % 8 || (c2 > 0 && !x2) || groups <= 0 || groups > 32 || C % groups) return PP_ERR_BAD_ARG;
   const int S = C / 8;
   if (S > GN_MAX_T) return PP_ERR_UNSUPPORTED;
   int P = GN_MAX_T / S;
-  if (P > 16) P = 16;
-  const int nchunk = hw / 64 < 1 ? 1 : (hw / 64 > 64 ? 64 : hw / 64);
-  hipStream_t st = (hipStream_t)stream;
+  if (P > 8) P = 8;
   const size_t lds = (size_t)P * C * 2 * sizeof(float);
   if (lds > 64 * 1024) return PP_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunk, batch), dim3(S * P), lds, st, (const uint16_t*)x1, c1,
-                     (const uint16_t*)x2, c2, hw, groups, S, P, workspace);
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(gn_nchunk(hw), batch), dim3(S * P), lds, (hipStream_t)stream,
+                     (const uint16_t*)x1, c1, (const uint16_t*)x2, c2, hw, groups, S, P, workspace);
   PP_CHECK_LAUNCH("gn_stats_kernel");
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(batch), dim3(256), 0, st, workspace, nchunk, groups, C, hw, eps, gamma,
-                     beta, scale_shift);
-  PP_CHECK_LAUNCH("gn_finalize_kernel");
   return PP_OK;
 }
 
-extern "C" int pp_groupnorm_apply(const void* x1, int c1, const void* x2, int c2, int batch, int hw,
-                                  const float* scale_shift, int silu, void* y, void* stream) {
-  if (!x1 || !scale_shift || !y || c1 <= 0 || c1 % 8 || c2 % 8 || (c2 > 0 && !x2)) return PP_ERR_BAD_ARG;
+extern "C" int pp_groupnorm_apply(const void* x1, int c1, const void* x2, int c2, int batch, int hw, int groups,
+                                  float eps, const float* gamma, const float* beta, const float* workspace, int silu,
+                                  void* y, void* stream) {
+  if (!x1 || !workspace || !gamma || !beta || !y || c1 <= 0 || c1 % 8 || c2 % 8 || (c2 > 0 && !x2)) return PP_ERR_BAD_ARG;
   const int C = c1 + c2;
+  if (groups <= 0 || groups > 32 || C % groups) return PP_ERR_BAD_ARG;
   const long long total = (long long)hw * (C / 8);
-  int nb = (int)((total + 255) / 256);
-  if (nb > 1024) nb = 1024;
+  int nb = (int)((total + 256 * 8 - 1) / (256 * 8));    // >= 8 pieces per thread: amortise the fold prologue
+  if (nb > 512) nb = 512;
+  if (nb < 1) nb = 1;
+  const size_t lds = (size_t)(2 * C + 128) * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
+  const int nchunk = gn_nchunk(hw);
   if (silu)
-    hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(nb, batch), dim3(256), 0, st, (const uint16_t*)x1, c1,
-                       (const uint16_t*)x2, c2, hw, scale_shift, (uint16_t*)y);
+    hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(nb, batch), dim3(256), lds, st, (const uint16_t*)x1, c1,
+                       (const uint16_t*)x2, c2, hw, workspace, nchunk, groups, eps, gamma, beta, (uint16_t*)y);
   else
-    hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(nb, batch), dim3(256), 0, st, (const uint16_t*)x1, c1,
-                       (const uint16_t*)x2, c2, hw, scale_shift, (uint16_t*)y);
+    hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(nb, batch), dim3(256), lds, st, (const uint16_t*)x1, c1,
+                       (const uint16_t*)x2, c2, hw, workspace, nchunk, groups, eps, gamma, beta, (uint16_t*)y);
   PP_CHECK_LAUNCH("gn_apply_kernel");
   return PP_OK;
 }

@@ -171,9 +171,21 @@ class Plan:
             evs.append((name, e0, e1))
         stream_obj.synchronize()
         out: Dict[str, float] = {}
+        self.last_launch_ms = []
         for name, e0, e1 in evs:
-            out[name] = out.get(name, 0.0) + e0.elapsed_time(e1)
+            dt = e0.elapsed_time(e1)
+            out[name] = out.get(name, 0.0) + dt
+            self.last_launch_ms.append(dt)
         return out
+
+    def describe(self, i: int) -> str:
+        """Human-readable shape of launch i (GEMM-family launches carry a PPGemmArgs)."""
+        fn, args, name = self.calls[i]
+        a = getattr(args[0], "_obj", None) if args else None
+        if isinstance(a, L.PPGemmArgs):
+            return (f"{name} M={a.M} N={a.N} K={a.K} {'conv' if a.x_mode else 'lin'}"
+                    f"{' s2' if a.stride == 2 else ''}{' up' if a.up else ''}{' cat' if a.c2 else ''}")
+        return name
 
 
 class Builder:
@@ -269,13 +281,11 @@ class Builder:
         if out is None:
             out = self.new_act(x.B, x.H, x.W, Ct)
         m = self.mark()
-        ss = self.alloc(x.B * 2 * Ct * 4)
         ws = self.alloc(self.lib.pp_groupnorm_workspace_bytes(x.B, hw, Ct))
         x2p = x2.ptr if x2 is not None else None
-        self.plan.add("groupnorm_stats", self.lib.pp_groupnorm_stats, x.ptr, x.C, x2p, c2, x.B, hw, groups, eps,
-                      gamma, beta, ss, ws)
-        self.plan.add("groupnorm_apply", self.lib.pp_groupnorm_apply, x.ptr, x.C, x2p, c2, x.B, hw, ss, int(silu),
-                      out.ptr)
+        self.plan.add("groupnorm_stats", self.lib.pp_groupnorm_stats, x.ptr, x.C, x2p, c2, x.B, hw, groups, ws)
+        self.plan.add("groupnorm_apply", self.lib.pp_groupnorm_apply, x.ptr, x.C, x2p, c2, x.B, hw, groups, eps,
+                      gamma, beta, ws, int(silu), out.ptr)
         self.release(m)
         return out
 

@@ -89,13 +89,11 @@ def groupnorm(x: torch.Tensor, gamma, beta, eps: float, silu: bool, groups: int 
     B, H, W, C1 = x.shape
     C2 = x2.shape[3] if x2 is not None else 0
     Ct = C1 + C2
-    ss = torch.empty(B, 2, Ct, dtype=torch.float32, device=x.device)
     ws = torch.empty(lib.pp_groupnorm_workspace_bytes(B, H * W, Ct) // 4, dtype=torch.float32, device=x.device)
     y = torch.empty(B, H, W, Ct, dtype=torch.bfloat16, device=x.device)
-    L.check(lib.pp_groupnorm_stats(_p(x), C1, _p(x2), C2, B, H * W, groups, eps, _p(gamma), _p(beta), _p(ss), _p(ws),
-                                   _s()), "pp_groupnorm_stats")
-    L.check(lib.pp_groupnorm_apply(_p(x), C1, _p(x2), C2, B, H * W, _p(ss), int(silu), _p(y), _s()),
-            "pp_groupnorm_apply")
+    L.check(lib.pp_groupnorm_stats(_p(x), C1, _p(x2), C2, B, H * W, groups, _p(ws), _s()), "pp_groupnorm_stats")
+    L.check(lib.pp_groupnorm_apply(_p(x), C1, _p(x2), C2, B, H * W, groups, eps, _p(gamma), _p(beta), _p(ws),
+                                   int(silu), _p(y), _s()), "pp_groupnorm_apply")
     return y
 
 
