@@ -556,71 +556,99 @@ __global__ void __launch_bounds__(WM* WN * 64, 1) pp_gemm_kernel_v2(const PPGemm
         }
       }
     } else if (geglu) {
-      // 16 tile columns = 4 x (h0,h1,g0,g1) -> 8 outputs = one 16-B store
-      for (int q = tid; q < EPI_ROWS * (BN / 16); q += T) {
-        const int row = q / (BN / 16), c16 = q - row * (BN / 16);
-        const int m = m0 + row, n = n_blk + c16 * 16;
-        if (m >= a.M || n >= a.N) continue;
-        float o[8];
+      // thread = fixed 16-column strip (4 x (h0,h1,g0,g1) -> 8 outputs = one 16-B store), rows tid/GC + j*GR
+      constexpr int GC = BN / 16, GR = T / GC, GP = (EPI_ROWS + GR - 1) / GR;
+      const int c16 = tid % GC, r0 = tid / GC;
+      const int n = n_blk + c16 * 16;
+      if (r0 < GR && n < a.N) {
+        f32x4_t bs[4];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          f32x4_t v = *reinterpret_cast<const f32x4_t*>(smem + row * EPI_LD + (c16 * 16 + g * 4) * 4);
-          if (a.bias) v += *reinterpret_cast<const f32x4_t*>(a.bias + n + g * 4);
-          o[2 * g] = v[0] * gelu_erf_f(v[2]);
-          o[2 * g + 1] = v[1] * gelu_erf_f(v[3]);
+        for (int g = 0; g < 4; ++g)
+          bs[g] = a.bias ? *reinterpret_cast<const f32x4_t*>(a.bias + n + g * 4) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < GP; ++j) {
+          const int row = r0 + j * GR, m = m0 + row;
+          if (row < EPI_ROWS && m < a.M) {
+            float o[8];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const f32x4_t vv = *reinterpret_cast<const f32x4_t*>(smem + row * EPI_LD + (c16 * 16 + g * 4) * 4) + bs[g];
+              o[2 * g] = vv[0] * gelu_erf_f(vv[2]);
+              o[2 * g + 1] = vv[1] * gelu_erf_f(vv[3]);
+            }
+            u32x4_t w;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) w[jj] = pack2bf(o[2 * jj], o[2 * jj + 1]);
+            *reinterpret_cast<u32x4_t*>((uint16_t*)a.out + (size_t)m * a.ldo + (n >> 1)) = w;
+          }
         }
-        u32x4_t w;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) w[j] = pack2bf(o[2 * j], o[2 * j + 1]);
-        *reinterpret_cast<u32x4_t*>((uint16_t*)a.out + (size_t)m * a.ldo + (n >> 1)) = w;
       }
     } else {
-      for (int q = tid; q < EPI_ROWS * (BN / 8); q += T) {
-        const int row = q / (BN / 8), c8 = q - row * (BN / 8);
-        const int m = m0 + row, n = n_blk + c8 * 8;
-        if (m >= a.M || n >= a.N) continue;
-        f32x4_t v0 = *reinterpret_cast<const f32x4_t*>(smem + row * EPI_LD + c8 * 32);
-        f32x4_t v1 = *reinterpret_cast<const f32x4_t*>(smem + row * EPI_LD + c8 * 32 + 16);
+      // thread = fixed 8-column strip, rows tid/EC + j*ER.  All residual loads of the pass are issued BEFORE the math so
+      // their latencies overlap (a load -> use -> store loop would serialise ~1 us of memory latency per piece).
+      constexpr int EC = BN / 8, ER = T / EC, EP = (EPI_ROWS + ER - 1) / ER;
+      const int c8 = tid % EC, r0 = tid / EC;
+      const int n = n_blk + c8 * 8;
+      if (r0 < ER && n < a.N) {
         if (splitk) {
-          float* wsp = a.workspace + ((size_t)split * a.M + m) * a.N + n;
-          *reinterpret_cast<f32x4_t*>(wsp) = v0;
-          *reinterpret_cast<f32x4_t*>(wsp + 4) = v1;
-          continue;
-        }
-        if (a.bias) {
-          v0 += *reinterpret_cast<const f32x4_t*>(a.bias + n);
-          v1 += *reinterpret_cast<const f32x4_t*>(a.bias + n + 4);
-        }
-        if (a.rowvec) {
-          const float* rv = a.rowvec + (size_t)(m / a.rows_per_batch) * a.ld_rowvec + n;
-          v0 += *reinterpret_cast<const f32x4_t*>(rv);
-          v1 += *reinterpret_cast<const f32x4_t*>(rv + 4);
-        }
-        v0 *= a.scale;
-        v1 *= a.scale;
-        if (a.res1) {
-          const u32x4_t r = *reinterpret_cast<const u32x4_t*>((const uint16_t*)a.res1 + (size_t)m * a.ldres1 + n);
-          v0[0] += bflo(r[0]); v0[1] += bfhi(r[0]); v0[2] += bflo(r[1]); v0[3] += bfhi(r[1]);
-          v1[0] += bflo(r[2]); v1[1] += bfhi(r[2]); v1[2] += bflo(r[3]); v1[3] += bfhi(r[3]);
-        }
-        if (a.res2) {
-          const u32x4_t r = *reinterpret_cast<const u32x4_t*>((const uint16_t*)a.res2 + (size_t)m * a.ldres2 + n);
-          v0[0] += bflo(r[0]); v0[1] += bfhi(r[0]); v0[2] += bflo(r[1]); v0[3] += bfhi(r[1]);
-          v1[0] += bflo(r[2]); v1[1] += bfhi(r[2]); v1[2] += bflo(r[3]); v1[3] += bfhi(r[3]);
-        }
-        if (a.act == PP_ACT_SILU) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) { v0[j] = silu_f(v0[j]); v1[j] = silu_f(v1[j]); }
-        }
-        if (a.out_f32) {
-          float* op = (float*)a.out + (size_t)m * a.ldo + n;
-          *reinterpret_cast<f32x4_t*>(op) = v0;
-          *reinterpret_cast<f32x4_t*>(op + 4) = v1;
+          for (int j = 0; j < EP; ++j) {
+            const int row = r0 + j * ER, m = m0 + row;
+            if (row < EPI_ROWS && m < a.M) {
+              float* wsp = a.workspace + ((size_t)split * a.M + m) * a.N + n;
+              *reinterpret_cast<f32x4_t*>(wsp) = *reinterpret_cast<const f32x4_t*>(smem + row * EPI_LD + c8 * 32);
+              *reinterpret_cast<f32x4_t*>(wsp + 4) = *reinterpret_cast<const f32x4_t*>(smem + row * EPI_LD + c8 * 32 + 16);
+            }
+          }
         } else {
-          u32x4_t o;
-          o[0] = pack2bf(v0[0], v0[1]); o[1] = pack2bf(v0[2], v0[3]);
-          o[2] = pack2bf(v1[0], v1[1]); o[3] = pack2bf(v1[2], v1[3]);
-          *reinterpret_cast<u32x4_t*>((uint16_t*)a.out + (size_t)m * a.ldo + n) = o;
+          u32x4_t r1[EP], r2[EP];
+#pragma unroll
+          for (int j = 0; j < EP; ++j) {
+            const int row = r0 + j * ER, m = m0 + row;
+            const bool ok = row < EPI_ROWS && m < a.M;
+            r1[j] = (ok && a.res1) ? *reinterpret_cast<const u32x4_t*>((const uint16_t*)a.res1 + (size_t)m * a.ldres1 + n)
+                                   : u32x4_t{0u, 0u, 0u, 0u};
+            r2[j] = (ok && a.res2) ? *reinterpret_cast<const u32x4_t*>((const uint16_t*)a.res2 + (size_t)m * a.ldres2 + n)
+                                   : u32x4_t{0u, 0u, 0u, 0u};
+          }
+          f32x4_t bs0 = {0.f, 0.f, 0.f, 0.f}, bs1 = {0.f, 0.f, 0.f, 0.f};
+          if (a.bias) {
+            bs0 = *reinterpret_cast<const f32x4_t*>(a.bias + n);
+            bs1 = *reinterpret_cast<const f32x4_t*>(a.bias + n + 4);
+          }
+#pragma unroll
+          for (int j = 0; j < EP; ++j) {
+            const int row = r0 + j * ER, m = m0 + row;
+            if (row < EPI_ROWS && m < a.M) {
+              f32x4_t v0 = *reinterpret_cast<const f32x4_t*>(smem + row * EPI_LD + c8 * 32) + bs0;
+              f32x4_t v1 = *reinterpret_cast<const f32x4_t*>(smem + row * EPI_LD + c8 * 32 + 16) + bs1;
+              if (a.rowvec) {
+                const float* rv = a.rowvec + (size_t)(m / a.rows_per_batch) * a.ld_rowvec + n;
+                v0 += *reinterpret_cast<const f32x4_t*>(rv);
+                v1 += *reinterpret_cast<const f32x4_t*>(rv + 4);
+              }
+              v0 *= a.scale;
+              v1 *= a.scale;
+              v0[0] += bflo(r1[j][0]) + bflo(r2[j][0]); v0[1] += bfhi(r1[j][0]) + bfhi(r2[j][0]);
+              v0[2] += bflo(r1[j][1]) + bflo(r2[j][1]); v0[3] += bfhi(r1[j][1]) + bfhi(r2[j][1]);
+              v1[0] += bflo(r1[j][2]) + bflo(r2[j][2]); v1[1] += bfhi(r1[j][2]) + bfhi(r2[j][2]);
+              v1[2] += bflo(r1[j][3]) + bflo(r2[j][3]); v1[3] += bfhi(r1[j][3]) + bfhi(r2[j][3]);
+              if (a.act == PP_ACT_SILU) {
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) { v0[jj] = silu_f(v0[jj]); v1[jj] = silu_f(v1[jj]); }
+              }
+              if (a.out_f32) {
+                float* op = (float*)a.out + (size_t)m * a.ldo + n;
+                *reinterpret_cast<f32x4_t*>(op) = v0;
+                *reinterpret_cast<f32x4_t*>(op + 4) = v1;
+              } else {
+                u32x4_t o;
+                o[0] = pack2bf(v0[0], v0[1]); o[1] = pack2bf(v0[2], v0[3]);
+                o[2] = pack2bf(v1[0], v1[1]); o[3] = pack2bf(v1[2], v1[3]);
+                *reinterpret_cast<u32x4_t*>((uint16_t*)a.out + (size_t)m * a.ldo + n) = o;
+              }
+            }
+          }
         }
       }
     }

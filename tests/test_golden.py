@@ -1,0 +1,78 @@
+"""Golden vectors produced by the REFERENCE'S OWN model code (tests/golden/make_ref_wiring.py, through oracle/ref_shim.py).
+
+CPU: the oracle reproduces them (pins the oracle's wiring -- BrushNet residual routing, from_unet, skip capture order).
+GPU (-m gpu): the HIP path reproduces them within bf16 tolerance.
+"""
+import os
+import sys
+
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+import make_ref_wiring as G  # noqa: E402
+
+from oracle import sd_modules as OM  # noqa: E402
+
+GOLD = torch.load(os.path.join(HERE, "golden", "ref_wiring.pt"), weights_only=False)
+
+
+def _oracle_outputs():
+    u9, u4 = G.oracle_models()
+    inp = GOLD["inputs"]
+    with torch.no_grad():
+        eps9 = u9(inp["x9"], inp["t"], inp["ehs"])[0]
+        ob = OM.randomize_zero_convs(OM.BrushNetModel.from_unet(u4).eval(), seed=11)
+        dn, md, up = ob(inp["x4"], inp["t"], inp["ehs_b"], inp["cond"], conditioning_scale=inp["scale"])
+        res = list(dn) + [md] + list(up)
+        eps4b = u4(inp["x4"], inp["t"], inp["ehs"], down_block_add_samples=list(dn), mid_block_add_sample=md,
+                   up_block_add_samples=list(up))[0]
+        eps4p = u4(inp["x4"], inp["t"], inp["ehs"])[0]
+    return u9, u4, ob, eps9, res, eps4b, eps4p
+
+
+def test_oracle_reproduces_reference_outputs():
+    _, _, _, eps9, res, eps4b, eps4p = _oracle_outputs()
+    assert (GOLD["n_down"], GOLD["n_up"]) == (8, 11)
+    assert [tuple(t.shape) for t in res] == GOLD["res_shapes"]
+    assert torch.allclose(eps9, GOLD["eps9"], atol=2e-6, rtol=1e-5)
+    assert torch.allclose(eps4p, GOLD["eps4_plain"], atol=2e-6, rtol=1e-5)
+    assert torch.allclose(eps4b, GOLD["eps4_brush"], atol=2e-6, rtol=1e-5)
+    assert not torch.allclose(eps4b, eps4p, atol=1e-3)          # the residuals really act
+    summ = torch.stack([G.summary(t) for t in res])
+    assert torch.allclose(summ, GOLD["res_summary"], atol=2e-6, rtol=1e-5)
+
+
+@pytest.mark.gpu
+def test_hip_path_reproduces_reference_outputs():
+    from powerpaint_amd import models as PM
+    u9, u4, ob, *_ = _oracle_outputs()
+    inp = GOLD["inputs"]
+    dev = "cuda"
+    cfg = dict(GOLD["cfg"])
+    cfg.pop("attention_head_dim")
+
+    def close(out, ref, what):
+        out, ref = out.float().cpu(), ref.float()
+        cos = torch.nn.functional.cosine_similarity(out.flatten(), ref.flatten(), dim=0).item()
+        err = (out - ref).abs().max().item()
+        assert cos >= 0.999 and err <= 3e-2 * max(1.0, ref.abs().max().item()), f"{what}: cos {cos:.6f} err {err:.4g}"
+
+    h9 = PM.UNet2DConditionModel(in_channels=9, device=dev, **cfg).load_state_dict(u9.state_dict())
+    close(h9(inp["x9"].to(dev), inp["t"], inp["ehs"].to(dev), return_dict=False)[0], GOLD["eps9"], "eps9")
+    h4 = PM.UNet2DConditionModel(in_channels=4, device=dev, **cfg).load_state_dict(u4.state_dict(), keep_state_dict=True)
+    close(h4(inp["x4"].to(dev), inp["t"], inp["ehs"].to(dev), return_dict=False)[0], GOLD["eps4_plain"], "eps4 plain")
+    # from_unet on the HIP side, then the randomised zero-convs of the fixture
+    hb0 = PM.BrushNetModel.from_unet(h4)
+    d0, m0, u0 = hb0(inp["x4"].to(dev), inp["t"], inp["ehs_b"].to(dev), inp["cond"].to(dev), return_dict=False)
+    assert all(float(t.float().abs().max()) == 0.0 for t in d0 + [m0] + u0)        # zero-convs -> exact zeros
+    hb = PM.BrushNetModel(in_channels=4, conditioning_channels=5, device=dev, **cfg).load_state_dict(ob.state_dict())
+    dn, md, up = hb(inp["x4"].to(dev), inp["t"], inp["ehs_b"].to(dev), inp["cond"].to(dev),
+                    conditioning_scale=inp["scale"], return_dict=False)
+    assert (len(dn), len(up)) == (GOLD["n_down"], GOLD["n_up"])
+    summ = torch.stack([G.summary(t.float().cpu()) for t in dn + [md] + up])
+    assert torch.allclose(summ[:, :3], GOLD["res_summary"][:, :3], atol=2e-2, rtol=5e-2)
+    out = h4(inp["x4"].to(dev), inp["t"], inp["ehs"].to(dev), down_block_add_samples=dn, mid_block_add_sample=md,
+             up_block_add_samples=up, return_dict=False)[0]
+    close(out, GOLD["eps4_brush"], "eps4 + brushnet residuals")
