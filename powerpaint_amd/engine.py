@@ -620,10 +620,18 @@ class SDNet:
         hs = pb.linear(n.ptr, rows, Cc, P[f"{pre}.proj_in.weight"], Cc, P[f"{pre}.proj_in.bias"], name="conv1x1")
         # self-attention: fused QKV GEMM, V written transposed by the epilogue
         ln = pb.layernorm(hs, rows, Cc, P[f"{tb}.norm1.weight"], P[f"{tb}.norm1.bias"])
-        vt = pb.alloc(x.B * Cc * hw * 2)
-        qk = pb.linear(ln, rows, Cc, P[f"{tb}.attn1.qkv.weight"], 3 * Cc, out_vt=vt, vt_col0=2 * Cc, vt_ld=hw,
-                       rows_per_batch=hw, name="linear")
-        a = pb.attention(qk, 2 * Cc, qk + 2 * Cc, 2 * Cc, vt, hw, x.B, self.heads, hw, hw, d)
+        if hw % 8 == 0:
+            vt = pb.alloc(x.B * Cc * hw * 2)
+            qk = pb.linear(ln, rows, Cc, P[f"{tb}.attn1.qkv.weight"], 3 * Cc, out_vt=vt, vt_col0=2 * Cc, vt_ld=hw,
+                           rows_per_batch=hw, name="linear")
+            a = pb.attention(qk, 2 * Cc, qk + 2 * Cc, 2 * Cc, vt, hw, x.B, self.heads, hw, hw, d)
+        else:
+            # tiny latents (hw < 8, e.g. 2x2): V^T rows must be 16-byte aligned and zero padded -> unfused transpose
+            ldvt = _align(hw, 8)
+            vt = pb.alloc(x.B * Cc * ldvt * 2)
+            qkv = pb.linear(ln, rows, Cc, P[f"{tb}.attn1.qkv.weight"], 3 * Cc, name="linear")
+            pb.plan.add("transpose_v", pb.lib.pp_transpose_v, qkv + 4 * Cc, 3 * Cc, x.B, hw, Cc, vt, ldvt)
+            a = pb.attention(qkv, 3 * Cc, qkv + 2 * Cc, 3 * Cc, vt, ldvt, x.B, self.heads, hw, hw, d)
         hs = pb.linear(a, rows, Cc, P[f"{tb}.attn1.to_out.weight"], Cc, P[f"{tb}.attn1.to_out.bias"], res1=hs,
                        name="linear")
         # cross-attention (K / V^T hoisted out of the step: encoder_hidden_states are step-invariant)
