@@ -51,6 +51,9 @@ attn_fwd_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __restr
                 float scale_log2e) {
   using C = Cfg<D>;
   constexpr int BUF = C::KBYTES + C::VBYTES;
+  // (Folding scale and -max into the spare contraction slot of the padded d = 40 QK^T was tried: it needs Q pre-scaled
+  //  in bf16, a second rounding that large scores amplify -- rejected by test_attention_strided_qkv_and_spike.)
+  constexpr bool MFMA_SUM = C::VROWS > D;       // row D of V^T := 1 -> the P.V MFMAs also produce the denominator
   extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x (K tile | V^T tile)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -58,22 +61,17 @@ attn_fwd_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __restr
   const int q0 = blockIdx.x * (QW * NW) + wave * QW;
   const int qi = lane & 31, half = lane >> 5;
 
-  // zero the V^T rows >= D of both buffers once (they only feed output rows that are never stored, but must stay finite)
-  // Padding rows of the V^T tile (both buffers), written once: row D is ALL ONES, so the P.V MFMAs also produce the
-  // softmax denominator sum_k P[k][q] as output row D (no VALU adds; it is rescaled together with O for free).
-  // The remaining padding rows are zero (they feed output rows that are never stored, but must stay finite).
-  constexpr bool MFMA_SUM = C::VROWS > D;
-  if constexpr (MFMA_SUM) {
-    constexpr int PADP = (C::VROWS - D) * (C::VS / 8);   // 8-B pieces of padding rows per buffer
+  if constexpr (MFMA_SUM) {   // padding rows of the V^T tile (both buffers), written once: row D all ones, the rest zero
+    constexpr int PADP = (C::VROWS - D) * (C::VS / 8);
     for (int i = tid; i < 2 * PADP; i += 256) {
       const int bufi = i / PADP, r = i - bufi * PADP;
-      const uint32_t v = (r < C::VS / 8) ? 0x3F803F80u : 0u;   // bf16 1.0 pairs for row D
+      const uint32_t v = (r < C::VS / 8) ? 0x3F803F80u : 0u;
       *reinterpret_cast<u32x2_t*>(smem + bufi * BUF + C::KBYTES + D * C::VS + r * 8) = u32x2_t{v, v};
     }
   }
 
   // ---- Q fragments (B operand): lane = query qi, k-slot = 8*half + jj  ->  Q[q0+qi][16 s + 8 half + jj]
-  bf16x8_t qf[C::DS];
+  u32x4_t qraw[C::DS];
   {
     const int qrow = q0 + qi;
     const uint16_t* qp = q + ((size_t)b * nq + (qrow < nq ? qrow : 0)) * ldq + h * D;
@@ -82,33 +80,42 @@ attn_fwd_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __restr
       const int dc = 16 * s + 8 * half;
       u32x4_t v = {0u, 0u, 0u, 0u};
       if (qrow < nq && dc < D) v = *reinterpret_cast<const u32x4_t*>(qp + dc);
-      qf[s] = __builtin_bit_cast(bf16x8_t, v);
+      qraw[s] = v;
     }
   }
 
-  const __amdgpu_buffer_rsrc_t rs_k = make_rsrc(k + (size_t)b * nk * ldk, (uint32_t)nk * (uint32_t)ldk * 2u);
+  // ---- tile loads: per-piece voffsets are constants; the walk over key tiles is SCALAR arithmetic on the buffer
+  // descriptors (base += tile, size shrinks), and rows past the end of K fall outside the descriptor -> zeros.
+  const uint16_t* k_b = k + (size_t)b * nk * ldk;
   const uint16_t* vt_bh = vt + ((size_t)b * heads + h) * D * (size_t)ldvt;
-  const __amdgpu_buffer_rsrc_t rs_v = make_rsrc(vt_bh, (uint32_t)D * (uint32_t)ldvt * 2u);
-
+  constexpr int KSL = C::DP / 8;          // 16-B pieces per K row in LDS
+  constexpr int KSLV = D / 8;             // ... of which come from memory
+  int kvo[C::KPT], vvo[C::VPT];
+#pragma unroll
+  for (int i = 0; i < C::KPT; ++i) {
+    const int pc = tid + i * 256;
+    const int row = pc / KSL, sl = pc - row * KSL;
+    kvo[i] = (pc < C::KPIECES && sl < KSLV) ? (row * ldk + h * D + sl * 8) * 2 : (int)PP_OOB;
+  }
+#pragma unroll
+  for (int i = 0; i < C::VPT; ++i) {
+    const int pc = tid + i * 256;
+    vvo[i] = (pc < C::VPIECES) ? ((pc >> 3) * ldvt + (pc & 7) * 8) * 2 : (int)PP_OOB;
+  }
   u32x4_t kreg[C::KPT], vreg[C::VPT];
   auto load_tile = [&](int t0) {
+    const int left = nk - t0;                                  // keys remaining (>= 1)
+    const __amdgpu_buffer_rsrc_t rs_k = make_rsrc(k_b + (size_t)t0 * ldk, (uint32_t)left * (uint32_t)ldk * 2u);
+    const __amdgpu_buffer_rsrc_t rs_v = make_rsrc(vt_bh + t0, ((uint32_t)D * (uint32_t)ldvt - (uint32_t)t0) * 2u);
 #pragma unroll
     for (int i = 0; i < C::KPT; ++i) {
-      const int pc = tid + i * 256;
-      const int row = pc / (C::DP / 8), sl = pc - row * (C::DP / 8);
-      const int key = t0 + row;
-      const bool ok = pc < C::KPIECES && key < nk && sl * 8 < D;
-      const uint32_t off = ok ? (uint32_t)(key * ldk + h * D + sl * 8) * 2u : PP_OOB;
-      kreg[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_k, off, 0, 0);
+      const int vo = kvo[i];
+      kreg[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_k, vo, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < C::VPT; ++i) {
-      const int pc = tid + i * 256;
-      const int row = pc >> 3, sl = pc & 7;
-      const int key = t0 + sl * 8;
-      const bool ok = pc < C::VPIECES && key < nk;
-      const uint32_t off = ok ? (uint32_t)(row * ldvt + key) * 2u : PP_OOB;
-      vreg[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_v, off, 0, 0);
+      const int vo = (((tid + i * 256) & 7) * 8 < left) ? vvo[i] : (int)PP_OOB;
+      vreg[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_v, vo, 0, 0);
     }
   };
   auto store_tile = [&](int bufi) {
@@ -118,7 +125,7 @@ attn_fwd_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __restr
     for (int i = 0; i < C::KPT; ++i) {
       const int pc = tid + i * 256;
       if (pc < C::KPIECES) {
-        const int row = pc / (C::DP / 8), sl = pc - row * (C::DP / 8);
+        const int row = pc / KSL, sl = pc - row * KSL;
         *reinterpret_cast<u32x4_t*>(ks + row * C::KS + sl * 16) = kreg[i];
       }
     }
@@ -130,9 +137,9 @@ attn_fwd_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __restr
         // keys are permuted inside every 16-key block to [0-3, 8-11 | 4-7, 12-15] so that the 8 keys one lane half
         // contracts over (it owns S^T rows 4h..4h+3 and 8+4h..8+4h+3) are ONE contiguous 16-byte fragment
         char* blk = vs + row * C::VS + (sl >> 1) * 32;
-        const int pos = (sl & 1) * 8;                       // 8-key piece: even -> keys 0-7, odd -> keys 8-15
-        *reinterpret_cast<u32x2_t*>(blk + pos) = u32x2_t{vreg[i][0], vreg[i][1]};        // keys +0..3
-        *reinterpret_cast<u32x2_t*>(blk + 16 + pos) = u32x2_t{vreg[i][2], vreg[i][3]};   // keys +4..7
+        const int pos = (sl & 1) * 8;
+        *reinterpret_cast<u32x2_t*>(blk + pos) = u32x2_t{vreg[i][0], vreg[i][1]};
+        *reinterpret_cast<u32x2_t*>(blk + 16 + pos) = u32x2_t{vreg[i][2], vreg[i][3]};
       }
     }
   };
@@ -142,7 +149,8 @@ attn_fwd_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __restr
   for (int t = 0; t < C::DT; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) oacc[t][r] = 0.f;
-  float m_run = -1.0e30f, l_run = 0.f;   // m_run in the log2 domain (raw score * scale * log2 e)
+  float m_run = -1.0e30f;   // running max in the log2 domain (raw score * scale * log2 e)
+  float l_run = 0.f;
 
   // one 64-key tile: S^T = K Q^T, online softmax (per-lane row state), O^T += V^T P^T
   auto tile = [&](const char* ks, const char* vs, int t0, auto tail_tag) {
@@ -154,21 +162,9 @@ attn_fwd_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __restr
 #pragma unroll
       for (int s = 0; s < C::DS; ++s) {
         const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(ks + (32 * j + qi) * C::KS + (16 * s + 8 * half) * 2);
-        sacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], s == 0 ? zero : sacc[j], 0, 0, 0);
+        sacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, __builtin_bit_cast(bf16x8_t, qraw[s]),
+                                                          s == 0 ? zero : sacc[j], 0, 0, 0);
       }
-    }
-    // V^T fragments of the whole tile are fetched NOW (D = 40), so their LDS latency hides behind the softmax VALU
-    // block instead of serialising with the P.V MFMAs
-    constexpr bool PREF = (C::DT <= 2);   // d = 40 (d = 80 would spill at 2 waves/SIMD)
-    bf16x8_t vpre[2][2][PREF ? C::DT : 1];
-    if constexpr (PREF) {
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-          for (int dt = 0; dt < C::DT; ++dt)
-            vpre[j][u][dt] = *reinterpret_cast<const bf16x8_t*>(vs + (dt * 32 + qi) * C::VS + (2 * j + u) * 32 + half * 16);
     }
     float tmax = -1.0e30f;
 #pragma unroll
@@ -181,43 +177,45 @@ attn_fwd_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __restr
         }
         tmax = fmaxf(tmax, sacc[j][r]);
       }
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64)) * scale_log2e;
-    // deferred rescale: keep the stale max while it is within 2^RESCALE_THR of the true one (P stays <= 2^THR; the
-    // decision precedes every exponentiation of this tile and all of the previous tile's P.V is already in O)
-    if (!__all(tmax - m_run <= RESCALE_THR)) {
-      const float m_new = fmaxf(m_run, tmax);
-      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-      m_run = m_new;
-      if constexpr (!MFMA_SUM) l_run *= alpha;
-#pragma unroll
-      for (int dt = 0; dt < C::DT; ++dt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
-    }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
     float psum = 0.f;
     bf16x8_t pf[2][2];
-    const f32x2_t c2 = {scale_log2e, scale_log2e}, nm2 = {-m_run, -m_run};
+    float p[2][16];
+    {
+      tmax *= scale_log2e;
+      if (!__all(tmax - m_run <= RESCALE_THR)) {
+        const float m_new = fmaxf(m_run, tmax);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        m_run = m_new;
+        if constexpr (!MFMA_SUM) l_run *= alpha;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      float p[16];
+        for (int dt = 0; dt < C::DT; ++dt)
 #pragma unroll
-      for (int r = 0; r < 16; r += 2) {
-        const f32x2_t s2 = {sacc[j][r], sacc[j][r + 1]};
-        const f32x2_t e2 = __builtin_elementwise_fma(s2, c2, nm2);        // v_pk_fma_f32: two scores per VALU op
-        p[r] = __builtin_amdgcn_exp2f(e2[0]);
-        p[r + 1] = __builtin_amdgcn_exp2f(e2[1]);
-        if constexpr (!MFMA_SUM) psum += p[r] + p[r + 1];
+          for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
       }
+      const f32x2_t c2 = {scale_log2e, scale_log2e}, nm2 = {-m_run, -m_run};
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          const f32x2_t s2 = {sacc[j][r], sacc[j][r + 1]};
+          const f32x2_t e2 = __builtin_elementwise_fma(s2, c2, nm2);      // v_pk_fma_f32: two scores per VALU op
+          p[j][r] = __builtin_amdgcn_exp2f(e2[0]);
+          p[j][r + 1] = __builtin_amdgcn_exp2f(e2[1]);
+          if constexpr (!MFMA_SUM) psum += p[j][r] + p[j][r + 1];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         u32x4_t w;
-        w[0] = pack2bf(p[8 * u + 0], p[8 * u + 1]);
-        w[1] = pack2bf(p[8 * u + 2], p[8 * u + 3]);
-        w[2] = pack2bf(p[8 * u + 4], p[8 * u + 5]);
-        w[3] = pack2bf(p[8 * u + 6], p[8 * u + 7]);
+        w[0] = pack2bf(p[j][8 * u + 0], p[j][8 * u + 1]);
+        w[1] = pack2bf(p[j][8 * u + 2], p[j][8 * u + 3]);
+        w[2] = pack2bf(p[j][8 * u + 4], p[j][8 * u + 5]);
+        w[3] = pack2bf(p[j][8 * u + 6], p[j][8 * u + 7]);
         pf[j][u] = __builtin_bit_cast(bf16x8_t, w);
       }
-    }
     if constexpr (!MFMA_SUM) l_run += psum;
     // O^T += V^T P^T : key slot (half, jj) <-> key 16u + 4 half + jj (jj<4) | 16u + 8 + 4 half + jj-4
 #pragma unroll
@@ -226,9 +224,8 @@ attn_fwd_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __restr
       for (int u = 0; u < 2; ++u)
 #pragma unroll
         for (int dt = 0; dt < C::DT; ++dt) {
-          bf16x8_t vf;
-          if constexpr (PREF) vf = vpre[j][u][dt];
-          else vf = *reinterpret_cast<const bf16x8_t*>(vs + (dt * 32 + qi) * C::VS + (2 * j + u) * 32 + half * 16);
+          const bf16x8_t vf =
+              *reinterpret_cast<const bf16x8_t*>(vs + (dt * 32 + qi) * C::VS + (2 * j + u) * 32 + half * 16);
           oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[j][u], oacc[dt], 0, 0, 0);
         }
   };

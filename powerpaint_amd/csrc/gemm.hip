@@ -494,6 +494,7 @@ __global__ void __launch_bounds__(WM* WN * 64, 1) pp_gemm_kernel_v2(const PPGemm
           xf[ks][mi] = *reinterpret_cast<const bf16x8_t*>(xs + (xrow0 + mi * 16) * 128 + so);
       }
       __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);      // co-resident waves in their load / epilogue phase yield the issue slots
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -501,6 +502,7 @@ __global__ void __launch_bounds__(WM* WN * 64, 1) pp_gemm_kernel_v2(const PPGemm
 #pragma unroll
           for (int mi = 0; mi < MI; ++mi)
             acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][ni], xf[ks][mi], acc[ni][mi], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
     }
     stage = stage + 1 == NS ? 0 : stage + 1;
   }
@@ -699,7 +701,7 @@ Choice choose(const PPGemmArgs& a) {
       c.tile = (nb128 >= 256) ? PP_TILE_128x160 : PP_TILE_64x160;
       while (blocks(c.tile == PP_TILE_128x160 ? 128 : 64) * sk < 224 && kt / (sk * 2) >= 12 && sk < 8) sk *= 2;
     } else if (nb128 >= 512) {
-      c.tile = 21;
+      c.tile = 24;       // 8 waves, two co-resident blocks: 4 waves / SIMD
     } else if (nb64 >= 512) {
       if (conv && a.K > 8640) { c.tile = 21; sk = 2; }
       else c.tile = 22;
@@ -855,6 +857,7 @@ extern "C" int pp_gemm_bf16(const PPGemmArgs* args, void* stream) {
       PP_V2(42, 64, 2, 4)
       PP_V2(23, 256, 4, 2)
       PP_V2(33, 256, 4, 3)
+      PP_V2(24, 128, 4, 2)   // 8-wave 128x160 (wave tile 32x80): 4 waves / SIMD with two co-resident blocks
 #undef PP_V2
     default:
       return PP_ERR_BAD_ARG;

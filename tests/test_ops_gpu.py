@@ -40,7 +40,7 @@ def check(out, ref, atol, rtol, what=""):
 
 
 # ------------------------------------------------------------------------------------------------ GEMM
-ALL_TILES = [1, 2, 3, 21, 31, 22, 32, 42, 23, 33]
+ALL_TILES = [1, 2, 3, 21, 31, 22, 32, 42, 23, 33, 24]
 
 
 @pytest.mark.parametrize("tile", ALL_TILES)

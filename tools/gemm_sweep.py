@@ -70,11 +70,11 @@ def main():
         res["auto"] = time_launch(lib, a)
         if not args.quick:
             kt = a.K // 64
-            for tile in (1, 2, 3, 21, 31, 22, 32, 42, 23, 33):
+            for tile in (21, 31, 22, 32, 42, 23, 33, 24):
                 for sk in (1, 2, 3, 4, 6, 8):
                     if sk > 1 and (kt // sk < 8 or a.M * a.N * 4 * sk > ws.numel()):
                         continue
-                    bm = {1: 128, 2: 64, 3: 256}[tile % 10]
+                    bm = {1: 128, 2: 64, 3: 256, 4: 128}[tile % 10]
                     nblk = -(-a.M // bm) * -(-a.N // 160) * sk
                     if nblk > 4096 and sk > 1:
                         continue
