@@ -657,16 +657,32 @@ __global__ void __launch_bounds__(WM* WN * 64, 1) pp_gemm_kernel_v2(const PPGemm
   }
 }
 
+// Deterministic split-K combine + epilogue: thread = (row, 8 columns); the <= 8 partial slabs are read with all loads
+// in flight at once (a `for s: v += load` loop would serialise one memory latency per split), summed in slab order.
 __global__ void __launch_bounds__(256) pp_splitk_reduce_kernel(const PPGemmArgs a, int splits) {
-  const int n4 = a.N >> 2;
-  const long long total = (long long)a.M * n4;
+  const int n8 = a.N >> 3;
+  const long long total = (long long)a.M * n8;
+  const size_t slab = (size_t)a.M * a.N;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const int m = (int)(i / n4);
-    const int n = (int)(i - (long long)m * n4) * 4;
-    f32x4_t v = {0.f, 0.f, 0.f, 0.f};
-    for (int s = 0; s < splits; ++s)
-      v += *reinterpret_cast<const f32x4_t*>(a.workspace + ((size_t)s * a.M + m) * a.N + n);
-    epilogue4<160>(a, m, n, v);
+    const int m = (int)(i / n8);
+    const int n = (int)(i - (long long)m * n8) * 8;
+    const float* src = a.workspace + (size_t)m * a.N + n;
+    f32x4_t p0[8], p1[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      if (s < splits) {
+        p0[s] = *reinterpret_cast<const f32x4_t*>(src + s * slab);
+        p1[s] = *reinterpret_cast<const f32x4_t*>(src + s * slab + 4);
+      } else {
+        p0[s] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        p1[s] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    f32x4_t v0 = p0[0], v1 = p1[0];
+#pragma unroll
+    for (int s = 1; s < 8; ++s) { v0 += p0[s]; v1 += p1[s]; }
+    epilogue4<160>(a, m, n, v0);
+    epilogue4<160>(a, m, n + 4, v1);
   }
 }
 
@@ -722,6 +738,7 @@ Choice choose(const PPGemmArgs& a) {
     while (blocks(bm) * sk < 192 && kt / (sk * 2) >= 16 && sk < 8) sk *= 2;
     c.splitk = sk;
   }
+  if (a.N % 8) c.splitk = 1;   // the split-K combine works on 8-column strips
   return c;
 }
 
@@ -749,9 +766,9 @@ int launch(const PPGemmArgs& a, int splitk, hipStream_t st) {
   hipLaunchKernelGGL(kern, grid, dim3(T), LDS, st, a, d);
   PP_CHECK_LAUNCH("pp_gemm_kernel");
   if (splitk > 1) {
-    const long long total = (long long)a.M * (a.N / 4);
+    const long long total = (long long)a.M * (a.N / 8);
     int nb = (int)((total + 255) / 256);
-    if (nb > 2048) nb = 2048;
+    if (nb > 4096) nb = 4096;
     hipLaunchKernelGGL(pp_splitk_reduce_kernel, dim3(nb), dim3(256), 0, st, a, splitk);
     PP_CHECK_LAUNCH("pp_splitk_reduce_kernel");
   }
@@ -783,9 +800,9 @@ int launch2(const PPGemmArgs& a, int splitk, hipStream_t st) {
   hipLaunchKernelGGL(kern, grid, dim3(T), LDS, st, a, d);
   PP_CHECK_LAUNCH("pp_gemm_kernel_v2");
   if (splitk > 1) {
-    const long long total = (long long)a.M * (a.N / 4);
+    const long long total = (long long)a.M * (a.N / 8);
     int nb = (int)((total + 255) / 256);
-    if (nb > 2048) nb = 2048;
+    if (nb > 4096) nb = 4096;
     hipLaunchKernelGGL(pp_splitk_reduce_kernel, dim3(nb), dim3(256), 0, st, a, splitk);
     PP_CHECK_LAUNCH("pp_splitk_reduce_kernel");
   }
