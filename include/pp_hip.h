@@ -27,7 +27,7 @@ extern "C" {
 #define PP_ERR_LAUNCH (-3)       /* hipLaunchKernel / hipFuncSetAttribute failed                  */
 #define PP_ERR_WORKSPACE (-4)    /* workspace pointer null or too small                           */
 
-#define PP_ABI_VERSION 1
+#define PP_ABI_VERSION 2
 int pp_abi_version(void);
 /* hipGetLastError() text of the last PP_ERR_LAUNCH on this thread (host pointer, static storage). */
 const char* pp_last_error(void);
@@ -89,8 +89,21 @@ typedef struct PPGemmArgs {
   int32_t splitk;     /* 0 = auto */
   int32_t tile;       /* 0 = auto; else PP_TILE_* */
   float* workspace;   /* split-K partials, pp_gemm_workspace_bytes() */
-  /* optional per-(batch,group) GroupNorm statistics of the OUTPUT accumulated in the epilogue (not yet used) */
   int32_t reserved[4];
+  /* LayerNorm folded into the GEMM (BasicTransformerBlock.norm1/2/3 -> the Linear that follows):
+   *   LN(x) W^T = rstd * (x (gamma.W)^T - mean * colsum) + beta W^T, so the host packs W' = gamma (.) W, passes
+   *   ln_colsum[n] = sum_k W'[n][k] and adds beta W^T to the bias; mean / rstd come from per-row moments.
+   * Producer side: row_stats_out != NULL makes the epilogue write, for every output row m and N-tile t (160 columns),
+   *   (sum, sum of squares) of the stored bf16 values to row_stats_out[(m * tiles_n + t) * 2].
+   * Consumer side: ln_stats != NULL (layout above, ln_tiles tiles per row, ln_dim = row length) switches the epilogue to
+   *   v = rstd[m] * (acc - mean[m] * ln_colsum[n]) + bias[n] ... (then residuals / activation as usual). */
+  float* row_stats_out;
+  const float* ln_stats;
+  const float* ln_colsum;
+  int32_t ln_tiles;
+  int32_t ln_dim;
+  float ln_eps;
+  int32_t pad0;
 } PPGemmArgs;
 
 #define PP_TILE_AUTO 0

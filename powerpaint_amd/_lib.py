@@ -33,6 +33,8 @@ class PPGemmArgs(C.Structure):
         ("splitk", i32), ("tile", i32),
         ("workspace", vp),
         ("reserved", i32 * 4),
+        ("row_stats_out", vp), ("ln_stats", vp), ("ln_colsum", vp),
+        ("ln_tiles", i32), ("ln_dim", i32), ("ln_eps", f32), ("pad0", i32),
     ]
 
 
@@ -84,7 +86,7 @@ def lib():
             fn = getattr(l, name)
             fn.restype = res
             fn.argtypes = args
-        if l.pp_abi_version() != 1:
+        if l.pp_abi_version() != 2:
             raise PPError("libpp_hip.so ABI version mismatch")
         _lib = l
     return _lib

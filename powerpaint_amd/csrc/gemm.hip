@@ -26,9 +26,29 @@ struct GemmDerived {
   int tiles_m, tiles_n, kt_total, kt_per_split, ctiles;
 };
 
+// Folded LayerNorm: per-row (mean, rstd) from the producer's per-N-tile (sum, sum of squares) partials.
+PP_DEVINL void ln_row_moments(const PPGemmArgs& a, int m, float& mean, float& rstd) {
+  const f32x2_t* p = reinterpret_cast<const f32x2_t*>(a.ln_stats) + (size_t)m * a.ln_tiles;
+  float s = 0.f, q = 0.f;
+  for (int t = 0; t < a.ln_tiles; ++t) {
+    const f32x2_t v = p[t];
+    s += v[0];
+    q += v[1];
+  }
+  const float inv = 1.0f / (float)a.ln_dim;
+  mean = s * inv;
+  rstd = rsqrtf(fmaxf(q * inv - mean * mean, 0.f) + a.ln_eps);
+}
+
 template <int BN>
 PP_DEVINL void epilogue4(const PPGemmArgs& a, int m, int n, f32x4_t v) {
   // v holds columns n..n+3 of row m (fp32 accumulators)
+  if (a.ln_stats) {
+    float mean, rstd;
+    ln_row_moments(a, m, mean, rstd);
+    const f32x4_t cs = *reinterpret_cast<const f32x4_t*>(a.ln_colsum + n);
+    v = (v - cs * mean) * rstd;
+  }
   if (a.bias) {
     const f32x4_t b = *reinterpret_cast<const f32x4_t*>(a.bias + n);
     v += b;
@@ -52,8 +72,8 @@ PP_DEVINL void epilogue4(const PPGemmArgs& a, int m, int n, f32x4_t v) {
     v[0] += bflo(r[0]); v[1] += bfhi(r[0]); v[2] += bflo(r[1]); v[3] += bfhi(r[1]);
   }
   if (a.act == PP_ACT_GEGLU) {
-    const float o0 = v[0] * gelu_erf_f(v[2]);
-    const float o1 = v[1] * gelu_erf_f(v[3]);
+    const float o0 = v[0] * gelu_fast_f(v[2]);
+    const float o1 = v[1] * gelu_fast_f(v[3]);
     *reinterpret_cast<uint32_t*>((uint16_t*)a.out + (size_t)m * a.ldo + (n >> 1)) = pack2bf(o0, o1);
     return;
   }
@@ -304,8 +324,14 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) pp_gemm_kernel(const PPGemmArg
 //   * epilogue: accumulators are staged through LDS (fp32, 64-row passes, row stride padded by 16 B => conflict-free
 //     ds_write_b128) and read back row-major, so bias / residual loads and the output stores are 16 B per lane along
 //     the contiguous axis: 320-byte full-row segments instead of 8-byte pieces scattered over 16 rows.
-template <int BM, int BN, int WM, int WN, int XMODE, int NS>
-__global__ void __launch_bounds__(WM* WN * 64, 1) pp_gemm_kernel_v2(const PPGemmArgs a, const GemmDerived d) {
+//   * EPI selects the epilogue family, as separate instantiations so that each keeps its register budget (64x160 and the
+//     8-wave 128x160 must stay <= 128 VGPRs for 4 waves/SIMD):  0 = standard;  1 = standard + folded LayerNorm (row
+//     moments out / mean-rstd correction in);  2 = GEGLU in registers (+ optional folded LayerNorm).  1 and 2 are
+//     PLAIN-only and prefetch their epilogue operands into LDS.
+template <int BM, int BN, int WM, int WN, int XMODE, int NS, int EPI>
+__global__ void __launch_bounds__(WM* WN * 64, ((BM / WM / 16) * (BN / WN / 16) <= 10 ? 4 : 2))
+pp_gemm_kernel_v2(const PPGemmArgs a, const GemmDerived d) {   // 2nd bound = waves / SIMD the register budget must allow
+  constexpr bool LNF = EPI != 0;
   constexpr int T = WM * WN * 64;
   constexpr int MI = BM / WM / 16;
   constexpr int NI = BN / WN / 16;
@@ -318,8 +344,14 @@ __global__ void __launch_bounds__(WM* WN * 64, 1) pp_gemm_kernel_v2(const PPGemm
   constexpr int EPI_LD = BN * 4 + 16;             // fp32 row stride in bytes (+16: bank spread for ds_write_b128)
   static_assert(BM % RPP == 0, "X tile must be whole passes");
   static_assert(P * (NS - 1) < 64, "vmcnt field");
-  static_assert(EPI_ROWS * EPI_LD <= NS * STAGE, "epilogue staging must fit in the pipeline stages");
+  constexpr int LN_OFF = EPI_ROWS * EPI_LD;       // folded-LN (mean, rstd) per block row
+  constexpr int RS_OFF = LN_OFF + BM * 8;         // producer row-moment partials [EPI_ROWS][BN/8] float2
+  static_assert(RS_OFF + EPI_ROWS * (BN / 8) * 8 <= NS * STAGE, "epilogue staging must fit in the pipeline stages");
   static_assert(MI * 16 <= EPI_ROWS && EPI_ROWS % (MI * 16) == 0, "wave rows vs epilogue pass");
+  // LNF: epilogue operands (bias, LN column sums, LN row-moment partials of this block's rows) are DMA'd into LDS behind
+  // the pipeline stages at kernel start, so the short-K epilogue never waits on a global load.
+  constexpr int LN_TMAX = 4;                      // row-moment partials per row kept in LDS (C <= 640); more -> global
+  constexpr int PRE_B = NS * STAGE, PRE_C = PRE_B + 1024, PRE_M = PRE_C + 1024;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -466,6 +498,28 @@ __global__ void __launch_bounds__(WM* WN * 64, 1) pp_gemm_kernel_v2(const PPGemm
   const int wrow0 = wn * (NI * 16) + frow;
   const int fsw = frow & 7;
 
+  const bool ln = LNF && a.ln_stats != nullptr;
+  const bool ln_lds = ln && a.ln_tiles <= LN_TMAX;
+  if (LNF) {   // older than every tile load -> covered by the counted vmcnt waits below
+    if (wave == 0) {
+      const __amdgpu_buffer_rsrc_t rb = make_rsrc(a.bias ? (const void*)a.bias : (const void*)a.w, a.bias ? (uint32_t)a.N * 4u : 0u);
+      const int vo = n_blk * 4 + lane * 16;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr_t)(smem + PRE_B), 16, vo, 0, 0, 0);
+    }
+    if (wave == 1) {
+      const __amdgpu_buffer_rsrc_t rc = make_rsrc(ln ? (const void*)a.ln_colsum : (const void*)a.w, ln ? (uint32_t)a.N * 4u : 0u);
+      const int vo = n_blk * 4 + lane * 16;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rc, (lds_ptr_t)(smem + PRE_C), 16, vo, 0, 0, 0);
+    }
+    if (ln_lds) {
+      const __amdgpu_buffer_rsrc_t rm = make_rsrc(a.ln_stats, (uint32_t)a.M * (uint32_t)a.ln_tiles * 8u);
+      const int chunks = (BM * a.ln_tiles * 8 + 1023) >> 10;
+      for (int c = wave; c < chunks; c += WM * WN) {
+        const int vo = m_blk * a.ln_tiles * 8 + c * 1024 + lane * 16;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rm, (lds_ptr_t)(smem + PRE_M + c * 1024), 16, vo, 0, 0, 0);
+      }
+    }
+  }
 #pragma unroll
   for (int s = 0; s < NS - 1; ++s) issue(kt_begin + s, s);
 
@@ -515,12 +569,71 @@ __global__ void __launch_bounds__(WM* WN * 64, 1) pp_gemm_kernel_v2(const PPGemm
   // ================= epilogue: 64-row passes through LDS =================
   const bool splitk = gridDim.y > 1;
   const bool vt_blk = !splitk && a.out_vt && n_blk >= a.vt_col0;
-  const bool geglu = !splitk && a.act == PP_ACT_GEGLU;
+  const bool geglu = EPI == 2;
   const int my_pass = (wm * (MI * 16)) / EPI_ROWS;
   const int my_row0 = (wm * (MI * 16)) % EPI_ROWS;
+  const bool rs_out = LNF && a.row_stats_out != nullptr && !splitk && !vt_blk && !geglu;
+  f32x2_t ln_mr = {0.f, 0.f};
+  if (ln && tid < BM && m_blk + tid < a.M) {
+    float mean, rstd;
+    if (ln_lds) {
+      const f32x2_t* pm = reinterpret_cast<const f32x2_t*>(smem + PRE_M) + tid * a.ln_tiles;
+      float sm = 0.f, sq = 0.f;
+      for (int t = 0; t < a.ln_tiles; ++t) { sm += pm[t][0]; sq += pm[t][1]; }
+      const float inv = 1.0f / (float)a.ln_dim;
+      mean = sm * inv;
+      rstd = rsqrtf(fmaxf(sq * inv - mean * mean, 0.f) + a.ln_eps);
+    } else {
+      ln_row_moments(a, m_blk + tid, mean, rstd);
+    }
+    ln_mr = f32x2_t{mean, rstd};
+  }
+  if constexpr (EPI == 2) {
+    // GEGLU in the MFMA register layout: the weight rows are interleaved (h0,h1,g0,g1), so each lane's accumulator quad is
+    // two complete (value, gate) pairs -> bias / LN correction / GELU happen in registers and only the bf16 result (a
+    // quarter of the fp32 tile) is staged through LDS for 16-byte row-contiguous stores.  One pass, one barrier pair.
+    constexpr int GLD = BN + 16;                       // staged row: BN/2 bf16 + 16 B pad
+    static_assert(BM * GLD + BM * 8 <= NS * STAGE, "GEGLU staging must fit in the pipeline stages");
+    constexpr int GLN = BM * GLD;                      // (mean, rstd) table behind the staged tile
+    asm volatile("s_barrier" ::: "memory");            // main loop done with LDS
+    if (ln) {
+      if (tid < BM) *reinterpret_cast<f32x2_t*>(smem + GLN + tid * 8) = ln_mr;
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    const int q4 = 4 * (lane >> 4);
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int nl = wn * (NI * 16) + ni * 16 + q4;    // column inside the block tile
+      f32x4_t bs, cs;
+      bs = *reinterpret_cast<const f32x4_t*>(smem + PRE_B + nl * 4);   // (prefetched; zero where absent / n >= N)
+      cs = *reinterpret_cast<const f32x4_t*>(smem + PRE_C + nl * 4);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        const int row = wm * (MI * 16) + mi * 16 + (lane & 15);
+        f32x4_t v = acc[ni][mi];
+        if (ln) {
+          const f32x2_t mr = *reinterpret_cast<const f32x2_t*>(smem + GLN + row * 8);
+          v = (v - cs * mr[0]) * mr[1];
+        }
+        v += bs;
+        *reinterpret_cast<uint32_t*>(smem + row * GLD + nl) = pack2bf(v[0] * gelu_fast_f(v[2]), v[1] * gelu_fast_f(v[3]));
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    constexpr int CH = BN / 16;                        // 16-byte chunks per staged row
+    for (int q = tid; q < BM * CH; q += T) {
+      const int row = q / CH, c = q - row * CH;
+      const int m = m_blk + row, n = n_blk + c * 16;
+      if (m < a.M && n < a.N)
+        *reinterpret_cast<u32x4_t*>((uint16_t*)a.out + (size_t)m * a.ldo + (n >> 1)) =
+            *reinterpret_cast<const u32x4_t*>(smem + row * GLD + c * 16);
+    }
+    return;
+  } else {
 #pragma unroll 1
   for (int pass = 0; pass < BM / EPI_ROWS; ++pass) {
     asm volatile("s_barrier" ::: "memory");            // LDS free: main loop (pass 0) / previous read-out finished
+    if (ln && pass == 0 && tid < BM) *reinterpret_cast<f32x2_t*>(smem + LN_OFF + tid * 8) = ln_mr;
     if (my_pass == pass) {
       // lane holds rows n = wn*NI*16 + ni*16 + 4*(lane>>4) + {0..3} of column m = my_row0 + mi*16 + (lane & 15)
 #pragma unroll
@@ -542,7 +655,15 @@ __global__ void __launch_bounds__(WM* WN * 64, 1) pp_gemm_kernel_v2(const PPGemm
         float v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const float*>(smem + (rg * 8 + j) * EPI_LD + col * 4);
-        const float bsv = a.bias ? a.bias[n] : 0.f;
+        if (ln) {
+          const float cs = *reinterpret_cast<const float*>(smem + PRE_C + col * 4);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const f32x2_t mr = *reinterpret_cast<const f32x2_t*>(smem + LN_OFF + (pass * EPI_ROWS + rg * 8 + j) * 8);
+            v[j] = (v[j] - mr[0] * cs) * mr[1];
+          }
+        }
+        const float bsv = LNF ? *reinterpret_cast<const float*>(smem + PRE_B + col * 4) : (a.bias ? a.bias[n] : 0.f);
         const int bidx = m / a.rows_per_batch, rin = m - bidx * a.rows_per_batch;
         uint16_t* dst = (uint16_t*)a.out_vt + ((size_t)bidx * ncols + (n - a.vt_col0)) * a.vt_ld;
         if ((a.rows_per_batch & 7) == 0 && (a.vt_ld & 7) == 0 && m + 8 <= a.M) {
@@ -554,34 +675,6 @@ __global__ void __launch_bounds__(WM* WN * 64, 1) pp_gemm_kernel_v2(const PPGemm
           for (int j = 0; j < 8 && m + j < a.M; ++j) {
             const int bj = (m + j) / a.rows_per_batch, rj = (m + j) - bj * a.rows_per_batch;
             ((uint16_t*)a.out_vt)[((size_t)bj * ncols + (n - a.vt_col0)) * a.vt_ld + rj] = f2bf((v[j] + bsv) * a.scale);
-          }
-        }
-      }
-    } else if (geglu) {
-      // thread = fixed 16-column strip (4 x (h0,h1,g0,g1) -> 8 outputs = one 16-B store), rows tid/GC + j*GR
-      constexpr int GC = BN / 16, GR = T / GC, GP = (EPI_ROWS + GR - 1) / GR;
-      const int c16 = tid % GC, r0 = tid / GC;
-      const int n = n_blk + c16 * 16;
-      if (r0 < GR && n < a.N) {
-        f32x4_t bs[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-          bs[g] = a.bias ? *reinterpret_cast<const f32x4_t*>(a.bias + n + g * 4) : f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int j = 0; j < GP; ++j) {
-          const int row = r0 + j * GR, m = m0 + row;
-          if (row < EPI_ROWS && m < a.M) {
-            float o[8];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-              const f32x4_t vv = *reinterpret_cast<const f32x4_t*>(smem + row * EPI_LD + (c16 * 16 + g * 4) * 4) + bs[g];
-              o[2 * g] = vv[0] * gelu_erf_f(vv[2]);
-              o[2 * g + 1] = vv[1] * gelu_erf_f(vv[3]);
-            }
-            u32x4_t w;
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) w[jj] = pack2bf(o[2 * jj], o[2 * jj + 1]);
-            *reinterpret_cast<u32x4_t*>((uint16_t*)a.out + (size_t)m * a.ldo + (n >> 1)) = w;
           }
         }
       }
@@ -614,7 +707,13 @@ __global__ void __launch_bounds__(WM* WN * 64, 1) pp_gemm_kernel_v2(const PPGemm
                                    : u32x4_t{0u, 0u, 0u, 0u};
           }
           f32x4_t bs0 = {0.f, 0.f, 0.f, 0.f}, bs1 = {0.f, 0.f, 0.f, 0.f};
-          if (a.bias) {
+          f32x4_t cs0 = {0.f, 0.f, 0.f, 0.f}, cs1 = {0.f, 0.f, 0.f, 0.f};
+          if (LNF) {
+            bs0 = *reinterpret_cast<const f32x4_t*>(smem + PRE_B + c8 * 32);
+            bs1 = *reinterpret_cast<const f32x4_t*>(smem + PRE_B + c8 * 32 + 16);
+            cs0 = *reinterpret_cast<const f32x4_t*>(smem + PRE_C + c8 * 32);
+            cs1 = *reinterpret_cast<const f32x4_t*>(smem + PRE_C + c8 * 32 + 16);
+          } else if (a.bias) {
             bs0 = *reinterpret_cast<const f32x4_t*>(a.bias + n);
             bs1 = *reinterpret_cast<const f32x4_t*>(a.bias + n + 4);
           }
@@ -622,8 +721,15 @@ __global__ void __launch_bounds__(WM* WN * 64, 1) pp_gemm_kernel_v2(const PPGemm
           for (int j = 0; j < EP; ++j) {
             const int row = r0 + j * ER, m = m0 + row;
             if (row < EPI_ROWS && m < a.M) {
-              f32x4_t v0 = *reinterpret_cast<const f32x4_t*>(smem + row * EPI_LD + c8 * 32) + bs0;
-              f32x4_t v1 = *reinterpret_cast<const f32x4_t*>(smem + row * EPI_LD + c8 * 32 + 16) + bs1;
+              f32x4_t v0 = *reinterpret_cast<const f32x4_t*>(smem + row * EPI_LD + c8 * 32);
+              f32x4_t v1 = *reinterpret_cast<const f32x4_t*>(smem + row * EPI_LD + c8 * 32 + 16);
+              if (ln) {
+                const f32x2_t mr = *reinterpret_cast<const f32x2_t*>(smem + LN_OFF + (pass * EPI_ROWS + row) * 8);
+                v0 = (v0 - cs0 * mr[0]) * mr[1];
+                v1 = (v1 - cs1 * mr[0]) * mr[1];
+              }
+              v0 += bs0;
+              v1 += bs1;
               if (a.rowvec) {
                 const float* rv = a.rowvec + (size_t)(m / a.rows_per_batch) * a.ld_rowvec + n;
                 v0 += *reinterpret_cast<const f32x4_t*>(rv);
@@ -648,13 +754,38 @@ __global__ void __launch_bounds__(WM* WN * 64, 1) pp_gemm_kernel_v2(const PPGemm
                 o[0] = pack2bf(v0[0], v0[1]); o[1] = pack2bf(v0[2], v0[3]);
                 o[2] = pack2bf(v1[0], v1[1]); o[3] = pack2bf(v1[2], v1[3]);
                 *reinterpret_cast<u32x4_t*>((uint16_t*)a.out + (size_t)m * a.ldo + n) = o;
+                if (rs_out) {   // moments of the values as stored (bf16-rounded), for the LayerNorm folded downstream
+                  float sm = 0.f, sq = 0.f;
+#pragma unroll
+                  for (int jj = 0; jj < 4; ++jj) {
+                    const float lo = bflo(o[jj]), hi = bfhi(o[jj]);
+                    sm += lo + hi;
+                    sq += lo * lo + hi * hi;
+                  }
+                  *reinterpret_cast<f32x2_t*>(smem + RS_OFF + (row * EC + c8) * 8) = f32x2_t{sm, sq};
+                }
               }
             }
           }
         }
       }
+      if (rs_out) {
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (tid < EPI_ROWS && m0 + tid < a.M) {
+          const int nc = min(EC, (a.N - n_blk) >> 3);
+          float sm = 0.f, sq = 0.f;
+          for (int c = 0; c < nc; ++c) {
+            const f32x2_t v = *reinterpret_cast<const f32x2_t*>(smem + RS_OFF + (tid * EC + c) * 8);
+            sm += v[0];
+            sq += v[1];
+          }
+          const int tiles_n = (a.N + BN - 1) / BN;
+          *reinterpret_cast<f32x2_t*>(a.row_stats_out + ((size_t)(m0 + tid) * tiles_n + n_blk / BN) * 2) = f32x2_t{sm, sq};
+        }
+      }
     }
   }
+  }   // EPI != 2
 }
 
 // Deterministic split-K combine + epilogue: thread = (row, 8 columns); the <= 8 partial slabs are read with all loads
@@ -739,6 +870,7 @@ Choice choose(const PPGemmArgs& a) {
     c.splitk = sk;
   }
   if (a.N % 8) c.splitk = 1;   // the split-K combine works on 8-column strips
+  if (a.row_stats_out) c.splitk = 1;   // row moments come out of the fused (single-pass) epilogue only
   return c;
 }
 
@@ -775,13 +907,21 @@ int launch(const PPGemmArgs& a, int splitk, hipStream_t st) {
   return PP_OK;
 }
 
-template <int BM, int BN, int WM, int WN, int XMODE, int NS>
+template <int BM, int BN, int WM, int WN, int XMODE, int NS, int EPI = 0>
 int launch2(const PPGemmArgs& a, int splitk, hipStream_t st) {
+  if constexpr (XMODE == PP_X_PLAIN && EPI == 0) {
+    if (a.act == PP_ACT_GEGLU && splitk == 1) return launch2<BM, BN, WM, WN, XMODE, NS, 2>(a, splitk, st);
+    if (a.ln_stats || a.row_stats_out) return launch2<BM, BN, WM, WN, XMODE, NS, 1>(a, splitk, st);
+  }
+  constexpr bool LNF = EPI != 0;
   constexpr int T = WM * WN * 64;
-  constexpr int LDS = NS * (BM + BN) * 128;
-  static_assert(LDS <= 160 * 1024, "LDS budget");
+  constexpr int LDS = NS * (BM + BN) * 128 + (LNF ? 2048 + BM * 32 : 0);   // + epilogue-operand prefetch (LNF)
+  static_assert(LDS <= 160 * 1024 || (LNF && NS > 2), "LDS budget");
+  if constexpr (LDS > 160 * 1024) {   // 256x160 x 3 stages has no room for the prefetch: drop to 2 stages
+    return launch2<BM, BN, WM, WN, XMODE, 2, EPI>(a, splitk, st);
+  } else {
   static bool attr_set = false;
-  auto kern = pp_gemm_kernel_v2<BM, BN, WM, WN, XMODE, NS>;
+  auto kern = pp_gemm_kernel_v2<BM, BN, WM, WN, XMODE, NS, EPI>;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) !=
         hipSuccess) {
@@ -807,6 +947,7 @@ int launch2(const PPGemmArgs& a, int splitk, hipStream_t st) {
     PP_CHECK_LAUNCH("pp_splitk_reduce_kernel");
   }
   return PP_OK;
+  }
 }
 
 int validate(const PPGemmArgs& a) {
@@ -833,8 +974,10 @@ int validate(const PPGemmArgs& a) {
   }
   if ((uint64_t)a.N * (uint64_t)a.K * 2u >= 0x80000000ull) return PP_ERR_UNSUPPORTED;
   if ((a.rowvec || a.out_vt) && a.rows_per_batch <= 0) return PP_ERR_BAD_ARG;
-  if (a.act == PP_ACT_GEGLU && (a.out_f32 || a.out_vt)) return PP_ERR_BAD_ARG;
+  if (a.act == PP_ACT_GEGLU && (a.out_f32 || a.out_vt || a.x_mode != PP_X_PLAIN)) return PP_ERR_BAD_ARG;
   if (a.out_vt && a.vt_col0 % 4 != 0) return PP_ERR_BAD_ARG;
+  if (a.ln_stats && (!a.ln_colsum || a.ln_tiles <= 0 || a.ln_dim <= 0)) return PP_ERR_BAD_ARG;
+  if (a.row_stats_out && (a.out_f32 || a.out_vt || a.act == PP_ACT_GEGLU || !v2_ok(a))) return PP_ERR_UNSUPPORTED;
   return PP_OK;
 }
 
@@ -854,6 +997,7 @@ extern "C" int pp_gemm_bf16(const PPGemmArgs* args, void* stream) {
   const Choice c = choose(a);
   if (c.splitk > 1 && !a.workspace) return PP_ERR_WORKSPACE;
   if (c.tile > 10 && !v2_ok(a)) return PP_ERR_BAD_ARG;
+  if (a.row_stats_out && c.tile < 10) return PP_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   const bool conv = a.x_mode == PP_X_CONV3X3;
   switch (c.tile) {

@@ -29,6 +29,19 @@ PP_DEVINL float bfhi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
 
 PP_DEVINL float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 PP_DEVINL float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// Exact-erf GELU, x * Phi(x), with erfc from Abramowitz-Stegun 7.1.26 (|erf error| <= 1.5e-7, far below bf16 output
+// rounding): Phi(-|x|) = 0.5 * erfc(|x|/sqrt 2) = 0.5 * poly(t) * exp(-x^2/2), t = 1/(1 + p|x|/sqrt 2).  ~15 VALU
+// instructions, branch-free, against ~45 for the library erff -- the GEGLU epilogue is VALU-bound at K = 320.
+PP_DEVINL float gelu_fast_f(float x) {
+  const float ax = __builtin_fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(ax, 0.3275911f * 0.70710678118654752440f, 1.0f));
+  float p = __builtin_fmaf(t, 0.5f * 1.061405429f, 0.5f * -1.453152027f);
+  p = __builtin_fmaf(t, p, 0.5f * 1.421413741f);
+  p = __builtin_fmaf(t, p, 0.5f * -0.284496736f);
+  p = __builtin_fmaf(t, p, 0.5f * 0.254829592f);
+  const float q = p * t * __builtin_amdgcn_exp2f(x * x * (-0.5f * 1.44269504088896340736f));   // Phi(-|x|)
+  return x * (x >= 0.f ? 1.0f - q : q);
+}
 
 // Buffer resource over [base, base+bytes): out-of-range voffset reads return 0 -> free zero padding for im2col.
 PP_DEVINL __amdgpu_buffer_rsrc_t make_rsrc(const void* base, uint32_t bytes) {

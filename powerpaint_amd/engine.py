@@ -12,6 +12,7 @@ Design (MI355X-first):
     coefficients, step counter), so a captured step replays with zero host->device traffic.
 """
 import ctypes as C
+import os
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -228,8 +229,10 @@ class Builder:
                x2: int = 0, K2: int = 0, ldx2: int = 0, res1: int = 0, ldres1: int = 0, res2: int = 0,
                ldres2: int = 0, scale: float = 1.0, act: int = 0, out: int = 0, ldo: Optional[int] = None,
                rowvec: int = 0, ld_rowvec: int = 0, rows_per_batch: int = 0, out_vt: int = 0, vt_col0: int = 0,
-               vt_ld: int = 0, out_f32: bool = False, name: str = "gemm") -> int:
-        """out[rows][N] = epilogue(X[rows][K(+K2)] @ W[N][K+K2]^T).  Returns the output pointer."""
+               vt_ld: int = 0, out_f32: bool = False, row_stats_out: int = 0, ln_stats: int = 0, ln_colsum: int = 0,
+               ln_tiles: int = 0, ln_dim: int = 0, ln_eps: float = 1e-5, name: str = "gemm") -> int:
+        """out[rows][N] = epilogue(X[rows][K(+K2)] @ W[N][K+K2]^T).  Returns the output pointer.
+        row_stats_out / ln_*: LayerNorm folded across two GEMMs (see include/pp_hip.h)."""
         n_out = N // 2 if act == L.PP_ACT_GEGLU else (vt_col0 if out_vt else N)
         if ldo is None:
             ldo = n_out
@@ -247,6 +250,9 @@ class Builder:
         a.scale, a.act = scale, act
         a.out, a.ldo, a.out_f32 = out, ldo, int(out_f32)
         a.out_vt, a.vt_col0, a.vt_ld = out_vt or None, vt_col0, vt_ld
+        a.row_stats_out = row_stats_out or None
+        if ln_stats:
+            a.ln_stats, a.ln_colsum, a.ln_tiles, a.ln_dim, a.ln_eps = ln_stats, ln_colsum, ln_tiles, ln_dim, ln_eps
         self._gemm(a, name)
         self.release(m)
         return out
@@ -339,6 +345,10 @@ class SDNet:
     *_add_samples), /root/reference/powerpaint/models/BrushNet_CA.py:690-952 (BrushNet) and the diffusers-0.27.0
     ControlNetModel used at /root/reference/powerpaint/pipelines/pipeline_PowerPaint_ControlNet.py:1686-1694.
     """
+
+    # BasicTransformerBlock.norm1/2/3 folded into the GEMMs on either side (no LayerNorm launch, no normalised copy in
+    # HBM).  PP_FOLD_LN=0 keeps the stand-alone pp_layernorm launches (A/B measurements, bisecting).
+    fold_ln = os.environ.get("PP_FOLD_LN", "1") != "0"
 
     def __init__(self, kind: str, in_channels: int, block_out_channels=(320, 640, 1280, 1280), layers_per_block=2,
                  heads=8, cross_attention_dim=768, groups=32, eps=1e-5,
@@ -553,19 +563,38 @@ class SDNet:
                 pk.add(f"{pre}.{pj}.weight", W(f"{pre}.{pj}.weight").reshape(c, c), bf)
                 pk.add(f"{pre}.{pj}.bias", W(f"{pre}.{pj}.bias"), f32)
             tb_ = f"{pre}.transformer_blocks.0"
-            for nrm in ("norm1", "norm2", "norm3"):
-                pk.add(f"{tb_}.{nrm}.weight", W(f"{tb_}.{nrm}.weight"), f32)
-                pk.add(f"{tb_}.{nrm}.bias", W(f"{tb_}.{nrm}.bias"), f32)
-            pk.add(f"{tb_}.attn1.qkv.weight", torch.cat([W(f"{tb_}.attn1.to_q.weight"), W(f"{tb_}.attn1.to_k.weight"),
-                                                         W(f"{tb_}.attn1.to_v.weight")], 0), bf)
+            wqkv = torch.cat([W(f"{tb_}.attn1.to_q.weight"), W(f"{tb_}.attn1.to_k.weight"),
+                              W(f"{tb_}.attn1.to_v.weight")], 0)
+            wff1, bff1 = W(f"{tb_}.ff.net.0.proj.weight"), W(f"{tb_}.ff.net.0.proj.bias")
+            if self.fold_ln:
+                # LayerNorm folded into the Linear that consumes it:  LN(x) W^T = rstd (x (g.W)^T - mean colsum) + W b
+                def fold(name, w, nrm, bias=None, il=False):
+                    g_, b_ = W(f"{tb_}.{nrm}.weight"), W(f"{tb_}.{nrm}.bias")
+                    wf = w * g_[None, :]
+                    cs = wf.to(bf).float().sum(1)          # of the weights as the MFMA sees them
+                    t = w @ b_ if bias is None else w @ b_ + bias
+                    if il:
+                        wf, cs, t = _geglu_interleave(wf), _geglu_interleave(cs), _geglu_interleave(t)
+                    pk.add(f"{name}.weight", wf, bf)
+                    pk.add(f"{name}.colsum", cs, f32)
+                    pk.add(f"{name}.bias", t, f32)
+
+                fold(f"{tb_}.attn1.qkv", wqkv, "norm1")
+                fold(f"{tb_}.attn2.to_q", W(f"{tb_}.attn2.to_q.weight"), "norm2")
+                fold(f"{tb_}.ff1", wff1, "norm3", bff1, il=True)
+            else:
+                for nrm in ("norm1", "norm2", "norm3"):
+                    pk.add(f"{tb_}.{nrm}.weight", W(f"{tb_}.{nrm}.weight"), f32)
+                    pk.add(f"{tb_}.{nrm}.bias", W(f"{tb_}.{nrm}.bias"), f32)
+                pk.add(f"{tb_}.attn1.qkv.weight", wqkv, bf)
+                pk.add(f"{tb_}.attn2.to_q.weight", W(f"{tb_}.attn2.to_q.weight"), bf)
+                pk.add(f"{tb_}.ff1.weight", _geglu_interleave(wff1), bf)
+                pk.add(f"{tb_}.ff1.bias", _geglu_interleave(bff1), f32)
             pk.add(f"{tb_}.attn1.to_out.weight", W(f"{tb_}.attn1.to_out.0.weight"), bf)
             pk.add(f"{tb_}.attn1.to_out.bias", W(f"{tb_}.attn1.to_out.0.bias"), f32)
-            pk.add(f"{tb_}.attn2.to_q.weight", W(f"{tb_}.attn2.to_q.weight"), bf)
             pk.add(f"{tb_}.attn2.kv.weight", torch.cat([W(f"{tb_}.attn2.to_k.weight"), W(f"{tb_}.attn2.to_v.weight")], 0), bf)
             pk.add(f"{tb_}.attn2.to_out.weight", W(f"{tb_}.attn2.to_out.0.weight"), bf)
             pk.add(f"{tb_}.attn2.to_out.bias", W(f"{tb_}.attn2.to_out.0.bias"), f32)
-            pk.add(f"{tb_}.ff1.weight", _geglu_interleave(W(f"{tb_}.ff.net.0.proj.weight")), bf)
-            pk.add(f"{tb_}.ff1.bias", _geglu_interleave(W(f"{tb_}.ff.net.0.proj.bias")), f32)
             pk.add(f"{tb_}.ff2.weight", W(f"{tb_}.ff.net.2.weight"), bf)
             pk.add(f"{tb_}.ff2.bias", W(f"{tb_}.ff.net.2.bias"), f32)
         if self.kind == "unet":
@@ -617,33 +646,50 @@ class SDNet:
         out = pb.new_act(x.B, x.H, x.W, Cc)
         m = pb.mark()
         n = pb.groupnorm(x, P[f"{pre}.norm.weight"], P[f"{pre}.norm.bias"], 1e-6, False, groups=self.groups)
-        hs = pb.linear(n.ptr, rows, Cc, P[f"{pre}.proj_in.weight"], Cc, P[f"{pre}.proj_in.bias"], name="conv1x1")
+        fold = self.fold_ln
+        tiles = (Cc + 159) // 160
+
+        def producer():     # row-moment buffer written by the GEMM that produces the next LayerNorm's input
+            return pb.alloc(rows * tiles * 8) if fold else 0
+
+        def normed(h, st, nrm, lin):
+            """-> (x pointer, kwargs) for the Linear `lin` applied to LayerNorm_nrm(h)."""
+            if fold:
+                return h, dict(bias=P[f"{tb}.{lin}.bias"], ln_stats=st, ln_colsum=P[f"{tb}.{lin}.colsum"],
+                               ln_tiles=tiles, ln_dim=Cc, ln_eps=1e-5)
+            xn = pb.layernorm(h, rows, Cc, P[f"{tb}.{nrm}.weight"], P[f"{tb}.{nrm}.bias"])
+            return xn, (dict(bias=P[f"{tb}.{lin}.bias"]) if lin == "ff1" else {})
+
+        st = producer()
+        hs = pb.linear(n.ptr, rows, Cc, P[f"{pre}.proj_in.weight"], Cc, P[f"{pre}.proj_in.bias"], row_stats_out=st,
+                       name="conv1x1")
         # self-attention: fused QKV GEMM, V written transposed by the epilogue
-        ln = pb.layernorm(hs, rows, Cc, P[f"{tb}.norm1.weight"], P[f"{tb}.norm1.bias"])
+        ln, kw = normed(hs, st, "norm1", "attn1.qkv")
         if hw % 8 == 0:
             vt = pb.alloc(x.B * Cc * hw * 2)
             qk = pb.linear(ln, rows, Cc, P[f"{tb}.attn1.qkv.weight"], 3 * Cc, out_vt=vt, vt_col0=2 * Cc, vt_ld=hw,
-                           rows_per_batch=hw, name="linear")
+                           rows_per_batch=hw, name="linear", **kw)
             a = pb.attention(qk, 2 * Cc, qk + 2 * Cc, 2 * Cc, vt, hw, x.B, self.heads, hw, hw, d)
         else:
             # tiny latents (hw < 8, e.g. 2x2): V^T rows must be 16-byte aligned and zero padded -> unfused transpose
             ldvt = _align(hw, 8)
             vt = pb.alloc(x.B * Cc * ldvt * 2)
-            qkv = pb.linear(ln, rows, Cc, P[f"{tb}.attn1.qkv.weight"], 3 * Cc, name="linear")
+            qkv = pb.linear(ln, rows, Cc, P[f"{tb}.attn1.qkv.weight"], 3 * Cc, name="linear", **kw)
             pb.plan.add("transpose_v", pb.lib.pp_transpose_v, qkv + 4 * Cc, 3 * Cc, x.B, hw, Cc, vt, ldvt)
             a = pb.attention(qkv, 3 * Cc, qkv + 2 * Cc, 3 * Cc, vt, ldvt, x.B, self.heads, hw, hw, d)
+        st = producer()
         hs = pb.linear(a, rows, Cc, P[f"{tb}.attn1.to_out.weight"], Cc, P[f"{tb}.attn1.to_out.bias"], res1=hs,
-                       name="linear")
+                       row_stats_out=st, name="linear")
         # cross-attention (K / V^T hoisted out of the step: encoder_hidden_states are step-invariant)
-        ln = pb.layernorm(hs, rows, Cc, P[f"{tb}.norm2.weight"], P[f"{tb}.norm2.bias"])
-        q = pb.linear(ln, rows, Cc, P[f"{tb}.attn2.to_q.weight"], Cc, name="linear")
+        ln, kw = normed(hs, st, "norm2", "attn2.to_q")
+        q = pb.linear(ln, rows, Cc, P[f"{tb}.attn2.to_q.weight"], Cc, name="linear", **kw)
         a = pb.attention(q, Cc, kv[0], kv[1], kv[2], kv[3], x.B, self.heads, hw, self._nctx, d)
+        st = producer()
         hs = pb.linear(a, rows, Cc, P[f"{tb}.attn2.to_out.weight"], Cc, P[f"{tb}.attn2.to_out.bias"], res1=hs,
-                       name="linear")
+                       row_stats_out=st, name="linear")
         # feed-forward: GEGLU fused into the first GEMM's epilogue
-        ln = pb.layernorm(hs, rows, Cc, P[f"{tb}.norm3.weight"], P[f"{tb}.norm3.bias"])
-        g = pb.linear(ln, rows, Cc, P[f"{tb}.ff1.weight"], 8 * Cc, P[f"{tb}.ff1.bias"], act=L.PP_ACT_GEGLU,
-                      name="linear_geglu")
+        ln, kw = normed(hs, st, "norm3", "ff1")
+        g = pb.linear(ln, rows, Cc, P[f"{tb}.ff1.weight"], 8 * Cc, act=L.PP_ACT_GEGLU, name="linear_geglu", **kw)
         hs = pb.linear(g, rows, 4 * Cc, P[f"{tb}.ff2.weight"], Cc, P[f"{tb}.ff2.bias"], res1=hs, name="linear")
         pb.linear(hs, rows, Cc, P[f"{pre}.proj_out.weight"], Cc, P[f"{pre}.proj_out.bias"], res1=x.ptr, res2=res2,
                   out=out.ptr, name="conv1x1")

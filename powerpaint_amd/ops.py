@@ -24,8 +24,11 @@ def _p(t: Optional[torch.Tensor]):
 
 def gemm(x: torch.Tensor, w: torch.Tensor, bias=None, x2=None, res1=None, res2=None, scale: float = 1.0, act: int = 0,
          rowvec=None, rows_per_batch: int = 0, out_f32: bool = False, vt_col0: int = 0, tile: int = 0,
-         splitk: int = 0):
-    """x [M,K1] (+ x2 [M,K2]) bf16, w [N,K1+K2] bf16 -> out [M,N] (or [M,N/2] for GEGLU; (out, vt) when vt_col0)."""
+         splitk: int = 0, row_stats: bool = False, ln_stats=None, ln_colsum=None, ln_dim: int = 0,
+         ln_eps: float = 1e-5):
+    """x [M,K1] (+ x2 [M,K2]) bf16, w [N,K1+K2] bf16 -> out [M,N] (or [M,N/2] for GEGLU; (out, vt) when vt_col0).
+    row_stats=True additionally returns the per-row (sum, sumsq) partials [M, ceil(N/160), 2] fp32;
+    ln_stats (that layout) + ln_colsum [N] fp32 apply the folded-LayerNorm correction (see include/pp_hip.h)."""
     lib = L.lib()
     M, K1 = x.shape
     K2 = x2.shape[1] if x2 is not None else 0
@@ -49,10 +52,18 @@ def gemm(x: torch.Tensor, w: torch.Tensor, bias=None, x2=None, res1=None, res2=N
         vt = torch.zeros(nb, N - vt_col0, rows_per_batch, dtype=torch.bfloat16, device=x.device)
         a.out_vt, a.vt_col0, a.vt_ld = _p(vt), vt_col0, rows_per_batch
     a.tile, a.splitk = tile, splitk
+    stats = None
+    if row_stats:
+        stats = torch.zeros(M, (N + 159) // 160, 2, dtype=torch.float32, device=x.device)
+        a.row_stats_out = _p(stats)
+    if ln_stats is not None:
+        a.ln_stats, a.ln_colsum, a.ln_tiles, a.ln_dim, a.ln_eps = _p(ln_stats), _p(ln_colsum), ln_stats.shape[1], ln_dim, ln_eps
     ws = lib.pp_gemm_workspace_bytes(C.byref(a))
     wsb = torch.empty(max(ws, 4) // 4, dtype=torch.float32, device=x.device) if ws else None
     a.workspace = _p(wsb)
     L.check(lib.pp_gemm_bf16(C.byref(a), _s()), "pp_gemm_bf16")
+    if row_stats:
+        return out, stats
     return (out, vt) if vt_col0 else out
 
 

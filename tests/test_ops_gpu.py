@@ -106,6 +106,64 @@ def test_gemm_vt_epilogue():
     check(vt, y[:, 2 * C:].reshape(B, hw, C).transpose(1, 2), 2e-2, 1e-2, "v^T part")
 
 
+V2_TILES = [21, 31, 22, 32, 42, 23, 33, 24]
+
+
+@pytest.mark.parametrize("tile", V2_TILES + [0])
+@pytest.mark.parametrize("M,N", [(520, 320), (1024, 640), (192, 1280)])
+def test_gemm_row_stats(tile, M, N):
+    """Producer side of the folded LayerNorm: per-row (sum, sumsq) of the STORED bf16 output, per 160-column tile."""
+    K = 320
+    x, w = bf(rnd(M, K, seed=1)), bf(rnd(N, K, seed=2, scale=K ** -0.5))
+    bias, res = rnd(N, seed=3), bf(rnd(M, N, seed=4))
+    out, st = ops.gemm(x, w, bias=bias, res1=res, tile=tile, row_stats=True)
+    o = out.float()
+    tiles = N // 160
+    ref = torch.stack([o.reshape(M, tiles, 160).sum(-1), (o * o).reshape(M, tiles, 160).sum(-1)], -1)
+    check(st, ref, 1e-3, 1e-5, "row moments")
+
+
+@pytest.mark.parametrize("tile", [1, 2, 3] + V2_TILES + [0])
+@pytest.mark.parametrize("kind", ["plain", "geglu", "vt"])
+def test_gemm_folded_layernorm(tile, kind):
+    """Consumer side: Linear(LayerNorm(h)) == rstd * (h (g.W)^T - mean * colsum) + W b  with moments from the producer."""
+    from powerpaint_amd.engine import _geglu_interleave
+    B, hw, C = 2, 264, 320
+    M = B * hw
+    N = {"plain": C, "geglu": 8 * C, "vt": 3 * C}[kind]
+    h = bf(rnd(M, C, seed=1, scale=3.0) + 0.7)
+    g, b = rnd(C, seed=5) * 0.3 + 1.0, rnd(C, seed=6) * 0.2
+    w = rnd(N, C, seed=2, scale=C ** -0.5)
+    bias = rnd(N, seed=3) if kind != "vt" else None
+    true = F.layer_norm(h.float(), (C,), g, b, 1e-5) @ w.t()          # what the network means (fp32 weights)
+    if bias is not None:
+        true = true + bias
+    hf = h.float()
+    tiles = C // 160
+    st = torch.stack([hf.reshape(M, tiles, 160).sum(-1), (hf * hf).reshape(M, tiles, 160).sum(-1)], -1).contiguous()
+    wf = bf(w * g[None, :])
+    cs = wf.float().sum(1)
+    t = w @ b if bias is None else w @ b + bias
+    # what the kernel is asked to compute, with the bf16 weights it actually multiplies
+    mean = hf.mean(-1, keepdim=True)
+    rstd = torch.rsqrt((hf * hf).mean(-1, keepdim=True) - mean * mean + 1e-5)
+    ref = rstd * (hf @ wf.float().t() - mean * cs) + t
+    check(ref, true, 6e-2, 2e-2, "fold algebra vs LayerNorm -> Linear")
+    kw = dict(ln_stats=st, ln_colsum=cs.contiguous(), ln_dim=C, tile=tile)
+    if kind == "plain":
+        check(ops.gemm(h, wf, bias=t.contiguous(), **kw), ref, 3e-2, 1e-2, "folded LN")
+    elif kind == "geglu":
+        kw["ln_colsum"] = _geglu_interleave(cs).contiguous()
+        out = ops.gemm(h, _geglu_interleave(wf).contiguous(), bias=_geglu_interleave(t).contiguous(),
+                       act=L.PP_ACT_GEGLU, **kw)
+        a_, g_ = ref.chunk(2, -1)
+        check(out, a_ * F.gelu(g_), 3e-2, 1e-2, "folded LN + GEGLU")
+    else:
+        out, vt = ops.gemm(h, wf, bias=t.contiguous(), vt_col0=2 * C, rows_per_batch=hw, **kw)
+        check(out, ref[:, :2 * C], 3e-2, 1e-2, "folded LN qk")
+        check(vt, ref[:, 2 * C:].reshape(B, hw, C).transpose(1, 2), 3e-2, 1e-2, "folded LN v^T")
+
+
 # ------------------------------------------------------------------------------------------------ conv3x3 (implicit GEMM)
 def conv_ref(x_nhwc, w_igemm, bias, stride=1, up=False):
     B, H, W, Cin = x_nhwc.shape
