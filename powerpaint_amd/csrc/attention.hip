@@ -16,6 +16,7 @@
 //     each 16-key block so that every MFMA operand fragment is ONE conflict-free ds_read_b128;
 //   * next K/V tile is prefetched into registers while the current one is consumed (global latency hidden behind
 //     the MFMAs), exp2 with the softmax scale folded into one FMA.
+#include <cstdlib>
 #include <type_traits>
 
 #include "pp_common.h"
@@ -316,12 +317,24 @@ static int launch_attn(const void* q, int ldq, const void* k, int ldk, const voi
   return PP_OK;
 }
 
+// attention_pipe.hip: software-pipelined kernel for the hot self-attention shapes (PP_ERR_UNSUPPORTED otherwise)
+int pp_attention_pipe_launch(const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt, void* o, int ldo,
+                             int batch, int heads, int nq, int nk, int d, float sl2, hipStream_t st);
+
 extern "C" int pp_attention_fwd(const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt, void* o,
                                 int ldo, int batch, int heads, int nq, int nk, int d, float scale, void* stream) {
   if (!q || !k || !vt || !o || batch <= 0 || heads <= 0 || nq <= 0 || nk <= 0) return PP_ERR_BAD_ARG;
   if (ldq % 8 || ldk % 8 || ldvt % 8 || ldo % 4 || ldvt < nk) return PP_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)stream;
   const float sl2 = scale * 1.4426950408889634f;
+  static const bool use_pipe = [] {   // PP_ATTN_PIPE=0: A/B measurements against the three-phase kernel
+    const char* e = getenv("PP_ATTN_PIPE");
+    return !(e && e[0] == '0');
+  }();
+  if (use_pipe) {
+    const int rc = pp_attention_pipe_launch(q, ldq, k, ldk, vt, ldvt, o, ldo, batch, heads, nq, nk, d, sl2, st);
+    if (rc != PP_ERR_UNSUPPORTED) return rc;
+  }
   switch (d) {
     case 40: return launch_attn<40>(q, ldq, k, ldk, vt, ldvt, o, ldo, batch, heads, nq, nk, sl2, st);
     case 80: return launch_attn<80>(q, ldq, k, ldk, vt, ldvt, o, ldo, batch, heads, nq, nk, sl2, st);

@@ -1,0 +1,383 @@
+// Software-pipelined flash attention for the hot self-attention shapes (head dim 40, N = 4096 / 1024 keys) on gfx950.
+//
+// Why a second kernel: in attn_fwd_kernel (attention.hip) every wave runs  QK^T MFMAs -> softmax VALU -> PV MFMAs  as
+// three serial phases, and the waves that share a SIMD run the same phases in lock step.  PMC counters on MI355X
+// (profiles/r01_attention_pmc.txt): VALU busy 52 % + MFMA busy 32 % + 16 % stalls = 100 %, i.e. the matrix pipe and the
+// vector ALUs never overlap.  tools/micro/valu_rate.hip shows that ONE wave does overlap its own in-flight MFMA with
+// independent VALU instructions that follow it in the instruction stream.  So the loop is restructured such that the
+// MFMAs and the VALU work inside one iteration are independent:
+//
+//     stage t :   S(t+1) = K(t+1) Q^T          6 MFMA      \   interleaved in ONE basic block with
+//                 O     += V(t-1)^T P(t-1)^T   8 MFMA      /   softmax(S(t)) -> P(t)      ~90 VALU (32 v_exp)
+//
+//   * S and P are double buffered in registers (the stage body is instantiated twice with the buffers swapped -> no
+//     register copies); the O rescale of the (rare) running-max update is deferred to the top of the next stage, after
+//     the PV MFMAs that still belong to the old max;
+//   * K / V^T tiles arrive by LDS-DMA (buffer_load ... lds, no staging registers, no ds_write): 3-deep K ring, 5-deep
+//     V^T ring, loads issued three tiles ahead with counted vmcnt + one s_barrier per stage;
+//   * LDS rows keep an odd number of 16-byte slots (K: 7, V^T: 9) -> conflict-free fragment reads; the DMA is lane-linear
+//     so the padding slot is just a lane whose source offset is out of range (the buffer descriptor returns 0);
+//   * V^T is stored with natural key order, each PV A-fragment is two ds_read_b64 (keys 4h..4h+3 and 8+4h..8+4h+3 of the
+//     16-key block = exactly the keys of the S^T accumulator registers this lane packed into its B-fragment);
+//   * the softmax denominator comes out of the PV MFMAs: V^T row 63 is all ones.
+// Restrictions (the host falls back to attn_fwd_kernel otherwise): d == 40, nk % 64 == 0.
+#include <cstdlib>
+
+#include "pp_common.h"
+
+namespace {
+
+constexpr int KB = 64;   // keys per tile
+constexpr int QW = 32;   // queries per wave
+constexpr int NW = 4;    // waves per block
+
+template <int D>
+struct PCfg {
+  static constexpr int DP = (D + 15) / 16 * 16;
+  static constexpr int DS = DP / 16;
+  static constexpr int VROWS = (D + 1 + 31) / 32 * 32;   // head-dim rows + the all-ones row, whole 32-row MFMA tiles
+  static constexpr int DT = VROWS / 32;
+  static constexpr int KSL = DP / 8 + 1;                 // 16-B slots per K row (odd)
+  static constexpr int KS = KSL * 16;
+  static constexpr int KTILE = KB * KS;
+  static constexpr int KI = KTILE / 1024;                // wave-wide DMA instructions per K tile
+  static constexpr int VSL = KB / 8 + 1;                 // 9 slots per V^T row
+  static constexpr int VS = VSL * 16;
+  static constexpr int VTILE = VROWS * VS;
+  static constexpr int VI = (D * VS + 1023) / 1024;      // DMA instructions for the streamed rows [0, D)
+  static constexpr int LPW = (KI + NW - 1) / NW + (VI + NW - 1) / NW;   // DMA instructions per wave per tile
+  static constexpr int NKB = 3, NVB = 5;                 // ring depths
+  static constexpr int VBASE = NKB * KTILE;
+  static constexpr int DUMMY = VBASE + NVB * VTILE;
+  static constexpr int LDS = DUMMY + 1024;
+  static_assert(KTILE % 1024 == 0, "K tile must be whole DMA instructions");
+  static_assert(VI * 1024 <= (VROWS - 1) * VS, "DMA spill of the V^T tile must stay below the ones row");
+  static_assert(KSL % 2 == 1 && VSL % 2 == 1, "odd slot counts");
+};
+
+constexpr float RESCALE_THR = 8.0f;
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+template <int D, int dbg>
+__global__ void __launch_bounds__(256, 2)
+attn_pipe_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __restrict__ k, int ldk,
+                 const uint16_t* __restrict__ vt, int ldvt, uint16_t* __restrict__ o, int ldo, int heads, int nq, int nk,
+                 float scale_log2e) {
+  // dbg (PP_ATTN_DBG, timing experiments only; results are garbage): 1 no MFMA, 2 no exp, 4 no tile DMA / barrier,
+  // 8 no LDS fragment reads
+  using C = PCfg<D>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int q0 = blockIdx.x * (QW * NW) + wave * QW;
+  const int qi = lane & 31, half = lane >> 5;
+  const int ntiles = nk / KB;
+
+  // ---- LDS init: V^T ring all zero (ring slot NVB-1 is read by stage 0 with P = 0; 0 x garbage could be NaN), ones row
+  for (int i = tid; i < C::NVB * C::VTILE / 16; i += 256)
+    *reinterpret_cast<u32x4_t*>(smem + C::VBASE + i * 16) = u32x4_t{0u, 0u, 0u, 0u};
+  __syncthreads();
+  for (int i = tid; i < C::NVB * (KB / 2); i += 256) {
+    const int bufi = i / (KB / 2), w = i - bufi * (KB / 2);
+    *reinterpret_cast<uint32_t*>(smem + C::VBASE + bufi * C::VTILE + (C::VROWS - 1) * C::VS + w * 4) = 0x3F803F80u;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  // ---- Q fragments (B operand): lane = query qi, k-slot = 8*half + jj  ->  Q[q0+qi][16 s + 8 half + jj]
+  u32x4_t qraw[C::DS];
+  {
+    const int qrow = q0 + qi;
+    const uint16_t* qp = q + ((size_t)b * nq + (qrow < nq ? qrow : 0)) * ldq + h * D;
+#pragma unroll
+    for (int s = 0; s < C::DS; ++s) {
+      const int dc = 16 * s + 8 * half;
+      u32x4_t v = {0u, 0u, 0u, 0u};
+      if (qrow < nq && dc < D) v = *reinterpret_cast<const u32x4_t*>(qp + dc);
+      qraw[s] = v;
+    }
+  }
+
+  // ---- DMA plan.  Per tile every wave issues LPW wave-wide 16-byte DMA instructions: i < LPK move K slots, the rest V^T
+  // slots; which slots = 64 * (i' * NW + wave).  Instructions past the end of a tile (and the padding slots inside it)
+  // carry an out-of-range source offset -> they write zeros, into a dummy KB of LDS when the whole instruction is dead.
+  // Everything that changes from tile to tile is SCALAR state advanced with a handful of SALU ops per stage (descriptor
+  // base / size, ring offsets) -- the per-stage bookkeeping must not eat the issue slots of the 2 waves per SIMD.
+  const uint16_t* k_bh = k + (size_t)b * nk * ldk + h * D;
+  const uint16_t* vt_bh = vt + ((size_t)b * heads + h) * D * (size_t)ldvt;
+  constexpr int LPK = (C::KI + NW - 1) / NW, LPV = (C::VI + NW - 1) / NW;
+  static_assert(LPK + LPV == C::LPW || LPK + LPV <= C::LPW, "DMA split");
+  int vo[LPK + LPV];
+  int rel[LPK + LPV];       // LDS offset inside the ring slot, or -1: dead instruction -> dummy area   (wave-uniform)
+#pragma unroll
+  for (int i = 0; i < LPK + LPV; ++i) {
+    int off = (int)PP_OOB;
+    if (i < LPK) {
+      const int g = i * NW + wave;
+      const int L = 64 * g + lane, r = L / C::KSL, p = L - r * C::KSL;
+      if (g < C::KI && p < D / 8) off = (r * ldk + p * 8) * 2;
+      rel[i] = g < C::KI ? g * 1024 : -1;
+    } else {
+      const int g = (i - LPK) * NW + wave;
+      const int L = 64 * g + lane, r = L / C::VSL, p = L - r * C::VSL;
+      if (g < C::VI && r < D && p < KB / 8) off = (r * ldvt + p * 8) * 2;
+      rel[i] = g < C::VI ? g * 1024 : -1;
+    }
+    vo[i] = off;
+  }
+  int kread = 1, vread = C::NVB - 1;        // ring slots stage t reads: K(t+1), V(t-1)
+  int kring = 0, vring = 0;                 // ring slots of the NEXT tile to issue
+  int t_issue = 0;                          // its index
+  auto issue = [&]() {
+    const int t0 = t_issue * KB;
+    const bool live = t_issue < ntiles;
+    const __amdgpu_buffer_rsrc_t rs_k =
+        make_rsrc(k_bh + (size_t)t0 * ldk, live ? (uint32_t)((nk - t0 - 1) * ldk + D) * 2u : 0u);
+    const __amdgpu_buffer_rsrc_t rs_v =
+        make_rsrc(vt_bh + t0, live ? ((uint32_t)D * (uint32_t)ldvt - (uint32_t)t0) * 2u : 0u);
+    char* kdst = smem + kring * C::KTILE;
+    char* vdst = smem + C::VBASE + vring * C::VTILE;
+#pragma unroll
+    for (int i = 0; i < LPK + LPV; ++i) {
+      const int voff = vo[i];
+      char* dst = rel[i] < 0 ? smem + C::DUMMY : (i < LPK ? kdst : vdst) + rel[i];
+      if (i < LPK) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_k, (lds_ptr_t)dst, 16, voff, 0, 0, 0);
+      else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_v, (lds_ptr_t)dst, 16, voff, 0, 0, 0);
+    }
+    ++t_issue;
+    kring = kring + 1 == C::NKB ? 0 : kring + 1;
+    vring = vring + 1 == C::NVB ? 0 : vring + 1;
+  };
+
+  f32x16_t oacc[C::DT];
+#pragma unroll
+  for (int t = 0; t < C::DT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[t][r] = 0.f;
+  float m_run = -1.0e30f;   // running max, log2 domain
+  float alpha = 1.0f;       // deferred O rescale factor of the previous stage
+  bool pend = false;        // wave-uniform: alpha != 1 somewhere
+
+  // plain (non-interleaved) pieces: prologue S(0) and the drain PV
+  auto qk = [&](const char* ks, f32x16_t (&sn)[2]) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const f32x16_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < C::DS; ++s) {
+        const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(ks + (32 * j + qi) * C::KS + (2 * s + half) * 16);
+        sn[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, __builtin_bit_cast(bf16x8_t, qraw[s]), s == 0 ? zero : sn[j],
+                                                        0, 0, 0);
+      }
+    }
+  };
+  auto vfrag = [&](const char* vs, int j, int u, int dt) {
+    const char* src = vs + (dt * 32 + qi) * C::VS + (32 * j + 16 * u + 4 * half) * 2;
+    const u32x2_t lo = *reinterpret_cast<const u32x2_t*>(src);
+    const u32x2_t hi = *reinterpret_cast<const u32x2_t*>(src + 16);
+    const u32x4_t w = {lo[0], lo[1], hi[0], hi[1]};
+    return __builtin_bit_cast(bf16x8_t, w);
+  };
+  auto pv = [&](const char* vs, const bf16x8_t (&pp)[2][2]) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int dt = 0; dt < C::DT; ++dt)
+          oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfrag(vs, j, u, dt), pp[j][u], oacc[dt], 0, 0, 0);
+  };
+
+  // stage t: consumes S(t) (sc) and P(t-1) (pp); produces S(t+1) (sn) and P(t) (pc).
+  // The body is choreographed by hand: NM = 2*DS + 4*DT MFMAs, one per slot; every slot also carries its share of the
+  // softmax VALU work and the LDS fragment reads of the MFMA two slots ahead.  sched_barrier(0) between slots keeps the
+  // compiler from regrouping (left alone it emits all MFMAs back to back, then the VALU block: zero overlap).
+  auto stage = [&](int t, const f32x16_t (&sc)[2], f32x16_t (&sn)[2], bf16x8_t (&pc)[2][2], const bf16x8_t (&pp)[2][2]) {
+    if (!(dbg & 4)) {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::LPW) : "memory");   // tile t+1 (issued two stages ago) has landed
+    asm volatile("s_barrier" ::: "memory");                         // ... for every wave; stage t-1 reads are done
+    issue();
+    }
+    if (pend) {                                                     // deferred rescale: after PV(t-2), before PV(t-1)
+#pragma unroll
+      for (int dt = 0; dt < C::DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+    }
+    const char* ks = smem + kread * C::KTILE;            // K(t+1)
+    const char* vs = smem + C::VBASE + vread * C::VTILE; // V(t-1)
+    kread = kread + 1 == C::NKB ? 0 : kread + 1;
+    vread = vread + 1 == C::NVB ? 0 : vread + 1;
+    constexpr int NQK = 2 * C::DS, NM = NQK + 4 * C::DT;
+    constexpr int FD = (dbg >> 4) ? (dbg >> 4) : 2;   // fragment prefetch distance in slots (experiment: dbg / 16)
+    constexpr int MAXSLOTS = 4;                  // slots carrying the running-max phase
+    constexpr int ESLOTS = NM - MAXSLOTS;        // slots carrying the 16 exp steps
+    bf16x8_t frag[NM];
+    auto fetch = [&](int f) {
+      if (dbg & 8) { frag[f] = __builtin_bit_cast(bf16x8_t, qraw[0]); return; }
+      if (f < NQK) {
+        const int j = f / C::DS, sidx = f % C::DS;
+        frag[f] = *reinterpret_cast<const bf16x8_t*>(ks + (32 * j + qi) * C::KS + (2 * sidx + half) * 16);
+      } else {
+        const int g = f - NQK, ju = g / C::DT, dt = g % C::DT;
+        frag[f] = vfrag(vs, ju >> 1, ju & 1, dt);
+      }
+    };
+#pragma unroll
+    for (int f = 0; f < FD; ++f) fetch(f);
+    float tmax = -1.0e30f;
+    f32x2_t c2 = {scale_log2e, scale_log2e}, nm2 = {0.f, 0.f};
+    u32x4_t w[2][2];
+    int es = 0;                                  // exp steps done (compile-time after unrolling)
+#pragma unroll
+    for (int f = 0; f < NM; ++f) {
+      if (f + FD < NM) fetch(f + FD);
+      if (dbg & 1) {
+        asm volatile("" ::"v"(frag[f]));
+      } else if (f < NQK) {
+        const int j = f / C::DS, sidx = f % C::DS;
+        const f32x16_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        sn[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag[f], __builtin_bit_cast(bf16x8_t, qraw[sidx]),
+                                                        sidx == 0 ? zero : sn[j], 0, 0, 0);
+      } else {
+        const int g = f - NQK, ju = g / C::DT, dt = g % C::DT;
+        oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag[f], pp[ju >> 1][ju & 1], oacc[dt], 0, 0, 0);
+      }
+      if (f < MAXSLOTS) {                        // running max over this lane's 32 scores, 8 per slot
+        const int j = f >> 1, r0 = (f & 1) * 8;
+#pragma unroll
+        for (int r = r0; r < r0 + 8; r += 2) tmax = __builtin_fmaxf(__builtin_fmaxf(tmax, sc[j][r]), sc[j][r + 1]);
+        if (f == MAXSLOTS - 1) {
+          tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+          const float ts = tmax * scale_log2e;
+          const bool need = !__all(ts - m_run <= RESCALE_THR);
+          const float m_new = need ? fmaxf(m_run, ts) : m_run;
+          alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+          pend = need;
+          m_run = m_new;
+          nm2 = f32x2_t{-m_new, -m_new};
+        }
+      } else {                                   // exp steps: 2 scores each (pk_fma, 2 x exp2, cvt_pk)
+        const int k = f - MAXSLOTS;
+        const int upto = (16 * (k + 1) + ESLOTS - 1) / ESLOTS;
+#pragma unroll
+        for (; es < upto; ++es) {
+          const int j = es >> 3, u = (es >> 2) & 1, e = es & 3;
+          const f32x2_t s2 = {sc[j][8 * u + 2 * e], sc[j][8 * u + 2 * e + 1]};
+          const f32x2_t e2 = __builtin_elementwise_fma(s2, c2, nm2);
+          w[j][u][e] = (dbg & 2) ? pack2bf(e2[0], e2[1]) : pack2bf(__builtin_amdgcn_exp2f(e2[0]), __builtin_amdgcn_exp2f(e2[1]));
+          asm volatile("" ::"v"(w[j][u][e]));    // P(t) is only consumed next stage: keep LLVM from sinking the exps there
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) pc[j][u] = __builtin_bit_cast(bf16x8_t, w[j][u]);
+  };
+
+  f32x16_t sA[2], sB[2];
+  bf16x8_t pA[2][2], pB[2][2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      pA[j][u] = __builtin_bit_cast(bf16x8_t, u32x4_t{0u, 0u, 0u, 0u});
+      pB[j][u] = pA[j][u];
+    }
+
+  issue();
+  issue();
+  issue();
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * C::LPW) : "memory");
+  asm volatile("s_barrier" ::: "memory");
+  qk(smem, sA);                                                    // S(0)
+
+  for (int t = 0; t < ntiles; t += 2) {
+    stage(t, sA, sB, pA, pB);
+    if (t + 1 < ntiles) stage(t + 1, sB, sA, pB, pA);
+  }
+  // ---- drain: PV of the last tile
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (pend) {
+#pragma unroll
+    for (int dt = 0; dt < C::DT; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+  }
+  {
+    const char* vs = smem + C::VBASE + ((ntiles - 1) % C::NVB) * C::VTILE;
+    if (ntiles & 1) pv(vs, pA);
+    else pv(vs, pB);
+  }
+
+  // ---- epilogue: denominator = O^T row VROWS-1 (tile DT-1, r = 15, lane half 1)
+  const float l_tot = __shfl(oacc[C::DT - 1][15], qi + 32, 64);
+  const float inv = 1.0f / l_tot;
+  const int qrow = q0 + qi;
+  if (qrow < nq) {
+    uint16_t* op = o + ((size_t)b * nq + qrow) * ldo + h * D;
+#pragma unroll
+    for (int dt = 0; dt < C::DT; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int dc = dt * 32 + 8 * g + 4 * half;
+        if (dc < D) {
+          u32x2_t w;
+          w[0] = pack2bf(oacc[dt][4 * g + 0] * inv, oacc[dt][4 * g + 1] * inv);
+          w[1] = pack2bf(oacc[dt][4 * g + 2] * inv, oacc[dt][4 * g + 3] * inv);
+          *reinterpret_cast<u32x2_t*>(op + dc) = w;
+        }
+      }
+  }
+}
+
+}  // namespace
+
+// Returns PP_ERR_UNSUPPORTED for shapes this kernel does not cover (the caller then uses attn_fwd_kernel).
+int pp_attention_pipe_launch(const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt, void* o, int ldo,
+                             int batch, int heads, int nq, int nk, int d, float sl2, hipStream_t st) {
+  if (d != 40 || nk % KB != 0 || nk < 2 * KB) return PP_ERR_UNSUPPORTED;
+  using C = PCfg<40>;
+  static const int dbg = [] { const char* e = getenv("PP_ATTN_DBG"); return e ? atoi(e) : 0; }();
+  const dim3 grid((nq + QW * NW - 1) / (QW * NW), heads, batch), block(256);
+#define PP_LAUNCH_DBG(V)                                                                                              \
+  case V: {                                                                                                           \
+    static bool attr_set = false;                                                                                     \
+    if (!attr_set) {                                                                                                  \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_pipe_kernel<40, V>),                                 \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS) != hipSuccess) {                    \
+        pp_set_last_error("hipFuncSetAttribute(attention pipe)", hipGetLastError());                                  \
+        return PP_ERR_LAUNCH;                                                                                         \
+      }                                                                                                               \
+      attr_set = true;                                                                                                \
+    }                                                                                                                 \
+    hipLaunchKernelGGL((attn_pipe_kernel<40, V>), grid, block, C::LDS, st, (const uint16_t*)q, ldq, (const uint16_t*)k, \
+                       ldk, (const uint16_t*)vt, ldvt, (uint16_t*)o, ldo, heads, nq, nk, sl2);                         \
+    break;                                                                                                            \
+  }
+  switch (dbg) {
+    PP_LAUNCH_DBG(0)
+    PP_LAUNCH_DBG(1)
+    PP_LAUNCH_DBG(2)
+    PP_LAUNCH_DBG(3)
+    PP_LAUNCH_DBG(4)
+    PP_LAUNCH_DBG(8)
+    PP_LAUNCH_DBG(9)
+    PP_LAUNCH_DBG(12)
+    PP_LAUNCH_DBG(13)
+    PP_LAUNCH_DBG(15)
+    PP_LAUNCH_DBG(48)
+    PP_LAUNCH_DBG(64)
+    PP_LAUNCH_DBG(96)
+    PP_LAUNCH_DBG(128)
+    default: return PP_ERR_BAD_ARG;
+  }
+#undef PP_LAUNCH_DBG
+  PP_CHECK_LAUNCH("attn_pipe_kernel");
+  return PP_OK;
+}

@@ -239,7 +239,8 @@ def test_layernorm(C):
 
 # ------------------------------------------------------------------------------------------------ attention
 @pytest.mark.parametrize("d,nq,nk", [(40, 256, 256), (80, 256, 256), (160, 64, 64), (40, 1024, 77), (80, 200, 77),
-                                     (160, 256, 77), (40, 4096, 4096)])
+                                     (160, 256, 77), (40, 4096, 4096), (40, 200, 192), (40, 128, 128), (40, 64, 64),
+                                     (40, 1000, 960)])
 def test_attention(d, nq, nk):
     B, Hh = 2, 8
     C = Hh * d
