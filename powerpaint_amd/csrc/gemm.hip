@@ -833,32 +833,40 @@ bool v2_ok(const PPGemmArgs& a) {
 }
 
 Choice choose(const PPGemmArgs& a) {
-  // Heuristic distilled from tools/gemm_sweep.py on MI355X (profiles/r01_gemm_sweep*.txt).  The unit is "blocks per
-  // CU" of the 256-CU chip: two co-resident 128x160 / 64x160 blocks (NS = 2) hide each other's barrier and LDS latency;
-  // below that, one block per CU with a 3-stage pipeline, and split-K once even 64-row tiles cannot fill the chip.
+  // Heuristic distilled from tools/gemm_sweep.py --cold on MI355X (profiles/r01_gemm_sweep_cold.txt): every candidate
+  // is timed behind a 1 GiB memset, i.e. with L2 / MALL / instruction cache as cold as inside the real ~350-launch step
+  // (hot back-to-back sweeps overrate split-K: its combine kernel costs ~8 us hot and ~31 us in the pipeline, and
+  // underrate the 3-stage pipelines, which ride out HBM latency better).  Unit = blocks per CU of the 256-CU chip:
+  //   >= 2 blocks of 128 rows per CU : 8-wave 128x160 (two co-resident blocks), or 256x160 x 3 stages for long K;
+  //   ~ 1 block per CU               : 128x160 x 3 stages, split-K 2 only for very long conv K;
+  //   less                           : 64x160 x 3 stages when that fills the chip, else split-K over 256-row tiles.
   // Tensors the 16-byte staged epilogue cannot address fall back to the register-staged v1 kernel.
   Choice c{a.tile, a.splitk};
   const int tn = (a.N + 159) / 160;
   auto blocks = [&](int bm) { return ((a.M + bm - 1) / bm) * tn; };
   const bool conv = a.x_mode == PP_X_CONV3X3;
-  const int nb128 = blocks(128), nb64 = blocks(64), kt = a.K / 64;
+  const int nb256 = blocks(256), nb128 = blocks(128), nb64 = blocks(64), kt = a.K / 64;
   if (c.tile == PP_TILE_AUTO) {
     int sk = 1;
     if (!v2_ok(a)) {
       c.tile = (nb128 >= 256) ? PP_TILE_128x160 : PP_TILE_64x160;
       while (blocks(c.tile == PP_TILE_128x160 ? 128 : 64) * sk < 224 && kt / (sk * 2) >= 12 && sk < 8) sk *= 2;
     } else if (nb128 >= 512) {
-      c.tile = 24;       // 8 waves, two co-resident blocks: 4 waves / SIMD
-    } else if (nb64 >= 512) {
-      if (conv && a.K > 8640) { c.tile = 21; sk = 2; }
-      else c.tile = 22;
+      c.tile = (kt >= 20 && nb256 >= 256) ? 33 : 24;
+    } else if (nb128 >= 256) {
+      if (conv && kt > 140) { c.tile = 33; sk = 2; }
+      else c.tile = a.out_vt ? 21 : 31;
     } else if (a.K <= 2880) {
       c.tile = 32;
-      while (nb64 * sk < 128 && kt / (sk * 2) >= 16 && sk < 8) sk *= 2;
+      while (nb64 * sk < 128 && kt / (sk * 2) >= 24 && sk < 8) sk *= 2;
+    } else if (nb64 >= 256 && kt <= 100) {
+      c.tile = 32;
+    } else if (nb256 >= 32) {
+      c.tile = 33;
+      while (nb256 * sk < 256 && sk < 8) sk *= 2;
     } else {
-      c.tile = 21;
-      while (nb128 * sk < 384 && kt / (sk * 2) >= 16 && sk < 8) sk *= 2;
-      if (!conv && sk == 1) c.tile = 32;
+      c.tile = 31;
+      while (nb128 * sk < 256 && kt / (sk * 2) >= 4 && sk < 8) sk *= 2;
     }
     if (c.splitk <= 0) c.splitk = sk;
   }
