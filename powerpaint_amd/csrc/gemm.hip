@@ -790,6 +790,10 @@ pp_gemm_kernel_v2(const PPGemmArgs a, const GemmDerived d) {   // 2nd bound = wa
 
 // Deterministic split-K combine + epilogue: thread = (row, 8 columns); the <= 8 partial slabs are read with all loads
 // in flight at once (a `for s: v += load` loop would serialise one memory latency per split), summed in slab order.
+// LEAN = the common conv / linear epilogue (bias, per-batch row vector, scale, two residuals, bf16 store) as straight,
+// short code: this kernel runs ~38 times per UNet forward with a cold instruction cache, where its duration (~30 us in
+// the rocprof trace against ~8 us back to back) is dominated by fetching its own instructions.
+template <bool LEAN>
 __global__ void __launch_bounds__(256) pp_splitk_reduce_kernel(const PPGemmArgs a, int splits) {
   const int n8 = a.N >> 3;
   const long long total = (long long)a.M * n8;
@@ -809,12 +813,46 @@ __global__ void __launch_bounds__(256) pp_splitk_reduce_kernel(const PPGemmArgs 
         p1[s] = f32x4_t{0.f, 0.f, 0.f, 0.f};
       }
     }
-    f32x4_t v0 = p0[0], v1 = p1[0];
+    if (LEAN) {
+      u32x4_t r1 = {0u, 0u, 0u, 0u}, r2 = {0u, 0u, 0u, 0u};
+      if (a.res1) r1 = *reinterpret_cast<const u32x4_t*>((const uint16_t*)a.res1 + (size_t)m * a.ldres1 + n);
+      if (a.res2) r2 = *reinterpret_cast<const u32x4_t*>((const uint16_t*)a.res2 + (size_t)m * a.ldres2 + n);
+      f32x4_t v0 = p0[0], v1 = p1[0];
 #pragma unroll
-    for (int s = 1; s < 8; ++s) { v0 += p0[s]; v1 += p1[s]; }
-    epilogue4<160>(a, m, n, v0);
-    epilogue4<160>(a, m, n + 4, v1);
+      for (int s = 1; s < 8; ++s) { v0 += p0[s]; v1 += p1[s]; }
+      if (a.bias) {
+        v0 += *reinterpret_cast<const f32x4_t*>(a.bias + n);
+        v1 += *reinterpret_cast<const f32x4_t*>(a.bias + n + 4);
+      }
+      if (a.rowvec) {
+        const float* rv = a.rowvec + (size_t)(m / a.rows_per_batch) * a.ld_rowvec + n;
+        v0 += *reinterpret_cast<const f32x4_t*>(rv);
+        v1 += *reinterpret_cast<const f32x4_t*>(rv + 4);
+      }
+      v0 *= a.scale;
+      v1 *= a.scale;
+      v0[0] += bflo(r1[0]) + bflo(r2[0]); v0[1] += bfhi(r1[0]) + bfhi(r2[0]);
+      v0[2] += bflo(r1[1]) + bflo(r2[1]); v0[3] += bfhi(r1[1]) + bfhi(r2[1]);
+      v1[0] += bflo(r1[2]) + bflo(r2[2]); v1[1] += bfhi(r1[2]) + bfhi(r2[2]);
+      v1[2] += bflo(r1[3]) + bflo(r2[3]); v1[3] += bfhi(r1[3]) + bfhi(r2[3]);
+      u32x4_t o;
+      o[0] = pack2bf(v0[0], v0[1]); o[1] = pack2bf(v0[2], v0[3]);
+      o[2] = pack2bf(v1[0], v1[1]); o[3] = pack2bf(v1[2], v1[3]);
+      *reinterpret_cast<u32x4_t*>((uint16_t*)a.out + (size_t)m * a.ldo + n) = o;
+    } else {
+      f32x4_t v0 = p0[0], v1 = p1[0];
+#pragma unroll
+      for (int s = 1; s < 8; ++s) { v0 += p0[s]; v1 += p1[s]; }
+      epilogue4<160>(a, m, n, v0);
+      epilogue4<160>(a, m, n + 4, v1);
+    }
   }
+}
+
+// the LEAN combine handles: no activation, bf16 output, no transposed / GEGLU / folded-LN epilogue, 16-byte aligned rows
+bool reduce_lean_ok(const PPGemmArgs& a) {
+  return a.act == PP_ACT_NONE && !a.out_f32 && !a.out_vt && !a.ln_stats && a.ldo % 8 == 0 &&
+         (!a.res1 || a.ldres1 % 8 == 0) && (!a.res2 || a.ldres2 % 8 == 0);
 }
 
 struct Choice {
@@ -909,7 +947,8 @@ int launch(const PPGemmArgs& a, int splitk, hipStream_t st) {
     const long long total = (long long)a.M * (a.N / 8);
     int nb = (int)((total + 255) / 256);
     if (nb > 4096) nb = 4096;
-    hipLaunchKernelGGL(pp_splitk_reduce_kernel, dim3(nb), dim3(256), 0, st, a, splitk);
+    if (reduce_lean_ok(a)) hipLaunchKernelGGL(pp_splitk_reduce_kernel<true>, dim3(nb), dim3(256), 0, st, a, splitk);
+    else hipLaunchKernelGGL(pp_splitk_reduce_kernel<false>, dim3(nb), dim3(256), 0, st, a, splitk);
     PP_CHECK_LAUNCH("pp_splitk_reduce_kernel");
   }
   return PP_OK;
@@ -951,7 +990,8 @@ int launch2(const PPGemmArgs& a, int splitk, hipStream_t st) {
     const long long total = (long long)a.M * (a.N / 8);
     int nb = (int)((total + 255) / 256);
     if (nb > 4096) nb = 4096;
-    hipLaunchKernelGGL(pp_splitk_reduce_kernel, dim3(nb), dim3(256), 0, st, a, splitk);
+    if (reduce_lean_ok(a)) hipLaunchKernelGGL(pp_splitk_reduce_kernel<true>, dim3(nb), dim3(256), 0, st, a, splitk);
+    else hipLaunchKernelGGL(pp_splitk_reduce_kernel<false>, dim3(nb), dim3(256), 0, st, a, splitk);
     PP_CHECK_LAUNCH("pp_splitk_reduce_kernel");
   }
   return PP_OK;
