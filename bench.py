@@ -113,7 +113,29 @@ def roofline_pass(pipe):
     counts = {}
     for _, _, name in loop.program.calls:
         counts[name] = counts.get(name, 0) + 1
-    return per, flops, counts
+    # algorithmic HBM bytes of the 3x3 implicit-GEMM launches: input pixels once, weights once, output once,
+    # residual operands once (bf16 = 2 B, temb row vector fp32)
+    from powerpaint_amd import _lib as L
+    alg_bytes = 0.0
+    for fn, args, name in loop.program.calls:
+        if name != "conv3x3":
+            continue
+        a = args[0]._obj
+        if isinstance(a, L.PPGemmArgs):
+            alg_bytes += 2.0 * a.batch * a.hin * a.win * (a.c1 + a.c2) + 2.0 * a.N * a.K + 2.0 * a.M * a.N
+            alg_bytes += (2.0 * a.M * a.N if a.res1 else 0.0) + (2.0 * a.M * a.N if a.res2 else 0.0)
+    return per, flops, counts, alg_bytes
+
+
+def measured_traffic():
+    """HBM bytes per 3x3 implicit-GEMM launch from the committed PMC passes (tools/hbm_traffic.sh -> profiles/; two
+    rocprofv3 --pmc runs of this benchmark cannot happen inside this process).  None if the profile is absent."""
+    path = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+    try:
+        fam = json.load(open(path))["families"]["conv3x3 implicit GEMM"]
+        return fam["bytes_per_launch"]
+    except Exception:
+        return None
 
 
 def cpu_baseline():
@@ -207,15 +229,17 @@ def main():
             "unet_step_mfma_util": tflop_step / (ms_denoise_step * 1e-3) / MFMA_PEAK_TFLOPS,
         }
         if not args.no_roofline:
-            per, flops, counts = roofline_pass(pipe)
+            per, flops, counts, alg_bytes = roofline_pass(pipe)
             # dominant kernel = the implicit-GEMM 3x3 convolution launches of pp_gemm_kernel
             k = "conv3x3"
             ach = flops[k] / 1e12 / (per[k] * 1e-3)
             res["roofline"] = {"bound": "mfma", "kernel": "pp_gemm_kernel<...,CONV3X3> (implicit-GEMM 3x3 conv)",
                                "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": ach / MFMA_PEAK_TFLOPS, "traffic": None,
+                               "frac": ach / MFMA_PEAK_TFLOPS, "traffic": measured_traffic(),
+                               "traffic_unit": "bytes / launch (2 x FETCH_SIZE + WRITE_SIZE, profiles/r01_hbm_traffic.json)",
                                "launches_per_step": counts[k], "avg_launch_ms": per[k] / counts[k],
-                               "alg_flop_per_launch": flops[k] / counts[k]}
+                               "alg_flop_per_launch": flops[k] / counts[k],
+                               "alg_bytes_per_launch": alg_bytes / counts[k]}
             res["per_kernel_ms_per_denoise_step"] = {n: round(v, 4) for n, v in sorted(per.items(), key=lambda kv: -kv[1])}
             res["per_kernel_tflops"] = {n: round(flops[n] / 1e12 / (per[n] * 1e-3), 1) for n in flops if per.get(n)}
             if args.dump_launches:
