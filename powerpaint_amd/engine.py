@@ -349,6 +349,8 @@ class SDNet:
     # BasicTransformerBlock.norm1/2/3 folded into the GEMMs on either side (no LayerNorm launch, no normalised copy in
     # HBM).  PP_FOLD_LN=0 keeps the stand-alone pp_layernorm launches (A/B measurements, bisecting).
     fold_ln = os.environ.get("PP_FOLD_LN", "1") != "0"
+    # FeedForward.net[2] and Transformer2DModel.proj_out composed into one GEMM (PP_MERGE_FF2=0: two launches)
+    merge_ff2_proj_out = os.environ.get("PP_MERGE_FF2", "1") != "0"
 
     def __init__(self, kind: str, in_channels: int, block_out_channels=(320, 640, 1280, 1280), layers_per_block=2,
                  heads=8, cross_attention_dim=768, groups=32, eps=1e-5,
@@ -559,9 +561,20 @@ class SDNet:
         for pre, c in self._attn_specs():
             pk.add(f"{pre}.norm.weight", W(f"{pre}.norm.weight"), f32)
             pk.add(f"{pre}.norm.bias", W(f"{pre}.norm.bias"), f32)
-            for pj in ("proj_in", "proj_out"):
-                pk.add(f"{pre}.{pj}.weight", W(f"{pre}.{pj}.weight").reshape(c, c), bf)
-                pk.add(f"{pre}.{pj}.bias", W(f"{pre}.{pj}.bias"), f32)
+            pk.add(f"{pre}.proj_in.weight", W(f"{pre}.proj_in.weight").reshape(c, c), bf)
+            pk.add(f"{pre}.proj_in.bias", W(f"{pre}.proj_in.bias"), f32)
+            w_po, b_po = W(f"{pre}.proj_out.weight").reshape(c, c), W(f"{pre}.proj_out.bias")
+            if self.merge_ff2_proj_out:
+                # FF2 and proj_out are two linear maps with only a residual add between them:
+                #   proj_out(FF2(g) + hs) = [g | hs] [W_po W_ff2 | W_po]^T + (W_po b_ff2 + b_po)
+                # -> ONE GEMM over the K-concatenation of g and hs (same FLOPs, one launch and one hidden-state round
+                # trip less per transformer); composed in fp32 at pack time.
+                w_f2, b_f2 = W(f"{pre}.transformer_blocks.0.ff.net.2.weight"), W(f"{pre}.transformer_blocks.0.ff.net.2.bias")
+                pk.add(f"{pre}.ff2_proj_out.weight", torch.cat([w_po @ w_f2, w_po], 1), bf)
+                pk.add(f"{pre}.ff2_proj_out.bias", w_po @ b_f2 + b_po, f32)
+            else:
+                pk.add(f"{pre}.proj_out.weight", w_po, bf)
+                pk.add(f"{pre}.proj_out.bias", b_po, f32)
             tb_ = f"{pre}.transformer_blocks.0"
             wqkv = torch.cat([W(f"{tb_}.attn1.to_q.weight"), W(f"{tb_}.attn1.to_k.weight"),
                               W(f"{tb_}.attn1.to_v.weight")], 0)
@@ -595,8 +608,9 @@ class SDNet:
             pk.add(f"{tb_}.attn2.kv.weight", torch.cat([W(f"{tb_}.attn2.to_k.weight"), W(f"{tb_}.attn2.to_v.weight")], 0), bf)
             pk.add(f"{tb_}.attn2.to_out.weight", W(f"{tb_}.attn2.to_out.0.weight"), bf)
             pk.add(f"{tb_}.attn2.to_out.bias", W(f"{tb_}.attn2.to_out.0.bias"), f32)
-            pk.add(f"{tb_}.ff2.weight", W(f"{tb_}.ff.net.2.weight"), bf)
-            pk.add(f"{tb_}.ff2.bias", W(f"{tb_}.ff.net.2.bias"), f32)
+            if not self.merge_ff2_proj_out:
+                pk.add(f"{tb_}.ff2.weight", W(f"{tb_}.ff.net.2.weight"), bf)
+                pk.add(f"{tb_}.ff2.bias", W(f"{tb_}.ff.net.2.bias"), f32)
         if self.kind == "unet":
             pk.add("conv_norm_out.weight", W("conv_norm_out.weight"), f32)
             pk.add("conv_norm_out.bias", W("conv_norm_out.bias"), f32)
@@ -690,9 +704,13 @@ class SDNet:
         # feed-forward: GEGLU fused into the first GEMM's epilogue
         ln, kw = normed(hs, st, "norm3", "ff1")
         g = pb.linear(ln, rows, Cc, P[f"{tb}.ff1.weight"], 8 * Cc, act=L.PP_ACT_GEGLU, name="linear_geglu", **kw)
-        hs = pb.linear(g, rows, 4 * Cc, P[f"{tb}.ff2.weight"], Cc, P[f"{tb}.ff2.bias"], res1=hs, name="linear")
-        pb.linear(hs, rows, Cc, P[f"{pre}.proj_out.weight"], Cc, P[f"{pre}.proj_out.bias"], res1=x.ptr, res2=res2,
-                  out=out.ptr, name="conv1x1")
+        if self.merge_ff2_proj_out:
+            pb.linear(g, rows, 4 * Cc, P[f"{pre}.ff2_proj_out.weight"], Cc, P[f"{pre}.ff2_proj_out.bias"], x2=hs, K2=Cc,
+                      ldx2=Cc, res1=x.ptr, res2=res2, out=out.ptr, name="linear")
+        else:
+            hs = pb.linear(g, rows, 4 * Cc, P[f"{tb}.ff2.weight"], Cc, P[f"{tb}.ff2.bias"], res1=hs, name="linear")
+            pb.linear(hs, rows, Cc, P[f"{pre}.proj_out.weight"], Cc, P[f"{pre}.proj_out.bias"], res1=x.ptr, res2=res2,
+                      out=out.ptr, name="conv1x1")
         pb.release(m)
         return out
 

@@ -32,7 +32,8 @@ def test_full_size_plans_and_flop_accounting():
     """Launch plans of the real SD-1.5 shapes compile on the host; algorithmic FLOPs match SURVEY.md section 8d
     (minus the cross-attention K/V projections hoisted out of the step)."""
     # launches per forward: 3 LayerNorms per transformer (16 / 16 / 7) are folded into the neighbouring GEMMs
-    ln = 0 if SDNet.fold_ln else 3
+    # ... and FF2 + proj_out are one GEMM (one launch less per transformer)
+    ln = (0 if SDNet.fold_ln else 3) - (1 if SDNet.merge_ff2_proj_out else 0)
     exp = {"unet": (803.4, 352 + 16 * ln), "brushnet": (826.2, 377 + 16 * ln),
            "controlnet": (283.3 - 16.1, 167 + 7 * ln)}
     for kind, cin, tot, nk in (("unet", 9, 9, {}), ("brushnet", 4, 9, dict(conditioning_channels=5)),
