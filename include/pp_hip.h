@@ -27,7 +27,7 @@ extern "C" {
 #define PP_ERR_LAUNCH (-3)       /* hipLaunchKernel / hipFuncSetAttribute failed                  */
 #define PP_ERR_WORKSPACE (-4)    /* workspace pointer null or too small                           */
 
-#define PP_ABI_VERSION 2
+#define PP_ABI_VERSION 3
 int pp_abi_version(void);
 /* hipGetLastError() text of the last PP_ERR_LAUNCH on this thread (host pointer, static storage). */
 const char* pp_last_error(void);
@@ -104,7 +104,20 @@ typedef struct PPGemmArgs {
   int32_t ln_dim;
   float ln_eps;
   int32_t pad0;
+  /* GroupNorm statistics of the OUTPUT, accumulated by the epilogue (the stats launch of the consuming GroupNorm
+   * disappears).  Up to two consumers per tensor (a UNet skip tensor feeds the next layer's norm and, concatenated,
+   * an up-block norm):  gn_acc[k] -> int64 [batch][gn_groups[k]][2] = (sum, sum of squares) of the stored bf16 values
+   * in fixed point (PP_GN_SUM_SCALE / PP_GN_SQ_SCALE), added with 64-bit integer atomics => order-independent,
+   * bit-reproducible.  Column n of this GEMM is channel gn_c0[k] + n of the consumer's (possibly concatenated)
+   * input, whose groups are gn_cg[k] channels wide.  Requires rows_per_batch % 64 == 0 (set rows_per_batch), a v2
+   * tile, no GEGLU / V^T / fp32 output; pp_gemm_gn_stats_ok() tells.  The caller zeroes gn_acc before the launch. */
+  int64_t* gn_acc[2];
+  int32_t gn_cg[2];
+  int32_t gn_c0[2];
+  int32_t gn_groups[2];
 } PPGemmArgs;
+#define PP_GN_SUM_SCALE 16777216.0f /* 2^24 */
+#define PP_GN_SQ_SCALE 1048576.0f   /* 2^20 */
 
 #define PP_TILE_AUTO 0
 #define PP_TILE_128x160 1
@@ -113,6 +126,8 @@ typedef struct PPGemmArgs {
 
 int pp_gemm_bf16(const PPGemmArgs* args, void* stream);
 size_t pp_gemm_workspace_bytes(const PPGemmArgs* args);
+/* 1 if this launch (as pp_gemm_bf16 would configure it) can accumulate GroupNorm statistics (gn_acc), else 0 */
+int pp_gemm_gn_stats_ok(const PPGemmArgs* args);
 
 /* Small-M ("skinny") linear in fp32 accumulate: out[b][n] = act_in(x[b][:]) . W[n][:] + bias[n], b < rows <= 16.
  * Replaces TimestepEmbedding.linear_1/linear_2 and the 22 ResnetBlock2D.time_emb_proj (batched into one call by
@@ -140,6 +155,13 @@ int pp_groupnorm_stats(const void* x1, int c1, const void* x2, int c2, int batch
 int pp_groupnorm_apply(const void* x1, int c1, const void* x2, int c2, int batch, int hw, int groups, float eps,
                        const float* gamma, const float* beta, const float* workspace, int silu, void* y,
                        void* stream);
+
+/* GroupNorm apply from accumulated statistics: acc = int64 [batch][groups][2] filled by the producers' epilogues
+ * (PPGemmArgs.gn_acc); otherwise identical to pp_groupnorm_apply. */
+int pp_groupnorm_apply_acc(const void* x1, int c1, const void* x2, int c2, int batch, int hw, int groups, float eps,
+                           const float* gamma, const float* beta, const int64_t* acc, int silu, void* y, void* stream);
+/* dst[0..n) = 0 (64-bit words): one launch zeroes the statistics accumulators of a whole forward pass */
+int pp_zero_u64(void* dst, long long n, void* stream);
 
 /* LayerNorm over the last dim, bf16 [rows][C] -> bf16 [rows][C]; BasicTransformerBlock.norm1/2/3 (eps 1e-5). */
 int pp_layernorm(const void* x, int rows, int C, const float* gamma, const float* beta, float eps, void* y,

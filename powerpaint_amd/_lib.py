@@ -35,6 +35,7 @@ class PPGemmArgs(C.Structure):
         ("reserved", i32 * 4),
         ("row_stats_out", vp), ("ln_stats", vp), ("ln_colsum", vp),
         ("ln_tiles", i32), ("ln_dim", i32), ("ln_eps", f32), ("pad0", i32),
+        ("gn_acc", vp * 2), ("gn_cg", i32 * 2), ("gn_c0", i32 * 2), ("gn_groups", i32 * 2),
     ]
 
 
@@ -47,6 +48,10 @@ SIGNATURES = {
     "pp_linear_skinny": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp]),
     "pp_timestep_embedding": (C.c_int, [vp, C.c_int, C.c_int, vp, vp]),
     "pp_groupnorm_workspace_bytes": (sz, [C.c_int, C.c_int, C.c_int]),
+    "pp_gemm_gn_stats_ok": (C.c_int, [C.POINTER(PPGemmArgs)]),
+    "pp_groupnorm_apply_acc": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, f32, vp, vp, vp, C.c_int, vp,
+                                         vp]),
+    "pp_zero_u64": (C.c_int, [vp, C.c_longlong, vp]),
     "pp_groupnorm_stats": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
     "pp_groupnorm_apply": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, f32, vp, vp, vp, C.c_int, vp,
                                      vp]),
@@ -86,7 +91,7 @@ def lib():
             fn = getattr(l, name)
             fn.restype = res
             fn.argtypes = args
-        if l.pp_abi_version() != 2:
+        if l.pp_abi_version() != 3:
             raise PPError("libpp_hip.so ABI version mismatch")
         _lib = l
     return _lib

@@ -26,6 +26,42 @@ struct GemmDerived {
   int tiles_m, tiles_n, kt_total, kt_per_split, ctiles;
 };
 
+// GroupNorm statistics from an epilogue.  A pass / tile = up to 64 output rows of ONE batch item x the <= 160 columns
+// [n_blk, n_blk + ncols).  Stage 1 (gn_column): the thread that owns column `col` adds its column's (sum, sumsq), in
+// fixed point, to the LDS slot of the group the column belongs to (64-bit integer LDS atomics: order-independent).
+// Stage 2 (gn_flush, after a barrier): one thread per (subscription, group) moves the slot to the global accumulator
+// with a 64-bit integer atomic and clears it.  Integer arithmetic end to end => bit-reproducible.
+constexpr int GN_SLOTS = 24;   // >= groups one 160-column tile can touch (160 / 10 + 2)
+PP_DEVINL void gn_column(const PPGemmArgs& a, unsigned long long* slots, int n_blk, int col, float sm, float sq) {
+  const unsigned long long fs = (unsigned long long)(long long)__float2ll_rn(sm * PP_GN_SUM_SCALE);
+  const unsigned long long fq = (unsigned long long)(long long)__float2ll_rn(sq * PP_GN_SQ_SCALE);
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    if (!a.gn_acc[k]) continue;
+    const int cg = a.gn_cg[k], cbase = a.gn_c0[k] + n_blk;
+    const int gl = (cbase + col) / cg - cbase / cg;          // group index relative to the first group of the tile
+    __hip_atomic_fetch_add(slots + (k * GN_SLOTS + gl) * 2, fs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_fetch_add(slots + (k * GN_SLOTS + gl) * 2 + 1, fq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+}
+PP_DEVINL void gn_flush(const PPGemmArgs& a, unsigned long long* slots, int m0, int n_blk, int ncols, int tid) {
+  const int k = tid / GN_SLOTS, gl = tid - k * GN_SLOTS;
+  if (k < 2 && a.gn_acc[k]) {
+    const int cg = a.gn_cg[k], cbase = a.gn_c0[k] + n_blk;
+    const int g_first = cbase / cg, g_last = (cbase + ncols - 1) / cg;
+    if (g_first + gl <= g_last) {
+      const int b = m0 / a.rows_per_batch;
+      unsigned long long* dst =
+          reinterpret_cast<unsigned long long*>(a.gn_acc[k]) + ((size_t)b * a.gn_groups[k] + g_first + gl) * 2;
+      unsigned long long* sl = slots + (k * GN_SLOTS + gl) * 2;
+      __hip_atomic_fetch_add(dst, sl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(dst + 1, sl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      sl[0] = 0ull;
+      sl[1] = 0ull;
+    }
+  }
+}
+
 // Folded LayerNorm: per-row (mean, rstd) from the producer's per-N-tile (sum, sum of squares) partials.
 PP_DEVINL void ln_row_moments(const PPGemmArgs& a, int m, float& mean, float& rstd) {
   const f32x2_t* p = reinterpret_cast<const f32x2_t*>(a.ln_stats) + (size_t)m * a.ln_tiles;
@@ -326,12 +362,14 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) pp_gemm_kernel(const PPGemmArg
 //     the contiguous axis: 320-byte full-row segments instead of 8-byte pieces scattered over 16 rows.
 //   * EPI selects the epilogue family, as separate instantiations so that each keeps its register budget (64x160 and the
 //     8-wave 128x160 must stay <= 128 VGPRs for 4 waves/SIMD):  0 = standard;  1 = standard + folded LayerNorm (row
-//     moments out / mean-rstd correction in);  2 = GEGLU in registers (+ optional folded LayerNorm).  1 and 2 are
-//     PLAIN-only and prefetch their epilogue operands into LDS.
+//     moments out / mean-rstd correction in);  2 = GEGLU in registers (+ optional folded LayerNorm);  4 = standard +
+//     GroupNorm statistics of the output (gn_acc).  1 and 2 are PLAIN-only and prefetch their epilogue operands
+//     into LDS.
 template <int BM, int BN, int WM, int WN, int XMODE, int NS, int EPI>
 __global__ void __launch_bounds__(WM* WN * 64, ((BM / WM / 16) * (BN / WN / 16) <= 10 ? 4 : 2))
 pp_gemm_kernel_v2(const PPGemmArgs a, const GemmDerived d) {   // 2nd bound = waves / SIMD the register budget must allow
-  constexpr bool LNF = EPI != 0;
+  constexpr bool LNF = EPI == 1 || EPI == 2;
+  constexpr bool GNS = EPI == 4;
   constexpr int T = WM * WN * 64;
   constexpr int MI = BM / WM / 16;
   constexpr int NI = BN / WN / 16;
@@ -684,6 +722,11 @@ pp_gemm_kernel_v2(const PPGemmArgs a, const GemmDerived d) {   // 2nd bound = wa
       constexpr int EC = BN / 8, ER = T / EC, EP = (EPI_ROWS + ER - 1) / ER;
       const int c8 = tid % EC, r0 = tid / EC;
       const int n = n_blk + c8 * 8;
+      float gcs[8], gcq[8];
+      if (GNS) {
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) { gcs[jj] = 0.f; gcq[jj] = 0.f; }
+      }
       if (r0 < ER && n < a.N) {
         if (splitk) {
 #pragma unroll
@@ -754,6 +797,14 @@ pp_gemm_kernel_v2(const PPGemmArgs a, const GemmDerived d) {   // 2nd bound = wa
                 o[0] = pack2bf(v0[0], v0[1]); o[1] = pack2bf(v0[2], v0[3]);
                 o[2] = pack2bf(v1[0], v1[1]); o[3] = pack2bf(v1[2], v1[3]);
                 *reinterpret_cast<u32x4_t*>((uint16_t*)a.out + (size_t)m * a.ldo + n) = o;
+                if (GNS) {   // per-column moments of the values as stored, over this thread's rows of the pass
+#pragma unroll
+                  for (int jj = 0; jj < 4; ++jj) {
+                    const float lo = bflo(o[jj]), hi = bfhi(o[jj]);
+                    gcs[2 * jj] += lo; gcq[2 * jj] += lo * lo;
+                    gcs[2 * jj + 1] += hi; gcq[2 * jj + 1] += hi * hi;
+                  }
+                }
                 if (rs_out) {   // moments of the values as stored (bf16-rounded), for the LayerNorm folded downstream
                   float sm = 0.f, sq = 0.f;
 #pragma unroll
@@ -768,6 +819,33 @@ pp_gemm_kernel_v2(const PPGemmArgs a, const GemmDerived d) {   // 2nd bound = wa
             }
           }
         }
+      }
+      if (GNS && !splitk) {
+        // per-thread column moments -> LDS [row-thread][column] (over the staged tile, which everyone has finished
+        // reading) -> the 160 column threads fold the ER row-threads in fixed order and add into the groups' slots
+        unsigned long long* slots = reinterpret_cast<unsigned long long*>(smem + RS_OFF);
+        if (pass == 0 && tid < 2 * GN_SLOTS * 2) slots[tid] = 0ull;
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (r0 < ER && n < a.N) {
+          float* dstp = reinterpret_cast<float*>(smem) + ((size_t)r0 * BN + c8 * 8) * 2;
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj)
+            *reinterpret_cast<f32x4_t*>(dstp + 4 * jj) = f32x4_t{gcs[2 * jj], gcq[2 * jj], gcs[2 * jj + 1], gcq[2 * jj + 1]};
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        const int ncols = min(BN, a.N - n_blk);
+        if (tid < ncols) {
+          float sm = 0.f, sq = 0.f;
+#pragma unroll 5
+          for (int r = 0; r < ER; ++r) {
+            const f32x2_t v = *reinterpret_cast<const f32x2_t*>(smem + ((size_t)r * BN + tid) * 8);
+            sm += v[0];
+            sq += v[1];
+          }
+          gn_column(a, slots, n_blk, tid, sm, sq);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (m0 < a.M) gn_flush(a, slots, m0, n_blk, ncols, tid);
       }
       if (rs_out) {
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -847,6 +925,80 @@ __global__ void __launch_bounds__(256) pp_splitk_reduce_kernel(const PPGemmArgs 
       epilogue4<160>(a, m, n + 4, v1);
     }
   }
+}
+
+// Lean combine that also accumulates GroupNorm statistics: one block = 16 rows x 160 columns, 320 threads, thread =
+// (row, 8-column strip) -> every slab load of the block is in flight at once; the finished values go through an LDS
+// tile, the 160 column threads fold the 16 rows and feed the groups' integer slots (gn_column / gn_flush).
+__global__ void __launch_bounds__(320) pp_splitk_reduce_gn_kernel(const PPGemmArgs a, int splits, int tiles_n) {
+  constexpr int BN = 160, ROWS = 16, EC = BN / 8;
+  __shared__ __attribute__((aligned(16))) float tile[ROWS][BN + 4];
+  __shared__ unsigned long long slots[2 * GN_SLOTS * 2];
+  const int tid = threadIdx.x;
+  const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x - tile_m * tiles_n;
+  const int m0 = tile_m * ROWS, n_blk = tile_n * BN;
+  const int c8 = tid % EC, row = tid / EC;
+  const int m = m0 + row, n = n_blk + c8 * 8;
+  if (tid < 2 * GN_SLOTS * 2) slots[tid] = 0ull;
+  f32x4_t w0 = {0.f, 0.f, 0.f, 0.f}, w1 = {0.f, 0.f, 0.f, 0.f};
+  if (m < a.M && n < a.N) {
+    const size_t slab = (size_t)a.M * a.N;
+    const float* src = a.workspace + (size_t)m * a.N + n;
+    f32x4_t p0[8], p1[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      if (s < splits) {
+        p0[s] = *reinterpret_cast<const f32x4_t*>(src + s * slab);
+        p1[s] = *reinterpret_cast<const f32x4_t*>(src + s * slab + 4);
+      } else {
+        p0[s] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        p1[s] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    u32x4_t r1 = {0u, 0u, 0u, 0u}, r2 = {0u, 0u, 0u, 0u};
+    if (a.res1) r1 = *reinterpret_cast<const u32x4_t*>((const uint16_t*)a.res1 + (size_t)m * a.ldres1 + n);
+    if (a.res2) r2 = *reinterpret_cast<const u32x4_t*>((const uint16_t*)a.res2 + (size_t)m * a.ldres2 + n);
+    f32x4_t v0 = p0[0], v1 = p1[0];
+#pragma unroll
+    for (int s = 1; s < 8; ++s) { v0 += p0[s]; v1 += p1[s]; }
+    if (a.bias) {
+      v0 += *reinterpret_cast<const f32x4_t*>(a.bias + n);
+      v1 += *reinterpret_cast<const f32x4_t*>(a.bias + n + 4);
+    }
+    if (a.rowvec) {
+      const float* rv = a.rowvec + (size_t)(m / a.rows_per_batch) * a.ld_rowvec + n;
+      v0 += *reinterpret_cast<const f32x4_t*>(rv);
+      v1 += *reinterpret_cast<const f32x4_t*>(rv + 4);
+    }
+    v0 *= a.scale;
+    v1 *= a.scale;
+    v0[0] += bflo(r1[0]) + bflo(r2[0]); v0[1] += bfhi(r1[0]) + bfhi(r2[0]);
+    v0[2] += bflo(r1[1]) + bflo(r2[1]); v0[3] += bfhi(r1[1]) + bfhi(r2[1]);
+    v1[0] += bflo(r1[2]) + bflo(r2[2]); v1[1] += bfhi(r1[2]) + bfhi(r2[2]);
+    v1[2] += bflo(r1[3]) + bflo(r2[3]); v1[3] += bfhi(r1[3]) + bfhi(r2[3]);
+    u32x4_t o;
+    o[0] = pack2bf(v0[0], v0[1]); o[1] = pack2bf(v0[2], v0[3]);
+    o[2] = pack2bf(v1[0], v1[1]); o[3] = pack2bf(v1[2], v1[3]);
+    *reinterpret_cast<u32x4_t*>((uint16_t*)a.out + (size_t)m * a.ldo + n) = o;
+    w0 = f32x4_t{bflo(o[0]), bfhi(o[0]), bflo(o[1]), bfhi(o[1])};
+    w1 = f32x4_t{bflo(o[2]), bfhi(o[2]), bflo(o[3]), bfhi(o[3])};
+  }
+  *reinterpret_cast<f32x4_t*>(&tile[row][c8 * 8]) = w0;      // rows / columns past the edge contribute zeros
+  *reinterpret_cast<f32x4_t*>(&tile[row][c8 * 8 + 4]) = w1;
+  __syncthreads();
+  const int ncols = min(BN, a.N - n_blk);
+  if (tid < ncols) {
+    float sm = 0.f, sq = 0.f;
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+      const float v = tile[r][tid];
+      sm += v;
+      sq += v * v;
+    }
+    gn_column(a, slots, n_blk, tid, sm, sq);
+  }
+  __syncthreads();
+  gn_flush(a, slots, m0, n_blk, ncols, tid);
 }
 
 // the LEAN combine handles: no activation, bf16 output, no transposed / GEGLU / folded-LN epilogue, 16-byte aligned rows
@@ -947,7 +1099,10 @@ int launch(const PPGemmArgs& a, int splitk, hipStream_t st) {
     const long long total = (long long)a.M * (a.N / 8);
     int nb = (int)((total + 255) / 256);
     if (nb > 4096) nb = 4096;
-    if (reduce_lean_ok(a)) hipLaunchKernelGGL(pp_splitk_reduce_kernel<true>, dim3(nb), dim3(256), 0, st, a, splitk);
+    if (a.gn_acc[0] || a.gn_acc[1]) {
+      const int tn = (a.N + 159) / 160;
+      hipLaunchKernelGGL(pp_splitk_reduce_gn_kernel, dim3(((a.M + 15) / 16) * tn), dim3(320), 0, st, a, splitk, tn);
+    } else if (reduce_lean_ok(a)) hipLaunchKernelGGL(pp_splitk_reduce_kernel<true>, dim3(nb), dim3(256), 0, st, a, splitk);
     else hipLaunchKernelGGL(pp_splitk_reduce_kernel<false>, dim3(nb), dim3(256), 0, st, a, splitk);
     PP_CHECK_LAUNCH("pp_splitk_reduce_kernel");
   }
@@ -956,11 +1111,14 @@ int launch(const PPGemmArgs& a, int splitk, hipStream_t st) {
 
 template <int BM, int BN, int WM, int WN, int XMODE, int NS, int EPI = 0>
 int launch2(const PPGemmArgs& a, int splitk, hipStream_t st) {
+  if constexpr (EPI == 0) {
+    if ((a.gn_acc[0] || a.gn_acc[1]) && splitk == 1) return launch2<BM, BN, WM, WN, XMODE, NS, 4>(a, splitk, st);
+  }
   if constexpr (XMODE == PP_X_PLAIN && EPI == 0) {
     if (a.act == PP_ACT_GEGLU && splitk == 1) return launch2<BM, BN, WM, WN, XMODE, NS, 2>(a, splitk, st);
     if (a.ln_stats || a.row_stats_out) return launch2<BM, BN, WM, WN, XMODE, NS, 1>(a, splitk, st);
   }
-  constexpr bool LNF = EPI != 0;
+  constexpr bool LNF = EPI == 1 || EPI == 2;
   constexpr int T = WM * WN * 64;
   constexpr int LDS = NS * (BM + BN) * 128 + (LNF ? 2048 + BM * 32 : 0);   // + epilogue-operand prefetch (LNF)
   static_assert(LDS <= 160 * 1024 || (LNF && NS > 2), "LDS budget");
@@ -990,12 +1148,26 @@ int launch2(const PPGemmArgs& a, int splitk, hipStream_t st) {
     const long long total = (long long)a.M * (a.N / 8);
     int nb = (int)((total + 255) / 256);
     if (nb > 4096) nb = 4096;
-    if (reduce_lean_ok(a)) hipLaunchKernelGGL(pp_splitk_reduce_kernel<true>, dim3(nb), dim3(256), 0, st, a, splitk);
+    if (a.gn_acc[0] || a.gn_acc[1]) {
+      const int tn = (a.N + 159) / 160;
+      hipLaunchKernelGGL(pp_splitk_reduce_gn_kernel, dim3(((a.M + 15) / 16) * tn), dim3(320), 0, st, a, splitk, tn);
+    } else if (reduce_lean_ok(a)) hipLaunchKernelGGL(pp_splitk_reduce_kernel<true>, dim3(nb), dim3(256), 0, st, a, splitk);
     else hipLaunchKernelGGL(pp_splitk_reduce_kernel<false>, dim3(nb), dim3(256), 0, st, a, splitk);
     PP_CHECK_LAUNCH("pp_splitk_reduce_kernel");
   }
   return PP_OK;
   }
+}
+
+// GroupNorm statistics in the epilogue: plain bf16 output through the v2 staged epilogue or the lean split-K combine,
+// 64-row passes inside one batch item
+bool gn_stats_supported(const PPGemmArgs& a) {
+  if (a.act != PP_ACT_NONE || a.out_f32 || a.out_vt || a.ln_stats || a.row_stats_out) return false;
+  if (!v2_ok(a) || !reduce_lean_ok(a)) return false;
+  if (a.rows_per_batch <= 0 || a.rows_per_batch % 64) return false;
+  for (int k = 0; k < 2; ++k)
+    if (a.gn_acc[k] && (a.gn_cg[k] < 8 || a.gn_groups[k] <= 0 || a.gn_c0[k] < 0)) return false;   // <= GN_SLOTS groups / tile
+  return true;
 }
 
 int validate(const PPGemmArgs& a) {
@@ -1026,10 +1198,20 @@ int validate(const PPGemmArgs& a) {
   if (a.out_vt && a.vt_col0 % 4 != 0) return PP_ERR_BAD_ARG;
   if (a.ln_stats && (!a.ln_colsum || a.ln_tiles <= 0 || a.ln_dim <= 0)) return PP_ERR_BAD_ARG;
   if (a.row_stats_out && (a.out_f32 || a.out_vt || a.act == PP_ACT_GEGLU || !v2_ok(a))) return PP_ERR_UNSUPPORTED;
+  if ((a.gn_acc[0] || a.gn_acc[1]) && !gn_stats_supported(a)) return PP_ERR_UNSUPPORTED;
   return PP_OK;
 }
 
 }  // namespace
+
+extern "C" int pp_gemm_gn_stats_ok(const PPGemmArgs* args) {
+  if (!args) return 0;
+  PPGemmArgs a = *args;
+  a.gn_acc[0] = a.gn_acc[1] = nullptr;
+  if (validate(a) != PP_OK || !gn_stats_supported(a)) return 0;
+  const Choice c = choose(a);
+  return c.tile > 10 ? 1 : 0;
+}
 
 extern "C" size_t pp_gemm_workspace_bytes(const PPGemmArgs* args) {
   if (!args || validate(*args) != PP_OK) return 0;
@@ -1045,7 +1227,7 @@ extern "C" int pp_gemm_bf16(const PPGemmArgs* args, void* stream) {
   const Choice c = choose(a);
   if (c.splitk > 1 && !a.workspace) return PP_ERR_WORKSPACE;
   if (c.tile > 10 && !v2_ok(a)) return PP_ERR_BAD_ARG;
-  if (a.row_stats_out && c.tile < 10) return PP_ERR_UNSUPPORTED;
+  if ((a.row_stats_out || a.gn_acc[0] || a.gn_acc[1]) && c.tile < 10) return PP_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   const bool conv = a.x_mode == PP_X_CONV3X3;
   switch (c.tile) {

@@ -113,8 +113,35 @@ PP_DEVINL void gn_fold(const float* __restrict__ partial, int nchunk, int groups
   __syncthreads();
 }
 
-// grid (blocks, batch): flat over 16-B pieces of one batch item
-template <bool SILU>
+// Same tables from the fixed-point accumulators the producers' epilogues filled (PPGemmArgs.gn_acc): no partials to fold.
+PP_DEVINL void gn_fold_acc(const long long* __restrict__ acc, int groups, int C, int hw, float eps,
+                           const float* __restrict__ gamma, const float* __restrict__ beta, int b, float* mean_s,
+                           float* rstd_s, float* sc_s, float* sh_s) {
+  const int tid = threadIdx.x;
+  if (tid < groups) {
+    const double s = (double)acc[((size_t)b * groups + tid) * 2] * (1.0 / (double)PP_GN_SUM_SCALE);
+    const double q = (double)acc[((size_t)b * groups + tid) * 2 + 1] * (1.0 / (double)PP_GN_SQ_SCALE);
+    const double n = (double)hw * (double)(C / groups);
+    const double mean = s / n;
+    double var = q / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    mean_s[tid] = (float)mean;
+    rstd_s[tid] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+  __syncthreads();
+  const int cg = C / groups;
+  for (int c = tid; c < C; c += blockDim.x) {
+    const int gg = c / cg;
+    const float sc = rstd_s[gg] * gamma[c];
+    sc_s[c] = sc;
+    sh_s[c] = beta[c] - mean_s[gg] * sc;
+  }
+  __syncthreads();
+}
+
+// grid (blocks, batch): flat over 16-B pieces of one batch item.  ACC: statistics come from the int64 accumulators
+// (`partial` then points at them) instead of the chunk partials of gn_stats_kernel.
+template <bool SILU, bool ACC>
 __global__ void __launch_bounds__(256) gn_apply_kernel(const uint16_t* __restrict__ x1, int c1,
                                                       const uint16_t* __restrict__ x2, int c2, int hw,
                                                       const float* __restrict__ partial, int nchunk, int groups,
@@ -125,7 +152,9 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const uint16_t* __restric
   const int b = blockIdx.y;
   float* sc = tab;
   float* sh = tab + C;
-  gn_fold(partial, nchunk, groups, C, hw, eps, gamma, beta, b, tab + 2 * C, tab + 2 * C + 64, sc, sh);
+  if (ACC) gn_fold_acc(reinterpret_cast<const long long*>(partial), groups, C, hw, eps, gamma, beta, b, tab + 2 * C,
+                       tab + 2 * C + 64, sc, sh);
+  else gn_fold(partial, nchunk, groups, C, hw, eps, gamma, beta, b, tab + 2 * C, tab + 2 * C + 64, sc, sh);
   const int total = hw * S;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
     const int p = i / S;
@@ -252,12 +281,35 @@ extern "C" int pp_groupnorm_apply(const void* x1, int c1, const void* x2, int c2
   hipStream_t st = (hipStream_t)stream;
   const int nchunk = gn_nchunk(hw);
   if (silu)
-    hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(nb, batch), dim3(256), lds, st, (const uint16_t*)x1, c1,
+    hipLaunchKernelGGL((gn_apply_kernel<true, false>), dim3(nb, batch), dim3(256), lds, st, (const uint16_t*)x1, c1,
                        (const uint16_t*)x2, c2, hw, workspace, nchunk, groups, eps, gamma, beta, (uint16_t*)y);
   else
-    hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(nb, batch), dim3(256), lds, st, (const uint16_t*)x1, c1,
+    hipLaunchKernelGGL((gn_apply_kernel<false, false>), dim3(nb, batch), dim3(256), lds, st, (const uint16_t*)x1, c1,
                        (const uint16_t*)x2, c2, hw, workspace, nchunk, groups, eps, gamma, beta, (uint16_t*)y);
   PP_CHECK_LAUNCH("gn_apply_kernel");
+  return PP_OK;
+}
+
+extern "C" int pp_groupnorm_apply_acc(const void* x1, int c1, const void* x2, int c2, int batch, int hw, int groups,
+                                      float eps, const float* gamma, const float* beta, const int64_t* acc, int silu,
+                                      void* y, void* stream) {
+  if (!x1 || !acc || !gamma || !beta || !y || c1 <= 0 || c1 % 8 || c2 % 8 || (c2 > 0 && !x2)) return PP_ERR_BAD_ARG;
+  const int C = c1 + c2;
+  if (groups <= 0 || groups > 32 || C % groups) return PP_ERR_BAD_ARG;
+  const long long total = (long long)hw * (C / 8);
+  int nb = (int)((total + 256 * 8 - 1) / (256 * 8));
+  if (nb > 512) nb = 512;
+  if (nb < 1) nb = 1;
+  const size_t lds = (size_t)(2 * C + 128) * sizeof(float);
+  hipStream_t st = (hipStream_t)stream;
+  const float* accf = reinterpret_cast<const float*>(acc);
+  if (silu)
+    hipLaunchKernelGGL((gn_apply_kernel<true, true>), dim3(nb, batch), dim3(256), lds, st, (const uint16_t*)x1, c1,
+                       (const uint16_t*)x2, c2, hw, accf, 0, groups, eps, gamma, beta, (uint16_t*)y);
+  else
+    hipLaunchKernelGGL((gn_apply_kernel<false, true>), dim3(nb, batch), dim3(256), lds, st, (const uint16_t*)x1, c1,
+                       (const uint16_t*)x2, c2, hw, accf, 0, groups, eps, gamma, beta, (uint16_t*)y);
+  PP_CHECK_LAUNCH("gn_apply_kernel(acc)");
   return PP_OK;
 }
 

@@ -399,3 +399,18 @@ extern "C" int pp_mask_prep(int mode, const float* a, const float* b, float* out
   PP_CHECK_LAUNCH("mask_prep_kernel");
   return PP_OK;
 }
+
+namespace {
+__global__ void __launch_bounds__(256) zero_u64_kernel(unsigned long long* dst, long long n) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) dst[i] = 0ull;
+}
+}  // namespace
+
+extern "C" int pp_zero_u64(void* dst, long long n, void* stream) {
+  if (!dst || n <= 0) return PP_ERR_BAD_ARG;
+  int nb = (int)((n + 255) / 256);
+  if (nb > 1024) nb = 1024;
+  hipLaunchKernelGGL(zero_u64_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, (unsigned long long*)dst, n);
+  PP_CHECK_LAUNCH("zero_u64_kernel");
+  return PP_OK;
+}

@@ -28,6 +28,10 @@ def _align(x: int, a: int = ALIGN) -> int:
 
 
 # ------------------------------------------------------------------------------------------------------------------
+# PP_GN_EPILOGUE=0: every GroupNorm keeps its own statistics launch (A/B measurements, bisecting)
+GN_STATS_IN_EPILOGUE = os.environ.get("PP_GN_EPILOGUE", "1") != "0"
+
+
 class Arena:
     """Stack-scoped bump allocator over one device buffer (or a dry counting arena when device is None)."""
 
@@ -125,6 +129,7 @@ class Act:
     H: int
     W: int
     C: int
+    producer: object = None   # PPGemmArgs of the launch that writes this tensor (GroupNorm statistics subscribe to it)
 
     @property
     def rows(self) -> int:
@@ -198,6 +203,12 @@ class Builder:
         self.lib = L.lib()
         self.gemm_tile = 0       # tuning overrides (0 = auto)
         self.gemm_splitk = 0
+        self.last_gemm = None    # PPGemmArgs of the most recent GEMM launch
+        # GroupNorm statistics accumulated by the producers' epilogues: [gn_acc_base, +gn_acc_cap) bytes of persistent
+        # arena memory for the int64 accumulators (0 = every GroupNorm keeps its own statistics launch)
+        self.gn_acc_base = 0
+        self.gn_acc_cap = 0
+        self.gn_acc_used = 0
 
     # -- memory
     def alloc(self, nbytes: int) -> int:
@@ -222,6 +233,7 @@ class Builder:
         if ws:
             a.workspace = self.alloc(ws)
         self.plan.keep.append(a)
+        self.last_gemm = a
         self.plan.add(name, self.lib.pp_gemm_bf16, C.byref(a))
         self.plan.count(name, 2.0 * a.M * a.N * a.K)
 
@@ -276,6 +288,7 @@ class Builder:
         a.scale, a.act = scale, 0
         a.out, a.ldo, a.out_f32 = out.ptr, cout, 0
         self._gemm(a, name)
+        out.producer = a
         self.release(m)
         return out
 
@@ -286,14 +299,52 @@ class Builder:
         hw = x.H * x.W
         if out is None:
             out = self.new_act(x.B, x.H, x.W, Ct)
+        x2p = x2.ptr if x2 is not None else None
+        acc = self._subscribe_gn_stats(x, x2, groups)
+        if acc:
+            # the statistics arrive from the epilogues of the launches that produced x (and x2): no stats launch
+            self.plan.add("groupnorm_apply", self.lib.pp_groupnorm_apply_acc, x.ptr, x.C, x2p, c2, x.B, hw, groups, eps,
+                          gamma, beta, acc, int(silu), out.ptr)
+            return out
         m = self.mark()
         ws = self.alloc(self.lib.pp_groupnorm_workspace_bytes(x.B, hw, Ct))
-        x2p = x2.ptr if x2 is not None else None
         self.plan.add("groupnorm_stats", self.lib.pp_groupnorm_stats, x.ptr, x.C, x2p, c2, x.B, hw, groups, ws)
         self.plan.add("groupnorm_apply", self.lib.pp_groupnorm_apply, x.ptr, x.C, x2p, c2, x.B, hw, groups, eps,
                       gamma, beta, ws, int(silu), out.ptr)
         self.release(m)
         return out
+
+    def _subscribe_gn_stats(self, x: Act, x2: Optional[Act], groups: int) -> int:
+        """If every input tensor of this GroupNorm is written by a GEMM launch whose epilogue can accumulate the
+        statistics, patch those launches (PPGemmArgs.gn_acc slot) and return the accumulator pointer, else 0."""
+        if not (GN_STATS_IN_EPILOGUE and self.gn_acc_cap):
+            return 0
+        hw = x.H * x.W
+        parts = [(x, 0)] + ([(x2, x.C)] if x2 is not None else [])
+        Ct = x.C + (x2.C if x2 is not None else 0)
+        if hw % 64 or Ct % groups or Ct // groups < 8:     # (>= 8 channels per group: LDS group slots per 160-col tile)
+            return 0
+        for t, _ in parts:
+            a = t.producer
+            if a is None or (a.gn_acc[0] and a.gn_acc[1]):
+                return 0
+            rpb = a.rows_per_batch
+            a.rows_per_batch = hw
+            ok = self.lib.pp_gemm_gn_stats_ok(C.byref(a))
+            a.rows_per_batch = rpb
+            if not ok or (rpb not in (0, hw)):
+                return 0
+        nbytes = x.B * groups * 2 * 8
+        if self.gn_acc_used + nbytes > self.gn_acc_cap:
+            return 0
+        acc = self.gn_acc_base + self.gn_acc_used
+        self.gn_acc_used += nbytes
+        for t, c0 in parts:
+            a = t.producer
+            k = 0 if not a.gn_acc[0] else 1
+            a.rows_per_batch = hw
+            a.gn_acc[k], a.gn_cg[k], a.gn_c0[k], a.gn_groups[k] = acc, Ct // groups, c0, groups
+        return acc
 
     def layernorm(self, x: int, rows: int, Cc: int, gamma: int, beta: int, eps: float = 1e-5) -> int:
         out = self.alloc(rows * Cc * 2)
@@ -707,10 +758,12 @@ class SDNet:
         if self.merge_ff2_proj_out:
             pb.linear(g, rows, 4 * Cc, P[f"{pre}.ff2_proj_out.weight"], Cc, P[f"{pre}.ff2_proj_out.bias"], x2=hs, K2=Cc,
                       ldx2=Cc, res1=x.ptr, res2=res2, out=out.ptr, name="linear")
+            out.producer = pb.last_gemm
         else:
             hs = pb.linear(g, rows, 4 * Cc, P[f"{tb}.ff2.weight"], Cc, P[f"{tb}.ff2.bias"], res1=hs, name="linear")
             pb.linear(hs, rows, Cc, P[f"{pre}.proj_out.weight"], Cc, P[f"{pre}.proj_out.bias"], res1=x.ptr, res2=res2,
                       out=out.ptr, name="conv1x1")
+            out.producer = pb.last_gemm
         pb.release(m)
         return out
 

@@ -22,10 +22,30 @@ def _p(t: Optional[torch.Tensor]):
     return t.data_ptr() if t is not None else None
 
 
+def _set_gn(a, gn, rows_per_batch):
+    """gn: up to two (acc int64 [B][groups][2] (zeroed by the caller), channels_per_group, channel_offset, groups)."""
+    if not gn:
+        return
+    a.rows_per_batch = rows_per_batch
+    for k, (acc, cg, c0, groups) in enumerate(gn):
+        a.gn_acc[k], a.gn_cg[k], a.gn_c0[k], a.gn_groups[k] = acc.data_ptr(), cg, c0, groups
+
+
+def groupnorm_apply_acc(x: torch.Tensor, acc: torch.Tensor, gamma, beta, eps: float, silu: bool, groups: int = 32,
+                        x2=None):
+    """GroupNorm(+SiLU) of concat(x, x2) from statistics accumulated by the producers (PPGemmArgs.gn_acc)."""
+    B, H, W, C1 = x.shape
+    C2 = x2.shape[3] if x2 is not None else 0
+    y = torch.empty(B, H, W, C1 + C2, dtype=torch.bfloat16, device=x.device)
+    L.check(L.lib().pp_groupnorm_apply_acc(_p(x), C1, _p(x2), C2, B, H * W, groups, eps, _p(gamma), _p(beta), _p(acc),
+                                           int(silu), _p(y), _s()), "pp_groupnorm_apply_acc")
+    return y
+
+
 def gemm(x: torch.Tensor, w: torch.Tensor, bias=None, x2=None, res1=None, res2=None, scale: float = 1.0, act: int = 0,
          rowvec=None, rows_per_batch: int = 0, out_f32: bool = False, vt_col0: int = 0, tile: int = 0,
          splitk: int = 0, row_stats: bool = False, ln_stats=None, ln_colsum=None, ln_dim: int = 0,
-         ln_eps: float = 1e-5):
+         ln_eps: float = 1e-5, gn=None):
     """x [M,K1] (+ x2 [M,K2]) bf16, w [N,K1+K2] bf16 -> out [M,N] (or [M,N/2] for GEGLU; (out, vt) when vt_col0).
     row_stats=True additionally returns the per-row (sum, sumsq) partials [M, ceil(N/160), 2] fp32;
     ln_stats (that layout) + ln_colsum [N] fp32 apply the folded-LayerNorm correction (see include/pp_hip.h)."""
@@ -52,6 +72,7 @@ def gemm(x: torch.Tensor, w: torch.Tensor, bias=None, x2=None, res1=None, res2=N
         vt = torch.zeros(nb, N - vt_col0, rows_per_batch, dtype=torch.bfloat16, device=x.device)
         a.out_vt, a.vt_col0, a.vt_ld = _p(vt), vt_col0, rows_per_batch
     a.tile, a.splitk = tile, splitk
+    _set_gn(a, gn, rows_per_batch)
     stats = None
     if row_stats:
         stats = torch.zeros(M, (N + 159) // 160, 2, dtype=torch.float32, device=x.device)
@@ -68,7 +89,7 @@ def gemm(x: torch.Tensor, w: torch.Tensor, bias=None, x2=None, res1=None, res2=N
 
 
 def conv3x3(x: torch.Tensor, w: torch.Tensor, bias=None, stride: int = 1, up: bool = False, x2=None, rowvec=None,
-            res1=None, res2=None, scale: float = 1.0, tile: int = 0, splitk: int = 0):
+            res1=None, res2=None, scale: float = 1.0, tile: int = 0, splitk: int = 0, gn=None):
     """x NHWC bf16 [B,H,W,C1] (+x2 [B,H,W,C2]); w bf16 [Cout, 9*(C1+C2)] (k = (ky*3+kx)*C + c) -> NHWC bf16."""
     lib = L.lib()
     B, H, W, C1 = x.shape
@@ -87,6 +108,7 @@ def conv3x3(x: torch.Tensor, w: torch.Tensor, bias=None, stride: int = 1, up: bo
     a.res1, a.ldres1, a.res2, a.ldres2 = _p(res1), cout, _p(res2), cout
     a.scale, a.act, a.out, a.ldo = scale, 0, _p(out), cout
     a.tile, a.splitk = tile, splitk
+    _set_gn(a, gn, ho * wo)
     ws = lib.pp_gemm_workspace_bytes(C.byref(a))
     wsb = torch.empty(max(ws, 4) // 4, dtype=torch.float32, device=x.device) if ws else None
     a.workspace = _p(wsb)

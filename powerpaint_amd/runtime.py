@@ -38,6 +38,10 @@ class NetRuntime:
         pb_setup.gemm_tile, pb_setup.gemm_splitk = self.gemm_tile, self.gemm_splitk
         lay = {}
         lay["t_dev"] = arena.alloc(256)
+        # int64 accumulators of the GroupNorm statistics the GEMM epilogues produce (<= 96 norms per network); zeroed
+        # by the first launch of every step
+        gn_cap = 96 * B * 32 * 2 * 8
+        lay["gn_acc"] = arena.alloc(gn_cap)
         lay["x_in"] = Act(arena.alloc(B * H * W * cin_total * 2), B, H, W, cin_total)
         lay["ehs"] = arena.alloc(B * nctx * net.ctx_dim * 2)
         cond = None
@@ -56,6 +60,7 @@ class NetRuntime:
         net.build_setup(pb_setup, B, nctx, lay["ehs"], cond)
         pb = Builder(arena)
         pb.gemm_tile, pb.gemm_splitk = self.gemm_tile, self.gemm_splitk
+        pb.gn_acc_base, pb.gn_acc_cap = lay["gn_acc"], gn_cap
         kw = {}
         if net.kind == "unet" and kind == "brushnet":
             ptrs = wiring[1]
@@ -69,6 +74,8 @@ class NetRuntime:
             md = ptrs["mid"][0] if ptrs["mid"][0] else slots["mid"][0].ptr
             kw = dict(ctrl_down=dn, ctrl_mid=md)
         outs = net.build_step(pb, lay["x_in"], lay["t_dev"], scale=1.0, **kw)
+        if pb.gn_acc_used:
+            pb.plan.calls.insert(0, (L.lib().pp_zero_u64, (lay["gn_acc"], pb.gn_acc_used // 8), "zero_u64"))
         return lay, pb_setup.plan, pb.plan, outs
 
     def _residual_shapes(self, B, H, W, with_up: bool):

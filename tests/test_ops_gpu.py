@@ -212,6 +212,58 @@ def test_conv3x3_halo_exact():
         assert torch.equal(out[0, :, :, 319], cnt)
 
 
+# ------------------------------------------------------------------------------------------------ GroupNorm statistics in the epilogue
+def _gn_ref(t, cg, c0, groups):
+    """(sum, sumsq) per (batch, group) of tensor t [B, hw, C] placed at channel offset c0 of a `groups`-group norm."""
+    B, hw, C = t.shape
+    out = torch.zeros(B, groups, 2, dtype=torch.float64, device=t.device)
+    tf = t.double()
+    for c in range(C):
+        g = (c0 + c) // cg
+        out[:, g, 0] += tf[:, :, c].sum(1)
+        out[:, g, 1] += (tf[:, :, c] ** 2).sum(1)
+    return out
+
+
+@pytest.mark.parametrize("tile,splitk", [(0, 0), (21, 1), (22, 1), (24, 1), (33, 1), (31, 4), (32, 2), (33, 8)])
+def test_conv_epilogue_groupnorm_stats(tile, splitk):
+    """The conv epilogue (or the split-K combine) accumulates the consumer GroupNorms' (sum, sumsq): two consumers with
+    different groupings (own 32-group norm; a 1920-channel concat norm where this tensor sits at channel offset 1280,
+    so 60-channel groups straddle the 160-column tiles), bit-reproducible, and the apply kernel consumes them."""
+    B, H, Cin, Cout = 2, 16, 320, 640
+    x = bf(rnd(B, H, H, Cin, seed=1))
+    w = bf(rnd(Cout, 9 * Cin, seed=2, scale=(9 * Cin) ** -0.5))
+    bias, res = rnd(Cout, seed=3), bf(rnd(B, H, H, Cout, seed=4))
+    acc1 = torch.zeros(B, 32, 2, dtype=torch.int64, device=DEV)
+    acc2 = torch.zeros(B, 32, 2, dtype=torch.int64, device=DEV)
+    gn = [(acc1, Cout // 32, 0, 32), (acc2, 1920 // 32, 1280, 32)]
+    out = ops.conv3x3(x, w, bias, res1=res, tile=tile, splitk=splitk, gn=gn)
+    plain = ops.conv3x3(x, w, bias, res1=res, tile=tile, splitk=splitk)
+    assert torch.equal(out, plain)
+    o = out.float().reshape(B, H * H, Cout)
+    for acc, cg, c0 in ((acc1, 20, 0), (acc2, 60, 1280)):
+        ref = _gn_ref(o, cg, c0, 32)
+        got = torch.stack([acc[..., 0].double() / 2 ** 24, acc[..., 1].double() / 2 ** 20], -1)
+        assert torch.allclose(got, ref, rtol=1e-4, atol=1e-2), (cg, (got - ref).abs().max())
+    again1 = torch.zeros_like(acc1)
+    ops.conv3x3(x, w, bias, res1=res, tile=tile, splitk=splitk, gn=[(again1, 20, 0, 32)])
+    assert torch.equal(again1, acc1)                       # integer accumulation: order-independent
+    g, b = rnd(Cout, seed=5), rnd(Cout, seed=6)
+    y = ops.groupnorm_apply_acc(out, acc1, g, b, 1e-5, True)
+    ref = F.silu(F.group_norm(out.float().permute(0, 3, 1, 2), 32, g, b, 1e-5)).permute(0, 2, 3, 1)
+    check(y, ref, 2e-2, 1e-2, "groupnorm from accumulated statistics")
+
+
+def test_gemm_epilogue_groupnorm_stats_plain():
+    B, hw, K, N = 2, 256, 1600, 320
+    x, w = bf(rnd(B * hw, K, seed=1)), bf(rnd(N, K, seed=2, scale=K ** -0.5))
+    acc = torch.zeros(B, 32, 2, dtype=torch.int64, device=DEV)
+    out = ops.gemm(x, w, rows_per_batch=hw, gn=[(acc, 10, 0, 32)])
+    ref = _gn_ref(out.float().reshape(B, hw, N), 10, 0, 32)
+    got = torch.stack([acc[..., 0].double() / 2 ** 24, acc[..., 1].double() / 2 ** 20], -1)
+    assert torch.allclose(got, ref, rtol=1e-4, atol=1e-2)
+
+
 # ------------------------------------------------------------------------------------------------ norms
 @pytest.mark.parametrize("C1,C2,H", [(320, 0, 16), (640, 320, 8), (1280, 1280, 8), (1920, 0, 4), (320, 0, 64)])
 @pytest.mark.parametrize("silu", [True, False])
