@@ -27,19 +27,19 @@
 
 namespace {
 
-constexpr int KB = 64;   // keys per tile
 constexpr int QW = 32;   // queries per wave
 constexpr int NW = 4;    // waves per block
 
-template <int D>
+template <int D, int KB>
 struct PCfg {
+  static constexpr int JB = KB / 32;                      // 32-key S^T blocks per tile
   static constexpr int DP = (D + 15) / 16 * 16;
   static constexpr int DS = DP / 16;
   static constexpr int VROWS = (D + 1 + 31) / 32 * 32;   // head-dim rows + the all-ones row, whole 32-row MFMA tiles
   static constexpr int DT = VROWS / 32;
   static constexpr int KSL = DP / 8 + 1;                 // 16-B slots per K row (odd)
   static constexpr int KS = KSL * 16;
-  static constexpr int KTILE = KB * KS;
+  static constexpr int KTILE = (KB * KS + 1023) / 1024 * 1024;   // whole DMA instructions (tail slots unused)
   static constexpr int KI = KTILE / 1024;                // wave-wide DMA instructions per K tile
   static constexpr int VSL = KB / 8 + 1;                 // 9 slots per V^T row
   static constexpr int VS = VSL * 16;
@@ -50,7 +50,6 @@ struct PCfg {
   static constexpr int VBASE = NKB * KTILE;
   static constexpr int DUMMY = VBASE + NVB * VTILE;
   static constexpr int LDS = DUMMY + 1024;
-  static_assert(KTILE % 1024 == 0, "K tile must be whole DMA instructions");
   static_assert(VI * 1024 <= (VROWS - 1) * VS, "DMA spill of the V^T tile must stay below the ones row");
   static_assert(KSL % 2 == 1 && VSL % 2 == 1, "odd slot counts");
 };
@@ -59,14 +58,15 @@ constexpr float RESCALE_THR = 8.0f;
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-template <int D, int dbg>
-__global__ void __launch_bounds__(256, 2)
+template <int D, int KB, int dbg>
+__global__ void __launch_bounds__(256, (KB == 32 ? 4 : 2))
 attn_pipe_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __restrict__ k, int ldk,
                  const uint16_t* __restrict__ vt, int ldvt, uint16_t* __restrict__ o, int ldo, int heads, int nq, int nk,
                  float scale_log2e) {
   // dbg (PP_ATTN_DBG, timing experiments only; results are garbage): 1 no MFMA, 2 no exp, 4 no tile DMA / barrier,
   // 8 no LDS fragment reads
-  using C = PCfg<D>;
+  using C = PCfg<D, KB>;
+  constexpr int JB = C::JB;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -118,7 +118,7 @@ attn_pipe_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __rest
     if (i < LPK) {
       const int g = i * NW + wave;
       const int L = 64 * g + lane, r = L / C::KSL, p = L - r * C::KSL;
-      if (g < C::KI && p < D / 8) off = (r * ldk + p * 8) * 2;
+      if (g < C::KI && r < KB && p < D / 8) off = (r * ldk + p * 8) * 2;
       rel[i] = g < C::KI ? g * 1024 : -1;
     } else {
       const int g = (i - LPK) * NW + wave;
@@ -162,9 +162,9 @@ attn_pipe_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __rest
   bool pend = false;        // wave-uniform: alpha != 1 somewhere
 
   // plain (non-interleaved) pieces: prologue S(0) and the drain PV
-  auto qk = [&](const char* ks, f32x16_t (&sn)[2]) {
+  auto qk = [&](const char* ks, f32x16_t (&sn)[JB]) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < JB; ++j) {
       const f32x16_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int s = 0; s < C::DS; ++s) {
@@ -181,9 +181,9 @@ attn_pipe_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __rest
     const u32x4_t w = {lo[0], lo[1], hi[0], hi[1]};
     return __builtin_bit_cast(bf16x8_t, w);
   };
-  auto pv = [&](const char* vs, const bf16x8_t (&pp)[2][2]) {
+  auto pv = [&](const char* vs, const bf16x8_t (&pp)[JB][2]) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < JB; ++j)
 #pragma unroll
       for (int u = 0; u < 2; ++u)
 #pragma unroll
@@ -195,7 +195,7 @@ attn_pipe_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __rest
   // The body is choreographed by hand: NM = 2*DS + 4*DT MFMAs, one per slot; every slot also carries its share of the
   // softmax VALU work and the LDS fragment reads of the MFMA two slots ahead.  sched_barrier(0) between slots keeps the
   // compiler from regrouping (left alone it emits all MFMAs back to back, then the VALU block: zero overlap).
-  auto stage = [&](int t, const f32x16_t (&sc)[2], f32x16_t (&sn)[2], bf16x8_t (&pc)[2][2], const bf16x8_t (&pp)[2][2]) {
+  auto stage = [&](int t, const f32x16_t (&sc)[JB], f32x16_t (&sn)[JB], bf16x8_t (&pc)[JB][2], const bf16x8_t (&pp)[JB][2]) {
     if (!(dbg & 4)) {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::LPW) : "memory");   // tile t+1 (issued two stages ago) has landed
     asm volatile("s_barrier" ::: "memory");                         // ... for every wave; stage t-1 reads are done
@@ -211,10 +211,11 @@ attn_pipe_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __rest
     const char* vs = smem + C::VBASE + vread * C::VTILE; // V(t-1)
     kread = kread + 1 == C::NKB ? 0 : kread + 1;
     vread = vread + 1 == C::NVB ? 0 : vread + 1;
-    constexpr int NQK = 2 * C::DS, NM = NQK + 4 * C::DT;
+    constexpr int NQK = JB * C::DS, NM = NQK + JB * 2 * C::DT;
     constexpr int FD = (dbg >> 4) ? (dbg >> 4) : 2;   // fragment prefetch distance in slots (experiment: dbg / 16)
-    constexpr int MAXSLOTS = 4;                  // slots carrying the running-max phase
-    constexpr int ESLOTS = NM - MAXSLOTS;        // slots carrying the 16 exp steps
+    constexpr int MAXSLOTS = 2 * JB;             // slots carrying the running-max phase (8 scores each)
+    constexpr int NES = 8 * JB;                  // exp steps (2 scores each)
+    constexpr int ESLOTS = NM - MAXSLOTS;        // slots carrying them
     bf16x8_t frag[NM];
     auto fetch = [&](int f) {
       if (dbg & 8) { frag[f] = __builtin_bit_cast(bf16x8_t, qraw[0]); return; }
@@ -230,7 +231,7 @@ attn_pipe_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __rest
     for (int f = 0; f < FD; ++f) fetch(f);
     float tmax = -1.0e30f;
     f32x2_t c2 = {scale_log2e, scale_log2e}, nm2 = {0.f, 0.f};
-    u32x4_t w[2][2];
+    u32x4_t w[JB][2];
     int es = 0;                                  // exp steps done (compile-time after unrolling)
 #pragma unroll
     for (int f = 0; f < NM; ++f) {
@@ -262,7 +263,7 @@ attn_pipe_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __rest
         }
       } else {                                   // exp steps: 2 scores each (pk_fma, 2 x exp2, cvt_pk)
         const int k = f - MAXSLOTS;
-        const int upto = (16 * (k + 1) + ESLOTS - 1) / ESLOTS;
+        const int upto = (NES * (k + 1) + ESLOTS - 1) / ESLOTS;
 #pragma unroll
         for (; es < upto; ++es) {
           const int j = es >> 3, u = (es >> 2) & 1, e = es & 3;
@@ -275,15 +276,15 @@ attn_pipe_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __rest
       __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < JB; ++j)
 #pragma unroll
       for (int u = 0; u < 2; ++u) pc[j][u] = __builtin_bit_cast(bf16x8_t, w[j][u]);
   };
 
-  f32x16_t sA[2], sB[2];
-  bf16x8_t pA[2][2], pB[2][2];
+  f32x16_t sA[JB], sB[JB];
+  bf16x8_t pA[JB][2], pB[JB][2];
 #pragma unroll
-  for (int j = 0; j < 2; ++j)
+  for (int j = 0; j < JB; ++j)
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       pA[j][u] = __builtin_bit_cast(bf16x8_t, u32x4_t{0u, 0u, 0u, 0u});
@@ -339,45 +340,47 @@ attn_pipe_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __rest
 }  // namespace
 
 // Returns PP_ERR_UNSUPPORTED for shapes this kernel does not cover (the caller then uses attn_fwd_kernel).
-int pp_attention_pipe_launch(const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt, void* o, int ldo,
-                             int batch, int heads, int nq, int nk, int d, float sl2, hipStream_t st) {
-  if (d != 40 || nk % KB != 0 || nk < 2 * KB) return PP_ERR_UNSUPPORTED;
-  using C = PCfg<40>;
-  static const int dbg = [] { const char* e = getenv("PP_ATTN_DBG"); return e ? atoi(e) : 0; }();
+// Default: 64-key tiles, two workgroups (8 waves) per CU; carries the PP_ATTN_DBG ablation variants.  PP_ATTN_KB=32:
+// 32-key tiles, <= 128 VGPRs, four workgroups per CU -- measured identical (347 vs 346 us at N = 4096): doubling the
+// occupancy hides nothing, the SIMD is issue-bound (~230 instructions per wave-tile at ~4 cycles + 14 MFMA at 32).
+template <int KB, int DBG>
+static int launch_pipe(const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt, void* o, int ldo,
+                       int batch, int heads, int nq, int nk, float sl2, hipStream_t st) {
+  using C = PCfg<40, KB>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_pipe_kernel<40, KB, DBG>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS) != hipSuccess) {
+      pp_set_last_error("hipFuncSetAttribute(attention pipe)", hipGetLastError());
+      return PP_ERR_LAUNCH;
+    }
+    attr_set = true;
+  }
   const dim3 grid((nq + QW * NW - 1) / (QW * NW), heads, batch), block(256);
-#define PP_LAUNCH_DBG(V)                                                                                              \
-  case V: {                                                                                                           \
-    static bool attr_set = false;                                                                                     \
-    if (!attr_set) {                                                                                                  \
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_pipe_kernel<40, V>),                                 \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS) != hipSuccess) {                    \
-        pp_set_last_error("hipFuncSetAttribute(attention pipe)", hipGetLastError());                                  \
-        return PP_ERR_LAUNCH;                                                                                         \
-      }                                                                                                               \
-      attr_set = true;                                                                                                \
-    }                                                                                                                 \
-    hipLaunchKernelGGL((attn_pipe_kernel<40, V>), grid, block, C::LDS, st, (const uint16_t*)q, ldq, (const uint16_t*)k, \
-                       ldk, (const uint16_t*)vt, ldvt, (uint16_t*)o, ldo, heads, nq, nk, sl2);                         \
-    break;                                                                                                            \
-  }
-  switch (dbg) {
-    PP_LAUNCH_DBG(0)
-    PP_LAUNCH_DBG(1)
-    PP_LAUNCH_DBG(2)
-    PP_LAUNCH_DBG(3)
-    PP_LAUNCH_DBG(4)
-    PP_LAUNCH_DBG(8)
-    PP_LAUNCH_DBG(9)
-    PP_LAUNCH_DBG(12)
-    PP_LAUNCH_DBG(13)
-    PP_LAUNCH_DBG(15)
-    PP_LAUNCH_DBG(48)
-    PP_LAUNCH_DBG(64)
-    PP_LAUNCH_DBG(96)
-    PP_LAUNCH_DBG(128)
-    default: return PP_ERR_BAD_ARG;
-  }
-#undef PP_LAUNCH_DBG
+  hipLaunchKernelGGL((attn_pipe_kernel<40, KB, DBG>), grid, block, C::LDS, st, (const uint16_t*)q, ldq, (const uint16_t*)k,
+                     ldk, (const uint16_t*)vt, ldvt, (uint16_t*)o, ldo, heads, nq, nk, sl2);
   PP_CHECK_LAUNCH("attn_pipe_kernel");
   return PP_OK;
+}
+
+int pp_attention_pipe_launch(const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt, void* o, int ldo,
+                             int batch, int heads, int nq, int nk, int d, float sl2, hipStream_t st) {
+  static const int kb = [] { const char* e = getenv("PP_ATTN_KB"); return e ? atoi(e) : 64; }();
+  static const int dbg = [] { const char* e = getenv("PP_ATTN_DBG"); return e ? atoi(e) : 0; }();
+  if (d != 40 || nk % kb != 0 || nk < 4 * kb) return PP_ERR_UNSUPPORTED;
+#define PP_ARGS q, ldq, k, ldk, vt, ldvt, o, ldo, batch, heads, nq, nk, sl2, st
+  if (kb == 32) return launch_pipe<32, 0>(PP_ARGS);
+  if (kb != 64) return PP_ERR_BAD_ARG;
+  switch (dbg) {
+    case 0: return launch_pipe<64, 0>(PP_ARGS);
+    case 1: return launch_pipe<64, 1>(PP_ARGS);
+    case 2: return launch_pipe<64, 2>(PP_ARGS);
+    case 4: return launch_pipe<64, 4>(PP_ARGS);
+    case 8: return launch_pipe<64, 8>(PP_ARGS);
+    case 12: return launch_pipe<64, 12>(PP_ARGS);
+    case 13: return launch_pipe<64, 13>(PP_ARGS);
+    case 15: return launch_pipe<64, 15>(PP_ARGS);
+    default: return PP_ERR_BAD_ARG;
+  }
+#undef PP_ARGS
 }
