@@ -668,6 +668,44 @@ pp_gemm_kernel_v2(const PPGemmArgs a, const GemmDerived d) {   // 2nd bound = wa
     }
     return;
   } else {
+  // GroupNorm statistics (EPI 4): per-thread column moments of the stored values, folded into the groups' accumulators
+  // once per batch item the tile touches -- once per workgroup when a batch item spans whole tiles, else per 64-row pass
+  float gcs[8], gcq[8];
+#pragma unroll
+  for (int jj = 0; jj < 8; ++jj) { gcs[jj] = 0.f; gcq[jj] = 0.f; }
+  const bool gn_per_pass = GNS && (a.rows_per_batch % BM) != 0;
+  auto gn_fold_block = [&](int m_first, bool first_call) {
+    constexpr int EC = BN / 8, ER = T / EC;
+    const int c8 = tid % EC, r0 = tid / EC;
+    const int n = n_blk + c8 * 8;
+    // per-thread column moments -> LDS [row-thread][column] (over the staged tile, which everyone has finished reading)
+    // -> the 160 column threads fold the ER row-threads in fixed order and add into the groups' integer slots
+    unsigned long long* slots = reinterpret_cast<unsigned long long*>(smem + RS_OFF);
+    if (first_call && tid < 2 * GN_SLOTS * 2) slots[tid] = 0ull;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (r0 < ER && n < a.N) {
+      float* dstp = reinterpret_cast<float*>(smem) + ((size_t)r0 * BN + c8 * 8) * 2;
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        *reinterpret_cast<f32x4_t*>(dstp + 4 * jj) = f32x4_t{gcs[2 * jj], gcq[2 * jj], gcs[2 * jj + 1], gcq[2 * jj + 1]};
+        gcs[2 * jj] = gcq[2 * jj] = gcs[2 * jj + 1] = gcq[2 * jj + 1] = 0.f;
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    const int ncols = min(BN, a.N - n_blk);
+    if (tid < ncols) {
+      float sm = 0.f, sq = 0.f;
+#pragma unroll 5
+      for (int r = 0; r < ER; ++r) {
+        const f32x2_t v = *reinterpret_cast<const f32x2_t*>(smem + ((size_t)r * BN + tid) * 8);
+        sm += v[0];
+        sq += v[1];
+      }
+      gn_column(a, slots, n_blk, tid, sm, sq);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (m_first < a.M) gn_flush(a, slots, m_first, n_blk, ncols, tid);
+  };
 #pragma unroll 1
   for (int pass = 0; pass < BM / EPI_ROWS; ++pass) {
     asm volatile("s_barrier" ::: "memory");            // LDS free: main loop (pass 0) / previous read-out finished
@@ -722,11 +760,6 @@ pp_gemm_kernel_v2(const PPGemmArgs a, const GemmDerived d) {   // 2nd bound = wa
       constexpr int EC = BN / 8, ER = T / EC, EP = (EPI_ROWS + ER - 1) / ER;
       const int c8 = tid % EC, r0 = tid / EC;
       const int n = n_blk + c8 * 8;
-      float gcs[8], gcq[8];
-      if (GNS) {
-#pragma unroll
-        for (int jj = 0; jj < 8; ++jj) { gcs[jj] = 0.f; gcq[jj] = 0.f; }
-      }
       if (r0 < ER && n < a.N) {
         if (splitk) {
 #pragma unroll
@@ -820,33 +853,7 @@ pp_gemm_kernel_v2(const PPGemmArgs a, const GemmDerived d) {   // 2nd bound = wa
           }
         }
       }
-      if (GNS && !splitk) {
-        // per-thread column moments -> LDS [row-thread][column] (over the staged tile, which everyone has finished
-        // reading) -> the 160 column threads fold the ER row-threads in fixed order and add into the groups' slots
-        unsigned long long* slots = reinterpret_cast<unsigned long long*>(smem + RS_OFF);
-        if (pass == 0 && tid < 2 * GN_SLOTS * 2) slots[tid] = 0ull;
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        if (r0 < ER && n < a.N) {
-          float* dstp = reinterpret_cast<float*>(smem) + ((size_t)r0 * BN + c8 * 8) * 2;
-#pragma unroll
-          for (int jj = 0; jj < 4; ++jj)
-            *reinterpret_cast<f32x4_t*>(dstp + 4 * jj) = f32x4_t{gcs[2 * jj], gcq[2 * jj], gcs[2 * jj + 1], gcq[2 * jj + 1]};
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        const int ncols = min(BN, a.N - n_blk);
-        if (tid < ncols) {
-          float sm = 0.f, sq = 0.f;
-#pragma unroll 5
-          for (int r = 0; r < ER; ++r) {
-            const f32x2_t v = *reinterpret_cast<const f32x2_t*>(smem + ((size_t)r * BN + tid) * 8);
-            sm += v[0];
-            sq += v[1];
-          }
-          gn_column(a, slots, n_blk, tid, sm, sq);
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        if (m0 < a.M) gn_flush(a, slots, m0, n_blk, ncols, tid);
-      }
+      if (gn_per_pass && !splitk) gn_fold_block(m0, pass == 0);
       if (rs_out) {
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         if (tid < EPI_ROWS && m0 + tid < a.M) {
@@ -863,6 +870,7 @@ pp_gemm_kernel_v2(const PPGemmArgs a, const GemmDerived d) {   // 2nd bound = wa
       }
     }
   }
+  if (GNS && !splitk && !gn_per_pass) gn_fold_block(m_blk, true);
   }   // EPI != 2
 }
 
