@@ -27,7 +27,7 @@ extern "C" {
 #define PP_ERR_LAUNCH (-3)       /* hipLaunchKernel / hipFuncSetAttribute failed                  */
 #define PP_ERR_WORKSPACE (-4)    /* workspace pointer null or too small                           */
 
-#define PP_ABI_VERSION 3
+#define PP_ABI_VERSION 4
 int pp_abi_version(void);
 /* hipGetLastError() text of the last PP_ERR_LAUNCH on this thread (host pointer, static storage). */
 const char* pp_last_error(void);
@@ -115,6 +115,14 @@ typedef struct PPGemmArgs {
   int32_t gn_cg[2];
   int32_t gn_c0[2];
   int32_t gn_groups[2];
+  /* PP_X_CONV3X3 only: the contraction continues after the nine taps with c3 + c4 channels read at the OUTPUT pixel
+   * (a 1x1 convolution of concat(x3, x4), NHWC bf16 at the output resolution) -- ResnetBlock2D.conv_shortcut(input)
+   * summed into conv2:  K = 9 (c1 + c2) + c3 + c4, weight columns in that order.  Requires stride 1, no upsample,
+   * c3 % 64 == 0, c4 % 64 == 0, a v2 tile. */
+  const void* x3;
+  const void* x4;
+  int32_t c3;
+  int32_t c4;
 } PPGemmArgs;
 #define PP_GN_SUM_SCALE 16777216.0f /* 2^24 */
 #define PP_GN_SQ_SCALE 1048576.0f   /* 2^20 */

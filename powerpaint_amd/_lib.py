@@ -36,6 +36,7 @@ class PPGemmArgs(C.Structure):
         ("row_stats_out", vp), ("ln_stats", vp), ("ln_colsum", vp),
         ("ln_tiles", i32), ("ln_dim", i32), ("ln_eps", f32), ("pad0", i32),
         ("gn_acc", vp * 2), ("gn_cg", i32 * 2), ("gn_c0", i32 * 2), ("gn_groups", i32 * 2),
+        ("x3", vp), ("x4", vp), ("c3", i32), ("c4", i32),
     ]
 
 
@@ -91,7 +92,7 @@ def lib():
             fn = getattr(l, name)
             fn.restype = res
             fn.argtypes = args
-        if l.pp_abi_version() != 3:
+        if l.pp_abi_version() != 4:
             raise PPError("libpp_hip.so ABI version mismatch")
         _lib = l
     return _lib

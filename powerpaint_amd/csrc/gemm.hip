@@ -465,16 +465,30 @@ pp_gemm_kernel_v2(const PPGemmArgs a, const GemmDerived d) {   // 2nd bound = wa
     wlds[i] = (wave * 8 + strip * RPP) * 128;
   }
 
+  // conv K walk: taps 0..8 over the c1 + c2 channels of the (concatenated) input, then tap 9 = the optional 1x1 tail
+  // over c3 + c4 channels of (x3, x4) at the output pixel (ResnetBlock2D.conv_shortcut merged into conv2)
   int tap = 0, cc = 0;
   bool retap = true;
   if (XMODE == PP_X_CONV3X3) {
     tap = kt_begin / d.ctiles;
+    if (tap > 9) tap = 9;
     cc = (kt_begin - tap * d.ctiles) * 64;
   }
+  const uint64_t px1 = reinterpret_cast<uint64_t>(a.x1), px2 = reinterpret_cast<uint64_t>(a.x2);
+  const uint64_t px3 = XMODE == PP_X_CONV3X3 ? reinterpret_cast<uint64_t>(a.x3) : 0ull;
+  const uint64_t px4 = XMODE == PP_X_CONV3X3 ? reinterpret_cast<uint64_t>(a.x4) : 0ull;
+  const int pc1 = a.c1, pc2 = a.c2, pc3 = XMODE == PP_X_CONV3X3 ? a.c3 : 0, pc4 = XMODE == PP_X_CONV3X3 ? a.c4 : 0;
+  uint64_t cur_src = px1;            // source of the current (tap, channel range): updated only where it changes
+  uint32_t cur_bytes = 0u;
+  int cur_cA = pc1, cur_c0 = 0;
+  const uint32_t xbytes3 = (XMODE == PP_X_CONV3X3 && a.x3) ? (uint32_t)a.M * (uint32_t)a.c3 * 2u : 0u;
+  const uint32_t xbytes4 = (XMODE == PP_X_CONV3X3 && a.x4) ? (uint32_t)a.M * (uint32_t)a.c4 * 2u : 0u;
   const int hv = a.up ? a.hin * 2 : a.hin;
   const int wv = a.up ? a.win * 2 : a.win;
 
-  auto issue = [&](int kt, int stage) {
+  // (always_inline: once this lambda is outlined its by-reference captures force the whole kernel-argument struct into
+  //  scratch memory -- 700 B per lane and a 2.7x slower kernel)
+  auto issue = [&](int kt, int stage) __attribute__((always_inline)) {
     char* xs = smem + stage * STAGE;
     char* ws = xs + XBYTES;
     const bool live = kt < kt_end;
@@ -490,10 +504,22 @@ pp_gemm_kernel_v2(const PPGemmArgs a, const GemmDerived d) {   // 2nd bound = wa
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(xs + (wave * 8 + i * RPP) * 128), 16, vo, so, 0, 0);
       }
     } else {
-      const bool first = cc < a.c1;
-      if (live && (retap || cc == 0 || cc == a.c1)) {      // (tap, source) changed: refresh the per-lane offsets
-        const int ky = tap / 3, kx = tap - ky * 3;
-        const int csrc = first ? a.c1 : a.c2;
+      const bool tail = tap >= 9;                          // 1x1 phase over (x3, x4) at the output pixel
+      if (live && (retap || cc == 0 || cc == cur_cA)) {    // (tap, source) changed: refresh source + per-lane offsets
+        // plain if / else chains on purpose: a 4-way select over (x1..x4) is turned into a private-memory lookup table
+        // by LLVM (scratch traffic in the hot loop, 2.7x slower conv)
+        const bool first = cc < (tail ? pc3 : pc1);   // (a split-K slice may start in the middle of a source)
+        int csrc;
+        if (!tail) {
+          cur_cA = pc1;
+          if (first) { cur_src = px1; cur_bytes = xbytes1; csrc = pc1; cur_c0 = 0; }
+          else { cur_src = px2; cur_bytes = xbytes2; csrc = pc2; cur_c0 = pc1; }
+        } else {
+          cur_cA = pc3;
+          if (first) { cur_src = px3; cur_bytes = xbytes3; csrc = pc3; cur_c0 = 0; }
+          else { cur_src = px4; cur_bytes = xbytes4; csrc = pc4; cur_c0 = pc3; }
+        }
+        const int ky = tail ? 1 : tap / 3, kx = tail ? 1 : tap - (tap / 3) * 3;      // tail = centre tap geometry
 #pragma unroll
         for (int i = 0; i < XP; ++i) {
           const int iy = xb[i] + ky, ix = xc[i] + kx;
@@ -504,8 +530,8 @@ pp_gemm_kernel_v2(const PPGemmArgs a, const GemmDerived d) {   // 2nd bound = wa
         }
         retap = false;
       }
-      const __amdgpu_buffer_rsrc_t rs = make_rsrc(first ? a.x1 : a.x2, live ? (first ? xbytes1 : xbytes2) : 0u);
-      const int so = (first ? cc : cc - a.c1) * 2;
+      const __amdgpu_buffer_rsrc_t rs = make_rsrc(reinterpret_cast<const void*>(cur_src), live ? cur_bytes : 0u);
+      const int so = (cc - cur_c0) * 2;
 #pragma unroll
       for (int i = 0; i < XP; ++i) {
         const int vo = vx1[i];
@@ -513,7 +539,7 @@ pp_gemm_kernel_v2(const PPGemmArgs a, const GemmDerived d) {   // 2nd bound = wa
       }
       if (live) {
         cc += 64;
-        if (cc == ctot) { cc = 0; ++tap; }
+        if (!tail && cc == ctot) { cc = 0; ++tap; retap = true; }
       }
     }
     const __amdgpu_buffer_rsrc_t rsw = make_rsrc(a.w, live ? wbytes : 0u);
@@ -1190,7 +1216,10 @@ int validate(const PPGemmArgs& a) {
   } else if (a.x_mode == PP_X_CONV3X3) {
     if (a.c1 % 64 != 0 || a.c2 % 64 != 0 || a.c1 <= 0) return PP_ERR_BAD_ARG;
     if (a.c2 > 0 && !a.x2) return PP_ERR_BAD_ARG;
-    if (a.K != 9 * (a.c1 + a.c2)) return PP_ERR_BAD_ARG;
+    if (a.c3 < 0 || a.c4 < 0 || a.c3 % 64 || a.c4 % 64 || (a.c3 > 0 && !a.x3) || (a.c4 > 0 && (!a.x4 || a.c3 == 0)))
+      return PP_ERR_BAD_ARG;
+    if ((a.c3 > 0) && (a.stride != 1 || a.up)) return PP_ERR_UNSUPPORTED;
+    if (a.K != 9 * (a.c1 + a.c2) + a.c3 + a.c4) return PP_ERR_BAD_ARG;
     if (a.stride != 1 && a.stride != 2) return PP_ERR_BAD_ARG;
     if (a.M != a.batch * a.hout * a.wout) return PP_ERR_BAD_ARG;
     const int hv = a.up ? 2 * a.hin : a.hin, wv = a.up ? 2 * a.win : a.win;
@@ -1235,7 +1264,8 @@ extern "C" int pp_gemm_bf16(const PPGemmArgs* args, void* stream) {
   const Choice c = choose(a);
   if (c.splitk > 1 && !a.workspace) return PP_ERR_WORKSPACE;
   if (c.tile > 10 && !v2_ok(a)) return PP_ERR_BAD_ARG;
-  if ((a.row_stats_out || a.gn_acc[0] || a.gn_acc[1]) && c.tile < 10) return PP_ERR_UNSUPPORTED;
+  if ((a.row_stats_out || a.gn_acc[0] || a.gn_acc[1] || (a.x_mode == PP_X_CONV3X3 && a.c3 > 0)) && c.tile < 10)
+    return PP_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   const bool conv = a.x_mode == PP_X_CONV3X3;
   switch (c.tile) {

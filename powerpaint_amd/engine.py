@@ -271,7 +271,8 @@ class Builder:
 
     def conv3x3(self, x: Act, w: int, cout: int, bias: int = 0, stride: int = 1, up: bool = False,
                 x2: Optional[Act] = None, rowvec: int = 0, res1: int = 0, res2: int = 0, scale: float = 1.0,
-                out: Optional[Act] = None, name: str = "conv3x3") -> Act:
+                out: Optional[Act] = None, x3: Optional[Act] = None, x4: Optional[Act] = None,
+                name: str = "conv3x3") -> Act:
         hv, wv = (x.H * 2, x.W * 2) if up else (x.H, x.W)
         ho, wo = (hv + 2 - 3) // stride + 1, (wv + 2 - 3) // stride + 1
         if out is None:
@@ -279,8 +280,14 @@ class Builder:
         m = self.mark()
         a = L.PPGemmArgs()
         c2 = x2.C if x2 is not None else 0
-        a.M, a.N, a.K, a.x_mode = x.B * ho * wo, cout, 9 * (x.C + c2), L.PP_X_CONV3X3
+        c3 = x3.C if x3 is not None else 0
+        c4 = x4.C if x4 is not None else 0
+        a.M, a.N, a.K, a.x_mode = x.B * ho * wo, cout, 9 * (x.C + c2) + c3 + c4, L.PP_X_CONV3X3
         a.x1, a.x2, a.c1, a.c2 = x.ptr, (x2.ptr if x2 is not None else None), x.C, c2
+        if x3 is not None:          # 1x1 tail over concat(x3, x4) at the output pixel (merged conv_shortcut)
+            a.x3, a.c3 = x3.ptr, c3
+            if x4 is not None:
+                a.x4, a.c4 = x4.ptr, c4
         a.batch, a.hin, a.win, a.hout, a.wout, a.stride, a.up = x.B, x.H, x.W, ho, wo, stride, int(up)
         a.w, a.bias = w, bias or None
         a.rowvec, a.ld_rowvec, a.rows_per_batch = rowvec or None, 0, ho * wo
@@ -402,6 +409,8 @@ class SDNet:
     fold_ln = os.environ.get("PP_FOLD_LN", "1") != "0"
     # FeedForward.net[2] and Transformer2DModel.proj_out composed into one GEMM (PP_MERGE_FF2=0: two launches)
     merge_ff2_proj_out = os.environ.get("PP_MERGE_FF2", "1") != "0"
+    # ResnetBlock2D.conv_shortcut merged into conv2 as a 1x1 K tail (needs 64-channel multiples; PP_MERGE_SHORTCUT=0 off)
+    _merge_shortcut_env = os.environ.get("PP_MERGE_SHORTCUT", "1") != "0"
 
     def __init__(self, kind: str, in_channels: int, block_out_channels=(320, 640, 1280, 1280), layers_per_block=2,
                  heads=8, cross_attention_dim=768, groups=32, eps=1e-5,
@@ -413,6 +422,7 @@ class SDNet:
         self.in_channels = in_channels
         self.conditioning_channels = conditioning_channels
         self.boc = tuple(block_out_channels)
+        self.merge_shortcut = self._merge_shortcut_env and all(c % 64 == 0 for c in self.boc)
         self.L = layers_per_block
         self.heads = heads
         self.ctx_dim = cross_attention_dim
@@ -586,12 +596,19 @@ class SDNet:
             for nrm in ("norm1", "norm2"):
                 pk.add(f"{pre}.{nrm}.weight", W(f"{pre}.{nrm}.weight"), f32)
                 pk.add(f"{pre}.{nrm}.bias", W(f"{pre}.{nrm}.bias"), f32)
-            for cv in ("conv1", "conv2"):
-                pk.add(f"{pre}.{cv}.weight", _conv_igemm(W(f"{pre}.{cv}.weight")), bf)
-                pk.add(f"{pre}.{cv}.bias", W(f"{pre}.{cv}.bias"), f32)
-            if cin != cout:
-                pk.add(f"{pre}.conv_shortcut.weight", W(f"{pre}.conv_shortcut.weight").reshape(cout, cin), bf)
-                pk.add(f"{pre}.conv_shortcut.bias", W(f"{pre}.conv_shortcut.bias"), f32)
+            pk.add(f"{pre}.conv1.weight", _conv_igemm(W(f"{pre}.conv1.weight")), bf)
+            pk.add(f"{pre}.conv1.bias", W(f"{pre}.conv1.bias"), f32)
+            if cin != cout and self.merge_shortcut:
+                # conv2(h) + conv_shortcut(x) = one implicit GEMM: the 1x1 shortcut is a K tail over the block input
+                pk.add(f"{pre}.conv2.weight", torch.cat([_conv_igemm(W(f"{pre}.conv2.weight")),
+                                                          W(f"{pre}.conv_shortcut.weight").reshape(cout, cin)], 1), bf)
+                pk.add(f"{pre}.conv2.bias", W(f"{pre}.conv2.bias") + W(f"{pre}.conv_shortcut.bias"), f32)
+            else:
+                pk.add(f"{pre}.conv2.weight", _conv_igemm(W(f"{pre}.conv2.weight")), bf)
+                pk.add(f"{pre}.conv2.bias", W(f"{pre}.conv2.bias"), f32)
+                if cin != cout:
+                    pk.add(f"{pre}.conv_shortcut.weight", W(f"{pre}.conv_shortcut.weight").reshape(cout, cin), bf)
+                    pk.add(f"{pre}.conv_shortcut.bias", W(f"{pre}.conv_shortcut.bias"), f32)
             tw.append(W(f"{pre}.time_emb_proj.weight"))
             tb.append(W(f"{pre}.time_emb_proj.bias"))
             self.temb_off[pre] = off
@@ -691,6 +708,11 @@ class SDNet:
         h = pb.conv3x3(h, P[f"{pre}.conv1.weight"], cout, P[f"{pre}.conv1.bias"],
                        rowvec=temb_all + 4 * self.temb_off[pre], name="conv3x3")
         h = pb.groupnorm(h, P[f"{pre}.norm2.weight"], P[f"{pre}.norm2.bias"], self.eps, True, groups=self.groups)
+        if cin != cout and self.merge_shortcut:
+            pb.conv3x3(h, P[f"{pre}.conv2.weight"], cout, P[f"{pre}.conv2.bias"], res2=res2, out=out, x3=x, x4=x2,
+                       name="conv3x3")
+            pb.release(m)
+            return out
         if cin != cout:
             sc = pb.linear(x.ptr, x.rows, x.C, P[f"{pre}.conv_shortcut.weight"], cout, P[f"{pre}.conv_shortcut.bias"],
                            x2=(x2.ptr if x2 is not None else 0), K2=(x2.C if x2 is not None else 0), name="conv1x1")

@@ -89,7 +89,7 @@ def gemm(x: torch.Tensor, w: torch.Tensor, bias=None, x2=None, res1=None, res2=N
 
 
 def conv3x3(x: torch.Tensor, w: torch.Tensor, bias=None, stride: int = 1, up: bool = False, x2=None, rowvec=None,
-            res1=None, res2=None, scale: float = 1.0, tile: int = 0, splitk: int = 0, gn=None):
+            res1=None, res2=None, scale: float = 1.0, tile: int = 0, splitk: int = 0, gn=None, x3=None, x4=None):
     """x NHWC bf16 [B,H,W,C1] (+x2 [B,H,W,C2]); w bf16 [Cout, 9*(C1+C2)] (k = (ky*3+kx)*C + c) -> NHWC bf16."""
     lib = L.lib()
     B, H, W, C1 = x.shape
@@ -99,8 +99,11 @@ def conv3x3(x: torch.Tensor, w: torch.Tensor, bias=None, stride: int = 1, up: bo
     ho, wo = (hv - 1) // stride + 1, (wv - 1) // stride + 1
     out = torch.empty(B, ho, wo, cout, dtype=torch.bfloat16, device=x.device)
     a = L.PPGemmArgs()
-    a.M, a.N, a.K, a.x_mode = B * ho * wo, cout, 9 * (C1 + C2), L.PP_X_CONV3X3
+    C3 = x3.shape[3] if x3 is not None else 0
+    C4 = x4.shape[3] if x4 is not None else 0
+    a.M, a.N, a.K, a.x_mode = B * ho * wo, cout, 9 * (C1 + C2) + C3 + C4, L.PP_X_CONV3X3
     a.x1, a.x2, a.c1, a.c2 = _p(x), _p(x2), C1, C2
+    a.x3, a.x4, a.c3, a.c4 = _p(x3), _p(x4), C3, C4     # 1x1 tail over concat(x3, x4) at the output pixel
     a.batch, a.hin, a.win, a.hout, a.wout, a.stride, a.up = B, H, W, ho, wo, stride, int(up)
     a.w, a.bias, a.rowvec, a.ld_rowvec, a.rows_per_batch = _p(w), _p(bias), _p(rowvec), 0, ho * wo
     if rowvec is not None and rowvec.dim() == 2 and rowvec.shape[0] > 1:

@@ -212,6 +212,24 @@ def test_conv3x3_halo_exact():
         assert torch.equal(out[0, :, :, 319], cnt)
 
 
+@pytest.mark.parametrize("tile,splitk", [(0, 0), (21, 1), (22, 2), (33, 1), (24, 1), (31, 4)])
+@pytest.mark.parametrize("two", [False, True])
+def test_conv3x3_with_1x1_tail(tile, splitk, two):
+    """conv2(h) + conv_shortcut(concat(x, skip)) as ONE implicit GEMM: K = 9 C_h + C_x (+ C_skip)."""
+    B, H, Ch, Cx, Cs, Cout = 2, 16, 320, 640, 320, 320
+    h = bf(rnd(B, H, H, Ch, seed=1))
+    x = bf(rnd(B, H, H, Cx, seed=2))
+    sk = bf(rnd(B, H, H, Cs, seed=3)) if two else None
+    w2 = bf(rnd(Cout, 9 * Ch, seed=4, scale=(9 * Ch) ** -0.5))
+    cin = Cx + (Cs if two else 0)
+    wsc = bf(rnd(Cout, cin, seed=5, scale=cin ** -0.5))
+    bias = rnd(Cout, seed=6)
+    out = ops.conv3x3(h, torch.cat([w2, wsc], 1).contiguous(), bias, x3=x, x4=sk, tile=tile, splitk=splitk)
+    xin = torch.cat([x, sk], -1) if two else x
+    ref = conv_ref(h, w2, bias) + xin.float() @ wsc.float().t()
+    check(out, ref, 3e-2, 1e-2, "conv + 1x1 tail")
+
+
 # ------------------------------------------------------------------------------------------------ GroupNorm statistics in the epilogue
 def _gn_ref(t, cg, c0, groups):
     """(sum, sumsq) per (batch, group) of tensor t [B, hw, C] placed at channel offset c0 of a `groups`-group norm."""
