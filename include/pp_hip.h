@@ -232,6 +232,10 @@ int pp_add_bf16(const void* a, const void* b, void* out, long long n, void* stre
  *     x0   = a_inv * x - s_over_a * eps          (DPM-Solver++ data prediction; DDIM: folded into cx/c0)
  *     kind 0 (DDIM, eta=0): x_next = cx * x + c0 * eps
  *     kind 1 (DPM-Solver++ 2M): x_next = cx * x + c0 * x0 + cm * m_prev ; m_prev <- x0
+ *     kind 2 (PNDM / PLMS, PNDMScheduler(skip_prk_steps=True) -- the scheduler the SD-1.5 checkpoint config names):
+ *             table rows are 16 floats {w0..w3, a, b, slot(h1), slot(h2), slot(h3), push_slot | -1, use_saved, save};
+ *             m = w0 eps + w1 h1 + w2 h2 + w3 h3;  x_next = a * (use_saved ? saved : x) + b * m;  `m_prev` is the state
+ *             [5][n] fp32 (4 history slots + the saved sample), zero before the first step.  N steps = N + 1 rows.
  * `step_dev` (int32 on device) selects the row; it is NOT incremented here (pp_step_advance does).
  */
 int pp_cfg_sched_step(const float* eps2, int cfg, float guidance, float* latents, float* m_prev, int n, int kind,

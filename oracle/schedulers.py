@@ -1,4 +1,4 @@
-"""Oracle (TEST INFRASTRUCTURE): DDIM and DPM-Solver++(2M) restated from diffusers==0.27.0.
+"""Oracle (TEST INFRASTRUCTURE): DDIM, DPM-Solver++(2M) and PNDM (PLMS) restated from diffusers==0.27.0.
 
 The reference pipelines are scheduler-agnostic and only duck-type the scheduler
 (/root/reference/powerpaint/pipelines/pipeline_PowerPaint.py:906,993,1023,642;
@@ -65,6 +65,75 @@ class DDIMScheduler:
         while sa.dim() < x0.dim():
             sa, s1 = sa.unsqueeze(-1), s1.unsqueeze(-1)
         return sa * x0 + s1 * noise
+
+
+class PNDMScheduler:
+    """`PNDMScheduler(skip_prk_steps=True)` = PLMS, the scheduler the SD-1.5 (inpainting) checkpoint config names and
+    therefore what the reference's v1 app runs by default: epsilon prediction, `leading`
+    spacing, steps_offset=1, set_alpha_to_one=False.  N inference steps are N+1 UNet evaluations: the second timestep
+    of the schedule appears twice and the first transfer is redone with the average of the two first model outputs
+    (diffusers scheduling_pndm.py: set_timesteps / step_plms / _get_prev_sample)."""
+    order = 1
+    init_noise_sigma = 1.0
+
+    def __init__(self, num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, steps_offset=1,
+                 set_alpha_to_one=False):
+        self.config = type("C", (), dict(num_train_timesteps=num_train_timesteps, steps_offset=steps_offset,
+                                         beta_start=beta_start, beta_end=beta_end, skip_prk_steps=True))()
+        self.betas = sd_betas(num_train_timesteps, beta_start, beta_end)
+        self.alphas_cumprod = torch.cumprod(1.0 - self.betas, dim=0)
+        self.final_alpha_cumprod = torch.tensor(1.0) if set_alpha_to_one else self.alphas_cumprod[0]
+        self.num_inference_steps = None
+        self.timesteps = None
+
+    def set_timesteps(self, num_inference_steps: int, device=None):
+        self.num_inference_steps = num_inference_steps
+        step_ratio = self.config.num_train_timesteps // num_inference_steps
+        ts = (np.arange(0, num_inference_steps) * step_ratio).round().astype(np.int64) + self.config.steps_offset
+        plms = np.concatenate([ts[:-1], ts[-2:-1], ts[-1:]])[::-1].copy()
+        self.timesteps = torch.from_numpy(plms)
+        self.ets: List[torch.Tensor] = []
+        self.counter = 0
+        self.cur_sample = None
+
+    def scale_model_input(self, sample, timestep=None):
+        return sample
+
+    def _get_prev_sample(self, sample, timestep, prev_timestep, model_output):
+        a_t = self.alphas_cumprod[timestep]
+        a_p = self.alphas_cumprod[prev_timestep] if prev_timestep >= 0 else self.final_alpha_cumprod
+        b_t, b_p = 1 - a_t, 1 - a_p
+        sample_coeff = (a_p / a_t) ** 0.5
+        denom = a_t * b_p ** 0.5 + (a_t * b_t * a_p) ** 0.5
+        return sample_coeff * sample - (a_p - a_t) * model_output / denom
+
+    def step(self, model_output, timestep, sample, generator=None, return_dict=False):
+        t = int(timestep)
+        ratio = self.config.num_train_timesteps // self.num_inference_steps
+        prev_t = t - ratio
+        if self.counter != 1:
+            self.ets = self.ets[-3:]
+            self.ets.append(model_output)
+        else:
+            prev_t = t
+            t = t + ratio
+        if len(self.ets) == 1 and self.counter == 0:
+            self.cur_sample = sample
+        elif len(self.ets) == 1 and self.counter == 1:
+            model_output = (model_output + self.ets[-1]) / 2
+            sample = self.cur_sample
+            self.cur_sample = None
+        elif len(self.ets) == 2:
+            model_output = (3 * self.ets[-1] - self.ets[-2]) / 2
+        elif len(self.ets) == 3:
+            model_output = (23 * self.ets[-1] - 16 * self.ets[-2] + 5 * self.ets[-3]) / 12
+        else:
+            model_output = (1 / 24) * (55 * self.ets[-1] - 59 * self.ets[-2] + 37 * self.ets[-3] - 9 * self.ets[-4])
+        prev = self._get_prev_sample(sample, t, prev_t, model_output)
+        self.counter += 1
+        return (prev,)
+
+    add_noise = DDIMScheduler.add_noise
 
 
 class DPMSolverMultistepScheduler:
@@ -195,4 +264,43 @@ def dpm_run_f64(x, eps_list, N: int):
                 r0 = (lam0 - lamp) / h
                 x = (gt / g0) * x - c * m0 - 0.5 * c * (m0 - m1) / r0
         m1 = m0
+    return x
+
+
+def pndm_timesteps(N: int, T: int = 1000, offset: int = 1) -> np.ndarray:
+    ts = np.array([i * (T // N) + offset for i in range(N)], dtype=np.int64)
+    return np.concatenate([ts[:-1], ts[-2:-1], ts[-1:]])[::-1].copy()
+
+
+def pndm_run_f64(x, eps_list, N: int, T: int = 1000):
+    """All N+1 PLMS evaluations in float64 given the eps fed at every evaluation (independent re-derivation: the linear
+    multistep combination of the noise predictions, then the PNDM transfer formula (eq. 9 of the PNDM paper))."""
+    ac = alphas_cumprod_f64(T)
+    ts = pndm_timesteps(N, T)
+    ratio = T // N
+
+    def transfer(xx, t, tp, e):
+        a_t, a_p = ac[t], (ac[tp] if tp >= 0 else ac[0])
+        return math.sqrt(a_p / a_t) * xx - (a_p - a_t) * e / (a_t * math.sqrt(1 - a_p) + math.sqrt(a_t * (1 - a_t) * a_p))
+
+    x = np.asarray(x, dtype=np.float64)
+    hist: list = []
+    x_start = None
+    for k, t in enumerate(ts.tolist()):
+        e = np.asarray(eps_list[k], dtype=np.float64)
+        if k == 0:
+            hist = [e]
+            x_start = x
+            x = transfer(x, t, t - ratio, e)
+        elif k == 1:                        # same transfer again, from the saved sample, with the averaged prediction
+            x = transfer(x_start, t + ratio, t, 0.5 * (e + hist[-1]))
+        else:
+            hist = (hist + [e])[-4:]
+            if len(hist) == 2:
+                m = (3 * hist[-1] - hist[-2]) / 2
+            elif len(hist) == 3:
+                m = (23 * hist[-1] - 16 * hist[-2] + 5 * hist[-3]) / 12
+            else:
+                m = (55 * hist[-1] - 59 * hist[-2] + 37 * hist[-3] - 9 * hist[-4]) / 24
+            x = transfer(x, t, t - ratio, m)
     return x

@@ -201,6 +201,37 @@ __global__ void __launch_bounds__(256) cfg_sched_step_kernel(const float* __rest
                                                             float* __restrict__ x, float* __restrict__ m_prev, int n,
                                                             int kind, const float* __restrict__ coef,
                                                             const int32_t* __restrict__ step_dev) {
+  if (kind == 2) {
+    // PNDM / PLMS: table row (16 floats) = w0..w3 (linear multistep weights over eps, h1, h2, h3), a (sample coefficient),
+    // b (model-output coefficient), then as floats: ring slots of h1, h2, h3, the slot this eps is pushed to (-1: not
+    // stored), use_saved (transfer from the saved sample), save (keep the incoming sample).  state = [5][n]: 4 history
+    // slots + the saved sample (the first transfer is redone with the average of the first two predictions).
+    const float* c = coef + (size_t)step_dev[0] * 16;
+    const float w0 = c[0], w1 = c[1], w2 = c[2], w3 = c[3], ca = c[4], cb = c[5];
+    const float* h1 = m_prev + (size_t)(int)c[6] * n;
+    const float* h2 = m_prev + (size_t)(int)c[7] * n;
+    const float* h3 = m_prev + (size_t)(int)c[8] * n;
+    const int push = (int)c[9];
+    const bool use_saved = c[10] != 0.f, save = c[11] != 0.f;
+    float* hp = push >= 0 ? m_prev + (size_t)push * n : nullptr;
+    float* saved = m_prev + (size_t)4 * n;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+      float e;
+      if (cfg) {
+        const float eu = eps2[i], ec = eps2[n + i];
+        e = eu + g * (ec - eu);
+      } else {
+        e = eps2[i];
+      }
+      const float mo = w0 * e + w1 * h1[i] + w2 * h2[i] + w3 * h3[i];
+      const float xv = x[i];
+      const float src = use_saved ? saved[i] : xv;
+      if (save) saved[i] = xv;
+      if (hp) hp[i] = e;
+      x[i] = ca * src + cb * mo;
+    }
+    return;
+  }
   const float* c = coef + (size_t)step_dev[0] * 8;
   const float c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3], c4 = c[4], c5 = c[5];
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
@@ -366,8 +397,8 @@ extern "C" int pp_add_bf16(const void* a, const void* b, void* out, long long n,
 
 extern "C" int pp_cfg_sched_step(const float* eps2, int cfg, float guidance, float* latents, float* m_prev, int n,
                                  int kind, const float* coef_table, const int32_t* step_dev, void* stream) {
-  if (!eps2 || !latents || !coef_table || !step_dev || n <= 0 || (kind != 0 && kind != 1)) return PP_ERR_BAD_ARG;
-  if (kind == 1 && !m_prev) return PP_ERR_BAD_ARG;
+  if (!eps2 || !latents || !coef_table || !step_dev || n <= 0 || kind < 0 || kind > 2) return PP_ERR_BAD_ARG;
+  if (kind >= 1 && !m_prev) return PP_ERR_BAD_ARG;
   hipLaunchKernelGGL(cfg_sched_step_kernel, dim3(grid_for_host(n)), dim3(256), 0, (hipStream_t)stream, eps2, cfg,
                      guidance, latents, m_prev, n, kind, coef_table, step_dev);
   PP_CHECK_LAUNCH("cfg_sched_step_kernel");

@@ -64,7 +64,7 @@ class DenoiseLoop:
             side_rt.load_input(list(side_static_inputs))
 
         ts, step = sch.timesteps_f32(), sch.step_counter()
-        mp = sch.m_prev(lat) if sch.kind == 1 else None
+        mp = sch.m_prev(lat) if sch.kind >= 1 else None     # scheduler state: DPM m_{i-1}; PNDM history + saved sample
         key = (tuple(latents_shape), bool(do_cfg), float(guidance_scale), id(rt.step_plan),
                id(side_rt.step_plan) if side_rt is not None else None, sch.kind, ts.data_ptr(), step.data_ptr(),
                sch.coef_table().data_ptr(), mp.data_ptr() if mp is not None else 0, lat.data_ptr())
@@ -121,7 +121,7 @@ class DenoiseLoop:
             callback: Optional[Callable] = None, timesteps=None, scale_schedule: Optional[List[float]] = None):
         """Runs `num_steps` steps starting from step counter 0.  Returns the fp32 latents tensor (owned by the loop)."""
         self.scheduler.reset()
-        if self.scheduler.kind == 1:
+        if self.scheduler.kind >= 1:
             self._keep[2].zero_()
         self.latents.copy_(latents.to(self.latents.device, torch.float32))
         varying = scale_schedule is not None and len(set(scale_schedule)) > 1

@@ -70,9 +70,12 @@ class _SchedulerBase:
     def step_counter(self) -> torch.Tensor:
         return self._step_dev
 
+    state_slots = 1          # fp32 copies of the latents the step kernel keeps between steps (DPM: 1, PNDM: 5)
+
     def m_prev(self, like: torch.Tensor) -> torch.Tensor:
-        if self._m_prev is None or self._m_prev.shape != like.shape:
-            self._m_prev = torch.zeros_like(like, dtype=torch.float32)
+        shape = (self.state_slots,) + tuple(like.shape) if self.state_slots > 1 else tuple(like.shape)
+        if self._m_prev is None or tuple(self._m_prev.shape) != shape or self._m_prev.device != like.device:
+            self._m_prev = torch.zeros(shape, dtype=torch.float32, device=like.device)
         return self._m_prev
 
     def reset(self):
@@ -98,7 +101,7 @@ class _SchedulerBase:
         x = sample.detach().to(torch.float32).contiguous().clone()
         e = model_output.detach().to(torch.float32).contiguous()
         step = torch.full((1,), i, dtype=torch.int32, device=x.device)
-        mp = self.m_prev(x) if self.kind == 1 else None
+        mp = self.m_prev(x) if self.kind >= 1 else None
         L.check(L.lib().pp_cfg_sched_step(e.data_ptr(), 0, 0.0, x.data_ptr(), mp.data_ptr() if mp is not None else None,
                                            x.numel(), self.kind, self._coef_dev.data_ptr(), step.data_ptr(),
                                            torch.cuda.current_stream().cuda_stream), "pp_cfg_sched_step")
@@ -192,3 +195,80 @@ class DPMSolverMultistepScheduler(_SchedulerBase):
                 coef[i, 5] = 1.0 / r0
         self._coef = coef
         self._upload(device)
+
+
+class PNDMScheduler(_SchedulerBase):
+    """`PNDMScheduler(skip_prk_steps=True)` = PLMS with the SD-1.5 checkpoint config (`leading` spacing, steps_offset = 1,
+    set_alpha_to_one = False, epsilon prediction): what the reference's v1 app runs when no scheduler is chosen.
+    N inference steps are N + 1 entries in `.timesteps` (the second one repeats): the pipelines loop over
+    `scheduler.timesteps`, so nothing else changes.  Host side: one table row per evaluation (linear-multistep weights,
+    transfer coefficients, history ring slots); the tensor math runs in `pp_cfg_sched_step` (kind 2)."""
+    kind = 2
+    state_slots = 5
+
+    def __init__(self, num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, steps_offset=1,
+                 set_alpha_to_one=False, skip_prk_steps=True, **kw):
+        if not skip_prk_steps:
+            raise NotImplementedError("only the PLMS form (skip_prk_steps=True, the SD-1.5 config) is on the hot path")
+        super().__init__(num_train_timesteps, beta_start, beta_end, steps_offset=steps_offset,
+                         set_alpha_to_one=set_alpha_to_one, skip_prk_steps=True, timestep_spacing="leading",
+                         prediction_type="epsilon")
+        self.final_alpha_cumprod = torch.tensor(1.0) if set_alpha_to_one else self.alphas_cumprod[0]
+
+    def _transfer(self, t, prev_t):
+        a_t = self.alphas_cumprod[t]
+        a_p = self.alphas_cumprod[prev_t] if prev_t >= 0 else self.final_alpha_cumprod
+        b_t, b_p = 1 - a_t, 1 - a_p
+        sample_coeff = (a_p / a_t) ** 0.5
+        denom = a_t * b_p ** 0.5 + (a_t * b_t * a_p) ** 0.5
+        return float(sample_coeff), float(-(a_p - a_t) / denom)
+
+    def set_timesteps(self, num_inference_steps: int, device=None):
+        T = self.config.num_train_timesteps
+        self.num_inference_steps = num_inference_steps
+        ratio = T // num_inference_steps
+        ts = (np.arange(0, num_inference_steps) * ratio).round().astype(np.int64) + self.config.steps_offset
+        plms = np.concatenate([ts[:-1], ts[-2:-1], ts[-1:]])[::-1].copy()
+        self._ts_host = torch.from_numpy(plms)
+        self.timesteps = self._ts_host.clone()
+        rows = len(plms)
+        coef = torch.zeros(rows, 16, dtype=torch.float32)
+        n_hist, head = 0, 0                       # stored predictions so far, ring slot of the next push
+        for k, t in enumerate(plms.tolist()):
+            slot = lambda back: float((head - back) % 4)          # noqa: E731  (slot of the prediction `back` pushes ago)
+            if k == 1:
+                # second evaluation at the repeated timestep: redo the first transfer from the saved sample with the
+                # average of the two predictions; this prediction is not stored
+                a, b = self._transfer(t + ratio, t)
+                coef[k, :6] = torch.tensor([0.5, 0.5, 0.0, 0.0, a, b])
+                coef[k, 6:9] = torch.tensor([slot(1), slot(1), slot(1)])
+                coef[k, 9], coef[k, 10], coef[k, 11] = -1.0, 1.0, 0.0
+                continue
+            n_hist = min(n_hist + 1, 4)
+            w = {1: (1.0, 0.0, 0.0, 0.0), 2: (1.5, -0.5, 0.0, 0.0), 3: (23 / 12, -16 / 12, 5 / 12, 0.0),
+                 4: (55 / 24, -59 / 24, 37 / 24, -9 / 24)}[n_hist]
+            a, b = self._transfer(t, t - ratio)
+            coef[k, :6] = torch.tensor([w[0], w[1], w[2], w[3], a, b])
+            coef[k, 6:9] = torch.tensor([slot(1), slot(2), slot(3)])      # h1, h2, h3 = previous pushes
+            coef[k, 9] = float(head)                                      # this prediction goes to ring slot `head`
+            coef[k, 10], coef[k, 11] = 0.0, (1.0 if k == 0 else 0.0)      # the first evaluation saves its input sample
+            head = (head + 1) % 4
+        self._coef = coef
+        self._upload(device)
+
+    def _index_of(self, timestep) -> int:
+        """The repeated timestep is disambiguated by call order (a foreign loop calls step() once per entry)."""
+        t = int(timestep)
+        idx = (self._ts_host == t).nonzero().flatten().tolist()
+        if not idx:
+            raise ValueError(f"timestep {t} is not in the schedule")
+        if len(idx) == 1:
+            return idx[0]
+        self._dup_calls = getattr(self, "_dup_calls", 0)
+        i = idx[min(self._dup_calls, len(idx) - 1)]
+        self._dup_calls += 1
+        return i
+
+    def reset(self):
+        super().reset()
+        self._dup_calls = 0

@@ -135,13 +135,13 @@ def _v1_inputs(B, h, w, seed=0):
     return lat, mask, mil, pe
 
 
-@pytest.mark.parametrize("kind,N", [("ddim", 4), ("dpm", 5)])
+@pytest.mark.parametrize("kind,N", [("ddim", 4), ("dpm", 5), ("pndm", 6)])
 def test_pipeline_v1_loop(kind, N):
     o, h = make_tiny("unet", in_channels=9)
     B, hh = 2, 16
     lat, mask, mil, pe = _v1_inputs(B, hh, hh)
-    osch = OS.DDIMScheduler() if kind == "ddim" else OS.DPMSolverMultistepScheduler()
-    hsch = PS.DDIMScheduler() if kind == "ddim" else PS.DPMSolverMultistepScheduler()
+    osch = {"ddim": OS.DDIMScheduler, "dpm": OS.DPMSolverMultistepScheduler, "pndm": OS.PNDMScheduler}[kind]()
+    hsch = {"ddim": PS.DDIMScheduler, "dpm": PS.DPMSolverMultistepScheduler, "pndm": PS.PNDMScheduler}[kind]()
     rec = []
     ref = OL.loop_v1(o, osch, lat, torch.cat([mask] * 2), torch.cat([mil] * 2), pe, N, 7.5,
                      eps_hook=lambda i, t, l, e: rec.append((l.clone(), e.clone())))
@@ -152,7 +152,8 @@ def test_pipeline_v1_loop(kind, N):
     pipe.use_graph = False
     seen = []
     out_eager = pipe(callback=lambda i, t, l: seen.append((i, int(t), l.clone())), **kw)[0]
-    assert [s[0] for s in seen] == list(range(N)) and [s[1] for s in seen] == [int(t) for t in osch.timesteps]
+    evals = len(osch.timesteps)                                 # N, or N + 1 for PNDM (its second timestep repeats)
+    assert [s[0] for s in seen] == list(range(evals)) and [s[1] for s in seen] == [int(t) for t in osch.timesteps]
     close(out_eager, ref, f"v1 {kind} free-running", cos_min=0.995, rel=0.1)
     pipe.use_graph = True
     out_graph = pipe(**kw)[0]

@@ -451,3 +451,23 @@ def test_scheduler_step_kernel(kind, N):
         ref = OS.dpm_run_f64(x0.double().numpy(), comb, N)
     check(x.cpu(), torch.from_numpy(ref).float(), 2e-3, 2e-3, f"{kind} {N} steps")
     assert int(sch.step_counter()) == N
+
+
+@pytest.mark.parametrize("N", [4, 20])
+def test_pndm_step_kernel_vs_oracle(N):
+    """scheduler.step of the product PNDM (HIP kernel, kind 2: history ring + saved sample + table-driven multistep
+    weights) against the oracle's diffusers-protocol class on the same eps sequence."""
+    from oracle import schedulers as OS
+    from powerpaint_amd import schedulers as PS
+    o, h = OS.PNDMScheduler(), PS.PNDMScheduler()
+    o.set_timesteps(N)
+    h.set_timesteps(N, device=DEV)
+    assert h.timesteps.cpu().tolist() == o.timesteps.tolist()
+    g = torch.Generator("cpu").manual_seed(0)
+    x0 = torch.randn(2, 4, 8, 8, generator=g)
+    eps = [torch.randn(2, 4, 8, 8, generator=g) for _ in range(N + 1)]
+    xo, xh = x0, x0.to(DEV)
+    for k, t in enumerate(o.timesteps):
+        xo = o.step(eps[k], t, xo)[0]
+        xh = h.step(eps[k].to(DEV), t, xh, return_dict=False)[0]
+        check(xh.cpu(), xo, 1e-4 * max(1.0, float(xo.abs().max())), 1e-4, f"pndm evaluation {k}")

@@ -76,6 +76,35 @@ def test_dpm_torch_vs_float64_closed_form(N):
     assert torch.allclose(x, target, atol=1e-4)
 
 
+@pytest.mark.parametrize("N", [4, 10, 50])
+def test_pndm_torch_vs_float64_closed_form(N):
+    """PLMS (PNDMScheduler(skip_prk_steps=True), the SD-1.5 checkpoint's scheduler): N steps = N + 1 evaluations, the
+    second timestep repeats; the diffusers-protocol class against an independent float64 derivation."""
+    s = OS.PNDMScheduler(); s.set_timesteps(N)
+    ts = s.timesteps.tolist()
+    assert len(ts) == N + 1 and ts[1] == ts[2] and ts == OS.pndm_timesteps(N).tolist()
+    assert ts[0] == (N - 1) * (1000 // N) + 1 and ts[-1] == 1
+    g = torch.Generator().manual_seed(0)
+    x0 = torch.randn(2, 4, 8, 8, generator=g)
+    eps = [torch.randn(2, 4, 8, 8, generator=g) for _ in range(N + 1)]
+    x = x0
+    for t, e in zip(s.timesteps, eps):
+        x = s.step(e, t, x)[0]
+    ref = OS.pndm_run_f64(x0.double().numpy(), [e.double().numpy() for e in eps], N)
+    assert np.allclose(x.numpy(), ref, rtol=5e-4, atol=5e-4 * max(1.0, float(np.abs(ref).max())))
+    # a constant noise prediction makes every multistep combination that prediction and every transfer deterministic DDIM
+    s.set_timesteps(N)
+    e = torch.randn(2, 4, 8, 8, generator=g)
+    x = x0
+    for t in s.timesteps:
+        x = s.step(e, t, x)[0]
+    d = OS.DDIMScheduler(); d.set_timesteps(N)
+    y = x0
+    for t in d.timesteps:
+        y = d.step(e, t, y)[0]
+    assert torch.allclose(x, y, rtol=1e-3, atol=1e-3)
+
+
 def test_leaf_modules_against_functional():
     torch.manual_seed(0)
     a = OM.Attention(320, 768, 8, 40)
