@@ -126,6 +126,24 @@ def test_unet_full_sd15_32x32():
     close(out, ref, "SD-1.5 UNet 32x32")
 
 
+def test_baseline_config1_256_ddim10_full_unet():
+    """BASELINE.json configs[0]: ppt-v1 StableDiffusionInpaintPipeline, 256x256, 10-step DDIM, batch 1, CFG 7.5 --
+    the full SD-1.5 inpainting UNet (random init, bf16-rounded weights on both sides) through the product pipeline,
+    against the fp32 CPU oracle loop on the same latents."""
+    torch.manual_seed(0)
+    o = bf16_weights_(OM.UNet2DConditionModel(in_channels=9)).eval()
+    h = PM.UNet2DConditionModel(in_channels=9, device=DEV).load_state_dict(o.state_dict())
+    B, hh, N = 1, 32, 10
+    lat, mask, mil, pe = _v1_inputs(B, hh, hh, seed=3)
+    with torch.no_grad():
+        ref = OL.loop_v1(o, OS.DDIMScheduler(), lat, torch.cat([mask] * 2), torch.cat([mil] * 2), pe, N, 7.5)
+    pipe = PP.StableDiffusionInpaintPipeline(unet=h, scheduler=PS.DDIMScheduler())
+    out = pipe(prompt_embeds=pe[B:].to(DEV), negative_prompt_embeds=pe[:B].to(DEV), height=hh * 8, width=hh * 8,
+               num_inference_steps=N, guidance_scale=7.5, latents=lat.to(DEV), mask_latents=mask.to(DEV),
+               masked_image_latents=mil.to(DEV), output_type="latent", return_dict=False)[0]
+    close(out, ref, "config 1: 256x256, 10-step DDIM, full UNet", cos_min=0.995, rel=0.1)
+
+
 def _v1_inputs(B, h, w, seed=0):
     lat = gen(B, 4, h, w, seed=seed)
     mask = torch.zeros(B, 1, h, w)
