@@ -213,14 +213,16 @@ def main():
         scale_hw = (args.latent / 64.0) ** 2 if args.latent != 64 else 1.0
         tflop_step = gf * 2 * args.per_gpu * scale_hw / 1e3         # CFG doubles the batch
         ms_denoise_step = ms_per_step / unet_steps
+        px = args.latent * 8
         res = {
-            "metric": "inpainted images/sec @512x512, 50-step DDIM CFG, batch4/GPU",
+            "metric": ("inpainted images/sec @512x512, 50-step DDIM CFG, batch4/GPU" if (px, args.per_gpu, args.config) == (512, 4, "v1")
+                       else f"inpainted images/sec @{px}x{px}, 50-step, batch{args.per_gpu}/GPU ({args.config})"),
             "value": images / dt, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": {"v1": "ppt-v1 SD1.5-inpaint UNet (9-ch in), 512x512, 50-step DDIM, CFG=7.5, batch=4/GPU",
-                                    "v2": "ppt-v2 BrushNet + SD1.5 UNet, 512x512, 50-step DPMSolver++, CFG=7.5, batch=4/GPU",
-                                    "controlnet": "ppt-v1 + ControlNet, 512x512, 50-step DDIM, CFG=7.5, batch=4/GPU"}[args.config],
+            "config": {"workload": {"v1": f"ppt-v1 SD1.5-inpaint UNet (9-ch in), {px}x{px}, 50-step DDIM, CFG=7.5, batch={args.per_gpu}/GPU",
+                                    "v2": f"ppt-v2 BrushNet + SD1.5 UNet, {px}x{px}, 50-step DPMSolver++, CFG=7.5, batch={args.per_gpu}/GPU",
+                                    "controlnet": f"ppt-v1 + ControlNet, {px}x{px}, 50-step DDIM, CFG=7.5, batch={args.per_gpu}/GPU"}[args.config],
                        "global_batch": args.per_gpu * world, "latent": [4, args.latent, args.latent],
                        "denoise_steps": unet_steps, "parallelism": f"dp{world} (image shards, no step collectives)",
                        "hipgraph": not args.no_graph, "weights": "random init (no checkpoints offline)",
