@@ -9,6 +9,11 @@ pipeline_PowerPaint_Brushnet_CA.py:1384-1466, pipeline_PowerPaint_ControlNet.py:
     latents      <- scheduler.step(eps_u + g (eps_c - eps_u), t, latents)   (pp_cfg_sched_step, fp32)
     step         <- step + 1                                          (pp_step_advance)
 No host->device traffic and no host synchronisation inside the loop.
+
+A scheduler that is not one of powerpaint_amd.schedulers (any object with the diffusers protocol the reference
+duck-types: `.timesteps`, `.scale_model_input`, `.step(...)`, e.g. the UniPC scheduler app.py:197 installs) is driven
+the way the reference drives it: the network part of the step is the same captured launch program, the guidance
+combine and the scheduler's own `.step` run as that object's tensor code on the device, once per step.
 """
 from typing import Callable, List, Optional
 
@@ -21,10 +26,9 @@ from ..schedulers import _SchedulerBase
 
 class DenoiseLoop:
     def __init__(self, unet, scheduler, side=None, side_kind: Optional[str] = None):
-        if not isinstance(scheduler, _SchedulerBase):
-            raise TypeError(
-                "the HIP denoising loop needs powerpaint_amd.schedulers.{DDIMScheduler,DPMSolverMultistepScheduler}; "
-                f"got {type(scheduler).__name__}")
+        self.foreign = not isinstance(scheduler, _SchedulerBase)     # duck-typed scheduler: its own .step per step
+        if self.foreign and not (hasattr(scheduler, "step") and hasattr(scheduler, "timesteps")):
+            raise TypeError(f"{type(scheduler).__name__} does not follow the scheduler protocol (.timesteps, .step)")
         self.unet, self.scheduler, self.side, self.side_kind = unet, scheduler, side, side_kind
         self.lib = L.lib()
         self.program: Optional[Plan] = None
@@ -63,11 +67,26 @@ class DenoiseLoop:
         if side_rt is not None and side_static_inputs:
             side_rt.load_input(list(side_static_inputs))
 
-        ts, step = sch.timesteps_f32(), sch.step_counter()
-        mp = sch.m_prev(lat) if sch.kind >= 1 else None     # scheduler state: DPM m_{i-1}; PNDM history + saved sample
+        if self.foreign:
+            # network input (scaled by the scheduler per step), timestep table and step counter owned by the loop
+            tsv = torch.as_tensor(sch.timesteps).detach().to(dev, torch.float32).contiguous()
+            if getattr(self, "_f_ts", None) is None or self._f_ts.shape != tsv.shape:
+                self._f_ts = tsv
+                self._f_step = torch.zeros(1, dtype=torch.int32, device=dev)
+                self._f_x = torch.zeros(latents_shape, dtype=torch.float32, device=dev)
+            else:
+                self._f_ts.copy_(tsv)
+            if tuple(self._f_x.shape) != tuple(latents_shape):
+                self._f_x = torch.zeros(latents_shape, dtype=torch.float32, device=dev)
+            ts, step, mp, kind, src = self._f_ts, self._f_step, None, -1, self._f_x
+            self._do_cfg, self._g = bool(do_cfg), float(guidance_scale)
+        else:
+            ts, step = sch.timesteps_f32(), sch.step_counter()
+            mp = sch.m_prev(lat) if sch.kind >= 1 else None  # scheduler state: DPM m_{i-1}; PNDM history + saved sample
+            kind, src = sch.kind, lat
         key = (tuple(latents_shape), bool(do_cfg), float(guidance_scale), id(rt.step_plan),
-               id(side_rt.step_plan) if side_rt is not None else None, sch.kind, ts.data_ptr(), step.data_ptr(),
-               sch.coef_table().data_ptr(), mp.data_ptr() if mp is not None else 0, lat.data_ptr())
+               id(side_rt.step_plan) if side_rt is not None else None, kind, ts.data_ptr(), step.data_ptr(),
+               0 if self.foreign else sch.coef_table().data_ptr(), mp.data_ptr() if mp is not None else 0, src.data_ptr())
         if key == self._key and self.program is not None:
             return self
         self._key = key
@@ -76,15 +95,16 @@ class DenoiseLoop:
         for r in ([side_rt] if side_rt is not None else []) + [rt]:
             prog.add("step_select_t", lib.pp_step_select_t, ts.data_ptr(), step.data_ptr(), r.lay["t_dev"])
             x = r.lay["x_in"]
-            prog.add("nchw_to_nhwc", lib.pp_nchw_to_nhwc, lat.data_ptr(), 0, Be, Cl, hw, mod, x.ptr, x.C, 0)
+            prog.add("nchw_to_nhwc", lib.pp_nchw_to_nhwc, src.data_ptr(), 0, Be, Cl, hw, mod, x.ptr, x.C, 0)
         if side_rt is not None:
             prog.calls += side_rt.step_plan.calls
             prog.flops += side_rt.step_plan.flops
         prog.calls += rt.step_plan.calls
         prog.flops += rt.step_plan.flops
-        prog.add("cfg_sched_step", lib.pp_cfg_sched_step, rt.outputs["eps"], int(do_cfg), float(guidance_scale),
-                 lat.data_ptr(), mp.data_ptr() if mp is not None else None, lat.numel(), sch.kind,
-                 sch.coef_table().data_ptr(), step.data_ptr())
+        if not self.foreign:
+            prog.add("cfg_sched_step", lib.pp_cfg_sched_step, rt.outputs["eps"], int(do_cfg), float(guidance_scale),
+                     lat.data_ptr(), mp.data_ptr() if mp is not None else None, lat.numel(), sch.kind,
+                     sch.coef_table().data_ptr(), step.data_ptr())
         prog.add("step_advance", lib.pp_step_advance, step.data_ptr())
         self.program = prog
         self.rt, self.side_rt = rt, side_rt
@@ -96,7 +116,7 @@ class DenoiseLoop:
         """Capture one step into a hipGraph (torch.cuda.CUDAGraph).  The captured launches read the step counter from
         device memory, so the same graph serves every step."""
         torch.cuda.synchronize()
-        step = self.scheduler.step_counter()
+        step = self._keep[1]
         saved_step = step.clone()
         saved_lat = self.latents.clone()
         saved_m = self._keep[2].clone() if self._keep[2] is not None else None
@@ -120,6 +140,8 @@ class DenoiseLoop:
     def run(self, latents: torch.Tensor, num_steps: int, use_graph: bool = True,
             callback: Optional[Callable] = None, timesteps=None, scale_schedule: Optional[List[float]] = None):
         """Runs `num_steps` steps starting from step counter 0.  Returns the fp32 latents tensor (owned by the loop)."""
+        if self.foreign:
+            return self._run_foreign(latents, num_steps, use_graph, callback, timesteps, scale_schedule)
         self.scheduler.reset()
         if self.scheduler.kind >= 1:
             self._keep[2].zero_()
@@ -137,4 +159,37 @@ class DenoiseLoop:
                 self.program.run(stream)
             if callback is not None:
                 callback(i, timesteps[i] if timesteps is not None else None, self.latents)
+        return self.latents
+
+    def _run_foreign(self, latents, num_steps, use_graph, callback, timesteps, scale_schedule):
+        """Duck-typed scheduler: network part = the captured program (eps lands in the UNet runtime's fp32 output), then
+        the guidance combine and `scheduler.step` exactly as the reference's loop body does
+        (pipeline_PowerPaint.py:1018-1023)."""
+        sch = self.scheduler
+        tl = timesteps if timesteps is not None else sch.timesteps
+        self._f_step.zero_()
+        lat = latents.to(self.latents.device, torch.float32).clone()
+        varying = scale_schedule is not None and len(set(scale_schedule)) > 1
+        stream = torch.cuda.current_stream().cuda_stream
+        for i in range(num_steps):
+            t = tl[i]
+            x = sch.scale_model_input(lat, t) if hasattr(sch, "scale_model_input") else lat
+            self._f_x.copy_(x)
+            if varying and self.side_rt is not None:
+                self.side_rt._patch_scale(scale_schedule[i])
+            if use_graph and not varying:
+                if self.graph is None:
+                    self.capture()
+                    self._f_step.fill_(i)
+                self.graph.replay()
+            else:
+                self.program.run(stream)
+            eps = self.rt.eps_tensor()
+            if self._do_cfg:
+                eu, ec = eps.chunk(2)
+                eps = eu + self._g * (ec - eu)
+            lat = sch.step(eps, t, lat, return_dict=False)[0].to(torch.float32)
+            if callback is not None:
+                callback(i, t, lat)
+        self.latents.copy_(lat)
         return self.latents

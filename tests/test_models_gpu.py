@@ -185,6 +185,28 @@ def test_pipeline_v1_loop(kind, N):
         close(e, e_ref, f"teacher-forced eps step {i}")
 
 
+@pytest.mark.parametrize("kind", ["ddim", "pndm"])
+def test_pipeline_v1_duck_typed_scheduler(kind):
+    """Any scheduler object with the diffusers protocol (here: the oracle's classes, which are not
+    powerpaint_amd.schedulers) drives the same HIP network program; the result must agree with the fused-step path."""
+    o, h = make_tiny("unet", in_channels=9)
+    B, hh, N = 2, 16, 5
+    lat, mask, mil, pe = _v1_inputs(B, hh, hh)
+    kw = dict(prompt_embeds=pe[B:].to(DEV), negative_prompt_embeds=pe[:B].to(DEV), height=hh * 8, width=hh * 8,
+              num_inference_steps=N, guidance_scale=7.5, latents=lat.to(DEV), mask_latents=mask.to(DEV),
+              masked_image_latents=mil.to(DEV), output_type="latent", return_dict=False)
+    fused = PP.StableDiffusionInpaintPipeline(
+        unet=h, scheduler={"ddim": PS.DDIMScheduler, "pndm": PS.PNDMScheduler}[kind]())(**kw)[0]
+    seen = []
+    pipe = PP.StableDiffusionInpaintPipeline(
+        unet=h, scheduler={"ddim": OS.DDIMScheduler, "pndm": OS.PNDMScheduler}[kind]())
+    duck = pipe(callback=lambda i, t, l: seen.append(int(t)), **kw)[0]
+    assert seen == [int(t) for t in pipe.scheduler.timesteps]
+    close(duck, fused, f"duck-typed {kind} scheduler vs fused step", cos_min=0.9999, rel=2e-3)
+    pipe.use_graph = False
+    close(pipe(**kw)[0], duck, "duck-typed eager vs graph", cos_min=0.99999, rel=1e-4)
+
+
 def test_pipeline_v2_brushnet_loop():
     ob, hb = make_tiny("brushnet")
     ou, hu = make_tiny("unet", seed=1, in_channels=4)
