@@ -27,7 +27,7 @@ extern "C" {
 #define PP_ERR_LAUNCH (-3)       /* hipLaunchKernel / hipFuncSetAttribute failed                  */
 #define PP_ERR_WORKSPACE (-4)    /* workspace pointer null or too small                           */
 
-#define PP_ABI_VERSION 4
+#define PP_ABI_VERSION 5
 int pp_abi_version(void);
 /* hipGetLastError() text of the last PP_ERR_LAUNCH on this thread (host pointer, static storage). */
 const char* pp_last_error(void);
@@ -252,6 +252,18 @@ int pp_step_advance(int32_t* step_dev, void* stream);
  */
 int pp_mask_prep(int mode, const float* a, const float* b, float* out, int batch, int c, int h, int w, int ho, int wo,
                  void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Task-prompt embedding splice -- the gather half of EmbeddingLayerWithFixes.forward
+ * (/root/reference/powerpaint/utils/utils.py:378-483: ids >= num_embeddings -> row 0 of the base table, then the
+ * learned [n_vec][dim] block of each placeholder is spliced over every occurrence of its id run).
+ * The host walks the ids exactly as the reference does and hands over one source row per output row:
+ *   src_row[i] >= 0 : out[i] = table[src_row[i]]            (base nn.Embedding weight)
+ *   src_row[i] <  0 : out[i] = ext[-src_row[i] - 1]         (all external embeddings, concatenated along rows)
+ * Rows are copied as `row_bytes` raw bytes (any dtype; bit-exact).  `ext` may be NULL when no src_row is negative.
+ */
+int pp_embed_splice(const void* table, const void* ext, const int32_t* src_row, void* out, int n_rows,
+                    long long row_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -53,6 +53,7 @@ SIGNATURES = {
     "pp_groupnorm_apply_acc": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, f32, vp, vp, vp, C.c_int, vp,
                                          vp]),
     "pp_zero_u64": (C.c_int, [vp, C.c_longlong, vp]),
+    "pp_embed_splice": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_longlong, vp]),
     "pp_groupnorm_stats": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
     "pp_groupnorm_apply": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, f32, vp, vp, vp, C.c_int, vp,
                                      vp]),
@@ -92,7 +93,7 @@ def lib():
             fn = getattr(l, name)
             fn.restype = res
             fn.argtypes = args
-        if l.pp_abi_version() != 4:
+        if l.pp_abi_version() != 5:
             raise PPError("libpp_hip.so ABI version mismatch")
         _lib = l
     return _lib

@@ -445,3 +445,42 @@ extern "C" int pp_zero_u64(void* dst, long long n, void* stream) {
   PP_CHECK_LAUNCH("zero_u64_kernel");
   return PP_OK;
 }
+
+// ------------------------------------------------------------------------------------------------ embedding splice
+// One workgroup per output row; the row is a plain byte copy from one of two tables, so the kernel is dtype-agnostic
+// (fp32 / fp16 / bf16 token embeddings) and bit-exact by construction.
+namespace {
+template <typename V>
+__global__ __launch_bounds__(128) void embed_splice_kernel(const unsigned char* __restrict__ table,
+                                                           const unsigned char* __restrict__ ext,
+                                                           const int* __restrict__ src_row,
+                                                           unsigned char* __restrict__ out, long long row_bytes) {
+  const int r = blockIdx.x;
+  const int s = src_row[r];
+  const unsigned char* src = s >= 0 ? table + (long long)s * row_bytes : ext + (long long)(-s - 1) * row_bytes;
+  const V* sv = (const V*)src;
+  V* dv = (V*)(out + (long long)r * row_bytes);
+  const int nv = (int)(row_bytes / (long long)sizeof(V));
+  for (int i = threadIdx.x; i < nv; i += blockDim.x) dv[i] = sv[i];
+}
+}  // namespace
+
+extern "C" int pp_embed_splice(const void* table, const void* ext, const int32_t* src_row, void* out, int n_rows,
+                               long long row_bytes, void* stream) {
+  if (!table || !src_row || !out || n_rows <= 0 || row_bytes <= 0) return PP_ERR_BAD_ARG;
+  const unsigned char* t = (const unsigned char*)table;
+  const unsigned char* e = (const unsigned char*)(ext ? ext : table);
+  unsigned char* o = (unsigned char*)out;
+  const unsigned long long al = (unsigned long long)(uintptr_t)t | (unsigned long long)(uintptr_t)e |
+                                (unsigned long long)(uintptr_t)o | (unsigned long long)row_bytes;
+  hipStream_t st = (hipStream_t)stream;
+  if ((al & 15) == 0)
+    hipLaunchKernelGGL(embed_splice_kernel<uint4>, dim3(n_rows), dim3(128), 0, st, t, e, src_row, o, row_bytes);
+  else if ((al & 3) == 0)
+    hipLaunchKernelGGL(embed_splice_kernel<unsigned int>, dim3(n_rows), dim3(128), 0, st, t, e, src_row, o, row_bytes);
+  else
+    hipLaunchKernelGGL(embed_splice_kernel<unsigned char>, dim3(n_rows), dim3(128), 0, st, t, e, src_row, o,
+                       row_bytes);
+  PP_CHECK_LAUNCH("embed_splice_kernel");
+  return PP_OK;
+}
