@@ -265,6 +265,14 @@ int pp_mask_prep(int mode, const float* a, const float* b, float* out, int batch
 int pp_embed_splice(const void* table, const void* ext, const int32_t* src_row, void* out, int n_rows,
                     long long row_bytes, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * Row softmax  p[r][c] = softmax_c(scale * s[r][c]),  fp32 logits -> bf16 probabilities.
+ * The VAE mid-block attention (diffusers AutoencoderKL: one head of dim 512 over H*W tokens -- the call sites are
+ * /root/reference/powerpaint/pipelines/pipeline_PowerPaint.py:657-669,1051) is two pp_gemm_bf16 launches around this
+ * kernel; pp_attention_fwd covers the UNet's head dims only.  lds / ldp: row strides in elements (multiples of 4).
+ */
+int pp_softmax_rows(const float* s, long long lds, int rows, int n, float scale, void* p, long long ldp, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -484,3 +484,60 @@ extern "C" int pp_embed_splice(const void* table, const void* ext, const int32_t
   PP_CHECK_LAUNCH("embed_splice_kernel");
   return PP_OK;
 }
+
+// ------------------------------------------------------------------------------------------------ row softmax
+// p[r][:] = softmax(scale * s[r][:]) for fp32 logits (the single-head, head-dim-512 attention of the VAE mid blocks is
+// run as two GEMMs around this kernel: its logits are kept in fp32, only the probabilities are rounded to bf16).
+// One 256-thread block per row, two passes over the (L2-resident) row: running (max, sum), then normalise + store.
+namespace {
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ s, long long lds, int n,
+                                                           float scale_log2e, uint16_t* __restrict__ p,
+                                                           long long ldp) {
+  __shared__ float red_m[4], red_s[4];
+  const float* row = s + (long long)blockIdx.x * lds;
+  uint16_t* out = p + (long long)blockIdx.x * ldp;
+  const int tid = threadIdx.x;
+  float m = -INFINITY, sum = 0.f;
+  const int n4 = n >> 2;
+  for (int i = tid; i < n4; i += 256) {
+    const float4 v = reinterpret_cast<const float4*>(row)[i];
+    const float mx = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)) * scale_log2e;
+    if (mx > m) { sum *= exp2f(m - mx); m = mx; }
+    sum += exp2f(v.x * scale_log2e - m) + exp2f(v.y * scale_log2e - m) + exp2f(v.z * scale_log2e - m) +
+           exp2f(v.w * scale_log2e - m);
+  }
+  for (int i = (n4 << 2) + tid; i < n; i += 256) {
+    const float x = row[i] * scale_log2e;
+    if (x > m) { sum *= exp2f(m - x); m = x; }
+    sum += exp2f(x - m);
+  }
+  const float wm = wave_max(m);
+  sum *= (m == -INFINITY) ? 0.f : exp2f(m - wm);
+  const float ws = wave_sum(sum);
+  if ((tid & 63) == 0) { red_m[tid >> 6] = wm; red_s[tid >> 6] = ws; }
+  __syncthreads();
+  const float M = fmaxf(fmaxf(red_m[0], red_m[1]), fmaxf(red_m[2], red_m[3]));
+  float S = 0.f;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) S += (red_m[w] == -INFINITY) ? 0.f : red_s[w] * exp2f(red_m[w] - M);
+  const float inv = 1.0f / S;
+  for (int i = tid; i < n4; i += 256) {
+    const float4 v = reinterpret_cast<const float4*>(row)[i];
+    uint2 o;
+    o.x = pack2bf(exp2f(v.x * scale_log2e - M) * inv, exp2f(v.y * scale_log2e - M) * inv);
+    o.y = pack2bf(exp2f(v.z * scale_log2e - M) * inv, exp2f(v.w * scale_log2e - M) * inv);
+    reinterpret_cast<uint2*>(out)[i] = o;
+  }
+  for (int i = (n4 << 2) + tid; i < n; i += 256) out[i] = f2bf(exp2f(row[i] * scale_log2e - M) * inv);
+}
+}  // namespace
+
+extern "C" int pp_softmax_rows(const float* s, long long lds, int rows, int n, float scale, void* p, long long ldp,
+                               void* stream) {
+  if (!s || !p || rows <= 0 || n <= 0 || lds < n || ldp < n) return PP_ERR_BAD_ARG;
+  if ((lds & 3) || (ldp & 3) || ((uintptr_t)s & 15) || ((uintptr_t)p & 7)) return PP_ERR_BAD_ARG;
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, s, lds, n,
+                     scale * 1.44269504088896340736f, (uint16_t*)p, ldp);
+  PP_CHECK_LAUNCH("softmax_rows_kernel");
+  return PP_OK;
+}

@@ -149,6 +149,14 @@ def transpose_v(v: torch.Tensor, batch: int, nk: int, ldvt: Optional[int] = None
     return vt
 
 
+def softmax_rows(s: torch.Tensor, scale: float = 1.0):
+    """fp32 logits [rows, n] (row stride s.stride(0)) -> bf16 softmax(scale * s) [rows, n]."""
+    rows, n = s.shape
+    p = torch.empty(rows, n, dtype=torch.bfloat16, device=s.device)
+    L.check(L.lib().pp_softmax_rows(_p(s), s.stride(0), rows, n, float(scale), _p(p), n, _s()), "pp_softmax_rows")
+    return p
+
+
 def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, batch: int, heads: int, nq: int, nk: int, d: int,
               scale: Optional[float] = None):
     """q [batch*nq, >=heads*d] / k [batch*nk, ...] row-major bf16 (row strides taken from the tensors);

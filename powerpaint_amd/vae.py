@@ -1,0 +1,339 @@
+"""AutoencoderKL (the SD-1.5 VAE) compiled to HIP launch plans -- SURVEY.md §8f-1, the step either side of the loop:
+    /root/reference/powerpaint/pipelines/pipeline_PowerPaint.py:657-669   vae.encode(image).latent_dist.sample(generator)
+    /root/reference/powerpaint/pipelines/pipeline_PowerPaint.py:1051      vae.decode(latents / scaling_factor)[0]
+The class is diffusers' (autoencoder_kl.py, vae.py: Encoder / Decoder / UNetMidBlock2D / DownEncoderBlock2D /
+UpDecoderBlock2D); the state-dict key names below are diffusers' so `diffusion_pytorch_model.safetensors` of the
+checkpoint's `vae/` folder loads unchanged (the pre-0.15 attention names query / key / value / proj_attn are mapped).
+
+Everything runs on the kernels of the UNet path (include/pp_hip.h):
+  * 3x3 convs with 64-multiple channel counts: the MFMA implicit GEMM (`pp_gemm_bf16`, PP_X_CONV3X3), nearest x2
+    upsampling and stride 2 fused into its loader; GroupNorm(+SiLU): `pp_groupnorm_stats/apply` (eps 1e-6);
+  * the 3 / 4 / 8-channel ends (conv_in, conv_out, quant_conv, post_quant_conv): `pp_conv3x3_direct` /
+    `pp_conv3x3_smallcout` on tensors padded to 8 (4) channels -- a 1x1 conv is a 3x3 whose only non-zero tap is the
+    centre;
+  * the mid-block attention (ONE head of dim 512 over H*W tokens, outside `pp_attention_fwd`'s head dims): per image
+    S = Q K^T as a GEMM with fp32 output, `pp_softmax_rows`, O = P V as a GEMM against V^T (`pp_transpose_v`).
+
+Encoder trick: Downsample2D(padding=0) pads right / bottom only (F.pad((0,1,0,1)) + stride-2 conv).  With the image
+rotated by 180 degrees that is exactly a symmetric pad-1 stride-2 conv with 180-degree-rotated filters (for even
+sizes), and every other layer commutes with the rotation once its 3x3 filters are rotated too.  So the encoder runs
+"upside down" on the stock conv kernel -- rotated input, all encoder filters rotated at pack time, moments rotated
+back -- instead of growing a new padding mode in the hot GEMM loader.  tests/test_vae.py checks the identity on CPU.
+"""
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import _lib as L
+from .engine import Act, Arena, Builder, ParamPack, Plan, _align, _conv_direct, _conv_igemm
+
+EPS = 1e-6
+_LEGACY = {"query": "to_q", "key": "to_k", "value": "to_v", "proj_attn": "to_out.0"}
+
+
+def _pad_to(t: torch.Tensor, dim: int, n: int) -> torch.Tensor:
+    if t.shape[dim] == n:
+        return t
+    shp = list(t.shape)
+    shp[dim] = n - t.shape[dim]
+    return torch.cat([t, t.new_zeros(shp)], dim)
+
+
+def _rot(w: torch.Tensor) -> torch.Tensor:
+    return w.flip(2, 3)
+
+
+class VAENet:
+    """Architecture + parameters of one AutoencoderKL; `build_decode` / `build_encode` append launch plans."""
+
+    def __init__(self, in_channels: int = 3, out_channels: int = 3, latent_channels: int = 4,
+                 block_out_channels=(128, 256, 512, 512), layers_per_block: int = 2, norm_num_groups: int = 32):
+        self.cin, self.cout, self.lat = in_channels, out_channels, latent_channels
+        self.boc = tuple(block_out_channels)
+        self.L = layers_per_block
+        self.groups = norm_num_groups
+        if in_channels > 8 or out_channels > 4 or 2 * latent_channels > 8:
+            raise L.PPError("AutoencoderKL: in_channels <= 8, out_channels <= 4, latent_channels <= 4 supported")
+        if any(c % 64 or c % norm_num_groups for c in self.boc):
+            raise L.PPError("AutoencoderKL: block_out_channels must be multiples of 64 (MFMA K steps) and of the groups")
+        self.params: Optional[ParamPack] = None
+        self.P: Dict[str, int] = {}
+
+    # ---------------------------------------------------------------- structure
+    def _resnets(self) -> List[Tuple[str, int, int]]:
+        """(prefix, cin, cout) of every ResnetBlock2D, encoder then decoder, in diffusers order."""
+        out, boc = [], self.boc
+        for i, c in enumerate(boc):
+            for j in range(self.L):
+                out.append((f"encoder.down_blocks.{i}.resnets.{j}", boc[max(i - 1, 0)] if j == 0 else c, c))
+        out += [(f"encoder.mid_block.resnets.{j}", boc[-1], boc[-1]) for j in range(2)]
+        rev = list(reversed(boc))
+        out += [(f"decoder.mid_block.resnets.{j}", rev[0], rev[0]) for j in range(2)]
+        for i, c in enumerate(rev):
+            for j in range(self.L + 1):
+                out.append((f"decoder.up_blocks.{i}.resnets.{j}", rev[max(i - 1, 0)] if j == 0 else c, c))
+        return out
+
+    def _samplers(self) -> List[Tuple[str, int]]:
+        n = len(self.boc)
+        rev = list(reversed(self.boc))
+        return [(f"encoder.down_blocks.{i}.downsamplers.0.conv", self.boc[i]) for i in range(n - 1)] + \
+               [(f"decoder.up_blocks.{i}.upsamplers.0.conv", rev[i]) for i in range(n - 1)]
+
+    def state_dict_spec(self) -> Dict[str, Tuple[int, ...]]:
+        sp: Dict[str, Tuple[int, ...]] = {}
+
+        def conv(name, cout, cin, k):
+            sp[name + ".weight"], sp[name + ".bias"] = (cout, cin, k, k), (cout,)
+
+        def vec(name, c):
+            sp[name + ".weight"], sp[name + ".bias"] = (c,), (c,)
+
+        conv("encoder.conv_in", self.boc[0], self.cin, 3)
+        conv("decoder.conv_in", self.boc[-1], self.lat, 3)
+        for pre, cin, cout in self._resnets():
+            vec(pre + ".norm1", cin)
+            conv(pre + ".conv1", cout, cin, 3)
+            vec(pre + ".norm2", cout)
+            conv(pre + ".conv2", cout, cout, 3)
+            if cin != cout:
+                conv(pre + ".conv_shortcut", cout, cin, 1)
+        for pre, c in self._samplers():
+            conv(pre, c, c, 3)
+        for side in ("encoder", "decoder"):
+            a, c = f"{side}.mid_block.attentions.0", self.boc[-1]
+            vec(a + ".group_norm", c)
+            for n in ("to_q", "to_k", "to_v", "to_out.0"):
+                sp[f"{a}.{n}.weight"], sp[f"{a}.{n}.bias"] = (c, c), (c,)
+        vec("encoder.conv_norm_out", self.boc[-1])
+        conv("encoder.conv_out", 2 * self.lat, self.boc[-1], 3)
+        vec("decoder.conv_norm_out", self.boc[0])
+        conv("decoder.conv_out", self.cout, self.boc[0], 3)
+        conv("quant_conv", 2 * self.lat, 2 * self.lat, 1)
+        conv("post_quant_conv", self.lat, self.lat, 1)
+        return sp
+
+    def synthetic_state_dict(self, device="cpu", seed: int = 0) -> Dict[str, torch.Tensor]:
+        """Random-init weights (no checkpoints offline): fan-in scaled normal matrices, (1 + noise, noise) norm affine,
+        small biases -- nothing left at a value that would hide a wiring mistake."""
+        g = torch.Generator(device=device).manual_seed(seed)
+        sd = {}
+        for k, shp in self.state_dict_spec().items():
+            if len(shp) == 1:
+                base = 1.0 if (k.endswith(".weight") and ("norm" in k)) else 0.0
+                sd[k] = base + 0.05 * torch.randn(shp, generator=g, device=device)
+            else:
+                fan_in = 1
+                for d in shp[1:]:
+                    fan_in *= d
+                sd[k] = torch.randn(shp, generator=g, device=device) * (1.0 / fan_in) ** 0.5
+        return sd
+
+    # ---------------------------------------------------------------- parameters
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], device):
+        sd = dict(sd)
+        for k in list(sd):                                # pre-0.15 diffusers attention names; 1x1-conv shaped linears
+            for old, new in _LEGACY.items():
+                if f".attentions.0.{old}." in k:
+                    sd[k.replace(f".{old}.", f".{new}.")] = sd.pop(k)
+        missing = [k for k in self.state_dict_spec() if k not in sd]
+        if missing:
+            raise L.PPError(f"AutoencoderKL state dict misses {len(missing)} keys, e.g. {missing[:3]}")
+        pk = ParamPack()
+        bf, f32 = torch.bfloat16, torch.float32
+
+        def W(k):
+            return sd[k].float()
+
+        def direct(w, cin_pad, cout_pad):                 # [Cout,Cin,3,3] -> [3,3,cin_pad,cout_pad]
+            return _pad_to(_pad_to(_conv_direct(w), 2, cin_pad), 3, cout_pad)
+
+        def centre(w, n):                                 # 1x1 [Cout,Cin,1,1] as the centre tap of a 3x3, padded to n x n
+            full = torch.zeros(w.shape[0], w.shape[1], 3, 3)
+            full[:, :, 1, 1] = w[:, :, 0, 0]
+            return direct(full, n, n)
+
+        for pre, cin, cout in self._resnets():
+            rot = _rot if pre.startswith("encoder") else (lambda t: t)
+            for nrm in ("norm1", "norm2"):
+                pk.add(f"{pre}.{nrm}.weight", W(f"{pre}.{nrm}.weight"), f32)
+                pk.add(f"{pre}.{nrm}.bias", W(f"{pre}.{nrm}.bias"), f32)
+            for cv in ("conv1", "conv2"):
+                pk.add(f"{pre}.{cv}.weight", _conv_igemm(rot(W(f"{pre}.{cv}.weight"))), bf)
+                pk.add(f"{pre}.{cv}.bias", W(f"{pre}.{cv}.bias"), f32)
+            if cin != cout:
+                pk.add(f"{pre}.conv_shortcut.weight", W(f"{pre}.conv_shortcut.weight").reshape(cout, cin), bf)
+                pk.add(f"{pre}.conv_shortcut.bias", W(f"{pre}.conv_shortcut.bias"), f32)
+        for pre, c in self._samplers():
+            rot = _rot if pre.startswith("encoder") else (lambda t: t)
+            pk.add(pre + ".weight", _conv_igemm(rot(W(pre + ".weight"))), bf)
+            pk.add(pre + ".bias", W(pre + ".bias"), f32)
+        for side in ("encoder", "decoder"):
+            a, c = f"{side}.mid_block.attentions.0", self.boc[-1]
+            pk.add(a + ".group_norm.weight", W(a + ".group_norm.weight"), f32)
+            pk.add(a + ".group_norm.bias", W(a + ".group_norm.bias"), f32)
+            for n in ("to_q", "to_k", "to_v", "to_out.0"):
+                pk.add(f"{a}.{n}.weight", W(f"{a}.{n}.weight").reshape(c, c), bf)
+                pk.add(f"{a}.{n}.bias", W(f"{a}.{n}.bias"), f32)
+            pk.add(f"{side}.conv_norm_out.weight", W(f"{side}.conv_norm_out.weight"), f32)
+            pk.add(f"{side}.conv_norm_out.bias", W(f"{side}.conv_norm_out.bias"), f32)
+        # the narrow ends, channel-padded
+        pk.add("encoder.conv_in.weight", direct(_rot(W("encoder.conv_in.weight")), 8, self.boc[0]), bf)
+        pk.add("encoder.conv_in.bias", W("encoder.conv_in.bias"), f32)
+        pk.add("encoder.conv_out.weight", direct(_rot(W("encoder.conv_out.weight")), self.boc[-1], 8), bf)
+        pk.add("encoder.conv_out.bias", _pad_to(W("encoder.conv_out.bias"), 0, 8), f32)
+        pk.add("quant_conv.weight", centre(W("quant_conv.weight"), 8), bf)
+        pk.add("quant_conv.bias", _pad_to(W("quant_conv.bias"), 0, 8), f32)
+        pk.add("post_quant_conv.weight", centre(W("post_quant_conv.weight"), 8), bf)
+        pk.add("post_quant_conv.bias", _pad_to(W("post_quant_conv.bias"), 0, 8), f32)
+        pk.add("decoder.conv_in.weight", direct(W("decoder.conv_in.weight"), 8, self.boc[-1]), bf)
+        pk.add("decoder.conv_in.bias", W("decoder.conv_in.bias"), f32)
+        pk.add("decoder.conv_out.weight", _conv_igemm(_pad_to(W("decoder.conv_out.weight"), 0, 4)), bf)
+        pk.add("decoder.conv_out.bias", _pad_to(W("decoder.conv_out.bias"), 0, 4), f32)
+        pk.to_device(device)
+        self.params, self.P = pk, pk.ptr
+        return self
+
+    # ---------------------------------------------------------------- plan pieces
+    def _direct(self, pb: Builder, x: Act, name: str, cout: int) -> Act:
+        out = pb.new_act(x.B, x.H, x.W, cout)
+        pb.plan.add("conv3x3_direct", pb.lib.pp_conv3x3_direct, x.ptr, x.B, x.H, x.W, x.C, self.P[name + ".weight"],
+                    self.P[name + ".bias"], cout, 1, 0, None, out.ptr)
+        return out
+
+    def _resnet(self, pb: Builder, pre: str, x: Act, cout: int) -> Act:
+        P = self.P
+        out = pb.new_act(x.B, x.H, x.W, cout)
+        m = pb.mark()
+        h = pb.groupnorm(x, P[f"{pre}.norm1.weight"], P[f"{pre}.norm1.bias"], EPS, True, groups=self.groups)
+        h = pb.conv3x3(h, P[f"{pre}.conv1.weight"], cout, P[f"{pre}.conv1.bias"])
+        h = pb.groupnorm(h, P[f"{pre}.norm2.weight"], P[f"{pre}.norm2.bias"], EPS, True, groups=self.groups)
+        if x.C != cout:
+            sc = pb.linear(x.ptr, x.rows, x.C, P[f"{pre}.conv_shortcut.weight"], cout, P[f"{pre}.conv_shortcut.bias"],
+                           name="conv1x1")
+        else:
+            sc = x.ptr
+        pb.conv3x3(h, P[f"{pre}.conv2.weight"], cout, P[f"{pre}.conv2.bias"], res1=sc, out=out)
+        pb.release(m)
+        return out
+
+    def _attention(self, pb: Builder, pre: str, x: Act) -> Act:
+        """Single-head attention over the H*W tokens with residual (diffusers Attention(residual_connection=True))."""
+        P = self.P
+        Cc, n, B = x.C, x.H * x.W, x.B
+        if n % 64:
+            raise L.PPError(f"AutoencoderKL attention: H*W = {n} tokens must be a multiple of 64")
+        out = pb.new_act(B, x.H, x.W, Cc)
+        m = pb.mark()
+        h = pb.groupnorm(x, P[f"{pre}.group_norm.weight"], P[f"{pre}.group_norm.bias"], EPS, False,
+                         groups=self.groups)
+        q = pb.linear(h.ptr, x.rows, Cc, P[f"{pre}.to_q.weight"], Cc, P[f"{pre}.to_q.bias"], name="linear")
+        k = pb.linear(h.ptr, x.rows, Cc, P[f"{pre}.to_k.weight"], Cc, P[f"{pre}.to_k.bias"], name="linear")
+        v = pb.linear(h.ptr, x.rows, Cc, P[f"{pre}.to_v.weight"], Cc, P[f"{pre}.to_v.bias"], name="linear")
+        vt = pb.alloc(B * Cc * n * 2)
+        pb.plan.add("transpose_v", pb.lib.pp_transpose_v, v, Cc, B, n, Cc, vt, n)
+        o = pb.alloc(x.rows * Cc * 2)
+        s = pb.alloc(n * n * 4)
+        p = pb.alloc(n * n * 2)
+        for b in range(B):
+            tok = b * n * Cc * 2
+            pb.linear(q + tok, n, Cc, k + tok, n, out=s, ldo=n, out_f32=True, name="attn_qk")
+            pb.plan.add("softmax_rows", pb.lib.pp_softmax_rows, s, n, n, n, float(Cc) ** -0.5, p, n)
+            pb.linear(p, n, n, vt + b * Cc * n * 2, Cc, out=o + tok, ldo=Cc, name="attn_pv")
+        pb.linear(o, x.rows, Cc, P[f"{pre}.to_out.0.weight"], Cc, P[f"{pre}.to_out.0.bias"], res1=x.ptr, out=out.ptr,
+                  name="linear")
+        pb.release(m)
+        return out
+
+    def _mid(self, pb: Builder, side: str, x: Act) -> Act:
+        x = self._resnet(pb, f"{side}.mid_block.resnets.0", x, x.C)
+        x = self._attention(pb, f"{side}.mid_block.attentions.0", x)
+        return self._resnet(pb, f"{side}.mid_block.resnets.1", x, x.C)
+
+    # ---------------------------------------------------------------- plans
+    def build_decode(self, pb: Builder, z: Act, out_nchw: int):
+        """z: latents padded to 8 channels [B,h,w,8] -> fp32 NCHW image [B,4,8h,8w] at `out_nchw` (channel 3 is 0)."""
+        P = self.P
+        x = self._direct(pb, z, "post_quant_conv", 8)
+        x = self._direct(pb, x, "decoder.conv_in", self.boc[-1])
+        x = self._mid(pb, "decoder", x)
+        rev = list(reversed(self.boc))
+        for i, c in enumerate(rev):
+            for j in range(self.L + 1):
+                x = self._resnet(pb, f"decoder.up_blocks.{i}.resnets.{j}", x, c)
+            if i != len(rev) - 1:
+                pre = f"decoder.up_blocks.{i}.upsamplers.0.conv"
+                x = pb.conv3x3(x, P[pre + ".weight"], c, P[pre + ".bias"], up=True)
+        x = pb.groupnorm(x, P["decoder.conv_norm_out.weight"], P["decoder.conv_norm_out.bias"], EPS, True,
+                         groups=self.groups)
+        pb.plan.add("conv_out", pb.lib.pp_conv3x3_smallcout, x.ptr, x.B, x.H, x.W, x.C, P["decoder.conv_out.weight"],
+                    P["decoder.conv_out.bias"], 4, out_nchw)
+        return (x.B, 4, x.H, x.W)
+
+    def build_encode(self, pb: Builder, img: Act) -> Act:
+        """img: the 180-degree-rotated image padded to 8 channels [B,H,W,8] -> rotated moments [B,H/8,W/8,8]."""
+        P = self.P
+        x = self._direct(pb, img, "encoder.conv_in", self.boc[0])
+        for i, c in enumerate(self.boc):
+            for j in range(self.L):
+                x = self._resnet(pb, f"encoder.down_blocks.{i}.resnets.{j}", x, c)
+            if i != len(self.boc) - 1:
+                if x.H % 2 or x.W % 2:
+                    raise L.PPError("AutoencoderKL.encode: image sides must be multiples of 8")
+                pre = f"encoder.down_blocks.{i}.downsamplers.0.conv"
+                x = pb.conv3x3(x, P[pre + ".weight"], c, P[pre + ".bias"], stride=2)
+        x = self._mid(pb, "encoder", x)
+        x = pb.groupnorm(x, P["encoder.conv_norm_out.weight"], P["encoder.conv_norm_out.bias"], EPS, True,
+                         groups=self.groups)
+        x = self._direct(pb, x, "encoder.conv_out", 8)
+        return self._direct(pb, x, "quant_conv", 8)
+
+
+class VAERuntime:
+    """Device state (arena + launch plan) of one direction of one VAENet for one input shape."""
+
+    def __init__(self, net: VAENet, device, direction: str):
+        self.net, self.device, self.direction = net, torch.device(device), direction
+        self.key = None
+        self.plan: Optional[Plan] = None
+        self.arena: Optional[Arena] = None
+
+    def _build(self, arena: Arena, B: int, H: int, W: int):
+        pb = Builder(arena)
+        lay = {"x_in": Act(arena.alloc(B * H * W * 8 * 2), B, H, W, 8)}
+        if self.direction == "decode":
+            lay["img"] = arena.alloc(B * 4 * (8 * H) * (8 * W) * 4)
+            lay["shape"] = self.net.build_decode(pb, lay["x_in"], lay["img"])
+        else:
+            lay["moments"] = self.net.build_encode(pb, lay["x_in"])
+        return lay, pb.plan
+
+    def ensure(self, B: int, H: int, W: int):
+        if (B, H, W) == self.key:
+            return
+        dry = Arena()
+        self._build(dry, B, H, W)
+        self.arena = Arena(_align(dry.peak, 4096), self.device)      # zero-filled: the pad channels of x_in stay 0
+        self.lay, self.plan = self._build(self.arena, B, H, W)
+        self.key = (B, H, W)
+
+    def run(self, x: torch.Tensor) -> torch.Tensor:
+        """decode: latents [B,lat,h,w] -> fp32 [B,4,8h,8w] (a view of arena memory, valid until the next run);
+        encode: ROTATED image [B,cin,H,W] -> rotated fp32 moments [B,8,H/8,W/8]."""
+        B, Cc, H, W = x.shape
+        self.ensure(B, H, W)
+        stream = torch.cuda.current_stream().cuda_stream
+        x = x.to(self.device)
+        if x.dtype not in (torch.float32, torch.bfloat16, torch.float16):
+            x = x.float()
+        x = x.contiguous()
+        dt = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}[x.dtype]
+        xin = self.lay["x_in"]
+        L.check(L.lib().pp_nchw_to_nhwc(x.data_ptr(), dt, B, Cc, H * W, 0, xin.ptr, 8, 0, stream), "pp_nchw_to_nhwc")
+        self.plan.run(stream)
+        if self.direction == "decode":
+            return self.arena.view(self.lay["img"], self.lay["shape"], torch.float32)
+        m = self.lay["moments"]
+        out = torch.empty(m.B, 8, m.H, m.W, dtype=torch.float32, device=self.device)
+        L.check(L.lib().pp_nhwc_to_nchw(m.ptr, m.B, 8, m.H * m.W, out.data_ptr(), 0, stream), "pp_nhwc_to_nchw")
+        return out
