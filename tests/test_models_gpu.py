@@ -246,6 +246,37 @@ def test_pipeline_controlnet_loop():
     close(out, ref, "controlnet free-running", cos_min=0.995, rel=0.1)
 
 
+def test_pipeline_v1_pixels_in_pixels_out_with_vae():
+    """image + mask in pixel space -> VAE encode of the masked image -> fused loop -> VAE decode (output_type="pt"),
+    against the same chain of oracles (the VAE either side of the loop)."""
+    from oracle import vae as OV
+    cfg = dict(block_out_channels=(64, 128, 256, 256), layers_per_block=1)
+    o, h = make_tiny("unet", in_channels=9)
+    vae = PM.AutoencoderKL(device=DEV, **cfg)
+    sd = vae.net.synthetic_state_dict(seed=21)
+    vae.load_state_dict(sd)
+    ov = OV.AutoencoderKL(**cfg).eval()
+    ov.load_state_dict({k: (v.to(torch.bfloat16).float() if v.dim() >= 2 else v) for k, v in sd.items()})
+    B, side, N = 2, 128, 3
+    img = torch.rand(B, 3, side, side, generator=torch.Generator("cpu").manual_seed(1)) * 2 - 1
+    mask = torch.zeros(B, 1, side, side)
+    mask[:, :, 32:96, 40:100] = 1.0
+    lat, pe = gen(B, 4, side // 8, side // 8, seed=3), gen(2 * B, 77, 768, seed=4)
+    pipe = PP.StableDiffusionInpaintPipeline(vae=vae, unet=h, scheduler=PS.DDIMScheduler())
+    assert pipe.vae_scale_factor == 8
+    out = pipe(prompt_embeds=pe[B:].to(DEV), negative_prompt_embeds=pe[:B].to(DEV), image=img, mask=mask,
+               height=side, width=side, num_inference_steps=N, guidance_scale=7.5, latents=lat.to(DEV),
+               generator=torch.Generator("cpu").manual_seed(77), output_type="pt", return_dict=False)[0]
+    assert out.shape == (B, 3, side, side)
+    with torch.no_grad():
+        masked = (img * (mask < 0.5)).to(torch.bfloat16).float()
+        mil = ov.encode(masked).latent_dist.sample(torch.Generator("cpu").manual_seed(77)) * ov.config.scaling_factor
+        m = torch.nn.functional.interpolate(mask, size=(side // 8, side // 8))
+        fin = OL.loop_v1(o, OS.DDIMScheduler(), lat, torch.cat([m] * 2), torch.cat([mil] * 2), pe, N, 7.5)
+        ref = ov.decode(fin / ov.config.scaling_factor, return_dict=False)[0]
+    close(out, ref, "pixels in -> pixels out", cos_min=0.99, rel=0.15)
+
+
 def test_product_fails_loudly_without_extension(monkeypatch):
     from powerpaint_amd import _lib
     monkeypatch.setattr(_lib, "_lib", None)
