@@ -273,6 +273,15 @@ int pp_embed_splice(const void* table, const void* ext, const int32_t* src_row, 
  */
 int pp_softmax_rows(const float* s, long long lds, int rows, int n, float scale, void* p, long long ldp, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * Attention for short sequences: the CLIP text tower the pipelines call through `self.text_encoder(ids)[0]`
+ * (/root/reference/powerpaint/pipelines/pipeline_PowerPaint.py:378-423; transformers CLIPTextModel: 77 tokens, 12 heads
+ * of 64, causal mask).  q / k / v / o: bf16, element (b, t, h, j) at x[(b*n + t)*ld + h*d + j] (v NOT transposed).
+ * d == 64, nk <= 128; causal: key j visible to query i iff j <= i (needs nq == nk).
+ */
+int pp_attention_small(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* o, int ldo,
+                       int batch, int heads, int nq, int nk, int d, float scale, int causal, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -54,6 +54,8 @@ SIGNATURES = {
                                          vp]),
     "pp_zero_u64": (C.c_int, [vp, C.c_longlong, vp]),
     "pp_embed_splice": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_longlong, vp]),
+    "pp_attention_small": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int,
+                                     C.c_int, C.c_int, f32, C.c_int, vp]),
     "pp_softmax_rows": (C.c_int, [vp, C.c_longlong, C.c_int, C.c_int, f32, vp, C.c_longlong, vp]),
     "pp_groupnorm_stats": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
     "pp_groupnorm_apply": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, f32, vp, vp, vp, C.c_int, vp,

@@ -541,3 +541,79 @@ extern "C" int pp_softmax_rows(const float* s, long long lds, int rows, int n, f
   PP_CHECK_LAUNCH("softmax_rows_kernel");
   return PP_OK;
 }
+
+// ------------------------------------------------------------------------------------------------ small attention
+// Attention for short sequences (CLIP text tower: 77 tokens, 12 heads of 64, causal): one block per (head, batch item),
+// K / V of the head staged once in LDS, one wave per query row -- lanes over keys for the logits, lanes over the head
+// dim for P V.  ~150 MFLOP per call in total: latency, not throughput, is what matters here.
+namespace {
+constexpr int AS_D = 64, AS_MAXK = 128, AS_KS = AS_D + 2;   // K rows padded to 66 halves: lane j -> bank (33 j) mod 32
+
+__global__ __launch_bounds__(256) void attn_small_kernel(const uint16_t* __restrict__ q, int ldq,
+                                                         const uint16_t* __restrict__ k, int ldk,
+                                                         const uint16_t* __restrict__ v, int ldv,
+                                                         uint16_t* __restrict__ o, int ldo, int nq, int nk, float scale,
+                                                         int causal) {
+  __shared__ uint16_t Ks[AS_MAXK * AS_KS];
+  __shared__ uint16_t Vs[AS_MAXK * AS_D];
+  __shared__ float Qs[4][AS_D];
+  __shared__ float Ps[4][AS_MAXK];
+  const int h = blockIdx.x, b = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < nk * (AS_D / 2); i += 256) {          // 2 halves per thread-iteration
+    const int r = i / (AS_D / 2), c = (i - r * (AS_D / 2)) * 2;
+    const uint32_t kv = *reinterpret_cast<const uint32_t*>(k + ((size_t)b * nk + r) * ldk + h * AS_D + c);
+    const uint32_t vv = *reinterpret_cast<const uint32_t*>(v + ((size_t)b * nk + r) * ldv + h * AS_D + c);
+    *reinterpret_cast<uint32_t*>(&Ks[r * AS_KS + c]) = kv;
+    *reinterpret_cast<uint32_t*>(&Vs[r * AS_D + c]) = vv;
+  }
+  __syncthreads();
+  const int nkb = (nk + 63) >> 6;
+  for (int i = wave; i < nq; i += 4) {
+    Qs[wave][lane] = bf2f(q[((size_t)b * nq + i) * ldq + h * AS_D + lane]);
+    __builtin_amdgcn_wave_barrier();
+    float sv[AS_MAXK / 64];
+    float m = -INFINITY;
+#pragma unroll
+    for (int jb = 0; jb < AS_MAXK / 64; ++jb) {
+      sv[jb] = -INFINITY;
+      const int j = jb * 64 + lane;
+      if (jb < nkb && j < nk && (!causal || j <= i)) {
+        float acc = 0.f;
+#pragma unroll 16
+        for (int c = 0; c < AS_D; ++c) acc += Qs[wave][c] * bf2f(Ks[j * AS_KS + c]);
+        sv[jb] = acc * scale;
+      }
+      m = fmaxf(m, sv[jb]);
+    }
+    m = wave_max(m);
+    float l = 0.f;
+#pragma unroll
+    for (int jb = 0; jb < AS_MAXK / 64; ++jb) {
+      const float p = (sv[jb] == -INFINITY) ? 0.f : __expf(sv[jb] - m);
+      l += p;
+      if (jb < nkb) Ps[wave][jb * 64 + lane] = p;
+    }
+    l = wave_sum(l);
+    __builtin_amdgcn_wave_barrier();
+    float acc = 0.f;
+    const int jend = causal ? (i + 1 < nk ? i + 1 : nk) : nk;
+    for (int j = 0; j < jend; ++j) acc += Ps[wave][j] * bf2f(Vs[j * AS_D + lane]);
+    o[((size_t)b * nq + i) * ldo + h * AS_D + lane] = f2bf(acc / l);
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+}  // namespace
+
+extern "C" int pp_attention_small(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* o,
+                                  int ldo, int batch, int heads, int nq, int nk, int d, float scale, int causal,
+                                  void* stream) {
+  if (!q || !k || !v || !o || batch <= 0 || heads <= 0 || nq <= 0 || nk <= 0) return PP_ERR_BAD_ARG;
+  if (d != AS_D || nk > AS_MAXK) return PP_ERR_UNSUPPORTED;
+  if ((ldk & 1) || (ldv & 1) || ((uintptr_t)k & 3) || ((uintptr_t)v & 3)) return PP_ERR_BAD_ARG;
+  if (causal && nq != nk) return PP_ERR_BAD_ARG;
+  hipLaunchKernelGGL(attn_small_kernel, dim3(heads, batch), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)q, ldq,
+                     (const uint16_t*)k, ldk, (const uint16_t*)v, ldv, (uint16_t*)o, ldo, nq, nk, scale, causal);
+  PP_CHECK_LAUNCH("attn_small_kernel");
+  return PP_OK;
+}

@@ -149,6 +149,17 @@ def transpose_v(v: torch.Tensor, batch: int, nk: int, ldvt: Optional[int] = None
     return vt
 
 
+def attention_small(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, batch: int, heads: int, nq: int, nk: int,
+                    causal: bool = False, scale: Optional[float] = None):
+    """q [batch*nq, >=heads*64], k / v [batch*nk, ...] row-major bf16 (row strides from the tensors) -> o [batch*nq, heads*64]."""
+    d = 64
+    o = torch.empty(batch * nq, heads * d, dtype=torch.bfloat16, device=q.device)
+    L.check(L.lib().pp_attention_small(_p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(o), heads * d,
+                                       batch, heads, nq, nk, d, scale if scale is not None else d ** -0.5, int(causal),
+                                       _s()), "pp_attention_small")
+    return o
+
+
 def softmax_rows(s: torch.Tensor, scale: float = 1.0):
     """fp32 logits [rows, n] (row stride s.stride(0)) -> bf16 softmax(scale * s) [rows, n]."""
     rows, n = s.shape

@@ -312,8 +312,10 @@ def add_tokens(tokenizer, text_encoder, placeholder_tokens: list, initialize_tok
         tokenizer.add_placeholder_token(p, num_vec_per_token=num_vectors_per_token)
     # transformers 4.x (the reference's pin) keeps the embeddings under `.text_model`; 5.x flattened CLIPTextModel
     holder = getattr(text_encoder, "text_model", text_encoder).embeddings
-    layer = EmbeddingLayerWithFixes(holder.token_embedding)
-    holder.token_embedding = layer
+    layer = holder.token_embedding
+    if not isinstance(layer, EmbeddingLayerWithFixes):     # powerpaint_amd.models.CLIPTextModel is born wrapped
+        layer = EmbeddingLayerWithFixes(layer)
+        holder.token_embedding = layer
     init = []
     for i, _ in enumerate(placeholder_tokens):
         if initialize_tokens is not None:
