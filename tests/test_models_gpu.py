@@ -277,6 +277,61 @@ def test_pipeline_v1_pixels_in_pixels_out_with_vae():
     close(out, ref, "pixels in -> pixels out", cos_min=0.99, rel=0.15)
 
 
+def test_pipeline_v1_text_and_pixels_in_pixels_out_all_hip():
+    """Task prompt strings + image + mask -> image with every stage on the HIP path (TokenizerWrapper + CLIPTextModel
+    with spliced task tokens, AutoencoderKL, UNet, fused loop).  Each stage has its own parity test; this one checks
+    the plumbing: the string / pixel entry points equal the same run fed with the intermediate tensors."""
+    import json
+    import os
+    import transformers
+    from powerpaint_amd.utils import TokenizerWrapper, add_task, add_tokens
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_task_tokens.json")) as f:
+        G = json.load(f)
+    tok = TokenizerWrapper(tokenizer=transformers.CLIPTokenizer(
+        vocab={t: i for i, t in enumerate(G["vocab"])}, merges=[tuple(m) for m in G["merges"]], model_max_length=77))
+    torch.manual_seed(5)
+    enc = PM.CLIPTextModel(device=DEV, vocab_size=G["n_base"], num_hidden_layers=2, eos_token_id=G["n_base"] - 1)
+    with torch.no_grad():
+        for p in enc.parameters():
+            if p.dim() >= 2:
+                p.mul_(2.0)
+    add_tokens(tokenizer=tok, text_encoder=enc, placeholder_tokens=["P_ctxt", "P_shape", "P_obj"],
+               initialize_tokens=["a", "a", "a"], num_vectors_per_token=10)
+    with torch.no_grad():
+        for e in enc.text_model.embeddings.token_embedding.external_embeddings:
+            e["embedding"].copy_(torch.randn_like(e["embedding"]) * 0.05)
+    _, h = make_tiny("unet", in_channels=9)
+    vae = PM.AutoencoderKL(device=DEV, block_out_channels=(64, 128, 256, 256), layers_per_block=1)
+    vae.load_state_dict(vae.net.synthetic_state_dict(seed=22))
+    pipe = PP.StableDiffusionInpaintPipeline(vae=vae, text_encoder=enc, tokenizer=tok, unet=h,
+                                             scheduler=PS.DDIMScheduler())
+    B, side, N = 1, 128, 3
+    img = torch.rand(B, 3, side, side, generator=torch.Generator("cpu").manual_seed(1)) * 2 - 1
+    mask = torch.zeros(B, 1, side, side)
+    mask[:, :, 16:100, 30:90] = 1.0
+    lat = gen(B, 4, side // 8, side // 8, seed=3)
+    pA, pB, nA, nB = add_task("the cat", "blur", "shape-guided")
+    common = dict(height=side, width=side, num_inference_steps=N, guidance_scale=7.5, latents=lat.to(DEV),
+                  output_type="pt", return_dict=False)
+    out = pipe(promptA=pA, promptB=pB, tradoff=0.4, tradoff_nag=0.6, negative_promptA=nA, negative_promptB=nB,
+               image=img, mask=mask, generator=torch.Generator("cpu").manual_seed(7), **common)[0]
+    assert out.shape == (B, 3, side, side) and torch.isfinite(out).all()
+
+    def emb(p):
+        ids = tok(p, padding="max_length", max_length=77, truncation=True, return_tensors="pt").input_ids
+        return enc(ids.to(DEV))[0]
+
+    pe, ne = emb(pA) * 0.4 + 0.6 * emb(pB), emb(nA) * 0.6 + 0.4 * emb(nB)
+    masked = img * (mask < 0.5)
+    mil = vae.encode(masked.to(DEV)).latent_dist.sample(torch.Generator("cpu").manual_seed(7)) * vae.config.scaling_factor
+    m = torch.nn.functional.interpolate(mask, size=(side // 8, side // 8)).to(DEV)
+    again = pipe(prompt_embeds=pe, negative_prompt_embeds=ne, mask_latents=m, masked_image_latents=mil, **common)[0]
+    assert torch.equal(out, again)
+    other = pipe(promptA=pA, promptB=pB, tradoff=1.0, tradoff_nag=0.6, negative_promptA=nA, negative_promptB=nB,
+                 image=img, mask=mask, generator=torch.Generator("cpu").manual_seed(7), **common)[0]
+    assert not torch.equal(other, out)                      # the blend weight reaches the image
+
+
 def test_product_fails_loudly_without_extension(monkeypatch):
     from powerpaint_amd import _lib
     monkeypatch.setattr(_lib, "_lib", None)
