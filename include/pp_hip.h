@@ -236,6 +236,10 @@ int pp_add_bf16(const void* a, const void* b, void* out, long long n, void* stre
  *             table rows are 16 floats {w0..w3, a, b, slot(h1), slot(h2), slot(h3), push_slot | -1, use_saved, save};
  *             m = w0 eps + w1 h1 + w2 h2 + w3 h3;  x_next = a * (use_saved ? saved : x) + b * m;  `m_prev` is the state
  *             [5][n] fp32 (4 history slots + the saved sample), zero before the first step.  N steps = N + 1 rows.
+ *     kind 3 (UniPC, predict_x0 / bh1|bh2 / order <= 3 -- what app.py:197 installs on the ppt-v2 pipeline):
+ *             rows are 16 floats {sigma_t, alpha_t, use_corr, k_last, k_m1, k_m2, k_m3, k_x0, p_xc, p_x0, p_m1, p_m2};
+ *             x0 = (x - sigma_t eps) / alpha_t;  xc = use_corr ? k . (last, m1, m2, m3, x0) : x;
+ *             x_next = p . (xc, x0, m1, m2);  state [4][n] fp32 <- (xc, x0, m1, m2), zero before the first step.
  * `step_dev` (int32 on device) selects the row; it is NOT incremented here (pp_step_advance does).
  */
 int pp_cfg_sched_step(const float* eps2, int cfg, float guidance, float* latents, float* m_prev, int n, int kind,

@@ -1,4 +1,4 @@
-"""Oracle (TEST INFRASTRUCTURE): DDIM, DPM-Solver++(2M) and PNDM (PLMS) restated from diffusers==0.27.0.
+"""Oracle (TEST INFRASTRUCTURE): DDIM, DPM-Solver++(2M), PNDM (PLMS) and UniPC restated from diffusers==0.27.0.
 
 The reference pipelines are scheduler-agnostic and only duck-type the scheduler
 (/root/reference/powerpaint/pipelines/pipeline_PowerPaint.py:906,993,1023,642;
@@ -210,6 +210,145 @@ class DPMSolverMultistepScheduler:
 # ---------------------------------------------------------------------------------------
 # independent float64 closed forms (pins for the classes above and for the HIP step kernel)
 # ---------------------------------------------------------------------------------------
+class UniPCMultistepScheduler:
+    """UniPC (Zhao et al. 2023, arXiv:2302.04867) as diffusers==0.27.0 `UniPCMultistepScheduler` runs it -- the scheduler
+    app.py:197 puts on the ppt-v2 pipeline (`UniPCMultistepScheduler.from_config(pipe.scheduler.config)`): data
+    prediction (predict_x0), B(h) = expm1 ("bh2"), solver_order 2 (3 supported), lower_order_final, corrector on every
+    step after the first.  Restated in the library's own shape -- history lists, a `multistep_uni_p_bh_update`
+    predictor and a `multistep_uni_c_bh_update` corrector -- in fp32; **parity unpinned** (diffusers is not
+    installable here); tests pin it to the paper's structure instead (UniP-1 == DDIM, order of convergence on a
+    closed-form ODE).  `timestep_spacing` / `steps_offset` come from the pipeline's scheduler config ("leading", 1 for
+    the SD-1.5 family); `linspace` is the class default."""
+    order = 1
+    init_noise_sigma = 1.0
+
+    def __init__(self, num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, solver_order=2,
+                 solver_type="bh2", lower_order_final=True, disable_corrector=(), timestep_spacing="linspace",
+                 steps_offset=0):
+        self.T = num_train_timesteps
+        self.alphas_cumprod = torch.cumprod(1.0 - sd_betas(num_train_timesteps, beta_start, beta_end), dim=0)
+        self.solver_order, self.solver_type, self.lower_order_final = solver_order, solver_type, lower_order_final
+        self.disable_corrector = list(disable_corrector)
+        self.timestep_spacing, self.steps_offset = timestep_spacing, steps_offset
+        self.timesteps = None
+
+    def set_timesteps(self, num_inference_steps: int, device=None):
+        N, T = num_inference_steps, self.T
+        if self.timestep_spacing == "linspace":
+            ts = np.linspace(0, T - 1, N + 1).round()[::-1][:-1].copy().astype(np.int64)
+        elif self.timestep_spacing == "leading":
+            ts = (np.arange(0, N + 1) * (T // (N + 1))).round()[::-1][:-1].copy().astype(np.int64) + self.steps_offset
+        elif self.timestep_spacing == "trailing":
+            ts = (np.arange(T, 0, -T / N).round() - 1).astype(np.int64)
+        else:
+            raise ValueError(self.timestep_spacing)
+        sig = (((1 - self.alphas_cumprod) / self.alphas_cumprod) ** 0.5).numpy()
+        sigma_last = ((1 - self.alphas_cumprod[0]) / self.alphas_cumprod[0]) ** 0.5
+        sig = np.concatenate([np.interp(ts, np.arange(0, len(sig)), sig), [float(sigma_last)]]).astype(np.float32)
+        self.sigmas = torch.from_numpy(sig)
+        self.timesteps = torch.from_numpy(ts)
+        self.num_inference_steps = N
+        self.model_outputs = [None] * self.solver_order
+        self.lower_order_nums = 0
+        self.last_sample = None
+        self.step_index = 0
+        self.this_order = 1
+
+    def scale_model_input(self, sample, timestep=None):
+        return sample
+
+    @staticmethod
+    def _alpha_sigma(sigma):
+        alpha_t = 1 / ((sigma ** 2 + 1) ** 0.5)
+        return alpha_t, sigma * alpha_t
+
+    def _lambda(self, i):
+        a, s = self._alpha_sigma(self.sigmas[i])
+        return torch.log(a) - torch.log(s)
+
+    def _bh(self, order, rks, hh):
+        """R, b of the UniPC linear system and the scalars h*phi_1(h), B(h)."""
+        h_phi_1 = torch.expm1(hh)
+        h_phi_k = h_phi_1 / hh - 1
+        B_h = hh if self.solver_type == "bh1" else torch.expm1(hh)
+        R, b, fact = [], [], 1
+        for i in range(1, order + 1):
+            R.append(torch.pow(rks, i - 1))
+            b.append(h_phi_k * fact / B_h)
+            fact *= i + 1
+            h_phi_k = h_phi_k / hh - 1 / fact
+        return torch.stack(R), torch.stack(b), h_phi_1, B_h
+
+    def _predict(self, sample, order):
+        """multistep_uni_p_bh_update: x_{i+1} from the (corrected) x_i and the x0 history."""
+        i = self.step_index
+        m0, x = self.model_outputs[-1], sample
+        alpha_t, sigma_t = self._alpha_sigma(self.sigmas[i + 1])
+        _, sigma_s0 = self._alpha_sigma(self.sigmas[i])
+        h = self._lambda(i + 1) - self._lambda(i)
+        rks, D1s = [], []
+        for k in range(1, order):
+            rk = (self._lambda(i - k) - self._lambda(i)) / h
+            rks.append(rk)
+            D1s.append((self.model_outputs[-(k + 1)] - m0) / rk)
+        rks.append(torch.tensor(1.0))
+        rks = torch.stack(rks)
+        hh = -h
+        R, b, h_phi_1, B_h = self._bh(order, rks, hh)
+        x_t_ = sigma_t / sigma_s0 * x - alpha_t * h_phi_1 * m0
+        pred_res = 0
+        if D1s:
+            rhos_p = torch.tensor([0.5]) if order == 2 else torch.linalg.solve(R[:-1, :-1], b[:-1])
+            pred_res = sum(r * d for r, d in zip(rhos_p, D1s))
+        return x_t_ - alpha_t * B_h * pred_res
+
+    def _correct(self, this_model_output, last_sample, order):
+        """multistep_uni_c_bh_update: x_i re-estimated from x_{i-1} with the x0 prediction at x_i included."""
+        i = self.step_index
+        m0, x = self.model_outputs[-1], last_sample
+        alpha_t, sigma_t = self._alpha_sigma(self.sigmas[i])
+        _, sigma_s0 = self._alpha_sigma(self.sigmas[i - 1])
+        h = self._lambda(i) - self._lambda(i - 1)
+        rks, D1s = [], []
+        for k in range(1, order):
+            rk = (self._lambda(i - (k + 1)) - self._lambda(i - 1)) / h
+            rks.append(rk)
+            D1s.append((self.model_outputs[-(k + 1)] - m0) / rk)
+        rks.append(torch.tensor(1.0))
+        rks = torch.stack(rks)
+        hh = -h
+        R, b, h_phi_1, B_h = self._bh(order, rks, hh)
+        rhos_c = torch.tensor([0.5]) if order == 1 else torch.linalg.solve(R, b)
+        x_t_ = sigma_t / sigma_s0 * x - alpha_t * h_phi_1 * m0
+        corr_res = sum(r * d for r, d in zip(rhos_c[:-1], D1s)) if D1s else 0
+        D1_t = this_model_output - m0
+        return x_t_ - alpha_t * B_h * (corr_res + rhos_c[-1] * D1_t)
+
+    def step(self, model_output, timestep, sample, generator=None, return_dict=False):
+        i = self.step_index
+        use_corrector = i > 0 and (i - 1) not in self.disable_corrector and self.last_sample is not None
+        alpha_t, sigma_t = self._alpha_sigma(self.sigmas[i])
+        x0 = (sample - sigma_t * model_output) / alpha_t                       # convert_model_output (epsilon, predict_x0)
+        if use_corrector:
+            sample = self._correct(x0, self.last_sample, self.this_order)
+        self.model_outputs = self.model_outputs[1:] + [x0]
+        this_order = min(self.solver_order, len(self.timesteps) - i) if self.lower_order_final else self.solver_order
+        self.this_order = min(this_order, self.lower_order_nums + 1)           # warm-up
+        self.last_sample = sample
+        prev = self._predict(sample, self.this_order)
+        if self.lower_order_nums < self.solver_order:
+            self.lower_order_nums += 1
+        self.step_index += 1
+        return (prev,)
+
+    def add_noise(self, x0, noise, timesteps):
+        a = self.alphas_cumprod[timesteps.long()].to(x0.dtype)
+        sa, s1 = (a ** 0.5).flatten(), ((1 - a) ** 0.5).flatten()
+        while sa.dim() < x0.dim():
+            sa, s1 = sa.unsqueeze(-1), s1.unsqueeze(-1)
+        return sa * x0 + s1 * noise
+
+
 def alphas_cumprod_f64(T=1000, beta_start=0.00085, beta_end=0.012) -> np.ndarray:
     betas = np.linspace(beta_start ** 0.5, beta_end ** 0.5, T, dtype=np.float64) ** 2
     return np.cumprod(1.0 - betas)

@@ -232,6 +232,40 @@ __global__ void __launch_bounds__(256) cfg_sched_step_kernel(const float* __rest
     }
     return;
   }
+  if (kind == 3) {
+    // UniPC (predict_x0, order <= 3): row (16 floats) = sigma_t, alpha_t, use_corr, corrector weights over
+    // (last, m1, m2, m3, x0), predictor weights over (xc, x0, m1, m2); state = [4][n]: last corrected sample and the
+    // three most recent x0 predictions.  All weights come from the host's float64 solve of the UniPC conditions.
+    const float* c = coef + (size_t)step_dev[0] * 16;
+    const float sg = c[0], al = c[1];
+    const bool corr = c[2] != 0.f;
+    const float k_last = c[3], k_m1 = c[4], k_m2 = c[5], k_m3 = c[6], k_x0 = c[7];
+    const float p_xc = c[8], p_x0 = c[9], p_m1 = c[10], p_m2 = c[11];
+    float* last = m_prev;
+    float* m1 = m_prev + (size_t)n;
+    float* m2 = m_prev + (size_t)2 * n;
+    float* m3 = m_prev + (size_t)3 * n;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+      float e;
+      if (cfg) {
+        const float eu = eps2[i], ec = eps2[n + i];
+        e = eu + g * (ec - eu);
+      } else {
+        e = eps2[i];
+      }
+      const float xv = x[i];
+      const float x0 = (xv - sg * e) / al;
+      const float a1 = m1[i], a2 = m2[i];
+      float xc = xv;
+      if (corr) xc = k_last * last[i] + k_m1 * a1 + k_m2 * a2 + k_m3 * m3[i] + k_x0 * x0;
+      x[i] = p_xc * xc + p_x0 * x0 + p_m1 * a1 + p_m2 * a2;
+      last[i] = xc;
+      m3[i] = a2;
+      m2[i] = a1;
+      m1[i] = x0;
+    }
+    return;
+  }
   const float* c = coef + (size_t)step_dev[0] * 8;
   const float c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3], c4 = c[4], c5 = c[5];
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
@@ -397,7 +431,7 @@ extern "C" int pp_add_bf16(const void* a, const void* b, void* out, long long n,
 
 extern "C" int pp_cfg_sched_step(const float* eps2, int cfg, float guidance, float* latents, float* m_prev, int n,
                                  int kind, const float* coef_table, const int32_t* step_dev, void* stream) {
-  if (!eps2 || !latents || !coef_table || !step_dev || n <= 0 || kind < 0 || kind > 2) return PP_ERR_BAD_ARG;
+  if (!eps2 || !latents || !coef_table || !step_dev || n <= 0 || kind < 0 || kind > 3) return PP_ERR_BAD_ARG;
   if (kind >= 1 && !m_prev) return PP_ERR_BAD_ARG;
   hipLaunchKernelGGL(cfg_sched_step_kernel, dim3(grid_for_host(n)), dim3(256), 0, (hipStream_t)stream, eps2, cfg,
                      guidance, latents, m_prev, n, kind, coef_table, step_dev);

@@ -272,3 +272,122 @@ class PNDMScheduler(_SchedulerBase):
     def reset(self):
         super().reset()
         self._dup_calls = 0
+
+
+class UniPCMultistepScheduler(_SchedulerBase):
+    """UniPC (arXiv:2302.04867) as diffusers' `UniPCMultistepScheduler` runs it -- the scheduler app.py:197 installs on
+    the ppt-v2 pipeline: predict_x0, solver_type "bh2", solver_order 2 (3 supported), lower_order_final, corrector on
+    every step after the first (minus `disable_corrector`).
+
+    Every step is linear in (sample, eps, last_sample, m1, m2, m3): the host solves the small UniPC systems per step
+    in float64 and uploads one 16-float row; `pp_cfg_sched_step` (kind 3) evaluates
+        x0 = (x - c0 eps) / c1
+        xc = use_corr ? c3 last + c4 m1 + c5 m2 + c6 m3 + c7 x0 : x          (UniC on the previous transition)
+        x' = c8 xc + c9 x0 + c10 m1 + c11 m2                                  (UniP to the next time step)
+        (last, m1, m2, m3) <- (xc, x0, m1, m2)
+    on the state [4][n] kept between steps."""
+    kind = 3
+    state_slots = 4
+
+    def __init__(self, num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, solver_order=2,
+                 solver_type="bh2", lower_order_final=True, disable_corrector=(), timestep_spacing="linspace",
+                 steps_offset=0, predict_x0=True, prediction_type="epsilon", **kw):
+        super().__init__(num_train_timesteps, beta_start, beta_end, solver_order=solver_order, solver_type=solver_type,
+                         lower_order_final=lower_order_final, disable_corrector=list(disable_corrector),
+                         timestep_spacing=timestep_spacing, steps_offset=steps_offset, predict_x0=predict_x0,
+                         prediction_type=prediction_type)
+        if solver_order not in (1, 2, 3) or solver_type not in ("bh1", "bh2") or not predict_x0 or \
+                prediction_type != "epsilon":
+            raise NotImplementedError("UniPC: solver_order 1-3, bh1 / bh2, predict_x0, epsilon prediction")
+
+    @classmethod
+    def from_config(cls, config, **kw):
+        """`UniPCMultistepScheduler.from_config(pipe.scheduler.config)` (app.py:197): the keys this class shares with
+        the donor scheduler's config are taken over (betas, timestep_spacing, steps_offset), the rest keep defaults."""
+        src = dict(config) if isinstance(config, dict) else dict(vars(config))
+        take = ("num_train_timesteps", "beta_start", "beta_end", "timestep_spacing", "steps_offset", "prediction_type")
+        args = {k: src[k] for k in take if k in src}
+        if src.get("solver_order") in (1, 2, 3) and "solver_type" in src and src["solver_type"] in ("bh1", "bh2"):
+            args["solver_order"], args["solver_type"] = src["solver_order"], src["solver_type"]
+        args.update(kw)
+        return cls(**args)
+
+    def _grid(self, N):
+        T, sp = self.config.num_train_timesteps, self.config.timestep_spacing
+        if sp == "linspace":
+            return np.linspace(0, T - 1, N + 1).round()[::-1][:-1].copy().astype(np.int64)
+        if sp == "leading":
+            return (np.arange(0, N + 1) * (T // (N + 1))).round()[::-1][:-1].copy().astype(np.int64) + \
+                self.config.steps_offset
+        if sp == "trailing":
+            return (np.arange(T, 0, -T / N).round() - 1).astype(np.int64)
+        raise ValueError(f"unknown timestep_spacing {sp}")
+
+    def _system(self, order, rks, hh):
+        """b / R of the UniPC conditions and h*phi_1, B(h); float64."""
+        h_phi_1 = np.expm1(hh)
+        h_phi_k = h_phi_1 / hh - 1.0
+        B_h = hh if self.config.solver_type == "bh1" else np.expm1(hh)
+        R, b, fact = [], [], 1.0
+        for i in range(1, order + 1):
+            R.append(rks ** (i - 1))
+            b.append(h_phi_k * fact / B_h)
+            fact *= i + 1
+            h_phi_k = h_phi_k / hh - 1.0 / fact
+        return np.stack(R), np.array(b), h_phi_1, B_h
+
+    def set_timesteps(self, num_inference_steps: int, device=None):
+        N = num_inference_steps
+        self.num_inference_steps = N
+        ts = self._grid(N)
+        sig_all = (((1 - self.alphas_cumprod) / self.alphas_cumprod) ** 0.5).numpy()      # fp32, as the library does
+        sig = np.concatenate([np.interp(ts, np.arange(0, len(sig_all)), sig_all), [sig_all[0]]]).astype(np.float32)
+        self.sigmas = torch.from_numpy(sig)
+        sg = sig.astype(np.float64)                     # the library keeps the grid in fp32; coefficients from it in f64
+        alpha = 1.0 / np.sqrt(sg ** 2 + 1.0)
+        sigma = sg * alpha
+        lam = np.log(alpha) - np.log(sigma)
+        self._ts_host = torch.from_numpy(ts)
+        self.timesteps = self._ts_host.clone()
+        K = self.config.solver_order
+        coef = np.zeros((N, 16), dtype=np.float64)
+        lower, prev_order = 0, 1
+        for i in range(N):
+            c = coef[i]
+            c[0], c[1] = sigma[i], alpha[i]
+            # ---- UniC: re-estimate x_i from x_{i-1} (order = the order the previous predictor ran at)
+            if i > 0 and (i - 1) not in self.config.disable_corrector:
+                order = prev_order
+                h = lam[i] - lam[i - 1]
+                rks = np.array([(lam[i - (k + 1)] - lam[i - 1]) / h for k in range(1, order)] + [1.0])
+                R, b, h_phi_1, B_h = self._system(order, rks, -h)
+                rhos = np.array([0.5]) if order == 1 else np.linalg.solve(R, b)
+                c[2] = 1.0
+                c[3] = sigma[i] / sigma[i - 1]                                   # last_sample
+                m0 = -alpha[i] * h_phi_1 + alpha[i] * B_h * rhos[-1]
+                for k in range(1, order):                                         # D1s_k = (m_{-k} - m0) / rk_k
+                    w = -alpha[i] * B_h * rhos[k - 1] / rks[k - 1]
+                    c[4 + k] = w                                                  # m2 (k = 1), m3 (k = 2)
+                    m0 -= w
+                c[4] = m0                                                         # m1 = x0_{i-1}
+                c[7] = -alpha[i] * B_h * rhos[-1]                                 # x0_i  (D1_t = x0_i - m0)
+            # ---- UniP: x_{i+1} from the corrected x_i
+            order = min(K, N - i) if self.config.lower_order_final else K
+            order = min(order, lower + 1)
+            h = lam[i + 1] - lam[i]
+            rks = np.array([(lam[i - k] - lam[i]) / h for k in range(1, order)] + [1.0])
+            R, b, h_phi_1, B_h = self._system(order, rks, -h)
+            c[8] = sigma[i + 1] / sigma[i]
+            m0 = -alpha[i + 1] * h_phi_1
+            if order > 1:
+                rhos = np.array([0.5]) if order == 2 else np.linalg.solve(R[:-1, :-1], b[:-1])
+                for k in range(1, order):
+                    w = -alpha[i + 1] * B_h * rhos[k - 1] / rks[k - 1]
+                    c[9 + k] = w                                                  # m1 (k = 1), m2 (k = 2): older x0's
+                    m0 -= w
+            c[9] = m0                                                             # x0_i
+            prev_order = order
+            if lower < K:
+                lower += 1
+        self._coef = torch.from_numpy(coef.astype(np.float32))
+        self._upload(device)

@@ -153,13 +153,15 @@ def _v1_inputs(B, h, w, seed=0):
     return lat, mask, mil, pe
 
 
-@pytest.mark.parametrize("kind,N", [("ddim", 4), ("dpm", 5), ("pndm", 6)])
+@pytest.mark.parametrize("kind,N", [("ddim", 4), ("dpm", 5), ("pndm", 6), ("unipc", 5)])
 def test_pipeline_v1_loop(kind, N):
     o, h = make_tiny("unet", in_channels=9)
     B, hh = 2, 16
     lat, mask, mil, pe = _v1_inputs(B, hh, hh)
-    osch = {"ddim": OS.DDIMScheduler, "dpm": OS.DPMSolverMultistepScheduler, "pndm": OS.PNDMScheduler}[kind]()
-    hsch = {"ddim": PS.DDIMScheduler, "dpm": PS.DPMSolverMultistepScheduler, "pndm": PS.PNDMScheduler}[kind]()
+    osch = {"ddim": OS.DDIMScheduler, "dpm": OS.DPMSolverMultistepScheduler, "pndm": OS.PNDMScheduler,
+            "unipc": lambda: OS.UniPCMultistepScheduler(timestep_spacing="leading", steps_offset=1)}[kind]()
+    hsch = {"ddim": PS.DDIMScheduler, "dpm": PS.DPMSolverMultistepScheduler, "pndm": PS.PNDMScheduler,
+            "unipc": lambda: PS.UniPCMultistepScheduler(timestep_spacing="leading", steps_offset=1)}[kind]()
     rec = []
     ref = OL.loop_v1(o, osch, lat, torch.cat([mask] * 2), torch.cat([mil] * 2), pe, N, 7.5,
                      eps_hook=lambda i, t, l, e: rec.append((l.clone(), e.clone())))
@@ -229,6 +231,30 @@ def test_pipeline_v2_brushnet_loop():
                       control_guidance_end=0.5)
     out2 = pipe(control_guidance_end=0.5, **kw)[0]
     close(out2, ref2, "v2 guidance window", cos_min=0.995, rel=0.1)
+
+
+def test_pipeline_v2_brushnet_unipc():
+    """What app.py:197 configures for ppt-v2: BrushNet + UNet under UniPCMultistepScheduler.from_config(<SD-1.5 config>)."""
+    ob, hb = make_tiny("brushnet")
+    ou, hu = make_tiny("unet", seed=1, in_channels=4)
+    B, hh, N = 2, 16, 4
+    lat = gen(B, 4, hh, hh, seed=0)
+    mask = torch.zeros(B, 1, hh, hh); mask[:, :, 4:12, 4:12] = 1.0
+    cl = torch.cat([gen(B, 4, hh, hh, seed=1, scale=0.5), mask], 1)
+    pe, peU = gen(2 * B, 77, 768, seed=2), gen(2 * B, 77, 768, seed=3)
+    donor = dict(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, timestep_spacing="leading",
+                 steps_offset=1, skip_prk_steps=True, set_alpha_to_one=False)
+    hs = PS.UniPCMultistepScheduler.from_config(donor)
+    ref = OL.loop_v2(ou, ob, OS.UniPCMultistepScheduler(timestep_spacing="leading", steps_offset=1), lat,
+                     torch.cat([cl] * 2), pe, peU, N, 7.5, 1.0)
+    pipe = PP.StableDiffusionPowerPaintBrushNetPipeline(unet=hu, brushnet=hb, scheduler=hs)
+    kw = dict(prompt_embeds=pe[B:].to(DEV), negative_prompt_embeds=pe[:B].to(DEV), prompt_embedsU=peU[B:].to(DEV),
+              negative_prompt_embedsU=peU[:B].to(DEV), conditioning_latents=cl.to(DEV), num_inference_steps=N,
+              guidance_scale=7.5, latents=lat.to(DEV), output_type="latent", return_dict=False)
+    out = pipe(**kw)[0]
+    close(out, ref, "v2 UniPC free-running", cos_min=0.995, rel=0.1)
+    pipe.use_graph = False
+    assert torch.equal(out, pipe(**kw)[0])
 
 
 def test_pipeline_controlnet_loop():

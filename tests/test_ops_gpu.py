@@ -471,3 +471,24 @@ def test_pndm_step_kernel_vs_oracle(N):
         xo = o.step(eps[k], t, xo)[0]
         xh = h.step(eps[k].to(DEV), t, xh, return_dict=False)[0]
         check(xh.cpu(), xo, 1e-4 * max(1.0, float(xo.abs().max())), 1e-4, f"pndm evaluation {k}")
+
+
+@pytest.mark.parametrize("K,N,spacing,off", [(2, 10, "leading", 1), (3, 6, "linspace", 0), (1, 3, "trailing", 0)])
+def test_unipc_step_kernel_vs_oracle(K, N, spacing, off):
+    """scheduler.step of the product UniPC (HIP kernel, kind 3: corrector + predictor as one linear form over the
+    [last, m1, m2, m3] state) against the oracle's diffusers-protocol class on the same eps sequence."""
+    from oracle import schedulers as OS
+    from powerpaint_amd import schedulers as PS
+    kw = dict(solver_order=K, timestep_spacing=spacing, steps_offset=off)
+    o, h = OS.UniPCMultistepScheduler(**kw), PS.UniPCMultistepScheduler(**kw)
+    o.set_timesteps(N)
+    h.set_timesteps(N, device=DEV)
+    assert h.timesteps.cpu().tolist() == o.timesteps.tolist()
+    g = torch.Generator("cpu").manual_seed(0)
+    x0 = torch.randn(2, 4, 8, 8, generator=g)
+    eps = [torch.randn(2, 4, 8, 8, generator=g) for _ in range(N)]
+    xo, xh = x0, x0.to(DEV)
+    for k, t in enumerate(o.timesteps):
+        xo = o.step(eps[k], t, xo)[0]
+        xh = h.step(eps[k].to(DEV), t, xh, return_dict=False)[0]
+        check(xh.cpu(), xo, 1e-4 * max(1.0, float(xo.abs().max())), 1e-4, f"unipc step {k}")
