@@ -6,6 +6,7 @@ import torch
 
 from .. import _lib as L
 from ..engine import SDNet
+from ..loaders import PretrainedMixin
 from ..runtime import NetRuntime
 
 SD15_DOWN = ("CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "DownBlock2D")
@@ -19,7 +20,7 @@ class Output(SimpleNamespace):
         return list(self.__dict__.values())[i]
 
 
-class _HipModel:
+class _HipModel(PretrainedMixin):
     """Base: config namespace, parameter loading into the packed device buffer, runtime handle."""
     kind = "unet"
 

@@ -11,6 +11,7 @@ from typing import Dict, Optional
 import torch
 
 from .. import _lib as L
+from ..loaders import PretrainedMixin
 from ..vae import VAENet, VAERuntime
 from ._base import Output
 
@@ -40,7 +41,7 @@ class DiagonalGaussianDistribution:
         return self.mean
 
 
-class AutoencoderKL:
+class AutoencoderKL(PretrainedMixin):
     def __init__(self, in_channels: int = 3, out_channels: int = 3,
                  down_block_types=("DownEncoderBlock2D",) * 4, up_block_types=("UpDecoderBlock2D",) * 4,
                  block_out_channels=(128, 256, 512, 512), layers_per_block: int = 2, act_fn: str = "silu",

@@ -22,6 +22,7 @@ from .. import _lib as L
 from ..clip import CLIPRuntime, CLIPTextNet
 from ..utils.utils import EmbeddingLayerWithFixes
 from ._base import Output
+from ..loaders import PretrainedMixin
 
 
 class _Attn(nn.Module):
@@ -66,7 +67,7 @@ class _TextTransformer(nn.Module):
         self.final_layer_norm = nn.LayerNorm(cfg.hidden_size, eps=cfg.layer_norm_eps)
 
 
-class CLIPTextModel(nn.Module):
+class CLIPTextModel(nn.Module, PretrainedMixin):
     def __init__(self, config=None, device="cuda", **kw):
         super().__init__()
         d = dict(vocab_size=49408, hidden_size=768, intermediate_size=3072, num_hidden_layers=12,

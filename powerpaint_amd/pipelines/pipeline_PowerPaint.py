@@ -10,6 +10,7 @@ import torch
 
 from ._base import PipelineBase, hip_mask_prep, prepare_mask_and_masked_image, randn_tensor
 from ._loop import DenoiseLoop
+from .image_processor import VaeImageProcessor
 
 
 class StableDiffusionInpaintPipeline(PipelineBase):
@@ -18,6 +19,7 @@ class StableDiffusionInpaintPipeline(PipelineBase):
         self.register_modules(vae=vae, text_encoder=text_encoder, tokenizer=tokenizer, unet=unet, scheduler=scheduler,
                               safety_checker=safety_checker, feature_extractor=feature_extractor)
         self.vae_scale_factor = 2 ** (len(vae.config.block_out_channels) - 1) if vae is not None else 8
+        self.image_processor = VaeImageProcessor(vae_scale_factor=self.vae_scale_factor) if vae is not None else None
         self._loop = None
         self.use_graph = True
 

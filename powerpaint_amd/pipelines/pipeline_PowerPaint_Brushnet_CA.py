@@ -12,6 +12,7 @@ import torch
 
 from ._base import PipelineBase, hip_mask_prep, randn_tensor
 from ._loop import DenoiseLoop
+from .image_processor import VaeImageProcessor
 
 
 def retrieve_timesteps(scheduler, num_inference_steps=None, device=None, timesteps=None, **kwargs):
@@ -31,6 +32,7 @@ class StableDiffusionPowerPaintBrushNetPipeline(PipelineBase):
                               safety_checker=safety_checker, feature_extractor=feature_extractor,
                               image_encoder=image_encoder)
         self.vae_scale_factor = 2 ** (len(vae.config.block_out_channels) - 1) if vae is not None else 8
+        self.image_processor = VaeImageProcessor(vae_scale_factor=self.vae_scale_factor) if vae is not None else None
         self._loop = None
         self.use_graph = True
 

@@ -9,6 +9,7 @@ import torch
 
 from ._base import PipelineBase, prepare_mask_and_masked_image, randn_tensor
 from ._loop import DenoiseLoop
+from .image_processor import VaeImageProcessor
 from .pipeline_PowerPaint import StableDiffusionInpaintPipeline
 
 
@@ -17,6 +18,8 @@ class StableDiffusionControlNetInpaintPipeline(StableDiffusionInpaintPipeline):
                  safety_checker=None, feature_extractor=None, requires_safety_checker: bool = False):
         super().__init__(vae, text_encoder, tokenizer, unet, scheduler, safety_checker, feature_extractor)
         self.controlnet = controlnet
+        self.control_image_processor = VaeImageProcessor(vae_scale_factor=self.vae_scale_factor, do_convert_rgb=True,
+                                                         do_normalize=False)
 
     def prepare_control_image(self, image, width, height, batch_size, num_images_per_prompt, device, dtype,
                               do_classifier_free_guidance=False, guess_mode=False):

@@ -300,7 +300,13 @@ def test_pipeline_v1_pixels_in_pixels_out_with_vae():
         m = torch.nn.functional.interpolate(mask, size=(side // 8, side // 8))
         fin = OL.loop_v1(o, OS.DDIMScheduler(), lat, torch.cat([m] * 2), torch.cat([mil] * 2), pe, N, 7.5)
         ref = ov.decode(fin / ov.config.scaling_factor, return_dict=False)[0]
-    close(out, ref, "pixels in -> pixels out", cos_min=0.99, rel=0.15)
+        ref = (ref / 2 + 0.5).clamp(0, 1)                    # image_processor.postprocess(output_type="pt")
+    assert float(out.min()) >= 0.0 and float(out.max()) <= 1.0
+    close(out, ref, "pixels in -> pixels out", cos_min=0.995, rel=0.1)
+    pil = pipe(prompt_embeds=pe[B:].to(DEV), negative_prompt_embeds=pe[:B].to(DEV), image=img, mask=mask,
+               height=side, width=side, num_inference_steps=N, guidance_scale=7.5, latents=lat.to(DEV),
+               generator=torch.Generator("cpu").manual_seed(77)).images
+    assert len(pil) == B and pil[0].size == (side, side)     # default output_type="pil", like the reference
 
 
 def test_pipeline_v1_text_and_pixels_in_pixels_out_all_hip():
