@@ -365,7 +365,7 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) pp_gemm_kernel(const PPGemmArg
 //     moments out / mean-rstd correction in);  2 = GEGLU in registers (+ optional folded LayerNorm);  4 = standard +
 //     GroupNorm statistics of the output (gn_acc).  1 and 2 are PLAIN-only and prefetch their epilogue operands
 //     into LDS.
-template <int BM, int BN, int WM, int WN, int XMODE, int NS, int EPI>
+template <int BM, int BN, int WM, int WN, int XMODE, int NS, int EPI, bool DMAI = false>
 __global__ void __launch_bounds__(WM* WN * 64, ((BM / WM / 16) * (BN / WN / 16) <= 10 ? 4 : 2))
 pp_gemm_kernel_v2(const PPGemmArgs a, const GemmDerived d) {   // 2nd bound = waves / SIMD the register budget must allow
   constexpr bool LNF = EPI == 1 || EPI == 2;
@@ -488,21 +488,22 @@ pp_gemm_kernel_v2(const PPGemmArgs a, const GemmDerived d) {   // 2nd bound = wa
 
   // (always_inline: once this lambda is outlined its by-reference captures force the whole kernel-argument struct into
   //  scratch memory -- 700 B per lane and a 2.7x slower kernel)
-  auto issue = [&](int kt, int stage) __attribute__((always_inline)) {
-    char* xs = smem + stage * STAGE;
-    char* ws = xs + XBYTES;
+  // One tile refill = issue_begin (descriptors, the conv (tap, source) refresh, K walk) + P single-instruction pieces
+  // (XP of the X tile, WP of the W tile), so that the main loop can spread the pieces over its MFMA burst.
+  __amdgpu_buffer_rsrc_t is_rsx, is_rsw;
+  int is_sox = 0, is_sow = 0, is_second = 0;
+  char* is_xs = smem;
+  char* is_ws = smem;
+  auto issue_begin = [&](int kt, int stage) __attribute__((always_inline)) {
+    is_xs = smem + stage * STAGE;
+    is_ws = is_xs + XBYTES;
     const bool live = kt < kt_end;
     const int k0 = kt * 64;
     if (XMODE == PP_X_PLAIN) {
       const bool first = k0 < a.c1;
-      const __amdgpu_buffer_rsrc_t rs = make_rsrc(first ? a.x1 : a.x2, live ? (first ? xbytes1 : xbytes2) : 0u);
-      const int so = (first ? k0 : k0 - a.c1) * 2;
-#pragma unroll
-      for (int i = 0; i < XP; ++i) {
-        const int vo = first ? vx1[i] : vx2[i];   // (local copy: passing the captured array element straight to the
-                                                  //  builtin makes clang drop the HOST stub of this kernel)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(xs + (wave * 8 + i * RPP) * 128), 16, vo, so, 0, 0);
-      }
+      is_rsx = make_rsrc(first ? a.x1 : a.x2, live ? (first ? xbytes1 : xbytes2) : 0u);
+      is_sox = (first ? k0 : k0 - a.c1) * 2;
+      is_second = first ? 0 : 1;
     } else {
       const bool tail = tap >= 9;                          // 1x1 phase over (x3, x4) at the output pixel
       if (live && (retap || cc == 0 || cc == cur_cA)) {    // (tap, source) changed: refresh source + per-lane offsets
@@ -530,24 +531,33 @@ pp_gemm_kernel_v2(const PPGemmArgs a, const GemmDerived d) {   // 2nd bound = wa
         }
         retap = false;
       }
-      const __amdgpu_buffer_rsrc_t rs = make_rsrc(reinterpret_cast<const void*>(cur_src), live ? cur_bytes : 0u);
-      const int so = (cc - cur_c0) * 2;
-#pragma unroll
-      for (int i = 0; i < XP; ++i) {
-        const int vo = vx1[i];
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(xs + (wave * 8 + i * RPP) * 128), 16, vo, so, 0, 0);
-      }
+      is_rsx = make_rsrc(reinterpret_cast<const void*>(cur_src), live ? cur_bytes : 0u);
+      is_sox = (cc - cur_c0) * 2;
       if (live) {
         cc += 64;
         if (!tail && cc == ctot) { cc = 0; ++tap; retap = true; }
       }
     }
-    const __amdgpu_buffer_rsrc_t rsw = make_rsrc(a.w, live ? wbytes : 0u);
-#pragma unroll
-    for (int i = 0; i < WP; ++i) {
-      const int vo = vw[i], lo = wlds[i];
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr_t)(ws + lo), 16, vo, k0 * 2, 0, 0);
+    is_rsw = make_rsrc(a.w, live ? wbytes : 0u);
+    is_sow = k0 * 2;
+  };
+  auto issue_piece = [&](int i) __attribute__((always_inline)) {      // i is a compile-time constant at every call site
+    if (i < XP) {
+      // (local copy: passing the captured array element straight to the builtin makes clang drop the HOST stub)
+      const int ii = i < XP ? i : 0;
+      const int vo = (XMODE == PP_X_PLAIN && is_second) ? vx2[ii] : vx1[ii];
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(is_rsx, (lds_ptr_t)(is_xs + (wave * 8 + ii * RPP) * 128), 16, vo, is_sox,
+                                               0, 0);
+    } else {
+      const int j = i - XP < WP ? i - XP : 0;
+      const int vo = vw[j], lo = wlds[j];
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(is_rsw, (lds_ptr_t)(is_ws + lo), 16, vo, is_sow, 0, 0);
     }
+  };
+  auto issue = [&](int kt, int stage) __attribute__((always_inline)) {
+    issue_begin(kt, stage);
+#pragma unroll
+    for (int i = 0; i < P; ++i) issue_piece(i);
   };
 
   f32x4_t acc[NI][MI];
@@ -593,7 +603,8 @@ pp_gemm_kernel_v2(const PPGemmArgs a, const GemmDerived d) {   // 2nd bound = wa
     asm volatile("s_barrier" ::: "memory");                               // everyone's have; everyone left tile t-1
     int nstage = stage + (NS - 1);
     if (nstage >= NS) nstage -= NS;
-    issue((dbg & 1) ? kt_end : kt_begin + t + NS - 1, nstage);            // refill the stage consumed last iteration
+    if constexpr (DMAI) issue_begin(kt_begin + t + NS - 1, nstage);       // the P DMA pieces ride inside the MFMA burst
+    else issue((dbg & 1) ? kt_end : kt_begin + t + NS - 1, nstage);       // refill the stage consumed last iteration
 
     const char* xs = smem + stage * STAGE;
     const char* ws = xs + XBYTES;
@@ -613,13 +624,37 @@ pp_gemm_kernel_v2(const PPGemmArgs a, const GemmDerived d) {   // 2nd bound = wa
       }
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_setprio(1);      // co-resident waves in their load / epilogue phase yield the issue slots
+      if constexpr (DMAI) {
+        // All waves of the block leave the barrier together; when each then fires its P DMA instructions back to back,
+        // 8 x P of them queue on the CU's one texture-address unit (~16 cycles per wave-wide 16-byte load) and every
+        // wave sits in VMEM issue for up to ~900 cycles before its first MFMA.  Spread over the burst -- one piece
+        // every `per` MFMAs -- the address unit keeps its pace and the matrix pipe starts right after the barrier.
+        constexpr int NM = 2 * MI * NI, per = NM / P > 0 ? NM / P : 1;
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
+          for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-          for (int mi = 0; mi < MI; ++mi)
-            acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][ni], xf[ks][mi], acc[ni][mi], 0, 0, 0);
+            for (int mi = 0; mi < MI; ++mi) {
+              acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][ni], xf[ks][mi], acc[ni][mi], 0, 0, 0);
+              const int idx = (ks * NI + ni) * MI + mi + 1;
+              if (idx % per == 0 && idx / per <= P) {
+                __builtin_amdgcn_sched_barrier(0);
+                issue_piece(idx / per - 1);
+                __builtin_amdgcn_sched_barrier(0);
+              }
+            }
+#pragma unroll
+        for (int i = NM / per; i < P; ++i) issue_piece(i);
+      } else {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+              acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][ni], xf[ks][mi], acc[ni][mi], 0, 0, 0);
+      }
       __builtin_amdgcn_s_setprio(0);
     }
     stage = stage + 1 == NS ? 0 : stage + 1;
@@ -1143,6 +1178,15 @@ int launch(const PPGemmArgs& a, int splitk, hipStream_t st) {
   return PP_OK;
 }
 
+// PP_GEMM_DMAI=0|1: tile refills as one DMA burst after the barrier (0) or spread over the MFMA burst (1, default)
+bool gemm_dma_interleave() {
+  static const int v = [] {
+    const char* e = getenv("PP_GEMM_DMAI");
+    return e ? atoi(e) : 1;
+  }();
+  return v != 0;
+}
+
 template <int BM, int BN, int WM, int WN, int XMODE, int NS, int EPI = 0>
 int launch2(const PPGemmArgs& a, int splitk, hipStream_t st) {
   if constexpr (EPI == 0) {
@@ -1160,7 +1204,11 @@ int launch2(const PPGemmArgs& a, int splitk, hipStream_t st) {
     return launch2<BM, BN, WM, WN, XMODE, 2, EPI>(a, splitk, st);
   } else {
   static bool attr_set = false;
-  auto kern = pp_gemm_kernel_v2<BM, BN, WM, WN, XMODE, NS, EPI>;
+  // (2-stage pipelines need their single in-flight refill as early as possible: the spread costs them time)
+  auto kern = pp_gemm_kernel_v2<BM, BN, WM, WN, XMODE, NS, EPI, false>;
+  if constexpr (NS >= 3) {
+    if (gemm_dma_interleave()) kern = pp_gemm_kernel_v2<BM, BN, WM, WN, XMODE, NS, EPI, true>;
+  }
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) !=
         hipSuccess) {

@@ -41,12 +41,13 @@ def run(M, N, K, tile, sk, dbg, res=True, iters=20):
     return e0.elapsed_time(e1) / iters * 1e3
 
 
-names = {0: "full", 4: "no-epi", 5: "no-epi,no-refill", 6: "no-epi,no-mfma", 7: "nothing(loop only)", 1: "no-refill", 2: "no-mfma"}
-for (M, N, K) in [(2048, 1280, 1280), (512, 1280, 1280), (32768, 320, 320), (32768, 2560, 320), (8192, 640, 640),
-                  (2048, 1280, 11520), (32768, 320, 2880)]:
-    for tile in (21, 22, 42, 23):
-        line = f"M={M:6d} N={N:5d} K={K:6d} tile={tile:3d}: "
-        for dbg in (0, 4, 5, 6, 7):
-            t = run(M, N, K, tile, 1, dbg)
-            line += f"{names[dbg]}={t:7.1f}  "
-        print(line, flush=True)
+if __name__ == "__main__":
+    names = {0: "full", 4: "no-epi", 5: "no-epi,no-refill", 6: "no-epi,no-mfma", 7: "nothing(loop only)", 1: "no-refill", 2: "no-mfma"}
+    for (M, N, K) in [(2048, 1280, 1280), (512, 1280, 1280), (32768, 320, 320), (32768, 2560, 320), (8192, 640, 640),
+                      (2048, 1280, 11520), (32768, 320, 2880)]:
+        for tile in (21, 22, 42, 23):
+            line = f"M={M:6d} N={N:5d} K={K:6d} tile={tile:3d}: "
+            for dbg in (0, 4, 5, 6, 7):
+                t = run(M, N, K, tile, 1, dbg)
+                line += f"{names[dbg]}={t:7.1f}  "
+            print(line, flush=True)
