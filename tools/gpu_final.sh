@@ -14,3 +14,4 @@ timeout 600 python bench.py --config controlnet --steps 2 --warmup 1 --no-cpu-ba
 (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d /root/repo/$O/prof -o r -- python /root/repo/bench.py --steps 1 --warmup 1 --no-cpu-baseline > /root/repo/$O/prof.log 2>&1; echo "prof rc=$?")
 python tools/prof_summary.py $(find $O/prof -name "*.db" | head -1) $O/kernel_stats.txt "bench.py --steps 1 --warmup 1" > /dev/null 2>&1; rm -rf $O/prof; head -25 $O/kernel_stats.txt
 timeout 300 python tools/plan_ablate.py > $O/plan_ablate.txt 2>&1; tail -14 $O/plan_ablate.txt
+timeout 200 python tools/vae_time.py > $O/vae_time.txt 2>&1; tail -5 $O/vae_time.txt

@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""Wall time of AutoencoderKL decode / encode on the HIP path (synthetic weights).  python tools/vae_time.py [--batch 4] [--latent 64]"""
+"""Wall time of the stages either side of the loop on the HIP path (synthetic weights): AutoencoderKL decode / encode
+and the CLIP text tower.    python tools/vae_time.py [--batch 4] [--latent 64]"""
 import argparse
 import os
 import sys
@@ -8,7 +9,7 @@ import time
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from powerpaint_amd.models import AutoencoderKL  # noqa: E402
+from powerpaint_amd.models import AutoencoderKL, CLIPTextModel  # noqa: E402
 
 
 def main():
@@ -36,6 +37,17 @@ def main():
         per = rt.plan.run_timed(torch.cuda.current_stream())
         top = sorted(per.items(), key=lambda kv: -kv[1])[:6]
         print("   per kernel family (ms, eager): " + ", ".join(f"{k} {v:.2f}" for k, v in top), flush=True)
+    enc = CLIPTextModel(device="cuda")
+    ids = torch.randint(0, 49406, (args.batch, 77), device="cuda")
+    enc(ids)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.iters):
+        enc(ids)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / args.iters * 1e3
+    print(f"clip text tower: {ms:8.2f} ms / {args.batch} prompts of 77 tokens   {len(enc._rt.plan.calls)} launches "
+          f"(eager, incl. the host-side splice plan)", flush=True)
 
 
 if __name__ == "__main__":
