@@ -257,6 +257,44 @@ def test_pipeline_v2_brushnet_unipc():
     assert torch.equal(out, pipe(**kw)[0])
 
 
+def test_pipeline_v2_pil_in_pil_out_with_vae():
+    """ppt-v2 entry as app.py drives it: PIL image (already masked) + PIL mask -> image_processor.preprocess ->
+    VAE encode -> conditioning latents (pipeline_PowerPaint_Brushnet_CA.py:1305-1345) -> BrushNet + UNet loop ->
+    VAE decode -> PIL.  Checked against the same run fed with the conditioning latents built by hand."""
+    import numpy as np
+    import PIL.Image
+    _, hb = make_tiny("brushnet")
+    _, hu = make_tiny("unet", seed=1, in_channels=4)
+    vae = PM.AutoencoderKL(device=DEV, block_out_channels=(64, 128, 256, 256), layers_per_block=1)
+    vae.load_state_dict(vae.net.synthetic_state_dict(seed=23))
+    pipe = PP.StableDiffusionPowerPaintBrushNetPipeline(vae=vae, unet=hu, brushnet=hb,
+                                                        scheduler=PS.UniPCMultistepScheduler(timestep_spacing="leading",
+                                                                                             steps_offset=1))
+    side, N, B = 128, 3, 1
+    rng = np.random.default_rng(0)
+    m = np.zeros((side, side, 3), dtype=np.uint8)
+    m[24:100, 40:110] = 255
+    arr = rng.integers(0, 256, size=(side, side, 3), dtype=np.uint8) * (m == 0)          # app.py:339-342 masks the image
+    img, mask = PIL.Image.fromarray(arr.astype(np.uint8)), PIL.Image.fromarray(m)
+    pe, peU = gen(2 * B, 77, 768, seed=2), gen(2 * B, 77, 768, seed=3)
+    lat = gen(B, 4, side // 8, side // 8, seed=0)
+    kw = dict(prompt_embeds=pe[B:].to(DEV), negative_prompt_embeds=pe[:B].to(DEV), prompt_embedsU=peU[B:].to(DEV),
+              negative_prompt_embedsU=peU[:B].to(DEV), num_inference_steps=N, guidance_scale=7.5, latents=lat.to(DEV),
+              brushnet_conditioning_scale=1.0)
+    torch.manual_seed(11)
+    out = pipe(image=img, mask=mask, width=side, height=side, **kw).images
+    assert len(out) == 1 and out[0].size == (side, side)
+    ip = pipe.image_processor
+    it, mt = ip.preprocess(img, height=side, width=side).to(DEV), ip.preprocess(mask, height=side, width=side).to(DEV)
+    keep = (mt.sum(1, keepdim=True) < 0).float()                                          # :1312 original_mask
+    torch.manual_seed(11)
+    cl = vae.encode(it).latent_dist.sample() * vae.config.scaling_factor
+    ml = torch.nn.functional.interpolate(keep, size=cl.shape[-2:])
+    again = pipe(conditioning_latents=torch.cat([cl, ml], 1), **kw).images
+    assert np.array_equal(np.array(out[0]), np.array(again[0]))
+    assert np.array(out[0]).std() > 1.0
+
+
 def test_pipeline_controlnet_loop():
     oc, hc = make_tiny("controlnet")
     ou, hu = make_tiny("unet", seed=1, in_channels=9)
