@@ -26,6 +26,8 @@ class NetRuntime:
         self.outputs: Dict[str, object] = {}
         self._ctx_id = None
         self._cond_id = None
+        self._ctx_keep = None
+        self._cond_keep = None
         self.graph = None
         self.lib = L.lib()
         self.gemm_tile = 0
@@ -127,6 +129,7 @@ class NetRuntime:
             self._patch_scale(scale)
         self._ctx_id = None
         self._cond_id = None
+        self._ctx_keep = self._cond_keep = None
         self.graph = None
         self.B, self.H, self.W, self.nctx = B, H, W, nctx
 
@@ -157,6 +160,8 @@ class NetRuntime:
         if self.net.kind != "controlnet" or self._cond_id is not None:
             self.setup_plan.run(_stream())
         self._ctx_id = ident
+        self._ctx_keep = ehs      # the identity is only an identity while the tensor lives: a freed temporary's address
+        #                           (and version 0) is handed to the next temporary by the caching allocator
 
     def set_cond(self, cond: torch.Tensor):
         """ControlNet conditioning image [B,3,8H,8W] (NCHW, any float dtype)."""
@@ -166,6 +171,7 @@ class NetRuntime:
         c = self.lay["cond"]
         self.load_nchw(cond, c.ptr, c.C, 0, c.H * c.W)
         self._cond_id = ident
+        self._cond_keep = cond    # (same reason as _ctx_keep)
         if self._ctx_id is not None:
             self.setup_plan.run(_stream())
 
