@@ -51,6 +51,33 @@ def broadcast_params(buffers: List[torch.Tensor], src: int = 0):
         dist.broadcast(b, src=src)
 
 
+def broadcast_models(models, src: int = 0):
+    """Start-up weight broadcast for any mix of the networks: the packed-buffer models (UNet / BrushNet / ControlNet /
+    AutoencoderKL: one collective each, their `param_buffer()`), and nn.Modules (CLIPTextModel: parameters and buffers
+    flattened into one contiguous tensor per dtype, broadcast, scattered back -- a handful of collectives instead of
+    one per tensor).  Ranks other than `src` only need the same architecture; their values are overwritten."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return
+    for m in models:
+        if hasattr(m, "param_buffer"):
+            dist.broadcast(m.param_buffer(), src=src)
+            continue
+        if not isinstance(m, torch.nn.Module):
+            raise TypeError(f"cannot broadcast {type(m).__name__}: neither param_buffer() nor an nn.Module")
+        by_dtype = {}
+        for t in list(m.parameters()) + list(m.buffers()):
+            by_dtype.setdefault((t.dtype, t.device), []).append(t)
+        for ts in by_dtype.values():
+            flat = torch.cat([t.detach().reshape(-1) for t in ts])
+            dist.broadcast(flat, src=src)
+            off = 0
+            with torch.no_grad():
+                for t in ts:
+                    n = t.numel()
+                    t.copy_(flat[off:off + n].view_as(t))
+                    off += n
+
+
 def gather_latents(local: torch.Tensor, global_batch: int) -> Optional[torch.Tensor]:
     """All-gather the per-rank final latents into global image order (equal shards required)."""
     if not dist.is_initialized() or dist.get_world_size() == 1:

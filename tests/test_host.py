@@ -163,6 +163,15 @@ def _worker(rank, world, port, q):
         assert int(net.params.buf.count_nonzero()) == 0
     ppdist.broadcast_params([net.params.buf], src=0)                   # the one collective of the path
     chk = float(net.params.buf.view(torch.int16).double().sum())
+    # the other networks of a pipeline: packed VAE buffer + the CLIP tower (an nn.Module, flattened per dtype)
+    from powerpaint_amd.models import AutoencoderKL, CLIPTextModel
+    vae = AutoencoderKL(device="cpu", block_out_channels=(64, 64, 64, 64), layers_per_block=1)
+    vae.load_state_dict(vae.net.synthetic_state_dict(seed=5 + r))        # different values per rank before the broadcast
+    torch.manual_seed(100 + r)
+    enc = CLIPTextModel(device="cpu", vocab_size=64, num_hidden_layers=1)
+    ppdist.broadcast_models([vae, enc], src=0)
+    chk += float(vae.param_buffer().view(torch.int16).double().sum())
+    chk += float(sum(p.double().sum() for p in enc.parameters()))
     # image shards: rank-count-invariant inputs, gather back in global order
     idx = list(ppdist.shard_range(4, r, w))
     local = torch.stack([torch.randn(4, 2, 2, generator=ppdist.image_generator(i)) for i in idx])
