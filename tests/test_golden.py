@@ -76,3 +76,28 @@ def test_hip_path_reproduces_reference_outputs():
     out = h4(inp["x4"].to(dev), inp["t"], inp["ehs"].to(dev), down_block_add_samples=dn, mid_block_add_sample=md,
              up_block_add_samples=up, return_dict=False)[0]
     close(out, GOLD["eps4_brush"], "eps4 + brushnet residuals")
+
+
+@pytest.mark.gpu
+def test_mask_prep_matches_reference_function():
+    """Row a20: `prepare_mask_and_masked_image` (binarise + mask the image in the HIP kernel) against the reference's
+    own function (tests/golden/ref_mask_prep.json, lifted out of pipeline_PowerPaint.py:39-153 by AST): bit-exact mask,
+    masked image and image for PIL, ndarray and tensor inputs."""
+    import hashlib
+    import json
+    import numpy as np
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    from make_ref_mask_prep import inputs
+    from powerpaint_amd.pipelines._base import prepare_mask_and_masked_image
+
+    def sha(t):
+        a = np.ascontiguousarray(t.detach().cpu().numpy().astype(np.float32))
+        return dict(shape=list(a.shape), sha=hashlib.sha256(a.tobytes()).hexdigest())
+
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_mask_prep.json")) as f:
+        G = json.load(f)
+    for c in G["cases"]:
+        img, msk = inputs(c["kind"], c["seed"], c["h"], c["w"], c["batch"])
+        m, mi, im = prepare_mask_and_masked_image(img, msk, c["h"], c["w"], "cuda", return_image=True)
+        assert m.is_cuda and sha(m) == c["mask"] and int(m.sum()) == c["ones"], c["kind"]
+        assert sha(mi) == c["masked"] and sha(im) == c["image"], c["kind"]
