@@ -217,3 +217,54 @@ def test_two_rank_broadcast_and_sharding_gloo():
     ref = torch.stack([torch.randn(4, 2, 2, generator=ppdist.image_generator(i)) for i in range(4)])
     assert torch.equal(res[0][2], ref) and torch.equal(res[1][2], ref)  # global order, independent of rank count
     assert res[0][3] == res[1][3] == 2.0
+
+
+def test_encode_prompt_matches_reference_method():
+    """Row a21 (blend) / a18 (CFG batch order): `PipelineBase._encode_prompt` against the reference's own
+    `StableDiffusionInpaintPipeline._encode_prompt` (tests/golden/ref_encode_prompt.pt, lifted out of
+    pipeline_PowerPaint.py:317-518 by AST).  Host logic over a torch text encoder: runs on CPU, compared exactly."""
+    import json
+    transformers = pytest.importorskip("transformers")
+    from powerpaint_amd.pipelines._base import PipelineBase
+    here = os.path.dirname(os.path.abspath(__file__))
+    G = torch.load(os.path.join(here, "golden", "ref_encode_prompt.pt"), weights_only=False)
+    with open(os.path.join(here, "golden", "ref_task_tokens.json")) as f:
+        T = json.load(f)
+    tok = transformers.CLIPTokenizer(vocab={t: i for i, t in enumerate(T["vocab"])},
+                                     merges=[tuple(m) for m in T["merges"]], model_max_length=77)
+    n = G["vocab_size"]
+    enc = transformers.CLIPTextModel(transformers.CLIPTextConfig(vocab_size=n, bos_token_id=n - 2, eos_token_id=n - 1,
+                                                                 pad_token_id=n - 1, **G["cfg"])).eval()
+    enc.load_state_dict(G["state_dict"])
+    pipe = PipelineBase()
+    pipe.register_modules(tokenizer=tok, text_encoder=enc)
+    dev = torch.device("cpu")
+    with torch.no_grad():
+        for c, want in zip(G["cases"], G["outs"]):
+            got = pipe._encode_prompt(c["promptA"], c["promptB"], c["t"], dev, c["n"], c["cfg"],
+                                      negative_promptA=c["nA"], negative_promptB=c["nB"], t_nag=c["tn"])
+            assert got.shape == want.shape and torch.equal(got, want), c
+        got = pipe._encode_prompt(None, None, 0.5, dev, 2, True, t_nag=0.5, prompt_embeds=G["pe"],
+                                  negative_prompt_embeds=G["ne"])
+        assert torch.equal(got, G["outs"][-1])
+
+
+def test_check_inputs_error_behaviour_matches_reference():
+    """Same inputs rejected, same exception type, as the reference's `check_inputs` (pipeline_PowerPaint.py:553-602;
+    tests/golden/ref_check_inputs.json holds its verdict on 1728 argument combinations)."""
+    import json
+    from powerpaint_amd.pipelines import StableDiffusionInpaintPipeline
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_check_inputs.json")) as f:
+        rows = json.load(f)
+    pipe = StableDiffusionInpaintPipeline()
+    emb = {"E": torch.zeros(1, 77, 8), "E2": torch.zeros(2, 77, 8), None: None}
+    n_ok = 0
+    for p, h, w, s, cb, ng, pe, ne, want in rows:
+        try:
+            pipe.check_inputs(p, h, w, s, cb, ng, emb[pe], emb[ne])
+            got = "ok"
+        except Exception as e:
+            got = type(e).__name__
+        assert got == want, (p, h, w, s, cb, ng, pe, ne, got, want)
+        n_ok += got == "ok"
+    assert 0 < n_ok < len(rows)
