@@ -66,9 +66,25 @@ def main():
             torch.randn(2, 77, 32, generator=torch.Generator().manual_seed(2))
         outs.append(ref(me, None, None, 0.5, torch.device("cpu"), 2, True, None, None, 0.5, prompt_embeds=pe,
                         negative_prompt_embeds=ne).clone())
-    torch.save(dict(cfg=CFG, vocab_size=n, state_dict=enc.state_dict(), cases=CASES, outs=outs, pe=pe, ne=ne),
-               os.path.join(HERE, "ref_encode_prompt.pt"))
-    print([tuple(o.shape) for o in outs])
+    # the plain (promptU) encoder of the BrushNet pipeline: pipeline_PowerPaint_Brushnet_CA.py:442-629
+    tree2 = ast.parse(open(REF.replace("pipeline_PowerPaint.py", "pipeline_PowerPaint_Brushnet_CA.py")).read())
+    cls2 = [n for n in tree2.body if isinstance(n, ast.ClassDef) and n.name == "StableDiffusionPowerPaintBrushNetPipeline"][0]
+    fn2 = [n for n in cls2.body if isinstance(n, ast.FunctionDef) and n.name == "encode_prompt"][0]
+    ns2 = dict(ns, USE_PEFT_BACKEND=False, adjust_lora_scale_text_encoder=lambda *a, **k: None,
+               scale_lora_layers=lambda *a, **k: None, unscale_lora_layers=lambda *a, **k: None)
+    exec(compile(ast.Module(body=[fn2], type_ignores=[]), "pipeline_PowerPaint_Brushnet_CA.py", "exec"), ns2)
+    ref2 = ns2["encode_prompt"]
+    U_CASES = [dict(prompt="the cat and the dog", n=1, neg="blur"), dict(prompt="the empty scene", n=2, neg=None),
+               dict(prompt=["the cat", "the dog"], n=1, neg=["blur", "the scene"]),
+               dict(prompt=["the cat", "blur"], n=3, neg=None)]
+    outs_u = []
+    with torch.no_grad():
+        for c in U_CASES:
+            outs_u.append(ref2(me, c["prompt"], torch.device("cpu"), c["n"], True, c["neg"]).clone())
+        outs_u.append(ref2(me, None, torch.device("cpu"), 2, True, None, prompt_embeds=pe, negative_prompt_embeds=ne).clone())
+    torch.save(dict(cfg=CFG, vocab_size=n, state_dict=enc.state_dict(), cases=CASES, outs=outs, pe=pe, ne=ne,
+                    u_cases=U_CASES, outs_u=outs_u), os.path.join(HERE, "ref_encode_prompt.pt"))
+    print([tuple(o.shape) for o in outs], [tuple(o.shape) for o in outs_u])
 
 
 if __name__ == "__main__":
