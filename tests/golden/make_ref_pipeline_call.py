@@ -1,0 +1,83 @@
+#!/usr/bin/env python
+"""Generate tests/golden/ref_pipeline_call.pt: final latents of the REFERENCE'S OWN
+`StableDiffusionInpaintPipeline.__call__` (pipeline_PowerPaint.py:723-1071, run through oracle/ref_pipeline.py) for a
+prompt-in / pixels-in call: promptA / promptB blend, image + mask tensors, VAE encode of the masked image, 9-channel
+UNet, CFG 7.5, DDIM.  Components are seeded stand-ins shared with the tests (`components()`): the oracle's reduced SD-1.5
+UNet and VAE (bf16-rounded matrix weights) and a one-layer transformers CLIP text encoder over the small vocabulary."""
+import json
+import os
+import sys
+
+import torch
+import transformers
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+from oracle import schedulers as OS, sd_modules as OM, vae as OV  # noqa: E402
+
+TINY = dict(block_out_channels=(320, 640), layers_per_block=1,
+            down_block_types=("CrossAttnDownBlock2D", "DownBlock2D"), up_block_types=("UpBlock2D", "CrossAttnUpBlock2D"))
+VAE_CFG = dict(block_out_channels=(64, 128, 256, 256), layers_per_block=1)
+CALL = dict(promptA="the cat and the dog", promptB="the empty scene", tradoff=0.4, tradoff_nag=0.6,
+            negative_promptA="blur", negative_promptB="the scene", height=128, width=128, num_inference_steps=3,
+            guidance_scale=7.5)
+
+
+def bf16_(m):
+    with torch.no_grad():
+        for p in m.parameters():
+            if p.dim() >= 2:
+                p.copy_(p.to(torch.bfloat16).float())
+    return m
+
+
+def components():
+    with open(os.path.join(HERE, "ref_task_tokens.json")) as f:
+        G = json.load(f)
+    tok = transformers.CLIPTokenizer(vocab={t: i for i, t in enumerate(G["vocab"])},
+                                     merges=[tuple(m) for m in G["merges"]], model_max_length=77)
+    n = len(tok)
+    torch.manual_seed(31)
+    enc = transformers.CLIPTextModel(transformers.CLIPTextConfig(
+        vocab_size=n, hidden_size=768, intermediate_size=3072, num_hidden_layers=1, num_attention_heads=12,
+        max_position_embeddings=77, hidden_act="quick_gelu", bos_token_id=n - 2, eos_token_id=n - 1,
+        pad_token_id=n - 1)).eval()
+    with torch.no_grad():
+        for p in enc.parameters():
+            if p.dim() >= 2:
+                p.mul_(3.0)
+    bf16_(enc)
+    torch.manual_seed(32)
+    unet = bf16_(OM.UNet2DConditionModel(in_channels=9, **TINY)).eval()
+    torch.manual_seed(33)
+    vae = bf16_(OV.AutoencoderKL(**VAE_CFG)).eval()
+    return tok, enc, unet, vae
+
+
+def inputs():
+    g = torch.Generator().manual_seed(41)
+    img = torch.rand(1, 3, 128, 128, generator=g) * 2 - 1
+    mask = torch.zeros(1, 1, 128, 128)
+    mask[:, :, 30:100, 20:90] = 1.0
+    lat = torch.randn(1, 4, 16, 16, generator=g)
+    return img, mask, lat
+
+
+def main():
+    from oracle import ref_pipeline
+    Pipe, _ = ref_pipeline.load_reference_pipeline_class()
+    tok, enc, unet, vae = components()
+    pipe = Pipe(vae=vae, text_encoder=enc, tokenizer=tok, unet=unet, scheduler=OS.DDIMScheduler(), safety_checker=None,
+                feature_extractor=None, requires_safety_checker=False)
+    img, mask, lat = inputs()
+    seen = []
+    with torch.no_grad():
+        out = pipe(image=img, mask=mask, latents=lat.clone(), generator=torch.Generator().manual_seed(5),
+                   output_type="latent", return_dict=False, callback=lambda i, t, l: seen.append((i, int(t), l.clone())),
+                   **CALL)[0]
+    torch.save(dict(latents=out, steps=seen), os.path.join(HERE, "ref_pipeline_call.pt"))
+    print(out.shape, float(out.abs().max()), [s[:2] for s in seen])
+
+
+if __name__ == "__main__":
+    main()

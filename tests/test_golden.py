@@ -101,3 +101,60 @@ def test_mask_prep_matches_reference_function():
         m, mi, im = prepare_mask_and_masked_image(img, msk, c["h"], c["w"], "cuda", return_image=True)
         assert m.is_cuda and sha(m) == c["mask"] and int(m.sum()) == c["ones"], c["kind"]
         assert sha(mi) == c["masked"] and sha(im) == c["image"], c["kind"]
+
+
+def _ref_call_fixture():
+    import make_ref_pipeline_call as M
+    gold = torch.load(os.path.join(HERE, "golden", "ref_pipeline_call.pt"), weights_only=False)
+    return M, gold
+
+
+def test_oracle_loop_reproduces_the_reference_call():
+    """Rows a1 / a18 / a19: the oracle's restated loop (oracle/loops.py), fed by the oracle VAE and the transformers
+    text encoder, against the final and per-step latents of the reference's OWN `StableDiffusionInpaintPipeline.__call__`
+    (tests/golden/ref_pipeline_call.pt, produced through oracle/ref_pipeline.py) -- fp32 on CPU, same operation order."""
+    from oracle import loops as OL, schedulers as OS
+    M, gold = _ref_call_fixture()
+    tok, enc, unet, vae = M.components()
+    img, mask, lat = M.inputs()
+    c = M.CALL
+
+    def emb(p):
+        ids = tok(p, padding="max_length", max_length=77, truncation=True, return_tensors="pt").input_ids
+        return enc(ids)[0]
+
+    with torch.no_grad():
+        pos = emb(c["promptA"]) * c["tradoff"] + (1 - c["tradoff"]) * emb(c["promptB"])
+        neg = emb(c["negative_promptA"]) * c["tradoff_nag"] + (1 - c["tradoff_nag"]) * emb(c["negative_promptB"])
+        mil = vae.encode(img * (mask < 0.5)).latent_dist.sample(torch.Generator().manual_seed(5)) * vae.config.scaling_factor
+        m = torch.nn.functional.interpolate(mask, size=(16, 16))
+        rec = []
+        out = OL.loop_v1(unet, OS.DDIMScheduler(), lat, torch.cat([m] * 2), torch.cat([mil] * 2), torch.cat([neg, pos]),
+                         c["num_inference_steps"], c["guidance_scale"],
+                         eps_hook=lambda i, t, l, e: rec.append((i, int(t), l.clone())))
+    assert [r[:2] for r in rec] == [s[:2] for s in gold["steps"]]
+    for (i, t, l_in), (_, _, l_prev) in zip(rec[1:], gold["steps"][:-1]):      # latents entering step i = leaving step i-1
+        assert torch.allclose(l_in, l_prev, atol=1e-4, rtol=1e-4), i
+    assert torch.allclose(out, gold["latents"], atol=1e-4, rtol=1e-4)
+
+
+@pytest.mark.gpu
+def test_hip_pipeline_reproduces_the_reference_call():
+    """The product (HIP UNet / VAE / CLIP tower, fused DDIM + CFG loop) on the call the reference's own `__call__` was
+    frozen on: strings and pixels in, latents out, bf16 against fp32."""
+    from powerpaint_amd import models as PM, pipelines as PP, schedulers as PS
+    M, gold = _ref_call_fixture()
+    tok, enc, unet, vae = M.components()
+    img, mask, lat = M.inputs()
+    hu = PM.UNet2DConditionModel(in_channels=9, device="cuda", **M.TINY).load_state_dict(unet.state_dict())
+    hv = PM.AutoencoderKL(device="cuda", **M.VAE_CFG).load_state_dict(vae.state_dict())
+    he = PM.CLIPTextModel(device="cuda", vocab_size=enc.config.vocab_size, num_hidden_layers=1,
+                          eos_token_id=enc.config.eos_token_id)
+    he.load_state_dict(enc.state_dict())
+    pipe = PP.StableDiffusionInpaintPipeline(vae=hv, text_encoder=he, tokenizer=tok, unet=hu, scheduler=PS.DDIMScheduler())
+    out = pipe(image=img, mask=mask, latents=lat.cuda(), generator=torch.Generator().manual_seed(5), output_type="latent",
+               return_dict=False, **M.CALL)[0]
+    want = gold["latents"]
+    cos = torch.nn.functional.cosine_similarity(out.float().cpu().flatten(), want.flatten(), dim=0).item()
+    err = (out.float().cpu() - want).abs().max().item()
+    assert cos >= 0.995 and err <= 0.1 * max(1.0, want.abs().max().item()), (cos, err)
