@@ -62,6 +62,12 @@ class _PassThroughImageProcessor:
     def __init__(self, vae_scale_factor=8, **kw):
         self.vae_scale_factor = vae_scale_factor
 
+    def preprocess(self, image, height=None, width=None):
+        """Tensor inputs only (already [B, C, H, W] in [-1, 1]): what diffusers' preprocess does to them is nothing."""
+        if not torch.is_tensor(image) or image.ndim != 4:
+            raise NotImplementedError("the harness feeds [B, C, H, W] tensors")
+        return image
+
     def postprocess(self, image, output_type="latent", do_denormalize=None):
         if output_type != "latent":
             raise NotImplementedError("the harness freezes latents; decode with the oracle VAE separately")
@@ -98,3 +104,36 @@ def load_reference_pipeline_class():
         ns[name] = dummy(name)
     exec(compile(mod, REF, "exec"), ns)
     return ns["StableDiffusionInpaintPipeline"], ns["prepare_mask_and_masked_image"]
+
+
+REF_V2 = "/root/reference/powerpaint/pipelines/pipeline_PowerPaint_Brushnet_CA.py"
+
+
+def load_reference_brushnet_pipeline_class(brushnet_cls):
+    """`StableDiffusionPowerPaintBrushNetPipeline` (pipeline_PowerPaint_Brushnet_CA.py) the same way; `brushnet_cls` is
+    the class the file's `isinstance(brushnet, BrushNetModel)` checks must recognise (the oracle's BrushNetModel)."""
+    tree = ast.parse(open(REF_V2).read())
+    fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "retrieve_timesteps"][0]
+    cls = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "StableDiffusionPowerPaintBrushNetPipeline"][0]
+    cls.bases = [ast.Name(id="_PipeBase", ctx=ast.Load())]
+    mod = ast.Module(body=[fn, cls], type_ignores=[])
+    ast.fix_missing_locations(mod)
+    quiet = types.SimpleNamespace(warning=lambda *a, **k: None, info=lambda *a, **k: None)
+    dummy = lambda name: type(name, (), {})                                   # noqa: E731
+    import torch.nn.functional as F
+    ns = dict(inspect=inspect, Any=Any, Callable=Callable, Dict=Dict, List=List, Optional=Optional, Union=Union,
+              Tuple=__import__("typing").Tuple, np=np, PIL=PIL, torch=torch, F=F, _PipeBase=_PipeBase, FrozenDict=dict,
+              VaeImageProcessor=_PassThroughImageProcessor, randn_tensor=randn_tensor, logger=quiet,
+              deprecate=lambda *a, **k: None, is_compiled_module=lambda m: False, is_torch_version=lambda *a: False,
+              USE_PEFT_BACKEND=False, adjust_lora_scale_text_encoder=lambda *a, **k: None,
+              scale_lora_layers=lambda *a, **k: None, unscale_lora_layers=lambda *a, **k: None,
+              BrushNetModel=brushnet_cls, replace_example_docstring=lambda doc: (lambda f: f), EXAMPLE_DOC_STRING="",
+              StableDiffusionPipelineOutput=lambda images, nsfw_content_detected: types.SimpleNamespace(
+                  images=images, nsfw_content_detected=nsfw_content_detected))
+    for name in ("LoraLoaderMixin", "TextualInversionLoaderMixin", "FromSingleFileMixin", "IPAdapterMixin",
+                 "StableDiffusionMixin", "AutoencoderKL", "UNet2DConditionModel", "ImageProjection", "CLIPImageProcessor",
+                 "CLIPTextModel", "CLIPTokenizer", "CLIPVisionModelWithProjection", "StableDiffusionSafetyChecker",
+                 "KarrasDiffusionSchedulers", "DiffusionPipeline", "PipelineImageInput", "MultiControlNetModel"):
+        ns[name] = dummy(name)
+    exec(compile(mod, REF_V2, "exec"), ns)
+    return ns["StableDiffusionPowerPaintBrushNetPipeline"]

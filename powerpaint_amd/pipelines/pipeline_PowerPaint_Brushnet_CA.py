@@ -129,6 +129,8 @@ class StableDiffusionPowerPaintBrushNetPipeline(PipelineBase):
             msk = ip.preprocess(mask, height=height, width=width).to(device=device, dtype=torch.float32)
             img = img.repeat_interleave(nb // img.shape[0], dim=0)
             msk = msk.repeat_interleave(nb // msk.shape[0], dim=0)
+            if do_cfg:      # prepare_image (:949-950) duplicates BEFORE the VAE: the two CFG halves get their own
+                img, msk = torch.cat([img] * 2), torch.cat([msk] * 2)   # posterior samples (and the RNG advances 2x)
             B0, C0, H0, W0 = msk.shape
             original_mask = hip_mask_prep(3, msk, None, (B0, 1, H0, W0), B0, C0, H0, W0)   # (mask.sum(1) < 0)  :1312
             height, width = img.shape[-2:]

@@ -79,5 +79,42 @@ def main():
     print(out.shape, float(out.abs().max()), [s[:2] for s in seen])
 
 
+CALL_V2 = dict(promptA="the cat", promptB="the scene", promptU="the dog", tradoff=0.4, tradoff_nag=0.6,
+               negative_promptA="blur", negative_promptB="the cat", negative_promptU="blur", num_inference_steps=3,
+               guidance_scale=7.5, brushnet_conditioning_scale=1.0, width=128, height=128)
+
+
+def components_v2():
+    tok, enc, _, vae = components()
+    torch.manual_seed(34)
+    unet = bf16_(OM.UNet2DConditionModel(in_channels=4, **TINY)).eval()
+    torch.manual_seed(35)
+    bn = OM.randomize_zero_convs(bf16_(OM.BrushNetModel(in_channels=4, conditioning_channels=5, **TINY))).eval()
+    return tok, enc, unet, bn, vae
+
+
+def inputs_v2():
+    img, mask, lat = inputs()
+    return img * (mask < 0.5), (mask * 2 - 1).repeat(1, 3, 1, 1), lat      # pre-masked image, RGB mask in [-1, 1]
+
+
+def main_v2():
+    """ref_pipeline_call_v2.pt: the same for `StableDiffusionPowerPaintBrushNetPipeline.__call__`
+    (pipeline_PowerPaint_Brushnet_CA.py:1026-1497): BrushNet + 4-channel UNet, DPM-Solver++, two prompt encoders."""
+    from oracle import ref_pipeline
+    Pipe = ref_pipeline.load_reference_brushnet_pipeline_class(OM.BrushNetModel)
+    tok, enc, unet, bn, vae = components_v2()
+    pipe = Pipe(vae=vae, text_encoder=enc, text_encoder_brushnet=enc, tokenizer=tok, unet=unet, brushnet=bn,
+                scheduler=OS.DPMSolverMultistepScheduler(), safety_checker=None, feature_extractor=None,
+                requires_safety_checker=False)
+    img, mask3, lat = inputs_v2()
+    torch.manual_seed(9)                                   # the conditioning latents are sampled from the global RNG
+    with torch.no_grad():
+        out = pipe(image=img, mask=mask3, latents=lat.clone(), output_type="latent", return_dict=False, **CALL_V2)[0]
+    torch.save(dict(latents=out), os.path.join(HERE, "ref_pipeline_call_v2.pt"))
+    print("v2", out.shape, float(out.abs().max()))
+
+
 if __name__ == "__main__":
     main()
+    main_v2()

@@ -158,3 +158,32 @@ def test_hip_pipeline_reproduces_the_reference_call():
     cos = torch.nn.functional.cosine_similarity(out.float().cpu().flatten(), want.flatten(), dim=0).item()
     err = (out.float().cpu() - want).abs().max().item()
     assert cos >= 0.995 and err <= 0.1 * max(1.0, want.abs().max().item()), (cos, err)
+
+
+def test_oracle_loop_v2_reproduces_the_reference_brushnet_call():
+    """Rows a2 / a16: the oracle's ppt-v2 loop (BrushNet residuals into the UNet, DPM-Solver++, two prompt encoders)
+    against the final latents of the reference's OWN `StableDiffusionPowerPaintBrushNetPipeline.__call__`
+    (tests/golden/ref_pipeline_call_v2.pt).  Reproduces its data flow exactly: the CFG twin of the image is VAE-encoded
+    too (prepare_image duplicates before the encoder), with posterior noise from the global RNG."""
+    from oracle import loops as OL, schedulers as OS
+    import make_ref_pipeline_call as M
+    gold = torch.load(os.path.join(HERE, "golden", "ref_pipeline_call_v2.pt"), weights_only=False)
+    tok, enc, unet, bn, vae = M.components_v2()
+    img, mask3, lat = M.inputs_v2()
+    c = M.CALL_V2
+
+    def emb(p):
+        ids = tok(p, padding="max_length", max_length=77, truncation=True, return_tensors="pt").input_ids
+        return enc(ids)[0]
+
+    with torch.no_grad():
+        pos = emb(c["promptA"]) * c["tradoff"] + (1 - c["tradoff"]) * emb(c["promptB"])
+        neg = emb(c["negative_promptA"]) * c["tradoff_nag"] + (1 - c["tradoff_nag"]) * emb(c["negative_promptB"])
+        peU = torch.cat([emb(c["negative_promptU"]), emb(c["promptU"])])
+        torch.manual_seed(9)
+        cl = vae.encode(torch.cat([img] * 2)).latent_dist.sample() * vae.config.scaling_factor
+        keep = (torch.cat([mask3] * 2).sum(1)[:, None] < 0).float()
+        cond = torch.cat([cl, torch.nn.functional.interpolate(keep, size=cl.shape[-2:])], 1)
+        out = OL.loop_v2(unet, bn, OS.DPMSolverMultistepScheduler(), lat, cond, torch.cat([neg, pos]), peU,
+                         c["num_inference_steps"], c["guidance_scale"], c["brushnet_conditioning_scale"])
+    assert torch.allclose(out, gold["latents"], atol=2e-4, rtol=1e-4)

@@ -333,8 +333,8 @@ def test_pipeline_v2_pil_in_pil_out_with_vae():
     it, mt = ip.preprocess(img, height=side, width=side).to(DEV), ip.preprocess(mask, height=side, width=side).to(DEV)
     keep = (mt.sum(1, keepdim=True) < 0).float()                                          # :1312 original_mask
     torch.manual_seed(11)
-    cl = vae.encode(it).latent_dist.sample() * vae.config.scaling_factor
-    ml = torch.nn.functional.interpolate(keep, size=cl.shape[-2:])
+    cl = vae.encode(torch.cat([it] * 2)).latent_dist.sample() * vae.config.scaling_factor   # CFG twin encoded too (:949)
+    ml = torch.nn.functional.interpolate(torch.cat([keep] * 2), size=cl.shape[-2:])
     again = pipe(conditioning_latents=torch.cat([cl, ml], 1), **kw).images
     assert np.array_equal(np.array(out[0]), np.array(again[0]))
     assert np.array(out[0]).std() > 1.0
