@@ -137,3 +137,35 @@ def load_reference_brushnet_pipeline_class(brushnet_cls):
         ns[name] = dummy(name)
     exec(compile(mod, REF_V2, "exec"), ns)
     return ns["StableDiffusionPowerPaintBrushNetPipeline"]
+
+
+REF_CN = "/root/reference/powerpaint/pipelines/pipeline_PowerPaint_ControlNet.py"
+
+
+def load_reference_controlnet_pipeline_class(controlnet_cls):
+    """`StableDiffusionControlNetInpaintPipeline` (pipeline_PowerPaint_ControlNet.py) the same way; `controlnet_cls` is
+    the class its `isinstance(controlnet, ControlNetModel)` checks must recognise (the oracle's ControlNetModel)."""
+    import warnings
+    import torch.nn.functional as F
+    tree = ast.parse(open(REF_CN).read())
+    fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "prepare_mask_and_masked_image"][0]
+    cls = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "StableDiffusionControlNetInpaintPipeline"][0]
+    cls.bases = [ast.Name(id="_PipeBase", ctx=ast.Load())]
+    mod = ast.Module(body=[fn, cls], type_ignores=[])
+    ast.fix_missing_locations(mod)
+    quiet = types.SimpleNamespace(warning=lambda *a, **k: None, info=lambda *a, **k: None)
+    dummy = lambda name: type(name, (), {})                                   # noqa: E731
+    ns = dict(inspect=inspect, warnings=warnings, Any=Any, Callable=Callable, Dict=Dict, List=List, Optional=Optional,
+              Union=Union, Tuple=__import__("typing").Tuple, np=np, PIL=PIL, torch=torch, F=F, _PipeBase=_PipeBase,
+              VaeImageProcessor=_PassThroughImageProcessor, randn_tensor=randn_tensor, logger=quiet,
+              deprecate=lambda *a, **k: None, is_compiled_module=lambda m: False,
+              is_accelerate_available=lambda: False, is_accelerate_version=lambda *a: False,
+              ControlNetModel=controlnet_cls, replace_example_docstring=lambda doc: (lambda f: f), EXAMPLE_DOC_STRING="",
+              StableDiffusionPipelineOutput=lambda images, nsfw_content_detected: types.SimpleNamespace(
+                  images=images, nsfw_content_detected=nsfw_content_detected))
+    for name in ("LoraLoaderMixin", "TextualInversionLoaderMixin", "FromSingleFileMixin", "AsymmetricAutoencoderKL",
+                 "AutoencoderKL", "UNet2DConditionModel", "CLIPImageProcessor", "CLIPTextModel", "CLIPTokenizer",
+                 "StableDiffusionSafetyChecker", "KarrasDiffusionSchedulers", "DiffusionPipeline", "MultiControlNetModel"):
+        ns[name] = dummy(name)
+    exec(compile(mod, REF_CN, "exec"), ns)
+    return ns["StableDiffusionControlNetInpaintPipeline"]

@@ -115,6 +115,40 @@ def main_v2():
     print("v2", out.shape, float(out.abs().max()))
 
 
+CALL_CN = dict(promptA="the cat", promptB="the cat", tradoff=1.0, tradoff_nag=1.0, negative_promptA="blur",
+               negative_promptB="blur", width=128, height=128, guidance_scale=7.5, controlnet_conditioning_scale=0.5,
+               num_inference_steps=3)
+
+
+def components_cn():
+    tok, enc, unet, vae = components()
+    torch.manual_seed(36)
+    cn = OM.randomize_zero_convs(bf16_(OM.ControlNetModel(
+        in_channels=4, **{k: v for k, v in TINY.items() if k != "up_block_types"}))).eval()
+    return tok, enc, unet, cn, vae
+
+
+def control_image():
+    return torch.rand(1, 3, 128, 128, generator=torch.Generator().manual_seed(42))
+
+
+def main_cn():
+    """ref_pipeline_call_cn.pt: `StableDiffusionControlNetInpaintPipeline.__call__`
+    (pipeline_PowerPaint_ControlNet.py:1349-1760): ControlNet residuals into the 9-channel UNet, DDIM."""
+    from oracle import ref_pipeline
+    Pipe = ref_pipeline.load_reference_controlnet_pipeline_class(OM.ControlNetModel)
+    tok, enc, unet, cn, vae = components_cn()
+    pipe = Pipe(vae=vae, text_encoder=enc, tokenizer=tok, unet=unet, controlnet=cn, scheduler=OS.DDIMScheduler(),
+                safety_checker=None, feature_extractor=None, requires_safety_checker=False)
+    img, mask, lat = inputs()
+    with torch.no_grad():
+        out = pipe(image=img, mask=mask, control_image=control_image(), latents=lat.clone(),
+                   generator=torch.Generator().manual_seed(5), output_type="latent", return_dict=False, **CALL_CN)[0]
+    torch.save(dict(latents=out), os.path.join(HERE, "ref_pipeline_call_cn.pt"))
+    print("controlnet", out.shape, float(out.abs().max()))
+
+
 if __name__ == "__main__":
     main()
     main_v2()
+    main_cn()

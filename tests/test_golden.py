@@ -187,3 +187,28 @@ def test_oracle_loop_v2_reproduces_the_reference_brushnet_call():
         out = OL.loop_v2(unet, bn, OS.DPMSolverMultistepScheduler(), lat, cond, torch.cat([neg, pos]), peU,
                          c["num_inference_steps"], c["guidance_scale"], c["brushnet_conditioning_scale"])
     assert torch.allclose(out, gold["latents"], atol=2e-4, rtol=1e-4)
+
+
+def test_oracle_loop_reproduces_the_reference_controlnet_call():
+    """Rows a3 / a17: the oracle's v1 loop with a ControlNet against the final latents of the reference's OWN
+    `StableDiffusionControlNetInpaintPipeline.__call__` (tests/golden/ref_pipeline_call_cn.pt)."""
+    from oracle import loops as OL, schedulers as OS
+    import make_ref_pipeline_call as M
+    gold = torch.load(os.path.join(HERE, "golden", "ref_pipeline_call_cn.pt"), weights_only=False)
+    tok, enc, unet, cn, vae = M.components_cn()
+    img, mask, lat = M.inputs()
+    c = M.CALL_CN
+
+    def emb(p):
+        ids = tok(p, padding="max_length", max_length=77, truncation=True, return_tensors="pt").input_ids
+        return enc(ids)[0]
+
+    with torch.no_grad():
+        pe = torch.cat([emb(c["negative_promptA"]), emb(c["promptA"])])           # tradoff = 1: promptA only
+        mil = vae.encode(img * (mask < 0.5)).latent_dist.sample(torch.Generator().manual_seed(5)) * vae.config.scaling_factor
+        m = torch.nn.functional.interpolate(mask, size=(16, 16))
+        out = OL.loop_v1(unet, OS.DDIMScheduler(), lat, torch.cat([m] * 2), torch.cat([mil] * 2), pe,
+                         c["num_inference_steps"], c["guidance_scale"], controlnet=cn,
+                         control_image=torch.cat([M.control_image()] * 2),
+                         controlnet_conditioning_scale=c["controlnet_conditioning_scale"])
+    assert torch.allclose(out, gold["latents"], atol=2e-4, rtol=1e-4)
