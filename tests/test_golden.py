@@ -212,3 +212,58 @@ def test_oracle_loop_reproduces_the_reference_controlnet_call():
                          control_image=torch.cat([M.control_image()] * 2),
                          controlnet_conditioning_scale=c["controlnet_conditioning_scale"])
     assert torch.allclose(out, gold["latents"], atol=2e-4, rtol=1e-4)
+
+
+def _close_latents(out, want, what):
+    cos = torch.nn.functional.cosine_similarity(out.float().cpu().flatten(), want.flatten(), dim=0).item()
+    err = (out.float().cpu() - want).abs().max().item()
+    assert cos >= 0.995 and err <= 0.1 * max(1.0, want.abs().max().item()), (what, cos, err)
+
+
+@pytest.mark.gpu
+def test_hip_controlnet_pipeline_reproduces_the_reference_call():
+    from powerpaint_amd import models as PM, pipelines as PP, schedulers as PS
+    import make_ref_pipeline_call as M
+    gold = torch.load(os.path.join(HERE, "golden", "ref_pipeline_call_cn.pt"), weights_only=False)
+    tok, enc, unet, cn, vae = M.components_cn()
+    img, mask, lat = M.inputs()
+    no_up = {k: v for k, v in M.TINY.items() if k != "up_block_types"}
+    hu = PM.UNet2DConditionModel(in_channels=9, device="cuda", **M.TINY).load_state_dict(unet.state_dict())
+    hc = PM.ControlNetModel(in_channels=4, device="cuda", **no_up).load_state_dict(cn.state_dict())
+    hv = PM.AutoencoderKL(device="cuda", **M.VAE_CFG).load_state_dict(vae.state_dict())
+    he = PM.CLIPTextModel(device="cuda", vocab_size=enc.config.vocab_size, num_hidden_layers=1,
+                          eos_token_id=enc.config.eos_token_id)
+    he.load_state_dict(enc.state_dict())
+    pipe = PP.StableDiffusionControlNetInpaintPipeline(vae=hv, text_encoder=he, tokenizer=tok, unet=hu, controlnet=hc,
+                                                       scheduler=PS.DDIMScheduler())
+    out = pipe(image=img, mask=mask, control_image=M.control_image(), latents=lat.cuda(),
+               generator=torch.Generator().manual_seed(5), output_type="latent", return_dict=False, **M.CALL_CN)[0]
+    _close_latents(out, gold["latents"], "controlnet pipeline vs the reference's own __call__")
+
+
+@pytest.mark.gpu
+def test_hip_brushnet_pipeline_reproduces_the_reference_call():
+    """The reference samples the conditioning latents from the global CPU RNG; the same noise is applied here to the
+    HIP VAE's posterior (mean, std), everything downstream is the product pipeline."""
+    from powerpaint_amd import models as PM, pipelines as PP, schedulers as PS
+    import make_ref_pipeline_call as M
+    gold = torch.load(os.path.join(HERE, "golden", "ref_pipeline_call_v2.pt"), weights_only=False)
+    tok, enc, unet, bn, vae = M.components_v2()
+    img, mask3, lat = M.inputs_v2()
+    hu = PM.UNet2DConditionModel(in_channels=4, device="cuda", **M.TINY).load_state_dict(unet.state_dict())
+    hb = PM.BrushNetModel(in_channels=4, conditioning_channels=5, device="cuda", **M.TINY).load_state_dict(bn.state_dict())
+    hv = PM.AutoencoderKL(device="cuda", **M.VAE_CFG).load_state_dict(vae.state_dict())
+    he = PM.CLIPTextModel(device="cuda", vocab_size=enc.config.vocab_size, num_hidden_layers=1,
+                          eos_token_id=enc.config.eos_token_id)
+    he.load_state_dict(enc.state_dict())
+    pipe = PP.StableDiffusionPowerPaintBrushNetPipeline(vae=hv, text_encoder=he, text_encoder_brushnet=he, tokenizer=tok,
+                                                        unet=hu, brushnet=hb, scheduler=PS.DPMSolverMultistepScheduler())
+    dist = hv.encode(torch.cat([img] * 2).cuda()).latent_dist
+    torch.manual_seed(9)
+    noise = torch.randn(dist.mean.shape)                                       # CPU global RNG, as in the reference run
+    cl = (dist.mean + dist.std * noise.cuda()) * hv.config.scaling_factor
+    keep = (torch.cat([mask3] * 2).sum(1)[:, None] < 0).float()
+    cond = torch.cat([cl, torch.nn.functional.interpolate(keep, size=cl.shape[-2:]).cuda()], 1)
+    c = dict(M.CALL_V2)
+    out = pipe(conditioning_latents=cond, latents=lat.cuda(), output_type="latent", return_dict=False, **c)[0]
+    _close_latents(out, gold["latents"], "BrushNet pipeline vs the reference's own __call__")
