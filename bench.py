@@ -168,6 +168,28 @@ def cpu_baseline():
                       f"scaled x{scale:.2f} (FLOP ratio to 64x64 latents) x50 steps"}
 
 
+def roofline_report(pipe, dump_launches=None) -> dict:
+    """`roofline` (dominant kernel = the implicit-GEMM 3x3 convolution launches of pp_gemm_kernel) and the per-kernel
+    tables, from one eager replay of the step program with a HIP event pair around every launch."""
+    per, flops, counts, alg_bytes = roofline_pass(pipe)
+    k = "conv3x3"
+    ach = flops[k] / 1e12 / (per[k] * 1e-3)
+    out = {"roofline": {"bound": "mfma", "kernel": "pp_gemm_kernel<...,CONV3X3> (implicit-GEMM 3x3 conv)",
+                        "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": ach / MFMA_PEAK_TFLOPS, "traffic": measured_traffic(),
+                        "traffic_unit": "bytes / launch (2 x FETCH_SIZE + WRITE_SIZE, profiles/r01_hbm_traffic.json)",
+                        "launches_per_step": counts[k], "avg_launch_ms": per[k] / counts[k],
+                        "alg_flop_per_launch": flops[k] / counts[k],
+                        "alg_bytes_per_launch": alg_bytes / counts[k]},
+           "per_kernel_ms_per_denoise_step": {n: round(v, 4) for n, v in sorted(per.items(), key=lambda kv: -kv[1])},
+           "per_kernel_tflops": {n: round(flops[n] / 1e12 / (per[n] * 1e-3), 1) for n in flops if per.get(n)}}
+    if dump_launches:
+        prog = pipe._loop.program
+        json.dump([{"i": i, "what": prog.describe(i), "ms": prog.last_launch_ms[i]}
+                   for i in range(len(prog.calls))], open(dump_launches, "w"))
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -231,25 +253,15 @@ def main():
             "unet_step_mfma_util": tflop_step / (ms_denoise_step * 1e-3) / MFMA_PEAK_TFLOPS,
         }
         if not args.no_roofline:
-            per, flops, counts, alg_bytes = roofline_pass(pipe)
-            # dominant kernel = the implicit-GEMM 3x3 convolution launches of pp_gemm_kernel
-            k = "conv3x3"
-            ach = flops[k] / 1e12 / (per[k] * 1e-3)
-            res["roofline"] = {"bound": "mfma", "kernel": "pp_gemm_kernel<...,CONV3X3> (implicit-GEMM 3x3 conv)",
-                               "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": ach / MFMA_PEAK_TFLOPS, "traffic": measured_traffic(),
-                               "traffic_unit": "bytes / launch (2 x FETCH_SIZE + WRITE_SIZE, profiles/r01_hbm_traffic.json)",
-                               "launches_per_step": counts[k], "avg_launch_ms": per[k] / counts[k],
-                               "alg_flop_per_launch": flops[k] / counts[k],
-                               "alg_bytes_per_launch": alg_bytes / counts[k]}
-            res["per_kernel_ms_per_denoise_step"] = {n: round(v, 4) for n, v in sorted(per.items(), key=lambda kv: -kv[1])}
-            res["per_kernel_tflops"] = {n: round(flops[n] / 1e12 / (per[n] * 1e-3), 1) for n in flops if per.get(n)}
-            if args.dump_launches:
-                prog = pipe._loop.program
-                json.dump([{"i": i, "what": prog.describe(i), "ms": prog.last_launch_ms[i]}
-                           for i in range(len(prog.calls))], open(args.dump_launches, "w"))
+            try:
+                res.update(roofline_report(pipe, args.dump_launches))
+            except Exception as e:      # the headline number must still be reported: keep the one JSON line
+                res["roofline"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline()
+            try:
+                res["cpu_baseline"] = cpu_baseline()
+            except Exception as e:
+                res["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
         print(json.dumps(res), flush=True)
     ppdist.barrier()
 
