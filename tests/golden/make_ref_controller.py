@@ -58,7 +58,8 @@ def load_reference():
     tree = ast.parse(open(REF).read())
     fns = {n.name: n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in ("add_task", "set_seed")}
     cls = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "PowerPaintController"][0]
-    meths = [n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name in ("predict", "infer")]
+    meths = [n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name in ("predict", "infer",
+                                                                                   "predict_controlnet")]
     stub = ast.ClassDef(name="Ref", bases=[], keywords=[], body=meths, decorator_list=[])
     mod = ast.Module(body=[fns["set_seed"], fns["add_task"], stub], type_ignores=[])
     ast.fix_missing_locations(mod)
@@ -97,9 +98,21 @@ def main():
         inp = make_inputs(240, 180, seed=100 + i)
         ctl.infer(inp, "tg", "tg-neg", "sg", "sg-neg", 0.5, 5, 7.0, 9, task, 1.2, 1.4, "op", "op-neg", "rm", "rm-neg")
         infer_cases.append(dict(task=task, version=version, input_seed=100 + i, call=ctl.pipe.calls[0]))
+    # ControlNet path: the annotator is a stand-in (HED slot, returns its input) -- the real ones are third-party models
+    cn_cases = []
+    for i, (w, hh) in enumerate(((300, 200), (200, 300))):
+        ctl = Ref()
+        ctl.version, ctl.control_pipe, ctl.current_control = "ppt-v1", RecordingPipe(), "hed"
+        ctl.hed = lambda im: im
+        inp = make_inputs(w, hh, seed=200 + i)
+        ctrl = make_inputs(90, 70, seed=300 + i)["image"]
+        out, res = ctl.predict_controlnet(inp, ctrl, "hed", "a dog", 7, 5.0, 3 + i, "bad", 0.8)
+        cn_cases.append(dict(size=[w, hh], input_seed=200 + i, ctrl_seed=300 + i, seed=3 + i,
+                             call=ctl.control_pipe.calls[0], out=[digest(o) for o in out],
+                             res=[digest(r) for r in res]))
     with open(os.path.join(HERE, "ref_controller.json"), "w") as f:
-        json.dump(dict(cases=cases, infer=infer_cases), f)
-    print(len(cases), "predict cases,", len(infer_cases), "infer cases")
+        json.dump(dict(cases=cases, infer=infer_cases, controlnet=cn_cases), f)
+    print(len(cases), "predict cases,", len(infer_cases), "infer cases,", len(cn_cases), "controlnet cases")
 
 
 if __name__ == "__main__":

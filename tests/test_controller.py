@@ -101,3 +101,19 @@ def test_helpers_and_controlnet_path():
     assert out[1].size == (960, 640) and res[0].size == (960, 640)
     with pytest.raises(ValueError):
         PowerPaintController(pipe).predict_controlnet(inp, ctrl, "a", 1, 1.0, 1, "", 1.0)
+
+
+def test_predict_controlnet_matches_reference(G):
+    """`predict_controlnet` (app.py:389-475) with the annotator output handed in: pipeline keywords, the paste-back
+    (Gaussian radius 4) and the red-tint preview equal the reference's, by SHA-256."""
+    for c in G["controlnet"]:
+        pipe = RecordingPipe()
+        seeds = []
+        ctl = PowerPaintController(None, control_pipe=pipe, seed_fn=seeds.append)
+        inp = make_inputs(*c["size"], seed=c["input_seed"])
+        ctrl = make_inputs(90, 70, seed=c["ctrl_seed"])["image"]
+        out, res = ctl.predict_controlnet(inp, ctrl, "a dog", 7, 5.0, c["seed"], "bad", 0.8)
+        assert pipe.calls[0] == c["call"], {k: (pipe.calls[0].get(k), c["call"].get(k)) for k in c["call"]
+                                             if pipe.calls[0].get(k) != c["call"].get(k)}
+        assert [digest(o) for o in out] == c["out"] and [digest(r) for r in res] == c["res"]
+        assert seeds == [c["seed"]]
