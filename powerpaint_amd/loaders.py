@@ -104,3 +104,60 @@ class PretrainedMixin:
 def _keeps(model) -> bool:
     import inspect
     return "keep_state_dict" in inspect.signature(model.load_state_dict).parameters
+
+
+def load_scheduler(d: str):
+    """`<dir>/scheduler_config.json` -> the fused scheduler of the same `_class_name` (DDIM / PNDM / DPM-Solver++ / UniPC);
+    other classes are refused by name -- pass a scheduler object (any duck-typed one works) instead."""
+    from .schedulers import SCHEDULERS
+    f = os.path.join(d, "scheduler_config.json")
+    if not os.path.isfile(f):
+        raise L.PPError(f"{f} not found")
+    with open(f) as fh:
+        cfg = json.load(fh)
+    name = cfg.get("_class_name", "")
+    if name not in SCHEDULERS:
+        raise L.PPError(f"scheduler class '{name}' has no fused implementation here ({', '.join(SCHEDULERS)}); "
+                        "construct the pipeline with scheduler=<object> instead")
+    return SCHEDULERS[name].from_config({k: v for k, v in cfg.items() if not k.startswith("_")})
+
+
+class PipelinePretrainedMixin:
+    """`Pipeline.from_pretrained(dir_or_cached_repo, **component_overrides)` over a diffusers pipeline folder
+    (`model_index.json` + one sub-folder per component), as app.py:90-92,168-176 call it.  Components: `unet`, `vae`,
+    `text_encoder` -> the HIP models, `tokenizer` -> transformers' CLIPTokenizer, `scheduler` -> `load_scheduler`;
+    `safety_checker` / `feature_extractor` / `image_encoder` are left out (None).  Keyword arguments naming a component
+    (e.g. `brushnet=`, `text_encoder_brushnet=`, `unet=`) are used as given instead of being loaded."""
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path, torch_dtype=None, device="cuda", local_files_only=True,
+                        revision=None, low_cpu_mem_usage=None, **overrides):
+        import inspect
+        from . import models as PM
+        root = resolve_dir(pretrained_model_name_or_path, None, revision=revision)
+        f = os.path.join(root, "model_index.json")
+        if not os.path.isfile(f):
+            raise L.PPError(f"{f} not found: not a diffusers pipeline folder")
+        with open(f) as fh:
+            index = {k: v for k, v in json.load(fh).items() if not k.startswith("_")}
+        loaders = {"unet": lambda: PM.UNet2DConditionModel.from_pretrained(root, subfolder="unet", device=device),
+                   "vae": lambda: PM.AutoencoderKL.from_pretrained(root, subfolder="vae", device=device),
+                   "text_encoder": lambda: PM.CLIPTextModel.from_pretrained(root, subfolder="text_encoder", device=device),
+                   "scheduler": lambda: load_scheduler(os.path.join(root, "scheduler"))}
+
+        def tokenizer():
+            import transformers
+            return transformers.CLIPTokenizer.from_pretrained(os.path.join(root, "tokenizer"))
+
+        loaders["tokenizer"] = tokenizer
+        wanted = [p for p in inspect.signature(cls.__init__).parameters if p != "self"]
+        comps = {}
+        for name in wanted:
+            if name in overrides:
+                comps[name] = overrides.pop(name)
+            elif name in loaders and name in index and index[name] and index[name][0] is not None:
+                comps[name] = loaders[name]()
+        unknown = [k for k in overrides if k not in wanted]
+        if unknown:
+            raise TypeError(f"{cls.__name__}.from_pretrained got unexpected components {unknown}")
+        return cls(**comps)

@@ -15,6 +15,7 @@ import numpy as np
 import torch
 
 from .. import _lib as L
+from ..loaders import PipelinePretrainedMixin
 
 
 class StableDiffusionPipelineOutput(SimpleNamespace):
@@ -91,7 +92,7 @@ def prepare_mask_and_masked_image(image, mask, height, width, device, return_ima
     return mask, masked_image
 
 
-class PipelineBase:
+class PipelineBase(PipelinePretrainedMixin):
     """Minimal DiffusionPipeline stand-in: component registry, device, progress bar, scheduler kwargs probing."""
 
     def register_modules(self, **mods):

@@ -40,6 +40,17 @@ class _SchedulerBase:
         self._m_prev = None
         self._device = None
 
+    @classmethod
+    def from_config(cls, config, **kw):
+        """`Scheduler.from_config(other.config)` / a `scheduler_config.json` dict: the keys this class's constructor
+        names are taken over, the rest (other schedulers' options, `_class_name`, ...) ignored."""
+        import inspect
+        src = dict(config) if isinstance(config, dict) else dict(vars(config))
+        names = set(inspect.signature(cls.__init__).parameters) - {"self", "kw", "cfg"}
+        args = {k: v for k, v in src.items() if k in names}
+        args.update(kw)
+        return cls(**args)
+
     # -- device state for the fused kernel
     def scale_model_input(self, sample, timestep=None):
         return sample
@@ -391,3 +402,7 @@ class UniPCMultistepScheduler(_SchedulerBase):
                 lower += 1
         self._coef = torch.from_numpy(coef.astype(np.float32))
         self._upload(device)
+
+
+SCHEDULERS = {"DDIMScheduler": DDIMScheduler, "DPMSolverMultistepScheduler": DPMSolverMultistepScheduler,
+              "PNDMScheduler": PNDMScheduler, "UniPCMultistepScheduler": UniPCMultistepScheduler}

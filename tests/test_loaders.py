@@ -138,3 +138,64 @@ def test_pipelines_register_processors():
     p2 = PP.StableDiffusionControlNetInpaintPipeline(vae=vae)
     assert p2.control_image_processor.config.do_normalize is False and p2.control_image_processor.config.do_convert_rgb
     assert PP.StableDiffusionPowerPaintBrushNetPipeline(vae=None).image_processor is None
+
+
+def test_pipeline_from_pretrained(tmp_path):
+    """`Pipeline.from_pretrained(folder)` over a diffusers pipeline folder (model_index.json + component sub-folders),
+    the first call of app.py:90; component overrides as app.py:168-176 passes them."""
+    transformers = pytest.importorskip("transformers")
+    from powerpaint_amd import pipelines as PP, schedulers as PS
+    root = str(tmp_path / "sd-inpainting")
+    unet = PM.UNet2DConditionModel(in_channels=9, device="cpu", **TINY)
+    write_dir(os.path.join(root, "unet"), dict(TINY, in_channels=9, out_channels=4, sample_size=64),
+              {k: v.half() for k, v in unet.net.synthetic_state_dict(seed=3).items()})
+    vcfg = dict(block_out_channels=(64, 64, 64, 64), layers_per_block=1, in_channels=3, out_channels=3, latent_channels=4,
+                norm_num_groups=32, scaling_factor=0.18215)
+    vae = PM.AutoencoderKL(device="cpu", **vcfg)
+    write_dir(os.path.join(root, "vae"), vcfg, vae.net.synthetic_state_dict(seed=5))
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_task_tokens.json")) as f:
+        G = json.load(f)
+    tok = transformers.CLIPTokenizer(vocab={t: i for i, t in enumerate(G["vocab"])},
+                                     merges=[tuple(m) for m in G["merges"]], model_max_length=77)
+    tok.save_pretrained(os.path.join(root, "tokenizer"))
+    n = len(tok)
+    hf = transformers.CLIPTextModel(transformers.CLIPTextConfig(
+        vocab_size=n, hidden_size=768, intermediate_size=3072, num_hidden_layers=1, num_attention_heads=12,
+        max_position_embeddings=77, hidden_act="quick_gelu", bos_token_id=n - 2, eos_token_id=n - 1, pad_token_id=n - 1))
+    hf.save_pretrained(os.path.join(root, "text_encoder"))
+    os.makedirs(os.path.join(root, "scheduler"))
+    with open(os.path.join(root, "scheduler", "scheduler_config.json"), "w") as f:
+        json.dump(dict(_class_name="PNDMScheduler", _diffusers_version="0.6.0", beta_end=0.012, beta_schedule="scaled_linear",
+                       beta_start=0.00085, num_train_timesteps=1000, set_alpha_to_one=False, skip_prk_steps=True,
+                       steps_offset=1, trained_betas=None, clip_sample=False), f)
+    with open(os.path.join(root, "model_index.json"), "w") as f:
+        json.dump({"_class_name": "StableDiffusionInpaintPipeline", "_diffusers_version": "0.6.0",
+                   "feature_extractor": ["transformers", "CLIPImageProcessor"],
+                   "safety_checker": ["stable_diffusion", "StableDiffusionSafetyChecker"],
+                   "scheduler": ["diffusers", "PNDMScheduler"], "text_encoder": ["transformers", "CLIPTextModel"],
+                   "tokenizer": ["transformers", "CLIPTokenizer"], "unet": ["diffusers", "UNet2DConditionModel"],
+                   "vae": ["diffusers", "AutoencoderKL"]}, f)
+    pipe = PP.StableDiffusionInpaintPipeline.from_pretrained(root, torch_dtype=torch.float16, device="cpu",
+                                                             local_files_only=True)
+    assert isinstance(pipe.unet, PM.UNet2DConditionModel) and pipe.unet.config.in_channels == 9
+    assert isinstance(pipe.vae, PM.AutoencoderKL) and pipe.vae_scale_factor == 8 and pipe.image_processor is not None
+    assert isinstance(pipe.text_encoder, PM.CLIPTextModel) and pipe.text_encoder.config.vocab_size == n
+    assert isinstance(pipe.scheduler, PS.PNDMScheduler) and pipe.scheduler.config.steps_offset == 1
+    assert pipe.tokenizer("the cat").input_ids == tok("the cat").input_ids
+    assert pipe.safety_checker is None and pipe.feature_extractor is None
+    # the scheduler swap of app.py:197, and a component handed in instead of loaded
+    pipe.scheduler = PS.UniPCMultistepScheduler.from_config(pipe.scheduler.config)
+    assert pipe.scheduler.config.timestep_spacing == "leading" and pipe.scheduler.config.steps_offset == 1
+    assert isinstance(PS.DDIMScheduler.from_config(pipe.scheduler.config), PS.DDIMScheduler)
+    mine = PS.DPMSolverMultistepScheduler()
+    p2 = PP.StableDiffusionPowerPaintBrushNetPipeline.from_pretrained(root, device="cpu", scheduler=mine, brushnet="B",
+                                                                      text_encoder_brushnet=pipe.text_encoder,
+                                                                      unet=pipe.unet, vae=pipe.vae)
+    assert p2.scheduler is mine and p2.brushnet == "B" and p2.unet is pipe.unet and p2.text_encoder_brushnet is pipe.text_encoder
+    with pytest.raises(TypeError):
+        PP.StableDiffusionInpaintPipeline.from_pretrained(root, device="cpu", brushnet="B")
+    with open(os.path.join(root, "scheduler", "scheduler_config.json"), "w") as f:
+        json.dump(dict(_class_name="EulerDiscreteScheduler"), f)
+    with pytest.raises(L.PPError):
+        PP.StableDiffusionInpaintPipeline.from_pretrained(root, device="cpu", unet=pipe.unet, vae=pipe.vae,
+                                                          text_encoder=pipe.text_encoder)
