@@ -126,6 +126,41 @@ class PipelineBase(PipelinePretrainedMixin):
     def set_progress_bar_config(self, **kw):
         self._progress_bar_config = kw
 
+    # Memory-saving switches of DiffusionPipeline that app.py flips (`enable_model_cpu_offload()`, app.py:199) or users
+    # habitually call.  With 288 GB of HBM and static arenas there is nothing to offload or slice: accepted, no effect.
+    def enable_model_cpu_offload(self, gpu_id=0, device="cuda"):
+        return None
+
+    def enable_sequential_cpu_offload(self, gpu_id=0, device="cuda"):
+        return None
+
+    def maybe_free_model_hooks(self):
+        return None
+
+    def enable_attention_slicing(self, slice_size="auto"):
+        return None
+
+    def disable_attention_slicing(self):
+        return None
+
+    def enable_vae_slicing(self):
+        return None
+
+    def disable_vae_slicing(self):
+        return None
+
+    def enable_vae_tiling(self):
+        return None
+
+    def disable_vae_tiling(self):
+        return None
+
+    def enable_xformers_memory_efficient_attention(self, attention_op=None):
+        return None
+
+    def disable_xformers_memory_efficient_attention(self):
+        return None
+
     def prepare_extra_step_kwargs(self, generator, eta):
         """pipeline_PowerPaint.py:536-551."""
         kw = {}

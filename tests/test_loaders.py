@@ -138,6 +138,11 @@ def test_pipelines_register_processors():
     p2 = PP.StableDiffusionControlNetInpaintPipeline(vae=vae)
     assert p2.control_image_processor.config.do_normalize is False and p2.control_image_processor.config.do_convert_rgb
     assert PP.StableDiffusionPowerPaintBrushNetPipeline(vae=None).image_processor is None
+    # the DiffusionPipeline memory switches app.py / users call are accepted (nothing to offload on 288 GB)
+    for name in ("enable_model_cpu_offload", "enable_vae_slicing", "enable_vae_tiling", "enable_attention_slicing",
+                 "enable_xformers_memory_efficient_attention", "maybe_free_model_hooks"):
+        assert getattr(p1, name)() is None
+    assert p1.to("cuda") is p1
 
 
 def test_pipeline_from_pretrained(tmp_path):
