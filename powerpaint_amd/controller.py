@@ -12,7 +12,7 @@ control image.
     snap_to_eight       app.py:314-318   both sides rounded down to multiples of 8, image and mask resized to it
     overlay_mask        app.py:366-377   the red-tinted preview of the masked region returned next to the result
 """
-from typing import Callable, Optional, Tuple
+from typing import Callable, Optional
 
 import numpy as np
 

@@ -6,7 +6,7 @@ tensors are zero-copy NCHW-logical views (channels_last strides, bf16) of the ru
 the next `forward` of this model -- exactly how the pipeline consumes them (produced and eaten within one step).
 """
 from types import SimpleNamespace
-from typing import List, Optional, Union
+from typing import Union
 
 import torch
 

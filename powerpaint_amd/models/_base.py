@@ -1,6 +1,6 @@
 """Shared host-side plumbing of the three model wrappers."""
 from types import SimpleNamespace
-from typing import Dict, List, Optional
+from typing import Dict
 
 import torch
 

@@ -9,7 +9,7 @@ without them.
 """
 import inspect
 from types import SimpleNamespace
-from typing import Callable, List, Optional, Union
+from typing import List, Optional, Union
 
 import numpy as np
 import torch

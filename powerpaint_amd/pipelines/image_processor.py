@@ -8,7 +8,7 @@ Host-side mirror of the diffusers class the reference pipelines instantiate
 installable here: these are the documented conversions (uint8 / 255, 2x - 1, Lanczos resize to multiples of the VAE
 factor, x / 2 + 0.5 clamped, round to uint8), restated; plain data-format glue, no tensor math of the hot path.
 """
-from typing import List, Optional, Union
+from typing import List, Optional
 
 import numpy as np
 import torch

@@ -10,7 +10,6 @@ fp32 torch exactly in the library's operation order and uploaded as a device tab
 that kernel, so a foreign loop calling `scheduler.step` still runs on the HIP path.
 """
 from types import SimpleNamespace
-from typing import Optional
 
 import numpy as np
 import torch
