@@ -141,16 +141,25 @@ class DPMSolverMultistepScheduler:
     order = 1
     init_noise_sigma = 1.0
 
-    def __init__(self, num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, solver_order=2):
+    def __init__(self, num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, solver_order=2,
+                 timestep_spacing="linspace", steps_offset=0):
         self.config = type("C", (), dict(num_train_timesteps=num_train_timesteps, solver_order=solver_order,
-                                         steps_offset=0))()
+                                         steps_offset=steps_offset, timestep_spacing=timestep_spacing))()
         self.betas = sd_betas(num_train_timesteps, beta_start, beta_end)
         self.alphas_cumprod = torch.cumprod(1.0 - self.betas, dim=0)
         self.timesteps = None
 
     def set_timesteps(self, num_inference_steps: int, device=None):
-        T = self.config.num_train_timesteps
-        ts = np.linspace(0, T - 1, num_inference_steps + 1).round()[::-1][:-1].copy().astype(np.int64)
+        T, N = self.config.num_train_timesteps, num_inference_steps
+        # diffusers 0.27 DPMSolverMultistepScheduler.set_timesteps, lambda_min_clipped = -inf (last_timestep = T)
+        if self.config.timestep_spacing == "linspace":
+            ts = np.linspace(0, T - 1, N + 1).round()[::-1][:-1].copy().astype(np.int64)
+        elif self.config.timestep_spacing == "leading":
+            ts = (np.arange(0, N + 1) * (T // (N + 1))).round()[::-1][:-1].copy().astype(np.int64) + self.config.steps_offset
+        elif self.config.timestep_spacing == "trailing":
+            ts = np.arange(T, 0, -T / N).round().copy().astype(np.int64) - 1
+        else:
+            raise ValueError(self.config.timestep_spacing)
         sig = (((1 - self.alphas_cumprod) / self.alphas_cumprod) ** 0.5).numpy()
         sig = np.interp(ts, np.arange(0, len(sig)), sig)
         sig = np.concatenate([sig, [0.0]]).astype(np.float32)

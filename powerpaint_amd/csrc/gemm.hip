@@ -365,8 +365,12 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) pp_gemm_kernel(const PPGemmArg
 //     moments out / mean-rstd correction in);  2 = GEGLU in registers (+ optional folded LayerNorm);  4 = standard +
 //     GroupNorm statistics of the output (gn_acc).  1 and 2 are PLAIN-only and prefetch their epilogue operands
 //     into LDS.
-template <int BM, int BN, int WM, int WN, int XMODE, int NS, int EPI, bool DMAI = false>
-__global__ void __launch_bounds__(WM* WN * 64, ((BM / WM / 16) * (BN / WN / 16) <= 10 ? 4 : 2))
+//   * PP ("ping-pong", 8-wave tiles, NS >= 3): the two waves of every SIMD run half a K step apart -- waves 0-3 issue the
+//     MFMAs of tile t while waves 4-7 read their fragments of tile t and issue the refill DMAs, then the roles swap
+//     (two raw barriers per K step, group 1 enters the loop one barrier late).  In the lock-step loop both waves of a
+//     SIMD sit in barrier / bookkeeping / LDS-latency at the same time and the matrix pipe idles ~1/3 of every K step.
+template <int BM, int BN, int WM, int WN, int XMODE, int NS, int EPI, bool DMAI = false, bool PP = false>
+__global__ void __launch_bounds__(WM* WN * 64, (PP ? 2 : ((BM / WM / 16) * (BN / WN / 16) <= 10 ? 4 : 2)))
 pp_gemm_kernel_v2(const PPGemmArgs a, const GemmDerived d) {   // 2nd bound = waves / SIMD the register budget must allow
   constexpr bool LNF = EPI == 1 || EPI == 2;
   constexpr bool GNS = EPI == 4;
@@ -413,7 +417,13 @@ pp_gemm_kernel_v2(const PPGemmArgs a, const GemmDerived d) {   // 2nd bound = wa
   int kt_end = kt_begin + d.kt_per_split;
   if (kt_end > d.kt_total) kt_end = d.kt_total;
   const int nkt = kt_end - kt_begin;
-  const int dbg = a.reserved[0];   // ablation switches (tools/gemm_ablate.py): 1 no refill, 2 no MFMA, 4 no epilogue
+  // ablation switches (tools/gemm_ablate.py): 1 no refill, 2 no MFMA, 4 no epilogue, 8 no s_setprio.  The ping-pong loop
+  // honours them only in a -DPP_GEMM_DBG build (seven branches per K step otherwise ride in its read phase).
+#ifdef PP_GEMM_DBG
+  const int dbg = a.reserved[0];
+#else
+  const int dbg = PP ? 0 : a.reserved[0];
+#endif
 
   // lane -> (row within the wave's 8-row strip, k-slot it must FETCH so that its lane-linear LDS position is swizzled)
   const int lrow = lane >> 3;
@@ -594,6 +604,198 @@ pp_gemm_kernel_v2(const PPGemmArgs a, const GemmDerived d) {   // 2nd bound = wa
       }
     }
   }
+  if constexpr (PP) {
+    static_assert(WM * WN == 8 && NS >= 3, "ping-pong: two groups of four waves (one wave of each per SIMD), >= 3 stages");
+    const int grp = wave >> 2;
+    // ---- issue side: the K walk as SEGMENTS of whole 64-deep tiles (one source tensor at one tap).  The per-tile work
+    //      is P DMA pieces + three scalar adds; descriptors and per-lane offsets are rebuilt only on a segment change
+    //      (a wave-uniform branch), and tiles past the end of this block's K range use zero-sized descriptors (the DMA
+    //      writes nothing useful but every wave keeps exactly P loads per tile in flight: uniform vmcnt arithmetic).
+    // segment = (tap, second source?): taps 0..8 over (x1, x2), tap 9 = the 1x1 tail over (x3, x4), tap 10 = past the end;
+    // PLAIN walks (x1, x2) as "tap 9".  Plain scalar state + two-way selects only: an index-driven formulation is turned
+    // into a private-memory lookup table by LLVM (scratch traffic in the loop).
+    const int n1 = pc1 >> 6, n2 = pc2 >> 6, n3 = pc3 >> 6, n4 = pc4 >> 6;
+    int tap_i = 0, seg_left = 0, tiles_left = nkt;
+    bool second = false;
+    int sox = 0, sow = kt_begin * 128;
+    const void* const qx1 = reinterpret_cast<const void*>(px1);
+    const void* const qw = a.w;
+    const int up_ = a.up, win_ = a.win;
+    __amdgpu_buffer_rsrc_t rsx = make_rsrc(qx1, 0u), rsw = make_rsrc(qw, wbytes);
+    int vx[XP];
+#pragma unroll
+    for (int i = 0; i < XP; ++i) vx[i] = (int)PP_OOB;
+    // The walk is written as MACROS over the kernel's locals, not lambdas: in a closure the by-reference captures are
+    // pointers, `second ? n2 : n1` becomes a load through a SELECTED closure field, the closure (and with it every
+    // captured variable) can no longer be promoted to registers, and the loop runs out of private memory.
+#define PP_SEG_LEN() (XMODE == PP_X_PLAIN ? (tap_i > 9 ? 0 : (second ? n2 : n1)) \
+                                          : (tap_i < 9 ? (second ? n2 : n1) : (tap_i == 9 ? (second ? n4 : n3) : 0)))
+#define PP_SEG_STEP()                     \
+  do {                                    \
+    if (!second) second = true;           \
+    else { second = false; ++tap_i; }     \
+  } while (0)
+    // enter the segment (tap_i, second) at its tile CHUNK0: skip absent sources (at most x2 -> x3 -> x4 in a row), then
+    // rebuild the X descriptor and the per-lane offsets; past the end: zero-sized descriptors
+#define PP_SEG_ENTER(CHUNK0)                                                                                         \
+  do {                                                                                                               \
+    int chunk0_ = (CHUNK0);                                                                                          \
+    if (tap_i <= 9 && PP_SEG_LEN() == 0) { PP_SEG_STEP(); chunk0_ = 0; }                                             \
+    if (tap_i <= 9 && PP_SEG_LEN() == 0) { PP_SEG_STEP(); chunk0_ = 0; }                                             \
+    if (tap_i <= 9 && PP_SEG_LEN() == 0) { PP_SEG_STEP(); chunk0_ = 0; }                                             \
+    if (tap_i > 9 || tiles_left <= 0) {                                                                              \
+      rsx = make_rsrc(qx1, 0u);                                                                                      \
+      rsw = make_rsrc(qw, 0u);                                                                                       \
+      seg_left = 1 << 30;                                                                                            \
+    } else {                                                                                                         \
+      int len_ = PP_SEG_LEN() - chunk0_;                                                                             \
+      if (len_ > tiles_left) len_ = tiles_left;                                                                      \
+      seg_left = len_;                                                                                               \
+      tiles_left -= len_;                                                                                            \
+      sox = chunk0_ * 128;                                                                                           \
+      uint64_t srcv_;                                                                                                \
+      uint32_t srcb_;                                                                                                \
+      if (XMODE == PP_X_PLAIN) {                                                                                     \
+        if (!second) { srcv_ = px1; srcb_ = xbytes1; }                                                               \
+        else { srcv_ = px2; srcb_ = xbytes2; }                                                                       \
+        rsx = make_rsrc(reinterpret_cast<const void*>(srcv_), srcb_);                                                \
+        _Pragma("unroll") for (int i = 0; i < XP; ++i) vx[i] = second ? vx2[i] : vx1[i];                             \
+      } else {                                                                                                       \
+        const bool tail_ = tap_i >= 9;                                                                               \
+        int csrc_;                                                                                                   \
+        if (!tail_) {                                                                                                \
+          if (!second) { srcv_ = px1; srcb_ = xbytes1; csrc_ = pc1; }                                                \
+          else { srcv_ = px2; srcb_ = xbytes2; csrc_ = pc2; }                                                        \
+        } else {                                                                                                     \
+          if (!second) { srcv_ = px3; srcb_ = xbytes3; csrc_ = pc3; }                                                \
+          else { srcv_ = px4; srcb_ = xbytes4; csrc_ = pc4; }                                                        \
+        }                                                                                                            \
+        rsx = make_rsrc(reinterpret_cast<const void*>(srcv_), srcb_);                                                \
+        const int ky_ = tail_ ? 1 : tap_i / 3, kx_ = tail_ ? 1 : tap_i - (tap_i / 3) * 3; /* tail = centre tap */    \
+        _Pragma("unroll") for (int i = 0; i < XP; ++i) {                                                             \
+          const int iy = xb[i] + ky_, ix = xc[i] + kx_;                                                              \
+          const bool ok = xa[i] >= 0 && (unsigned)iy < (unsigned)hv && (unsigned)ix < (unsigned)wv;                  \
+          const int sy = up_ ? (iy >> 1) : iy;                                                                       \
+          const int sx = up_ ? (ix >> 1) : ix;                                                                       \
+          vx[i] = ok ? ((xa[i] + sy * win_ + sx) * csrc_ + kslot * 8) * 2 : (int)PP_OOB;                             \
+        }                                                                                                            \
+      }                                                                                                              \
+    }                                                                                                                \
+  } while (0)
+    // one tile refill into stage STG: (segment change, rarely) + P DMA pieces + three scalar adds; split so that the
+    // main loop can interleave the pieces with its fragment reads
+#define PP_ISSUE_BEGIN(STG)                                                                                          \
+  do {                                                                                                               \
+    if (seg_left == 0) {                                                                                             \
+      PP_SEG_STEP();                                                                                                 \
+      PP_SEG_ENTER(0);                                                                                               \
+    }                                                                                                                \
+    is_xs = smem + (STG) * STAGE;                                                                                    \
+    is_ws = is_xs + XBYTES;                                                                                          \
+  } while (0)
+#define PP_PIECE(I)                                                                                                  \
+  do {                                                                                                               \
+    if ((I) < XP) {                                                                                                  \
+      const int ii_ = (I) < XP ? (I) : 0;                                                                            \
+      const int vo = vx[ii_];                                                                                        \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_ptr_t)(is_xs + (wave * 8 + ii_ * RPP) * 128), 16, vo, sox, 0, 0); \
+    } else {                                                                                                         \
+      const int jj_ = (I) - XP < WP ? (I) - XP : 0;                                                                  \
+      const int vo = vw[jj_], lo = wlds[jj_];                                                                        \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr_t)(is_ws + lo), 16, vo, sow, 0, 0);                     \
+    }                                                                                                                \
+  } while (0)
+#define PP_ISSUE_END()                                                                                               \
+  do {                                                                                                               \
+    sox += 128;                                                                                                      \
+    sow += 128;                                                                                                      \
+    --seg_left;                                                                                                      \
+  } while (0)
+#define PP_ISSUE(STG)                                                                                                \
+  do {                                                                                                               \
+    PP_ISSUE_BEGIN(STG);                                                                                             \
+    _Pragma("unroll") for (int i = 0; i < P; ++i) PP_PIECE(i);                                                       \
+    PP_ISSUE_END();                                                                                                  \
+  } while (0)
+    {   // position of this block's first K tile
+      int k = kt_begin;
+      if (XMODE == PP_X_PLAIN) {
+        tap_i = 9;
+        if (k >= n1) { second = true; k -= n1; }
+      } else {
+        tap_i = k / d.ctiles;
+        if (tap_i > 9) tap_i = 9;
+        k -= tap_i * d.ctiles;
+        const int nf = tap_i < 9 ? n1 : n3;
+        if (k >= nf) { second = true; k -= nf; }
+      }
+      PP_SEG_ENTER(k);
+    }
+#pragma nounroll
+    for (int s = 0; s < NS - 1; ++s) PP_ISSUE(s);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P * (NS - 2)) : "memory");   // this wave's pieces of tile 0 have landed
+    if (grp == 1) asm volatile("s_barrier" ::: "memory");                 // group 1 runs one phase behind group 0
+    int stage = 0;
+    for (int t = 0; t < nkt; ++t) {
+      asm volatile("s_barrier" ::: "memory");   // X: (everyone's) tile t is in LDS; the partner group left its read phase
+      // ---- read phase (the partner wave on this SIMD is in its MFMA phase).  The P refill DMAs of the stage tile t-1
+      //      occupied (both groups have left it) are spread between the fragment reads: issued as one burst behind
+      //      the reads they queue on the CU's address unit (~16 cycles each, 4 waves x P) AFTER the LDS has served the
+      //      reads, and the read phase (reads 425 + DMA issue 425 cycles measured) outlasts the partner's 640 MFMA
+      //      cycles; interleaved, the address unit and the LDS work side by side.
+      const char* xs = smem + stage * STAGE;
+      const char* ws = xs + XBYTES;
+      int nstage = stage + (NS - 1);
+      if (nstage >= NS) nstage -= NS;
+      const bool refill = !(dbg & 1);
+      if (refill) PP_ISSUE_BEGIN(nstage);
+      bf16x8_t xf[2][MI], wf[2][NI];
+      constexpr int NR = 2 * (MI + NI);
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        const int ks = r / (MI + NI), j = r % (MI + NI);
+        const int so = ((ks * 4 + fk) ^ fsw) << 4;
+        if (j < NI) wf[ks][j < NI ? j : 0] = *reinterpret_cast<const bf16x8_t*>(ws + (wrow0 + j * 16) * 128 + so);
+        else xf[ks][j >= NI ? j - NI : 0] = *reinterpret_cast<const bf16x8_t*>(xs + (xrow0 + (j - NI) * 16) * 128 + so);
+        // piece k goes after read number ceil((k + 1) * NR / (P + 1))
+        if (refill) {
+#pragma unroll
+          for (int k = 0; k < P; ++k)
+            if (((k + 1) * NR + P) / (P + 1) == r + 1) {
+              __builtin_amdgcn_sched_barrier(0);
+              PP_PIECE(k);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+      }
+      if (refill) PP_ISSUE_END();
+      // Y: this wave's pieces of tile t+1 have landed, its fragments of tile t are in registers
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(P * (NS - 2)) : "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- MFMA phase (the partner wave reads / refills)
+      if (!(dbg & 2)) {
+        if (!(dbg & 8)) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+              acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][ni], xf[ks][mi], acc[ni][mi], 0, 0, 0);
+        if (!(dbg & 8)) __builtin_amdgcn_s_setprio(0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      stage = stage + 1 == NS ? 0 : stage + 1;
+    }
+    if (grp == 0) asm volatile("s_barrier" ::: "memory");
+#undef PP_ISSUE
+#undef PP_ISSUE_BEGIN
+#undef PP_PIECE
+#undef PP_ISSUE_END
+#undef PP_SEG_ENTER
+#undef PP_SEG_LEN
+#undef PP_SEG_STEP
+  } else {
 #pragma unroll
   for (int s = 0; s < NS - 1; ++s) issue(kt_begin + s, s);
 
@@ -659,6 +861,7 @@ pp_gemm_kernel_v2(const PPGemmArgs a, const GemmDerived d) {   // 2nd bound = wa
     }
     stage = stage + 1 == NS ? 0 : stage + 1;
   }
+  }   // !PP
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the (zero-sized) tail prefetches before LDS is reused
   if (dbg & 4) {
     if (acc[0][0][0] == 123.456f) ((float*)a.out)[0] = 1.f;   // keep the accumulators live
@@ -1079,6 +1282,7 @@ bool reduce_lean_ok(const PPGemmArgs& a) {
 struct Choice {
   int tile, splitk;
 };
+bool gemm_pingpong();
 
 // v2 (LDS-direct pipeline + staged 16-byte epilogue) needs 16-byte aligned rows on every tensor the epilogue touches
 bool v2_ok(const PPGemmArgs& a) {
@@ -1128,6 +1332,15 @@ Choice choose(const PPGemmArgs& a) {
       while (nb128 * sk < 256 && kt / (sk * 2) >= 4 && sk < 8) sk *= 2;
     }
     if (c.splitk <= 0) c.splitk = sk;
+    // Ping-pong forms of the one-block-per-CU tiles (profiles/r02_pp_bench.txt: 256x160 +6..10 %, 128x160 +10..14 % on
+    // the UNet's conv shapes, never slower): 128x160 x 3 stages (4 waves) -> 8 waves x 4 stages; 256x160 x 3 stages ->
+    // ping-pong unless the folded-LayerNorm prefetch (which does not fit beside three 256-row stages) sends the launch
+    // to the 2-stage lock-step kernel anyway.
+    if (gemm_pingpong()) {
+      const bool lnf = a.x_mode == PP_X_PLAIN && (a.ln_stats || a.row_stats_out || a.act == PP_ACT_GEGLU);
+      if (c.tile == 31) c.tile = 54;
+      else if (c.tile == 33 && !lnf) c.tile = 53;
+    }
   }
   if (c.splitk <= 0) {
     const int tb = c.tile % 10;
@@ -1178,6 +1391,15 @@ int launch(const PPGemmArgs& a, int splitk, hipStream_t st) {
   return PP_OK;
 }
 
+// PP_GEMM_PP=0|1: A/B switch for the ping-pong tiles in the automatic choice (default 1)
+bool gemm_pingpong() {
+  static const int v = [] {
+    const char* e = getenv("PP_GEMM_PP");
+    return e ? atoi(e) : 1;
+  }();
+  return v != 0;
+}
+
 // PP_GEMM_DMAI=0|1: tile refills as one DMA burst after the barrier (0) or spread over the MFMA burst (1, default)
 bool gemm_dma_interleave() {
   static const int v = [] {
@@ -1187,27 +1409,27 @@ bool gemm_dma_interleave() {
   return v != 0;
 }
 
-template <int BM, int BN, int WM, int WN, int XMODE, int NS, int EPI = 0>
+template <int BM, int BN, int WM, int WN, int XMODE, int NS, int EPI = 0, bool PP = false>
 int launch2(const PPGemmArgs& a, int splitk, hipStream_t st) {
   if constexpr (EPI == 0) {
-    if ((a.gn_acc[0] || a.gn_acc[1]) && splitk == 1) return launch2<BM, BN, WM, WN, XMODE, NS, 4>(a, splitk, st);
+    if ((a.gn_acc[0] || a.gn_acc[1]) && splitk == 1) return launch2<BM, BN, WM, WN, XMODE, NS, 4, PP>(a, splitk, st);
   }
   if constexpr (XMODE == PP_X_PLAIN && EPI == 0) {
-    if (a.act == PP_ACT_GEGLU && splitk == 1) return launch2<BM, BN, WM, WN, XMODE, NS, 2>(a, splitk, st);
-    if (a.ln_stats || a.row_stats_out) return launch2<BM, BN, WM, WN, XMODE, NS, 1>(a, splitk, st);
+    if (a.act == PP_ACT_GEGLU && splitk == 1) return launch2<BM, BN, WM, WN, XMODE, NS, 2, PP>(a, splitk, st);
+    if (a.ln_stats || a.row_stats_out) return launch2<BM, BN, WM, WN, XMODE, NS, 1, PP>(a, splitk, st);
   }
   constexpr bool LNF = EPI == 1 || EPI == 2;
   constexpr int T = WM * WN * 64;
   constexpr int LDS = NS * (BM + BN) * 128 + (LNF ? 2048 + BM * 32 : 0);   // + epilogue-operand prefetch (LNF)
   static_assert(LDS <= 160 * 1024 || (LNF && NS > 2), "LDS budget");
-  if constexpr (LDS > 160 * 1024) {   // 256x160 x 3 stages has no room for the prefetch: drop to 2 stages
-    return launch2<BM, BN, WM, WN, XMODE, 2, EPI>(a, splitk, st);
+  if constexpr (LDS > 160 * 1024) {   // 256x160 x 3 stages has no room for the prefetch: drop to 2 stages (lock-step)
+    return launch2<BM, BN, WM, WN, XMODE, 2, EPI, false>(a, splitk, st);
   } else {
   static bool attr_set = false;
   // (2-stage pipelines need their single in-flight refill as early as possible: the spread costs them time)
-  auto kern = pp_gemm_kernel_v2<BM, BN, WM, WN, XMODE, NS, EPI, false>;
-  if constexpr (NS >= 3) {
-    if (gemm_dma_interleave()) kern = pp_gemm_kernel_v2<BM, BN, WM, WN, XMODE, NS, EPI, true>;
+  auto kern = pp_gemm_kernel_v2<BM, BN, WM, WN, XMODE, NS, EPI, false, PP>;
+  if constexpr (NS >= 3 && !PP) {
+    if (gemm_dma_interleave()) kern = pp_gemm_kernel_v2<BM, BN, WM, WN, XMODE, NS, EPI, true, false>;
   }
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) !=
@@ -1336,6 +1558,14 @@ extern "C" int pp_gemm_bf16(const PPGemmArgs* args, void* stream) {
       PP_V2(33, 256, 4, 3)
       PP_V2(24, 128, 4, 2)   // 8-wave 128x160 (wave tile 32x80): 4 waves / SIMD with two co-resident blocks
 #undef PP_V2
+#define PP_V3(ID, BM_, WM_, NS_)                                                                          \
+    case ID:                                                                                             \
+      return conv ? launch2<BM_, 160, WM_, 2, PP_X_CONV3X3, NS_, 0, true>(a, c.splitk, st)               \
+                  : launch2<BM_, 160, WM_, 2, PP_X_PLAIN, NS_, 0, true>(a, c.splitk, st);
+      PP_V3(53, 256, 4, 3)   // ping-pong 8-wave tiles (one block per CU)
+      PP_V3(44, 128, 4, 3)
+      PP_V3(54, 128, 4, 4)
+#undef PP_V3
     default:
       return PP_ERR_BAD_ARG;
   }

@@ -171,6 +171,14 @@ class PipelineBase(PipelinePretrainedMixin):
             kw["generator"] = generator
         return kw
 
+    @staticmethod
+    def _noise_dtype(prompt_embeds):
+        """The reference draws the initial noise in prompt_embeds.dtype (prepare_latents(..., prompt_embeds.dtype, ...),
+        pipeline_PowerPaint.py:930-940) and only then runs the loop; the HIP loop keeps latents in fp32, so the draw
+        happens in the reference's dtype (same generator state, same rounded values) and is widened afterwards."""
+        dt = getattr(prompt_embeds, "dtype", torch.float32)
+        return dt if dt in (torch.float16, torch.bfloat16, torch.float32) else torch.float32
+
     def get_timesteps(self, num_inference_steps, strength, device):
         """pipeline_PowerPaint.py:713-720."""
         init_timestep = min(int(num_inference_steps * strength), num_inference_steps)

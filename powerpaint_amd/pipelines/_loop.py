@@ -34,6 +34,7 @@ class DenoiseLoop:
         self.program: Optional[Plan] = None
         self.graph = None
         self._key = None
+        self._graph_scale = None      # side-branch conditioning scale baked into the captured graph (by-value kernel arg)
         self.latents: Optional[torch.Tensor] = None
 
     # ------------------------------------------------------------------
@@ -88,6 +89,10 @@ class DenoiseLoop:
                id(side_rt.step_plan) if side_rt is not None else None, kind, ts.data_ptr(), step.data_ptr(),
                0 if self.foreign else sch.coef_table().data_ptr(), mp.data_ptr() if mp is not None else 0, src.data_ptr())
         if key == self._key and self.program is not None:
+            # The conditioning scale is a by-value argument of the zero-conv launches: `prepare` has patched the launch
+            # records (eager runs see it), but a graph captured with another value still carries the old one.
+            if self.graph is not None and self._scale_now() != self._graph_scale:
+                self.graph = None
             return self
         self._key = key
         hw = h * w
@@ -112,9 +117,14 @@ class DenoiseLoop:
         self._keep = (ts, step, mp, lat)
         return self
 
+    def _scale_now(self):
+        sc = getattr(self.side_rt, "_scale", None) if getattr(self, "side_rt", None) is not None else None
+        return tuple(sc) if isinstance(sc, (list, tuple)) else sc
+
     def capture(self):
         """Capture one step into a hipGraph (torch.cuda.CUDAGraph).  The captured launches read the step counter from
         device memory, so the same graph serves every step."""
+        self._graph_scale = self._scale_now()
         torch.cuda.synchronize()
         step = self._keep[1]
         saved_step = step.clone()
@@ -147,7 +157,9 @@ class DenoiseLoop:
             self._keep[2].zero_()
         self.latents.copy_(latents.to(self.latents.device, torch.float32))
         varying = scale_schedule is not None and len(set(scale_schedule)) > 1
-        if use_graph and not varying and self.graph is None:
+        if not varying and scale_schedule and self.side_rt is not None and self._scale_now() != scale_schedule[0]:
+            self.side_rt._patch_scale(scale_schedule[0])      # (a previous call may have left a windowed value behind)
+        if use_graph and not varying and (self.graph is None or self._graph_scale != self._scale_now()):
             self.capture()
         stream = torch.cuda.current_stream().cuda_stream
         for i in range(num_steps):
@@ -178,7 +190,7 @@ class DenoiseLoop:
             if varying and self.side_rt is not None:
                 self.side_rt._patch_scale(scale_schedule[i])
             if use_graph and not varying:
-                if self.graph is None:
+                if self.graph is None or self._graph_scale != self._scale_now():
                     self.capture()
                     self._f_step.fill_(i)
                 self.graph.replay()

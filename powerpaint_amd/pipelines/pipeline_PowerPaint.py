@@ -106,6 +106,12 @@ class StableDiffusionInpaintPipeline(PipelineBase):
         if num_channels_unet != 9:
             raise NotImplementedError("the ppt-v1 hot path is the 9-channel inpainting UNet "
                                       "(pipeline_PowerPaint.py:965-975)")
+        # 6. latents -- drawn BEFORE the masked-image posterior is sampled, in the prompt dtype, as the reference does
+        #    (prepare_latents :930 precedes prepare_mask_latents :952): same seed / generator => same noise
+        shape = (nb, 4, h, w)
+        if latents is None:
+            latents = randn_tensor(shape, generator=generator, device=device, dtype=self._noise_dtype(prompt_embeds))
+        latents = latents.to(device=device, dtype=torch.float32) * self.scheduler.init_noise_sigma
         # 5./7. mask + masked-image latents
         if mask_latents is not None and masked_image_latents is not None:
             m = mask_latents.to(device=device, dtype=torch.float32)
@@ -119,11 +125,6 @@ class StableDiffusionInpaintPipeline(PipelineBase):
         if 4 + m.shape[1] + mil.shape[1] != num_channels_unet:
             raise ValueError("Incorrect configuration settings! mask / masked-image latents do not add up to "
                              f"unet.config.in_channels = {num_channels_unet}")
-        # 6. latents
-        shape = (nb, 4, h, w)
-        if latents is None:
-            latents = randn_tensor(shape, generator=generator, device=device, dtype=torch.float32)
-        latents = latents.to(device=device, dtype=torch.float32) * self.scheduler.init_noise_sigma
         # 10. fused denoising loop
         if self._loop is None or self._loop.scheduler is not self.scheduler or self._loop.unet is not self.unet:
             self._loop = DenoiseLoop(self.unet, self.scheduler)

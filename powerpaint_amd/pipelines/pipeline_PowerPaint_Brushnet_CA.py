@@ -134,6 +134,11 @@ class StableDiffusionPowerPaintBrushNetPipeline(PipelineBase):
             B0, C0, H0, W0 = msk.shape
             original_mask = hip_mask_prep(3, msk, None, (B0, 1, H0, W0), B0, C0, H0, W0)   # (mask.sum(1) < 0)  :1312
             height, width = img.shape[-2:]
+            # 6. latents are drawn BEFORE the conditioning posterior is sampled (:1323 precedes :1338)
+            if latents is None:
+                vs = getattr(self, "vae_scale_factor", 8)
+                latents = randn_tensor((nb, self.unet.config.in_channels, height // vs, width // vs), generator=generator,
+                                       device=device, dtype=self._noise_dtype(prompt_embeds))
             cl = self.vae.encode(img.to(next(iter(self.vae.parameters())).dtype)).latent_dist.sample() * \
                 self.vae.config.scaling_factor                                               # :1338-1341
             hl, wl = cl.shape[-2:]
@@ -147,7 +152,7 @@ class StableDiffusionPowerPaintBrushNetPipeline(PipelineBase):
         self._num_timesteps = len(timesteps)
         shape = (nb, self.unet.config.in_channels, h, w)
         if latents is None:
-            latents = randn_tensor(shape, generator=generator, device=device, dtype=torch.float32)
+            latents = randn_tensor(shape, generator=generator, device=device, dtype=self._noise_dtype(prompt_embeds))
         latents = latents.to(device=device, dtype=torch.float32) * self.scheduler.init_noise_sigma
         n = len(timesteps)
         keep = [1.0 - float(i / n < control_guidance_start or (i + 1) / n > control_guidance_end) for i in range(n)]

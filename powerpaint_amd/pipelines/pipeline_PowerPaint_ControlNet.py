@@ -81,6 +81,11 @@ class StableDiffusionControlNetInpaintPipeline(StableDiffusionInpaintPipeline):
         self.scheduler.set_timesteps(num_inference_steps, device=device)
         timesteps, num_inference_steps = self.get_timesteps(num_inference_steps, strength, device)
         h, w = height // self.vae_scale_factor, width // self.vae_scale_factor
+        # latents before the masked-image posterior sample (pipeline_PowerPaint_ControlNet.py:1614 precedes :1636)
+        shape = (nb, 4, h, w)
+        if latents is None:
+            latents = randn_tensor(shape, generator=generator, device=device, dtype=self._noise_dtype(prompt_embeds))
+        latents = latents.to(device=device, dtype=torch.float32) * self.scheduler.init_noise_sigma
         if mask_latents is not None and masked_image_latents is not None:
             m = mask_latents.to(device=device, dtype=torch.float32)
             mil = masked_image_latents.to(device)
@@ -90,10 +95,6 @@ class StableDiffusionControlNetInpaintPipeline(StableDiffusionInpaintPipeline):
             mk, masked_image = prepare_mask_and_masked_image(image, mask, height, width, device)
             m, mil = self.prepare_mask_latents(mk, masked_image, nb, height, width, prompt_embeds.dtype, device,
                                                generator, do_cfg, masked_image_latents)
-        shape = (nb, 4, h, w)
-        if latents is None:
-            latents = randn_tensor(shape, generator=generator, device=device, dtype=torch.float32)
-        latents = latents.to(device=device, dtype=torch.float32) * self.scheduler.init_noise_sigma
         n = len(timesteps)
         keep = [1.0 - float(i / n < control_guidance_start or (i + 1) / n > control_guidance_end) for i in range(n)]
         scales = [controlnet_conditioning_scale * k for k in keep]

@@ -21,6 +21,22 @@ def _betas(T, beta_start, beta_end):
     return torch.linspace(beta_start ** 0.5, beta_end ** 0.5, T, dtype=torch.float32) ** 2
 
 
+# Options of the diffusers schedulers that change the arithmetic and that the fused step kernel does not implement: a
+# config carrying another value is REFUSED (a silently dropped key would run and give wrong images).
+_ONLY = {"prediction_type": ("epsilon",), "beta_schedule": ("scaled_linear",), "clip_sample": (False,),
+         "thresholding": (False,), "rescale_betas_zero_snr": (False,), "use_karras_sigmas": (False,),
+         "use_lu_lambdas": (False,), "euler_at_final": (False,), "variance_type": (None,),
+         "trained_betas": (None,), "algorithm_type": ("dpmsolver++",), "solver_type": ("midpoint", "bh2"),
+         "final_sigmas_type": ("zero",), "lower_order_final": (True,), "lambda_min_clipped": (-float("inf"),),
+         "timestep_spacing": ("leading", "linspace", "trailing")}
+
+
+def _check_config(cls_name, cfg):
+    for k, ok in _ONLY.items():
+        if k in cfg and cfg[k] not in ok:
+            raise L.PPError(f"{cls_name}: {k}={cfg[k]!r} is not implemented on the HIP path (supported: {ok})")
+
+
 class _SchedulerBase:
     order = 1
     init_noise_sigma = 1.0
@@ -45,10 +61,10 @@ class _SchedulerBase:
         names are taken over, the rest (other schedulers' options, `_class_name`, ...) ignored."""
         import inspect
         src = dict(config) if isinstance(config, dict) else dict(vars(config))
+        src.update(kw)
+        _check_config(cls.__name__, src)
         names = set(inspect.signature(cls.__init__).parameters) - {"self", "kw", "cfg"}
-        args = {k: v for k, v in src.items() if k in names}
-        args.update(kw)
-        return cls(**args)
+        return cls(**{k: v for k, v in src.items() if k in names})
 
     # -- device state for the fused kernel
     def scale_model_input(self, sample, timestep=None):
@@ -134,7 +150,10 @@ class DDIMScheduler(_SchedulerBase):
     kind = 0
 
     def __init__(self, num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, steps_offset=1,
-                 set_alpha_to_one=False, **kw):
+                 set_alpha_to_one=False, timestep_spacing="leading", **kw):
+        _check_config("DDIMScheduler", kw)
+        if timestep_spacing != "leading":
+            raise L.PPError(f"DDIMScheduler: timestep_spacing={timestep_spacing!r} is not implemented (leading only)")
         super().__init__(num_train_timesteps, beta_start, beta_end, steps_offset=steps_offset,
                          set_alpha_to_one=set_alpha_to_one, timestep_spacing="leading", prediction_type="epsilon")
         self.final_alpha_cumprod = torch.tensor(1.0) if set_alpha_to_one else self.alphas_cumprod[0]
@@ -159,16 +178,33 @@ class DDIMScheduler(_SchedulerBase):
         self._upload(device)
 
 
+def dpm_timesteps(T, n, spacing="linspace", steps_offset=0):
+    """DPMSolverMultistepScheduler.set_timesteps of diffusers 0.27 (lambda_min_clipped = -inf => last_timestep = T):
+    what `DPMSolverMultistepScheduler.from_config(pipe.scheduler.config)` yields on an SD-1.5 checkpoint is the
+    `leading` form with steps_offset 1, the class default is `linspace`."""
+    if spacing == "linspace":
+        return np.linspace(0, T - 1, n + 1).round()[::-1][:-1].copy().astype(np.int64)
+    if spacing == "leading":
+        return (np.arange(0, n + 1) * (T // (n + 1))).round()[::-1][:-1].copy().astype(np.int64) + steps_offset
+    if spacing == "trailing":
+        return np.arange(T, 0, -T / n).round().copy().astype(np.int64) - 1
+    raise ValueError(f"unknown timestep_spacing {spacing}")
+
+
 class DPMSolverMultistepScheduler(_SchedulerBase):
     """dpmsolver++ (2M), midpoint, `linspace` spacing, final_sigmas_type = "zero", lower_order_final."""
     kind = 1
 
-    def __init__(self, num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, solver_order=2, **kw):
-        super().__init__(num_train_timesteps, beta_start, beta_end, solver_order=solver_order, steps_offset=0,
+    def __init__(self, num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, solver_order=2,
+                 timestep_spacing="linspace", steps_offset=0, **kw):
+        _check_config("DPMSolverMultistepScheduler", kw)
+        super().__init__(num_train_timesteps, beta_start, beta_end, solver_order=solver_order, steps_offset=steps_offset,
                          algorithm_type="dpmsolver++", solver_type="midpoint", final_sigmas_type="zero",
-                         timestep_spacing="linspace", prediction_type="epsilon")
+                         timestep_spacing=timestep_spacing, prediction_type="epsilon")
         if solver_order != 2:
             raise NotImplementedError("only the 2M solver is on the hot path")
+        if timestep_spacing not in ("linspace", "leading", "trailing"):
+            raise ValueError(f"unknown timestep_spacing {timestep_spacing}")
 
     @staticmethod
     def _alpha_sigma(sigma):
@@ -178,7 +214,7 @@ class DPMSolverMultistepScheduler(_SchedulerBase):
     def set_timesteps(self, num_inference_steps: int, device=None):
         T = self.config.num_train_timesteps
         self.num_inference_steps = num_inference_steps
-        ts = np.linspace(0, T - 1, num_inference_steps + 1).round()[::-1][:-1].copy().astype(np.int64)
+        ts = dpm_timesteps(T, num_inference_steps, self.config.timestep_spacing, self.config.steps_offset)
         sig = (((1 - self.alphas_cumprod) / self.alphas_cumprod) ** 0.5).numpy()
         sig = np.interp(ts, np.arange(0, len(sig)), sig)
         self.sigmas = torch.from_numpy(np.concatenate([sig, [0.0]]).astype(np.float32))
@@ -217,7 +253,10 @@ class PNDMScheduler(_SchedulerBase):
     state_slots = 5
 
     def __init__(self, num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, steps_offset=1,
-                 set_alpha_to_one=False, skip_prk_steps=True, **kw):
+                 set_alpha_to_one=False, skip_prk_steps=True, timestep_spacing="leading", **kw):
+        _check_config("PNDMScheduler", kw)
+        if timestep_spacing != "leading":
+            raise L.PPError(f"PNDMScheduler: timestep_spacing={timestep_spacing!r} is not implemented (leading only)")
         if not skip_prk_steps:
             raise NotImplementedError("only the PLMS form (skip_prk_steps=True, the SD-1.5 config) is on the hot path")
         super().__init__(num_train_timesteps, beta_start, beta_end, steps_offset=steps_offset,

@@ -355,6 +355,61 @@ def test_pipeline_controlnet_loop():
     close(out, ref, "controlnet free-running", cos_min=0.995, rel=0.1)
 
 
+def test_controlnet_scale_change_reaches_the_captured_graph():
+    """controlnet_conditioning_scale is a by-value argument of the zero-conv launches: a second call with another
+    scale (same shapes, steps, guidance -- app.py:438-451 takes it from a UI slider) must not replay the graph captured
+    with the first one.  Also after a call whose control_guidance window varied the scale per step."""
+    _, hc = make_tiny("controlnet")
+    _, hu = make_tiny("unet", seed=1, in_channels=9)
+    B, hh, N = 1, 16, 3
+    lat, mask, mil, pe = _v1_inputs(B, hh, hh)
+    img = torch.rand(B, 3, hh * 8, hh * 8, generator=torch.Generator("cpu").manual_seed(9))
+    pipe = PP.StableDiffusionControlNetInpaintPipeline(unet=hu, controlnet=hc, scheduler=PS.DDIMScheduler())
+    kw = dict(prompt_embeds=pe[B:].to(DEV), negative_prompt_embeds=pe[:B].to(DEV), control_image=img.to(DEV),
+              height=hh * 8, width=hh * 8, num_inference_steps=N, guidance_scale=7.5, latents=lat.to(DEV),
+              mask_latents=mask.to(DEV), masked_image_latents=mil.to(DEV), output_type="latent", return_dict=False)
+    pipe.use_graph = False
+    e10 = pipe(controlnet_conditioning_scale=1.0, **kw)[0].clone()
+    e05 = pipe(controlnet_conditioning_scale=0.5, **kw)[0].clone()
+    ewin = pipe(controlnet_conditioning_scale=1.0, control_guidance_end=0.5, **kw)[0].clone()
+    assert not torch.equal(e10, e05) and not torch.equal(e10, ewin)
+    pipe.use_graph = True
+    assert torch.equal(pipe(controlnet_conditioning_scale=1.0, **kw)[0], e10)
+    assert torch.equal(pipe(controlnet_conditioning_scale=0.5, **kw)[0], e05)       # (was: the 1.0 graph replayed)
+    assert torch.equal(pipe(controlnet_conditioning_scale=1.0, control_guidance_end=0.5, **kw)[0], ewin)
+    assert torch.equal(pipe(controlnet_conditioning_scale=1.0, **kw)[0], e10)       # (window left 0.0 behind)
+
+
+def test_pipelines_draw_the_noise_before_the_vae_posterior():
+    """RNG consumption order of the reference: prepare_latents (pipeline_PowerPaint.py:930) runs before
+    prepare_mask_latents (:952) samples the masked-image posterior, so with one generator the initial noise is the FIRST
+    draw.  Pinned by replaying the draw by hand: latents drawn first from an identical generator, the same generator
+    (now advanced) handed on for the VAE sample."""
+    from powerpaint_amd.pipelines._base import randn_tensor
+    _, h = make_tiny("unet", in_channels=9)
+    vae = PM.AutoencoderKL(device=DEV, block_out_channels=(64, 128, 256, 256), layers_per_block=1)
+    vae.load_state_dict(vae.net.synthetic_state_dict(seed=21))
+    B, side, N = 1, 128, 2
+    img = torch.rand(B, 3, side, side, generator=torch.Generator("cpu").manual_seed(1)) * 2 - 1
+    mask = torch.zeros(B, 1, side, side)
+    mask[:, :, 32:96, 40:100] = 1.0
+    pe = gen(2 * B, 77, 768, seed=4)
+    pipe = PP.StableDiffusionInpaintPipeline(vae=vae, unet=h, scheduler=PS.DDIMScheduler())
+    kw = dict(prompt_embeds=pe[B:].to(DEV), negative_prompt_embeds=pe[:B].to(DEV), image=img, mask=mask, height=side,
+              width=side, num_inference_steps=N, guidance_scale=7.5, output_type="latent", return_dict=False)
+    out = pipe(generator=torch.Generator("cpu").manual_seed(123), **kw)[0]
+    g = torch.Generator("cpu").manual_seed(123)
+    lat = randn_tensor((B, 4, side // 8, side // 8), generator=g, device=DEV, dtype=torch.float32)
+    again = pipe(latents=lat, generator=g, **kw)[0]
+    assert torch.equal(out, again)
+    # global RNG (generator=None, app.py's set_seed path): same order
+    torch.manual_seed(9)
+    o2 = pipe(**kw)[0]
+    torch.manual_seed(9)
+    lat = torch.randn((B, 4, side // 8, side // 8), device=DEV, dtype=torch.float32)
+    assert torch.equal(o2, pipe(latents=lat, **kw)[0])
+
+
 def test_pipeline_v1_pixels_in_pixels_out_with_vae():
     """image + mask in pixel space -> VAE encode of the masked image -> fused loop -> VAE decode (output_type="pt"),
     against the same chain of oracles (the VAE either side of the loop)."""

@@ -40,7 +40,8 @@ def check(out, ref, atol, rtol, what=""):
 
 
 # ------------------------------------------------------------------------------------------------ GEMM
-ALL_TILES = [1, 2, 3, 21, 31, 22, 32, 42, 23, 33, 24]
+PP_TILES = [53, 44, 54]      # ping-pong 8-wave tiles (256x160x3, 128x160x3, 128x160x4)
+ALL_TILES = [1, 2, 3, 21, 31, 22, 32, 42, 23, 33, 24] + PP_TILES
 
 
 @pytest.mark.parametrize("tile", ALL_TILES)
@@ -63,7 +64,7 @@ def test_gemm_transpose_detect():
     check(out, w.float().t(), 0, 0, "gemm identity")
 
 
-@pytest.mark.parametrize("tile", [2, 22, 42, 31])
+@pytest.mark.parametrize("tile", [2, 22, 42, 31, 53, 54])
 @pytest.mark.parametrize("splitk", [2, 4, 3])
 def test_gemm_splitk(splitk, tile):
     M, N, K = 512, 1280, 2560
@@ -106,7 +107,7 @@ def test_gemm_vt_epilogue():
     check(vt, y[:, 2 * C:].reshape(B, hw, C).transpose(1, 2), 2e-2, 1e-2, "v^T part")
 
 
-V2_TILES = [21, 31, 22, 32, 42, 23, 33, 24]
+V2_TILES = [21, 31, 22, 32, 42, 23, 33, 24] + PP_TILES
 
 
 @pytest.mark.parametrize("tile", V2_TILES + [0])
@@ -194,7 +195,7 @@ def test_conv3x3_concat_temb_res_splitk():
     bias, temb = rnd(Cout, seed=4), rnd(1, Cout, seed=5)
     r1, r2 = bf(rnd(B, H, W, Cout, seed=6)), bf(rnd(B, H, W, Cout, seed=7))
     ref = conv_ref(torch.cat([x1, x2], -1), w, bias) + temb.view(1, 1, 1, -1) + r1.float() + r2.float()
-    for tile in (2, 32, 31, 33):
+    for tile in (2, 32, 31, 33, 53, 44):
         for sk in (1, 4):
             out = ops.conv3x3(x1, w, bias, x2=x2, rowvec=temb, res1=r1, res2=r2, tile=tile, splitk=sk)
             check(out, ref, 3e-2, 1e-2, f"conv concat tile{tile} splitk{sk}")
@@ -206,13 +207,13 @@ def test_conv3x3_halo_exact():
     x = torch.ones(B, H, W, Cin, dtype=torch.bfloat16, device=DEV)
     w = torch.ones(Cout, 9 * Cin, dtype=torch.bfloat16, device=DEV) / 64
     cnt = F.conv2d(torch.ones(1, 1, H, W, device=DEV), torch.ones(1, 1, 3, 3, device=DEV), padding=1)[0, 0]
-    for tile in (2, 22, 21, 33):
+    for tile in (2, 22, 21, 33, 53, 54):
         out = ops.conv3x3(x, w, None, tile=tile, splitk=1).float()
         assert torch.equal(out[0, :, :, 0], cnt), (tile, out[0, :, :, 0], cnt)
         assert torch.equal(out[0, :, :, 319], cnt)
 
 
-@pytest.mark.parametrize("tile,splitk", [(0, 0), (21, 1), (22, 2), (33, 1), (24, 1), (31, 4)])
+@pytest.mark.parametrize("tile,splitk", [(0, 0), (21, 1), (22, 2), (33, 1), (24, 1), (31, 4), (53, 1), (53, 3), (54, 2), (44, 1)])
 @pytest.mark.parametrize("two", [False, True])
 def test_conv3x3_with_1x1_tail(tile, splitk, two):
     """conv2(h) + conv_shortcut(concat(x, skip)) as ONE implicit GEMM: K = 9 C_h + C_x (+ C_skip)."""
@@ -243,7 +244,7 @@ def _gn_ref(t, cg, c0, groups):
     return out
 
 
-@pytest.mark.parametrize("tile,splitk", [(0, 0), (21, 1), (22, 1), (24, 1), (33, 1), (31, 4), (32, 2), (33, 8)])
+@pytest.mark.parametrize("tile,splitk", [(0, 0), (21, 1), (22, 1), (24, 1), (33, 1), (31, 4), (32, 2), (33, 8), (53, 1), (54, 1), (53, 4)])
 def test_conv_epilogue_groupnorm_stats(tile, splitk):
     """The conv epilogue (or the split-K combine) accumulates the consumer GroupNorms' (sum, sumsq): two consumers with
     different groupings (own 32-group norm; a 1920-channel concat norm where this tensor sits at channel offset 1280,
