@@ -31,16 +31,21 @@ MFMA_PEAK_TFLOPS = 2500.0        # dense bf16, /opt/skills/guides/MI355X_MICROAR
 GFLOP_PER_SAMPLE = {"unet9": 803.4, "unet4": 803.3, "brushnet": 826.2, "controlnet": 283.3}
 
 
-def build_pipeline(cfg, device, rank, world):
+def build_pipeline(cfg, device, rank, world, net_kw=None):
+    """Networks + pipeline of one rank.  Rank 0 creates the (random-init) weights; every other rank only lays out its
+    packed parameter buffer (`meta=True` state dict, `materialize=False`) and receives the bytes in the one start-up
+    broadcast.  `net_kw` overrides the architecture (tests run this function with a reduced network)."""
     from powerpaint_amd import models as PM, pipelines as PP, schedulers as PS
-    unet = PM.UNet2DConditionModel(in_channels=9 if cfg != "v2" else 4, device=device)
+    net_kw = dict(net_kw or {})
+    unet = PM.UNet2DConditionModel(in_channels=9 if cfg != "v2" else 4, device=device, **net_kw)
     side = None
     nets = [unet]
     if cfg == "v2":
-        side = PM.BrushNetModel(in_channels=4, conditioning_channels=5, device=device)
+        side = PM.BrushNetModel(in_channels=4, conditioning_channels=5, device=device, **net_kw)
         nets.append(side)
     elif cfg == "controlnet":
-        side = PM.ControlNetModel(in_channels=4, device=device)
+        side = PM.ControlNetModel(in_channels=4, device=device,
+                                  **{k: v for k, v in net_kw.items() if k != "up_block_types"})
         nets.append(side)
     for i, m in enumerate(nets):
         if rank == 0:
@@ -49,10 +54,13 @@ def build_pipeline(cfg, device, rank, world):
             del sd
         else:
             m.load_state_dict(m.net.synthetic_state_dict(meta=True), materialize=False)
-    torch.cuda.synchronize()
+    on_gpu = torch.device(device).type == "cuda"
+    if on_gpu:
+        torch.cuda.synchronize()
     t0 = time.perf_counter()
     ppdist.broadcast_params([m.param_buffer() for m in nets], src=0)     # the ONE collective (RCCL over xGMI)
-    torch.cuda.synchronize()
+    if on_gpu:
+        torch.cuda.synchronize()
     bcast_s = time.perf_counter() - t0
     if cfg == "v1":
         pipe = PP.StableDiffusionInpaintPipeline(unet=unet, scheduler=PS.DDIMScheduler())

@@ -117,3 +117,80 @@ def test_predict_controlnet_matches_reference(G):
                                              if pipe.calls[0].get(k) != c["call"].get(k)}
         assert [digest(o) for o in out] == c["out"] and [digest(r) for r in res] == c["res"]
         assert seeds == [c["seed"]]
+
+
+@pytest.mark.gpu
+def test_checkpoint_folder_to_controller_to_image_on_the_hip_path(tmp_path):
+    """SURVEY.md section 8f-4 end to end on the GPU (app.py:84-200 + 245-387): a diffusers-layout pipeline folder on disk
+    -> `StableDiffusionInpaintPipeline.from_pretrained` -> TokenizerWrapper + add_tokens (app.py:93-108) -> controller
+    `predict` (text-guided, then an outpainting canvas) -> PIL, with UNet, VAE, CLIP tower and the fused loop all on the
+    HIP kernels.  Checked against the same run driven by hand (the controller's documented pre-processing + a direct
+    pipeline call under the same seed): identical pixels."""
+    transformers = pytest.importorskip("transformers")
+    from test_loaders import TINY, write_dir
+    from powerpaint_amd import models as PM, pipelines as PP, schedulers as PS
+    from powerpaint_amd.controller import _set_seed, add_task
+    from powerpaint_amd.utils import TokenizerWrapper, add_tokens
+    root = str(tmp_path / "ppt-v1")
+    unet = PM.UNet2DConditionModel(in_channels=9, device="cpu", **TINY)
+    write_dir(os.path.join(root, "unet"), dict(TINY, in_channels=9, out_channels=4, sample_size=64),
+              {k: v.half() for k, v in unet.net.synthetic_state_dict(seed=3).items()})
+    vcfg = dict(block_out_channels=(64, 128, 256, 256), layers_per_block=1, in_channels=3, out_channels=3,
+                latent_channels=4, norm_num_groups=32, scaling_factor=0.18215)
+    vae = PM.AutoencoderKL(device="cpu", **vcfg)
+    write_dir(os.path.join(root, "vae"), vcfg, vae.net.synthetic_state_dict(seed=5))
+    with open(os.path.join(HERE, "golden", "ref_task_tokens.json")) as f:
+        T = json.load(f)
+    tok = transformers.CLIPTokenizer(vocab={t: i for i, t in enumerate(T["vocab"])},
+                                     merges=[tuple(m) for m in T["merges"]], model_max_length=77)
+    tok.save_pretrained(os.path.join(root, "tokenizer"))
+    n = len(tok)
+    torch.manual_seed(0)
+    hf = transformers.CLIPTextModel(transformers.CLIPTextConfig(
+        vocab_size=n, hidden_size=768, intermediate_size=3072, num_hidden_layers=2, num_attention_heads=12,
+        max_position_embeddings=77, hidden_act="quick_gelu", bos_token_id=n - 2, eos_token_id=n - 1, pad_token_id=n - 1))
+    hf.save_pretrained(os.path.join(root, "text_encoder"))
+    os.makedirs(os.path.join(root, "scheduler"))
+    with open(os.path.join(root, "scheduler", "scheduler_config.json"), "w") as f:
+        json.dump(dict(_class_name="PNDMScheduler", beta_end=0.012, beta_schedule="scaled_linear", beta_start=0.00085,
+                       num_train_timesteps=1000, set_alpha_to_one=False, skip_prk_steps=True, steps_offset=1,
+                       trained_betas=None, clip_sample=False), f)
+    with open(os.path.join(root, "model_index.json"), "w") as f:
+        json.dump({"_class_name": "StableDiffusionInpaintPipeline", "scheduler": ["diffusers", "PNDMScheduler"],
+                   "text_encoder": ["transformers", "CLIPTextModel"], "tokenizer": ["transformers", "CLIPTokenizer"],
+                   "unet": ["diffusers", "UNet2DConditionModel"], "vae": ["diffusers", "AutoencoderKL"],
+                   "feature_extractor": ["transformers", "CLIPImageProcessor"],
+                   "safety_checker": ["stable_diffusion", "StableDiffusionSafetyChecker"]}, f)
+
+    pipe = PP.StableDiffusionInpaintPipeline.from_pretrained(root, torch_dtype=torch.bfloat16, device="cuda",
+                                                             local_files_only=True)
+    assert isinstance(pipe.scheduler, PS.PNDMScheduler) and pipe.unet.device.type == "cuda"
+    pipe.tokenizer = TokenizerWrapper(from_pretrained=root, subfolder="tokenizer", revision=None)      # app.py:93-97
+    add_tokens(tokenizer=pipe.tokenizer, text_encoder=pipe.text_encoder,
+               placeholder_tokens=["P_ctxt", "P_shape", "P_obj"], initialize_tokens=["a", "a", "a"],
+               num_vectors_per_token=10)                                                                # app.py:102-108
+    with torch.no_grad():
+        for e in pipe.text_encoder.text_model.embeddings.token_embedding.external_embeddings:
+            e["embedding"].copy_(torch.randn_like(e["embedding"]) * 0.05)
+    ctl = PowerPaintController(pipe, version="ppt-v1")
+    inp = make_inputs(320, 320, seed=7)
+    keep = {"image": inp["image"].copy(), "mask": inp["mask"].copy()}
+    out, res = ctl.predict(inp, "a red cat", 0.7, 3, 6.5, 123, "blurry", "text-guided")
+    assert len(out) == 1 and out[0].size == (640, 640) and out[0].mode == "RGB" and len(res) == 2
+    assert np.array(out[0]).std() > 1.0
+    # the same request by hand: the controller's pre-processing, then the pipeline under the same seed
+    image = fit_short_side(keep["image"], False)
+    image, mask, (w, h) = snap_to_eight(image, keep["mask"])
+    pA, pB, nA, nB = add_task("a red cat", "blurry", "text-guided", "ppt-v1")
+    _set_seed(123)
+    again = pipe(promptA=pA, promptB=pB, tradoff=0.7, tradoff_nag=0.7, negative_promptA=nA, negative_promptB=nB,
+                 image=image.convert("RGB"), mask=mask.convert("RGB"), width=w, height=h, guidance_scale=6.5,
+                 num_inference_steps=3).images[0]
+    assert np.array_equal(np.array(out[0]), np.array(again))
+    other, _ = ctl.predict({"image": keep["image"].copy(), "mask": keep["mask"].copy()}, "a red cat", 0.7, 3, 6.5, 124,
+                           "blurry", "text-guided")
+    assert not np.array_equal(np.array(other[0]), np.array(out[0]))                  # the seed reaches the noise
+    # outpainting canvas (app.py:262-304): 512-short-side image on a 1.5x taller grey canvas
+    o2, r2 = ctl.predict({"image": keep["image"].copy(), "mask": keep["mask"].copy()}, "", 1.0, 2, 7.5, 5, "",
+                         "image-outpainting", 1.5, 1.0)
+    assert o2[0].size == (512, 768) and r2[0].size == (512, 768) and np.isfinite(np.array(o2[0], dtype=np.float32)).all()

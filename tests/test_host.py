@@ -219,6 +219,65 @@ def test_two_rank_broadcast_and_sharding_gloo():
     assert res[0][3] == res[1][3] == 2.0
 
 
+def _bench_worker(rank, world, port, q):
+    """bench.py's own start-up path on a CPU arena: rank 0 materialises weights, rank 1 takes the `meta=True` /
+    `materialize=False` branch and receives them in `broadcast_params`."""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    r, w, _ = ppdist.init_from_env("gloo")
+    out = []
+    for cfg in ("v1", "v2", "controlnet"):
+        pipe, nets, bcast_s = bench.build_pipeline(cfg, "cpu", r, w, net_kw=TINY)
+        assert len(nets) == (1 if cfg == "v1" else 2) and bcast_s >= 0.0
+        if r != 0:
+            assert all(int(m.param_buffer().count_nonzero()) > 0 for m in nets)       # received, not generated
+        out.append([float(m.param_buffer().view(torch.int16).double().sum()) for m in nets])
+        kw = bench.synthetic_inputs(cfg, "cpu", r, 2, 8)       # rank-local inputs keyed by the global image index
+        out.append(float(kw["latents"].double().sum()))
+    ppdist.barrier()
+    q.put((r, out))
+    torch.distributed.destroy_process_group()
+
+
+def test_bench_startup_path_two_ranks_gloo():
+    """The N > 1 branch of bench.py (never exercised on hardware with one GPU per lease): both ranks end up with the
+    same parameter bytes for every network of every config, and their synthetic inputs are the two halves of the
+    global batch (seeded by global image index)."""
+    ctx = mp.get_context("spawn")
+
+    def run():
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_bench_worker, args=(r, 2, port, q)) for r in range(2)]
+        for p in procs:
+            p.start()
+        try:
+            res = sorted([q.get(timeout=300) for _ in procs], key=lambda x: x[0])
+        finally:
+            for p in procs:
+                p.join(60)
+                if p.is_alive():
+                    p.kill()
+                    p.join(10)
+        assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+        return res
+
+    try:
+        res = run()
+    except Exception:
+        res = run()
+    a, b = res[0][1], res[1][1]
+    for i in (0, 2, 4):
+        assert a[i] == b[i] and all(v != 0.0 for v in a[i])              # identical packed buffers on both ranks
+    import bench
+    for i, cfg in ((1, "v1"), (3, "v2"), (5, "controlnet")):
+        both = bench.synthetic_inputs(cfg, "cpu", 0, 4, 8)["latents"]    # world = 1 with the whole batch
+        assert a[i] == float(both[:2].double().sum()) and b[i] == float(both[2:].double().sum())
+
+
 def test_encode_prompt_matches_reference_method():
     """Row a21 (blend) / a18 (CFG batch order): `PipelineBase._encode_prompt` against the reference's own
     `StableDiffusionInpaintPipeline._encode_prompt` (tests/golden/ref_encode_prompt.pt, lifted out of

@@ -1,0 +1,151 @@
+"""-m gpu: oracle parity at the REAL shapes of BASELINE.json configs 2-4 ("parity holes at real shapes").
+
+The reduced-size tests (tests/test_models_gpu.py) never reach the 64x64-level launch configurations of the full
+networks -- 256x160 ping-pong tiles, `attn_pipe_kernel<40>` at N = 4096, GroupNorm statistics in epilogues at
+rows_per_batch = 4096 -- nor the full-width BrushNet (886 M parameters, 28 residuals) and ControlNet.  Here the fp32
+CPU oracle runs the full architectures once per test (10-25 s of host time each on the GPU box) on bf16-rounded
+random weights; the achieved cosine / max-abs are printed (run with -s) and asserted at the network-forward gate of
+SURVEY.md section 8d (cosine >= 0.999, max-abs <= 3e-2 * max(1, max|ref|)).
+
+Reference sites: /root/reference/powerpaint/models/unet_2d_condition.py:1040-1363, BrushNet_CA.py:690-952,
+pipeline_PowerPaint_Brushnet_CA.py:1384-1466; ControlNetModel is diffusers 0.27 (absent, oracle unpinned).
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import schedulers as OS  # noqa: E402
+from oracle import sd_modules as OM  # noqa: E402
+from powerpaint_amd import models as PM  # noqa: E402
+from powerpaint_amd import pipelines as PP  # noqa: E402
+from powerpaint_amd import schedulers as PS  # noqa: E402
+
+from test_models_gpu import DEV, bf16_weights_, close, gen  # noqa: E402
+
+
+def report(what, out, ref, **kw):
+    # achieved on MI355X (profiles/r02_real_shape_parity.txt): cosine >= 0.99996, max-abs <= 1.4e-2 on |ref| <= 1.6;
+    # gate at twice that error, tighter than the generic network-forward gate (0.999 / 3e-2)
+    kw.setdefault("cos_min", 0.9999)
+    kw.setdefault("rel", 2e-2)
+    cos, err = close(out, ref, what, **kw)
+    print(f"[real-shape parity] {what}: cosine {cos:.6f}  max-abs {err:.4g}  (max|ref| {float(ref.abs().max()):.4g})")
+    return cos, err
+
+
+@pytest.fixture(scope="module")
+def unet9():
+    torch.manual_seed(0)
+    o = bf16_weights_(OM.UNet2DConditionModel(in_channels=9)).eval()
+    h = PM.UNet2DConditionModel(in_channels=9, device=DEV).load_state_dict(o.state_dict())
+    return o, h
+
+
+@pytest.fixture(scope="module")
+def unet4():
+    torch.manual_seed(1)
+    o = bf16_weights_(OM.UNet2DConditionModel(in_channels=4)).eval()
+    h = PM.UNet2DConditionModel(in_channels=4, device=DEV).load_state_dict(o.state_dict())
+    return o, h
+
+
+def test_config2_unet_64x64_batch2_and_batch8_rows_vs_oracle(unet9):
+    """BASELINE config 2's UNet forward at its real latent size: one 64x64 CFG pair through the oracle; the HIP batch-2
+    forward and rows 0-1 / 6-7 of the HIP batch-8 forward (the benchmark's launch plan: other tiles, split-K and
+    GroupNorm-statistics paths than batch 2) must all reproduce it."""
+    o, h = unet9
+    x2, e2 = gen(2, 9, 64, 64, seed=11), gen(2, 77, 768, seed=12)
+    with torch.no_grad():
+        ref = o(x2, 681, e2)[0]
+    out2 = h(x2.to(DEV), 681, e2.to(DEV), return_dict=False)[0]
+    report("config 2 UNet 64x64, batch 2", out2, ref)
+    x8 = torch.cat([x2, gen(4, 9, 64, 64, seed=13), x2])
+    e8 = torch.cat([e2, gen(4, 77, 768, seed=14), e2])
+    out8 = h(x8.to(DEV), 681, e8.to(DEV), return_dict=False)[0]
+    report("config 2 UNet 64x64, batch 8 rows 0-1", out8[0:2], ref)
+    report("config 2 UNet 64x64, batch 8 rows 6-7", out8[6:8], ref)
+
+
+def test_config3_full_brushnet_32x32_residuals_and_unet(unet4):
+    """The full-width BrushNet_CA (BrushNet_CA.py:690-952: 886 M parameters, 12 + 1 + 15 residuals at 320..1280
+    channels) at 32x32, CFG pair, every residual against the oracle, then routed into the 4-channel UNet."""
+    ou, hu = unet4
+    torch.manual_seed(2)
+    ob = bf16_weights_(OM.randomize_zero_convs(OM.BrushNetModel(in_channels=4, conditioning_channels=5))).eval()
+    hb = PM.BrushNetModel(in_channels=4, conditioning_channels=5, device=DEV).load_state_dict(ob.state_dict())
+    x, e, eu = gen(2, 4, 32, 32, seed=21), gen(2, 77, 768, seed=22), gen(2, 77, 768, seed=23)
+    cond = gen(2, 5, 32, 32, seed=24)
+    with torch.no_grad():
+        dn, md, up = ob(x, 321, e, cond, conditioning_scale=1.0)
+        ref = ou(x, 321, eu, down_block_add_samples=list(dn), mid_block_add_sample=md, up_block_add_samples=list(up))[0]
+    hdn, hmd, hup = hb(x.to(DEV), 321, e.to(DEV), cond.to(DEV), conditioning_scale=1.0, return_dict=False)
+    assert (len(hdn), len(hup)) == (len(dn), len(up)) == (12, 15)
+    worst = 1.0
+    for i, (a, b) in enumerate(zip(hdn + [hmd] + hup, list(dn) + [md] + list(up))):
+        cos, _ = close(a, b, f"full BrushNet residual {i}", cos_min=0.998)
+        worst = min(worst, cos)
+    print(f"[real-shape parity] full BrushNet 32x32: 28 residuals, worst cosine {worst:.6f}")
+    out = hu(x.to(DEV), 321, eu.to(DEV), down_block_add_samples=list(hdn), mid_block_add_sample=hmd,
+             up_block_add_samples=list(hup), return_dict=False)[0]
+    report("full BrushNet -> full UNet, 32x32", out, ref)
+
+
+def test_config4_full_controlnet_32x32(unet9):
+    """Full-width ControlNet (SD-1.5 encoder copy + conditioning embedding + 13 zero convs) at 32x32 latents with a
+    256x256 control image, residuals against the oracle and routed into the 9-channel UNet."""
+    ou, hu = unet9
+    torch.manual_seed(3)
+    oc = bf16_weights_(OM.randomize_zero_convs(OM.ControlNetModel(in_channels=4))).eval()
+    hc = PM.ControlNetModel(in_channels=4, device=DEV).load_state_dict(oc.state_dict())
+    x4, x9, e = gen(2, 4, 32, 32, seed=31), gen(2, 9, 32, 32, seed=32), gen(2, 77, 768, seed=33)
+    img = torch.rand(2, 3, 256, 256, generator=torch.Generator("cpu").manual_seed(34))
+    with torch.no_grad():
+        dn, md = oc(x4, 700, e, img, conditioning_scale=0.5)
+        ref = ou(x9, 700, e, down_block_additional_residuals=dn, mid_block_additional_residual=md)[0]
+    hdn, hmd = hc(x4.to(DEV), 700, e.to(DEV), img.to(DEV), conditioning_scale=0.5, return_dict=False)
+    assert len(hdn) == len(dn) == 12
+    worst = 1.0
+    for i, (a, b) in enumerate(zip(hdn + [hmd], list(dn) + [md])):
+        cos, _ = close(a, b, f"full ControlNet residual {i}", cos_min=0.998)
+        worst = min(worst, cos)
+    print(f"[real-shape parity] full ControlNet 32x32 (256x256 control image): 13 residuals, worst cosine {worst:.6f}")
+    out = hu(x9.to(DEV), 700, e.to(DEV), down_block_additional_residuals=hdn, mid_block_additional_residual=hmd,
+             return_dict=False)[0]
+    report("full ControlNet -> full UNet, 32x32", out, ref)
+
+
+def test_config3_one_teacher_forced_dpm_step_64x64(unet4):
+    """BASELINE config 3 at its real shape: ONE denoising step (full BrushNet + full UNet at 64x64, CFG 7.5,
+    DPM-Solver++(2M) first step of a 50-step schedule) through the product pipeline against the oracle's loop body
+    (pipeline_PowerPaint_Brushnet_CA.py:1384-1466) on the same latents."""
+    from oracle import loops as OL
+    ou, hu = unet4
+    torch.manual_seed(4)
+    ob = bf16_weights_(OM.randomize_zero_convs(OM.BrushNetModel(in_channels=4, conditioning_channels=5))).eval()
+    hb = PM.BrushNetModel(in_channels=4, conditioning_channels=5, device=DEV).load_state_dict(ob.state_dict())
+    B, hh = 1, 64
+    lat = gen(B, 4, hh, hh, seed=41)
+    mask = torch.zeros(B, 1, hh, hh)
+    mask[:, :, 16:48, 16:48] = 1.0
+    cl = torch.cat([gen(B, 4, hh, hh, seed=42, scale=0.5), mask], 1)
+    pe, peU = gen(2 * B, 77, 768, seed=43), gen(2 * B, 77, 768, seed=44)
+    rec = {}
+
+    class OneStep(OS.DPMSolverMultistepScheduler):       # the first step of the 50-step schedule, then stop
+        def set_timesteps(self, n, device=None):
+            super().set_timesteps(50, device)
+            self.timesteps = self.timesteps[:1]
+
+    ref = OL.loop_v2(ou, ob, OneStep(), lat, torch.cat([cl] * 2), pe, peU, 50, 7.5, 1.0,
+                     eps_hook=lambda i, t, l, e: rec.setdefault("eps", e.clone()))
+    pipe = PP.StableDiffusionPowerPaintBrushNetPipeline(unet=hu, brushnet=hb, scheduler=PS.DPMSolverMultistepScheduler())
+    seen = {}
+    out = pipe(prompt_embeds=pe[B:].to(DEV), negative_prompt_embeds=pe[:B].to(DEV), prompt_embedsU=peU[B:].to(DEV),
+               negative_prompt_embedsU=peU[:B].to(DEV), conditioning_latents=cl.to(DEV), num_inference_steps=50,
+               guidance_scale=7.5, latents=lat.to(DEV), output_type="latent", return_dict=False,
+               callback=lambda i, t, l: seen.setdefault(i, l.clone()), callback_steps=1)[0]
+    assert torch.isfinite(out).all()
+    eps = pipe._loop.rt.eps_tensor()                     # (the last step's eps; the first step is checked via latents)
+    assert eps.shape == (2 * B, 4, hh, hh)
+    report("config 3, 64x64: latents after the first DPM-Solver++ step", seen[0], ref, cos_min=0.9995, rel=3e-2)
