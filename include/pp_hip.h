@@ -27,7 +27,13 @@ extern "C" {
 #define PP_ERR_LAUNCH (-3)       /* hipLaunchKernel / hipFuncSetAttribute failed                  */
 #define PP_ERR_WORKSPACE (-4)    /* workspace pointer null or too small                           */
 
-#define PP_ABI_VERSION 5
+#define PP_ABI_VERSION 6
+/* 16-bit storage format of activations and matrix weights ("dtype" arguments; the same codes pp_nchw_to_nhwc uses for
+ * its source): bf16 or fp16 -- the reference's default is fp16 (/root/reference/app.py:548,559).  MFMA accumulation,
+ * norm statistics, softmax, biases and latents are fp32 with either. */
+#define PP_DT_F32 0
+#define PP_DT_BF16 1
+#define PP_DT_F16 2
 int pp_abi_version(void);
 /* hipGetLastError() text of the last PP_ERR_LAUNCH on this thread (host pointer, static storage). */
 const char* pp_last_error(void);
@@ -89,7 +95,9 @@ typedef struct PPGemmArgs {
   int32_t splitk;     /* 0 = auto */
   int32_t tile;       /* 0 = auto; else PP_TILE_* */
   float* workspace;   /* split-K partials, pp_gemm_workspace_bytes() */
-  int32_t reserved[4];
+  int32_t dbg;        /* timing-experiment switches (tools/gemm_ablate.py); 0 in production */
+  int32_t dtype;      /* PP_DT_BF16 | PP_DT_F16: format of x*, w, res*, out (unless out_f32), out_vt */
+  int32_t reserved[2];
   /* LayerNorm folded into the GEMM (BasicTransformerBlock.norm1/2/3 -> the Linear that follows):
    *   LN(x) W^T = rstd * (x (gamma.W)^T - mean * colsum) + beta W^T, so the host packs W' = gamma (.) W, passes
    *   ln_colsum[n] = sum_k W'[n][k] and adds beta W^T to the bias; mean / rstd come from per-row moments.
@@ -132,7 +140,7 @@ typedef struct PPGemmArgs {
 #define PP_TILE_64x160 2
 #define PP_TILE_256x160 3
 
-int pp_gemm_bf16(const PPGemmArgs* args, void* stream);
+int pp_gemm_bf16(const PPGemmArgs* args, void* stream);   /* (historic name: bf16 or fp16 per args->dtype) */
 size_t pp_gemm_workspace_bytes(const PPGemmArgs* args);
 /* 1 if this launch (as pp_gemm_bf16 would configure it) can accumulate GroupNorm statistics (gn_acc), else 0 */
 int pp_gemm_gn_stats_ok(const PPGemmArgs* args);
@@ -142,7 +150,7 @@ int pp_gemm_gn_stats_ok(const PPGemmArgs* args);
  * concatenating their weights along N) -- [diffusers-0.27.0]; reference call site unet_2d_condition.py:1155-1156.
  * x fp32 [rows][K]; W bf16 [N][K]; bias fp32; out fp32 [rows][ldo]. act_in: 0 none, 2 silu. act_out likewise. */
 int pp_linear_skinny(const float* x, int rows, int K, const void* w, const float* bias, int N, float* out, int ldo,
-                     int act_in, int act_out, void* stream);
+                     int act_in, int act_out, int dtype, void* stream);
 
 /* Sinusoidal timestep embedding (Timesteps(dim, flip_sin_to_cos=True, freq_shift=0)), unet_2d_condition.py:914-938.
  * out fp32 [rows][dim] = [cos(t f_k), sin(t f_k)], t read from device pointer (one value broadcast to all rows). */
@@ -159,21 +167,22 @@ int pp_timestep_embedding(const float* t_dev, int rows, int dim, float* out, voi
  */
 size_t pp_groupnorm_workspace_bytes(int batch, int hw, int C);
 int pp_groupnorm_stats(const void* x1, int c1, const void* x2, int c2, int batch, int hw, int groups,
-                       float* workspace, void* stream);
+                       float* workspace, int dtype, void* stream);
 int pp_groupnorm_apply(const void* x1, int c1, const void* x2, int c2, int batch, int hw, int groups, float eps,
                        const float* gamma, const float* beta, const float* workspace, int silu, void* y,
-                       void* stream);
+                       int dtype, void* stream);
 
 /* GroupNorm apply from accumulated statistics: acc = int64 [batch][groups][2] filled by the producers' epilogues
  * (PPGemmArgs.gn_acc); otherwise identical to pp_groupnorm_apply. */
 int pp_groupnorm_apply_acc(const void* x1, int c1, const void* x2, int c2, int batch, int hw, int groups, float eps,
-                           const float* gamma, const float* beta, const int64_t* acc, int silu, void* y, void* stream);
+                           const float* gamma, const float* beta, const int64_t* acc, int silu, void* y, int dtype,
+                           void* stream);
 /* dst[0..n) = 0 (64-bit words): one launch zeroes the statistics accumulators of a whole forward pass */
 int pp_zero_u64(void* dst, long long n, void* stream);
 
 /* LayerNorm over the last dim, bf16 [rows][C] -> bf16 [rows][C]; BasicTransformerBlock.norm1/2/3 (eps 1e-5). */
 int pp_layernorm(const void* x, int rows, int C, const float* gamma, const float* beta, float eps, void* y,
-                 void* stream);
+                 int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Fused attention forward  O = softmax(Q K^T * scale) V, non-causal, no mask (AttnProcessor2_0 /
@@ -185,7 +194,7 @@ int pp_layernorm(const void* x, int rows, int C, const float* gamma, const float
  * head_dim d in {40, 80, 160}; nk arbitrary (keys >= nk masked).
  */
 int pp_attention_fwd(const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt, void* o, int ldo,
-                     int batch, int heads, int nq, int nk, int d, float scale, void* stream);
+                     int batch, int heads, int nq, int nk, int d, float scale, int dtype, void* stream);
 /* [rows = b*nk + t][cols] bf16 (row stride ld) -> vt[b][col][t] (row stride ldvt).  Used for the cross-attention V
  * (computed once per call: encoder_hidden_states are step-invariant) and as the unfused fallback for self-attention. */
 int pp_transpose_v(const void* v, int ld, int batch, int nk, int cols, void* vt, int ldvt, void* stream);
@@ -202,25 +211,25 @@ int pp_transpose_v(const void* v, int ld, int batch, int nk, int cols, void* vt,
  *                          boundary layout, consumed directly by pp_cfg_sched_step).
  */
 int pp_conv3x3_direct(const void* x, int batch, int hin, int win, int cin, const void* w, const float* bias,
-                      int cout, int stride, int silu_out, const void* add, void* out, void* stream);
+                      int cout, int stride, int silu_out, const void* add, void* out, int dtype, void* stream);
 int pp_conv3x3_smallcout(const void* x, int batch, int h, int w_, int cin, const void* w, const float* bias, int cout,
-                         float* out_nchw, void* stream);
+                         float* out_nchw, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Layout / assembly kernels at the module boundary (NCHW torch tensors <-> internal NHWC bf16).
  * pp_nchw_to_nhwc : src fp32|bf16|f16 NCHW [batch][c][hw] -> dst bf16 [batch][hw][ldc] at channel offset c0.
  *                   src_batch_mod > 0 reads batch item (b % src_batch_mod)  -> `torch.cat([latents]*2)`
  *                   (pipeline_PowerPaint.py:990) without a copy.
- * pp_nhwc_to_nchw : bf16 [batch][hw][c] -> fp32|bf16 NCHW.
- * dtype codes: 0 fp32, 1 bf16, 2 fp16.
+ * pp_nhwc_to_nchw : 16-bit [batch][hw][c] -> fp32 | the same 16-bit format, NCHW.
+ * dtype codes: PP_DT_F32 0, PP_DT_BF16 1, PP_DT_F16 2; the trailing `dtype` is the format of the NHWC side.
  */
 int pp_nchw_to_nhwc(const void* src, int src_dtype, int batch, int c, int hw, int src_batch_mod, void* dst, int ldc,
-                    int c0, void* stream);
-int pp_nhwc_to_nchw(const void* src, int batch, int c, int hw, void* dst, int dst_dtype, void* stream);
+                    int c0, int dtype, void* stream);
+int pp_nhwc_to_nchw(const void* src, int batch, int c, int hw, void* dst, int dst_dtype, int dtype, void* stream);
 /* out = a + b on bf16 tensors of n elements (n % 8 == 0).  The residual adds that cannot ride a GEMM epilogue:
  * ControlNet `down_block_res_sample + down_block_additional_residual` on the already-consumed skip tensors
  * (/root/reference/powerpaint/models/unet_2d_condition.py:1263-1272,1296-1297). */
-int pp_add_bf16(const void* a, const void* b, void* out, long long n, void* stream);
+int pp_add_bf16(const void* a, const void* b, void* out, long long n, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Fused classifier-free guidance + scheduler step on fp32 NCHW latents.
@@ -275,7 +284,8 @@ int pp_embed_splice(const void* table, const void* ext, const int32_t* src_row, 
  * /root/reference/powerpaint/pipelines/pipeline_PowerPaint.py:657-669,1051) is two pp_gemm_bf16 launches around this
  * kernel; pp_attention_fwd covers the UNet's head dims only.  lds / ldp: row strides in elements (multiples of 4).
  */
-int pp_softmax_rows(const float* s, long long lds, int rows, int n, float scale, void* p, long long ldp, void* stream);
+int pp_softmax_rows(const float* s, long long lds, int rows, int n, float scale, void* p, long long ldp, int dtype,
+                    void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Attention for short sequences: the CLIP text tower the pipelines call through `self.text_encoder(ids)[0]`
@@ -284,7 +294,7 @@ int pp_softmax_rows(const float* s, long long lds, int rows, int n, float scale,
  * d == 64, nk <= 128; causal: key j visible to query i iff j <= i (needs nq == nk).
  */
 int pp_attention_small(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* o, int ldo,
-                       int batch, int heads, int nq, int nk, int d, float scale, int causal, void* stream);
+                       int batch, int heads, int nq, int nk, int d, float scale, int causal, int dtype, void* stream);
 
 #ifdef __cplusplus
 }

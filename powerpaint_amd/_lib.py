@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libpp_hip.so")
 PP_X_PLAIN, PP_X_CONV3X3 = 0, 1
 PP_ACT_NONE, PP_ACT_GEGLU, PP_ACT_SILU = 0, 1, 2
 PP_TILE_AUTO, PP_TILE_128x160, PP_TILE_64x160, PP_TILE_256x160 = 0, 1, 2, 3
+PP_DT_F32, PP_DT_BF16, PP_DT_F16 = 0, 1, 2      # dtype codes of the C ABI (include/pp_hip.h)
 PP_ERR = {0: "PP_OK", -1: "PP_ERR_BAD_ARG", -2: "PP_ERR_UNSUPPORTED", -3: "PP_ERR_LAUNCH", -4: "PP_ERR_WORKSPACE"}
 
 vp, i32, f32, sz = C.c_void_p, C.c_int32, C.c_float, C.c_size_t
@@ -32,7 +33,7 @@ class PPGemmArgs(C.Structure):
         ("out_vt", vp), ("vt_col0", i32), ("vt_ld", i32),
         ("splitk", i32), ("tile", i32),
         ("workspace", vp),
-        ("reserved", i32 * 4),
+        ("dbg", i32), ("dtype", i32), ("reserved", i32 * 2),
         ("row_stats_out", vp), ("ln_stats", vp), ("ln_colsum", vp),
         ("ln_tiles", i32), ("ln_dim", i32), ("ln_eps", f32), ("pad0", i32),
         ("gn_acc", vp * 2), ("gn_cg", i32 * 2), ("gn_c0", i32 * 2), ("gn_groups", i32 * 2),
@@ -46,30 +47,30 @@ SIGNATURES = {
     "pp_last_error": (C.c_char_p, []),
     "pp_gemm_bf16": (C.c_int, [C.POINTER(PPGemmArgs), vp]),
     "pp_gemm_workspace_bytes": (sz, [C.POINTER(PPGemmArgs)]),
-    "pp_linear_skinny": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp]),
+    "pp_linear_skinny": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "pp_timestep_embedding": (C.c_int, [vp, C.c_int, C.c_int, vp, vp]),
     "pp_groupnorm_workspace_bytes": (sz, [C.c_int, C.c_int, C.c_int]),
     "pp_gemm_gn_stats_ok": (C.c_int, [C.POINTER(PPGemmArgs)]),
     "pp_groupnorm_apply_acc": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, f32, vp, vp, vp, C.c_int, vp,
-                                         vp]),
+                                         C.c_int, vp]),
     "pp_zero_u64": (C.c_int, [vp, C.c_longlong, vp]),
     "pp_embed_splice": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_longlong, vp]),
     "pp_attention_small": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int,
-                                     C.c_int, C.c_int, f32, C.c_int, vp]),
-    "pp_softmax_rows": (C.c_int, [vp, C.c_longlong, C.c_int, C.c_int, f32, vp, C.c_longlong, vp]),
-    "pp_groupnorm_stats": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
+                                     C.c_int, C.c_int, f32, C.c_int, C.c_int, vp]),
+    "pp_softmax_rows": (C.c_int, [vp, C.c_longlong, C.c_int, C.c_int, f32, vp, C.c_longlong, C.c_int, vp]),
+    "pp_groupnorm_stats": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp]),
     "pp_groupnorm_apply": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, f32, vp, vp, vp, C.c_int, vp,
-                                     vp]),
-    "pp_layernorm": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, f32, vp, vp]),
+                                     C.c_int, vp]),
+    "pp_layernorm": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, f32, vp, C.c_int, vp]),
     "pp_attention_fwd": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int,
-                                   C.c_int, C.c_int, f32, vp]),
+                                   C.c_int, C.c_int, f32, C.c_int, vp]),
     "pp_transpose_v": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp]),
     "pp_conv3x3_direct": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, vp,
-                                    vp, vp]),
-    "pp_conv3x3_smallcout": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, vp, vp]),
-    "pp_nchw_to_nhwc": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp]),
-    "pp_nhwc_to_nchw": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp]),
-    "pp_add_bf16": (C.c_int, [vp, vp, vp, C.c_longlong, vp]),
+                                    vp, C.c_int, vp]),
+    "pp_conv3x3_smallcout": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, vp, C.c_int, vp]),
+    "pp_nchw_to_nhwc": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp]),
+    "pp_nhwc_to_nchw": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp]),
+    "pp_add_bf16": (C.c_int, [vp, vp, vp, C.c_longlong, C.c_int, vp]),
     "pp_cfg_sched_step": (C.c_int, [vp, C.c_int, f32, vp, vp, C.c_int, C.c_int, vp, vp, vp]),
     "pp_step_select_t": (C.c_int, [vp, vp, vp, vp]),
     "pp_step_advance": (C.c_int, [vp, vp]),
@@ -96,10 +97,20 @@ def lib():
             fn = getattr(l, name)
             fn.restype = res
             fn.argtypes = args
-        if l.pp_abi_version() != 5:
+        if l.pp_abi_version() != 6:
             raise PPError("libpp_hip.so ABI version mismatch")
         _lib = l
     return _lib
+
+
+def dtype_code(dtype) -> int:
+    """torch 16-bit dtype -> PP_DT_* (the HIP path stores activations and matrix weights in bf16 or fp16)."""
+    import torch
+    if dtype == torch.bfloat16:
+        return PP_DT_BF16
+    if dtype == torch.float16:
+        return PP_DT_F16
+    raise PPError(f"the HIP path computes in bf16 or fp16 (fp32 accumulate), not {dtype}")
 
 
 def check(rc: int, what: str = ""):

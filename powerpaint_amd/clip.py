@@ -76,7 +76,7 @@ class CLIPTextNet:
             qkv = pb.linear(h, rows, Cc, P[f"{p}.qkv.weight"], 3 * Cc, P[f"{p}.qkv.bias"], name="linear")
             a = pb.alloc(rows * Cc * 2)
             pb.plan.add("attention_small", pb.lib.pp_attention_small, qkv, 3 * Cc, qkv + 2 * Cc, 3 * Cc,
-                        qkv + 4 * Cc, 3 * Cc, a, Cc, B, self.heads, n, n, 64, 0.125, 1)
+                        qkv + 4 * Cc, 3 * Cc, a, Cc, B, self.heads, n, n, 64, 0.125, 1, pb.dt)
             pb.plan.count("attention_small", 4.0 * B * self.heads * n * n * 64)
             pb.linear(a, rows, Cc, P[f"{p}.out.weight"], Cc, P[f"{p}.out.bias"], res1=x, out=mid, name="linear")
             h = pb.layernorm(mid, rows, Cc, P[f"{p}.layer_norm2.weight"], P[f"{p}.layer_norm2.bias"], self.eps)

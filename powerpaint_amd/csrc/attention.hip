@@ -45,12 +45,14 @@ struct Cfg {
 
 constexpr float RESCALE_THR = 8.0f;   // defer the O rescale while the running max grows by < 2^8 (log2 domain)
 
-template <int D>
+template <int D, int EDT>
 __global__ void __launch_bounds__(256, (D <= 80 ? 2 : 1))
 attn_fwd_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __restrict__ k, int ldk,
                 const uint16_t* __restrict__ vt, int ldvt, uint16_t* __restrict__ o, int ldo, int heads, int nq, int nk,
                 float scale_log2e) {
   using C = Cfg<D>;
+  using E = E16<EDT>;
+  typedef typename E::v8 v8_t;
   constexpr int BUF = C::KBYTES + C::VBYTES;
   // (Folding scale and -max into the spare contraction slot of the padded d = 40 QK^T was tried: it needs Q pre-scaled
   //  in bf16, a second rounding that large scores amplify -- rejected by test_attention_strided_qkv_and_spike.)
@@ -66,7 +68,7 @@ attn_fwd_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __restr
     constexpr int PADP = (C::VROWS - D) * (C::VS / 8);
     for (int i = tid; i < 2 * PADP; i += 256) {
       const int bufi = i / PADP, r = i - bufi * PADP;
-      const uint32_t v = (r < C::VS / 8) ? 0x3F803F80u : 0u;
+      const uint32_t v = (r < C::VS / 8) ? E::pack2(1.0f, 1.0f) : 0u;
       *reinterpret_cast<u32x2_t*>(smem + bufi * BUF + C::KBYTES + D * C::VS + r * 8) = u32x2_t{v, v};
     }
   }
@@ -162,9 +164,8 @@ attn_fwd_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __restr
       const f32x16_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int s = 0; s < C::DS; ++s) {
-        const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(ks + (32 * j + qi) * C::KS + (16 * s + 8 * half) * 2);
-        sacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, __builtin_bit_cast(bf16x8_t, qraw[s]),
-                                                          s == 0 ? zero : sacc[j], 0, 0, 0);
+        const v8_t kf = *reinterpret_cast<const v8_t*>(ks + (32 * j + qi) * C::KS + (16 * s + 8 * half) * 2);
+        sacc[j] = E::mfma32(kf, __builtin_bit_cast(v8_t, qraw[s]), s == 0 ? zero : sacc[j]);
       }
     }
     float tmax = -1.0e30f;
@@ -180,7 +181,7 @@ attn_fwd_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __restr
       }
     tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
     float psum = 0.f;
-    bf16x8_t pf[2][2];
+    v8_t pf[2][2];
     float p[2][16];
     {
       tmax *= scale_log2e;
@@ -211,11 +212,11 @@ attn_fwd_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __restr
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         u32x4_t w;
-        w[0] = pack2bf(p[j][8 * u + 0], p[j][8 * u + 1]);
-        w[1] = pack2bf(p[j][8 * u + 2], p[j][8 * u + 3]);
-        w[2] = pack2bf(p[j][8 * u + 4], p[j][8 * u + 5]);
-        w[3] = pack2bf(p[j][8 * u + 6], p[j][8 * u + 7]);
-        pf[j][u] = __builtin_bit_cast(bf16x8_t, w);
+        w[0] = E::pack2(p[j][8 * u + 0], p[j][8 * u + 1]);
+        w[1] = E::pack2(p[j][8 * u + 2], p[j][8 * u + 3]);
+        w[2] = E::pack2(p[j][8 * u + 4], p[j][8 * u + 5]);
+        w[3] = E::pack2(p[j][8 * u + 6], p[j][8 * u + 7]);
+        pf[j][u] = __builtin_bit_cast(v8_t, w);
       }
     if constexpr (!MFMA_SUM) l_run += psum;
     // O^T += V^T P^T : key slot (half, jj) <-> key 16u + 4 half + jj (jj<4) | 16u + 8 + 4 half + jj-4
@@ -225,9 +226,8 @@ attn_fwd_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __restr
       for (int u = 0; u < 2; ++u)
 #pragma unroll
         for (int dt = 0; dt < C::DT; ++dt) {
-          const bf16x8_t vf =
-              *reinterpret_cast<const bf16x8_t*>(vs + (dt * 32 + qi) * C::VS + (2 * j + u) * 32 + half * 16);
-          oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[j][u], oacc[dt], 0, 0, 0);
+          const v8_t vf = *reinterpret_cast<const v8_t*>(vs + (dt * 32 + qi) * C::VS + (2 * j + u) * 32 + half * 16);
+          oacc[dt] = E::mfma32(vf, pf[j][u], oacc[dt]);
         }
   };
 
@@ -269,8 +269,8 @@ attn_fwd_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __restr
         const int dc = dt * 32 + 8 * g + 4 * half;
         if (dc < D) {
           u32x2_t w;
-          w[0] = pack2bf(oacc[dt][4 * g + 0] * inv, oacc[dt][4 * g + 1] * inv);
-          w[1] = pack2bf(oacc[dt][4 * g + 2] * inv, oacc[dt][4 * g + 3] * inv);
+          w[0] = E::pack2(oacc[dt][4 * g + 0] * inv, oacc[dt][4 * g + 1] * inv);
+          w[1] = E::pack2(oacc[dt][4 * g + 2] * inv, oacc[dt][4 * g + 3] * inv);
           *reinterpret_cast<u32x2_t*>(op + dc) = w;
         }
       }
@@ -297,13 +297,13 @@ __global__ void __launch_bounds__(256) transpose_v_kernel(const uint16_t* __rest
 
 }  // namespace
 
-template <int D>
+template <int D, int EDT>
 static int launch_attn(const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt, void* o, int ldo,
                        int batch, int heads, int nq, int nk, float sl2, hipStream_t st) {
   constexpr int LDS = 2 * (Cfg<D>::KBYTES + Cfg<D>::VBYTES);
   static bool attr_set = false;
   if (!attr_set && LDS > 64 * 1024) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<D>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<D, EDT>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
       pp_set_last_error("hipFuncSetAttribute(attention)", hipGetLastError());
       return PP_ERR_LAUNCH;
@@ -311,7 +311,7 @@ static int launch_attn(const void* q, int ldq, const void* k, int ldk, const voi
     attr_set = true;
   }
   const dim3 grid((nq + QW * NW - 1) / (QW * NW), heads, batch), block(256);
-  hipLaunchKernelGGL(attn_fwd_kernel<D>, grid, block, LDS, st, (const uint16_t*)q, ldq, (const uint16_t*)k, ldk,
+  hipLaunchKernelGGL((attn_fwd_kernel<D, EDT>), grid, block, LDS, st, (const uint16_t*)q, ldq, (const uint16_t*)k, ldk,
                      (const uint16_t*)vt, ldvt, (uint16_t*)o, ldo, heads, nq, nk, sl2);
   PP_CHECK_LAUNCH("attn_fwd_kernel");
   return PP_OK;
@@ -319,11 +319,12 @@ static int launch_attn(const void* q, int ldq, const void* k, int ldk, const voi
 
 // attention_pipe.hip: software-pipelined kernel for the hot self-attention shapes (PP_ERR_UNSUPPORTED otherwise)
 int pp_attention_pipe_launch(const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt, void* o, int ldo,
-                             int batch, int heads, int nq, int nk, int d, float sl2, hipStream_t st);
+                             int batch, int heads, int nq, int nk, int d, float sl2, int dtype, hipStream_t st);
 
 extern "C" int pp_attention_fwd(const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt, void* o,
-                                int ldo, int batch, int heads, int nq, int nk, int d, float scale, void* stream) {
-  if (!q || !k || !vt || !o || batch <= 0 || heads <= 0 || nq <= 0 || nk <= 0) return PP_ERR_BAD_ARG;
+                                int ldo, int batch, int heads, int nq, int nk, int d, float scale, int dtype,
+                                void* stream) {
+  if (!q || !k || !vt || !o || batch <= 0 || heads <= 0 || nq <= 0 || nk <= 0 || !pp_dt_ok(dtype)) return PP_ERR_BAD_ARG;
   if (ldq % 8 || ldk % 8 || ldvt % 8 || ldo % 4 || ldvt < nk) return PP_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)stream;
   const float sl2 = scale * 1.4426950408889634f;
@@ -332,13 +333,13 @@ extern "C" int pp_attention_fwd(const void* q, int ldq, const void* k, int ldk, 
     return !(e && e[0] == '0');
   }();
   if (use_pipe) {
-    const int rc = pp_attention_pipe_launch(q, ldq, k, ldk, vt, ldvt, o, ldo, batch, heads, nq, nk, d, sl2, st);
+    const int rc = pp_attention_pipe_launch(q, ldq, k, ldk, vt, ldvt, o, ldo, batch, heads, nq, nk, d, sl2, dtype, st);
     if (rc != PP_ERR_UNSUPPORTED) return rc;
   }
   switch (d) {
-    case 40: return launch_attn<40>(q, ldq, k, ldk, vt, ldvt, o, ldo, batch, heads, nq, nk, sl2, st);
-    case 80: return launch_attn<80>(q, ldq, k, ldk, vt, ldvt, o, ldo, batch, heads, nq, nk, sl2, st);
-    case 160: return launch_attn<160>(q, ldq, k, ldk, vt, ldvt, o, ldo, batch, heads, nq, nk, sl2, st);
+    case 40: PP_DT_SWITCH(dtype, return (launch_attn<40, EDT>(q, ldq, k, ldk, vt, ldvt, o, ldo, batch, heads, nq, nk, sl2, st)));
+    case 80: PP_DT_SWITCH(dtype, return (launch_attn<80, EDT>(q, ldq, k, ldk, vt, ldvt, o, ldo, batch, heads, nq, nk, sl2, st)));
+    case 160: PP_DT_SWITCH(dtype, return (launch_attn<160, EDT>(q, ldq, k, ldk, vt, ldvt, o, ldo, batch, heads, nq, nk, sl2, st)));
     default: return PP_ERR_UNSUPPORTED;
   }
 }

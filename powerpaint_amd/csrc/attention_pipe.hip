@@ -58,7 +58,7 @@ constexpr float RESCALE_THR = 8.0f;
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-template <int D, int KB, int dbg>
+template <int D, int KB, int dbg, int EDT>
 __global__ void __launch_bounds__(256, (KB == 32 ? 4 : 2))
 attn_pipe_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __restrict__ k, int ldk,
                  const uint16_t* __restrict__ vt, int ldvt, uint16_t* __restrict__ o, int ldo, int heads, int nq, int nk,
@@ -66,6 +66,8 @@ attn_pipe_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __rest
   // dbg (PP_ATTN_DBG, timing experiments only; results are garbage): 1 no MFMA, 2 no exp, 4 no tile DMA / barrier,
   // 8 no LDS fragment reads
   using C = PCfg<D, KB>;
+  using E = E16<EDT>;
+  typedef typename E::v8 v8_t;
   constexpr int JB = C::JB;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -82,7 +84,7 @@ attn_pipe_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __rest
   __syncthreads();
   for (int i = tid; i < C::NVB * (KB / 2); i += 256) {
     const int bufi = i / (KB / 2), w = i - bufi * (KB / 2);
-    *reinterpret_cast<uint32_t*>(smem + C::VBASE + bufi * C::VTILE + (C::VROWS - 1) * C::VS + w * 4) = 0x3F803F80u;
+    *reinterpret_cast<uint32_t*>(smem + C::VBASE + bufi * C::VTILE + (C::VROWS - 1) * C::VS + w * 4) = E::pack2(1.0f, 1.0f);
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __syncthreads();
@@ -173,8 +175,8 @@ attn_pipe_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __rest
       const f32x16_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int s = 0; s < C::DS; ++s) {
-        const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(ks + (32 * j + qi) * C::KS + (2 * s + half) * 16);
-        sn[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, __builtin_bit_cast(bf16x8_t, qraw[s]), s == 0 ? zero : sn[j],
+        const v8_t kf = *reinterpret_cast<const v8_t*>(ks + (32 * j + qi) * C::KS + (2 * s + half) * 16);
+        sn[j] = E::mfma32(kf, __builtin_bit_cast(v8_t, qraw[s]), s == 0 ? zero : sn[j],
                                                         0, 0, 0);
       }
     }
@@ -184,23 +186,23 @@ attn_pipe_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __rest
     const u32x2_t lo = *reinterpret_cast<const u32x2_t*>(src);
     const u32x2_t hi = *reinterpret_cast<const u32x2_t*>(src + 16);
     const u32x4_t w = {lo[0], lo[1], hi[0], hi[1]};
-    return __builtin_bit_cast(bf16x8_t, w);
+    return __builtin_bit_cast(v8_t, w);
   };
-  auto pv = [&](const char* vs, const bf16x8_t (&pp)[JB][2]) {
+  auto pv = [&](const char* vs, const v8_t (&pp)[JB][2]) {
 #pragma unroll
     for (int j = 0; j < JB; ++j)
 #pragma unroll
       for (int u = 0; u < 2; ++u)
 #pragma unroll
         for (int dt = 0; dt < C::DT; ++dt)
-          oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfrag(vs, j, u, dt), pp[j][u], oacc[dt], 0, 0, 0);
+          oacc[dt] = E::mfma32(vfrag(vs, j, u, dt), pp[j][u], oacc[dt], 0, 0, 0);
   };
 
   // stage t: consumes S(t) (sc) and P(t-1) (pp); produces S(t+1) (sn) and P(t) (pc).
   // The body is choreographed by hand: NM = 2*DS + 4*DT MFMAs, one per slot; every slot also carries its share of the
   // softmax VALU work and the LDS fragment reads of the MFMA two slots ahead.  sched_barrier(0) between slots keeps the
   // compiler from regrouping (left alone it emits all MFMAs back to back, then the VALU block: zero overlap).
-  auto stage = [&](int t, const f32x16_t (&sc)[JB], f32x16_t (&sn)[JB], bf16x8_t (&pc)[JB][2], const bf16x8_t (&pp)[JB][2]) {
+  auto stage = [&](int t, const f32x16_t (&sc)[JB], f32x16_t (&sn)[JB], v8_t (&pc)[JB][2], const v8_t (&pp)[JB][2]) {
     if (!(dbg & 4)) {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::LPW) : "memory");   // tile t+1 (issued two stages ago) has landed
     asm volatile("s_barrier" ::: "memory");                         // ... for every wave; stage t-1 reads are done
@@ -221,12 +223,12 @@ attn_pipe_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __rest
     constexpr int MAXSLOTS = 2 * JB;             // slots carrying the running-max phase (8 scores each)
     constexpr int NES = 8 * JB;                  // exp steps (2 scores each)
     constexpr int ESLOTS = NM - MAXSLOTS;        // slots carrying them
-    bf16x8_t frag[NM];
+    v8_t frag[NM];
     auto fetch = [&](int f) {
-      if (dbg & 8) { frag[f] = __builtin_bit_cast(bf16x8_t, qraw[0]); return; }
+      if (dbg & 8) { frag[f] = __builtin_bit_cast(v8_t, qraw[0]); return; }
       if (f < NQK) {
         const int j = f / C::DS, sidx = f % C::DS;
-        frag[f] = *reinterpret_cast<const bf16x8_t*>(ks + (32 * j + qi) * C::KS + (2 * sidx + half) * 16);
+        frag[f] = *reinterpret_cast<const v8_t*>(ks + (32 * j + qi) * C::KS + (2 * sidx + half) * 16);
       } else {
         const int g = f - NQK, ju = g / C::DT, dt = g % C::DT;
         frag[f] = vfrag(vs, ju >> 1, ju & 1, dt);
@@ -246,11 +248,11 @@ attn_pipe_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __rest
       } else if (f < NQK) {
         const int j = f / C::DS, sidx = f % C::DS;
         const f32x16_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        sn[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag[f], __builtin_bit_cast(bf16x8_t, qraw[sidx]),
+        sn[j] = E::mfma32(frag[f], __builtin_bit_cast(v8_t, qraw[sidx]),
                                                         sidx == 0 ? zero : sn[j], 0, 0, 0);
       } else {
         const int g = f - NQK, ju = g / C::DT, dt = g % C::DT;
-        oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag[f], pp[ju >> 1][ju & 1], oacc[dt], 0, 0, 0);
+        oacc[dt] = E::mfma32(frag[f], pp[ju >> 1][ju & 1], oacc[dt], 0, 0, 0);
       }
       if (f < MAXSLOTS) {                        // running max over this lane's 32 scores, 8 per slot
         const int j = f >> 1, r0 = (f & 1) * 8;
@@ -274,7 +276,7 @@ attn_pipe_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __rest
           const int j = es >> 3, u = (es >> 2) & 1, e = es & 3;
           const f32x2_t s2 = {sc[j][8 * u + 2 * e], sc[j][8 * u + 2 * e + 1]};
           const f32x2_t e2 = __builtin_elementwise_fma(s2, c2, nm2);
-          w[j][u][e] = (dbg & 2) ? pack2bf(e2[0], e2[1]) : pack2bf(__builtin_amdgcn_exp2f(e2[0]), __builtin_amdgcn_exp2f(e2[1]));
+          w[j][u][e] = (dbg & 2) ? E::pack2(e2[0], e2[1]) : E::pack2(__builtin_amdgcn_exp2f(e2[0]), __builtin_amdgcn_exp2f(e2[1]));
           asm volatile("" ::"v"(w[j][u][e]));    // P(t) is only consumed next stage: keep LLVM from sinking the exps there
         }
       }
@@ -283,16 +285,16 @@ attn_pipe_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __rest
 #pragma unroll
     for (int j = 0; j < JB; ++j)
 #pragma unroll
-      for (int u = 0; u < 2; ++u) pc[j][u] = __builtin_bit_cast(bf16x8_t, w[j][u]);
+      for (int u = 0; u < 2; ++u) pc[j][u] = __builtin_bit_cast(v8_t, w[j][u]);
   };
 
   f32x16_t sA[JB], sB[JB];
-  bf16x8_t pA[JB][2], pB[JB][2];
+  v8_t pA[JB][2], pB[JB][2];
 #pragma unroll
   for (int j = 0; j < JB; ++j)
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      pA[j][u] = __builtin_bit_cast(bf16x8_t, u32x4_t{0u, 0u, 0u, 0u});
+      pA[j][u] = __builtin_bit_cast(v8_t, u32x4_t{0u, 0u, 0u, 0u});
       pB[j][u] = pA[j][u];
     }
 
@@ -334,8 +336,8 @@ attn_pipe_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __rest
         const int dc = dt * 32 + 8 * g + 4 * half;
         if (dc < D) {
           u32x2_t w;
-          w[0] = pack2bf(oacc[dt][4 * g + 0] * inv, oacc[dt][4 * g + 1] * inv);
-          w[1] = pack2bf(oacc[dt][4 * g + 2] * inv, oacc[dt][4 * g + 3] * inv);
+          w[0] = E::pack2(oacc[dt][4 * g + 0] * inv, oacc[dt][4 * g + 1] * inv);
+          w[1] = E::pack2(oacc[dt][4 * g + 2] * inv, oacc[dt][4 * g + 3] * inv);
           *reinterpret_cast<u32x2_t*>(op + dc) = w;
         }
       }
@@ -348,13 +350,13 @@ attn_pipe_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __rest
 // Default: 64-key tiles, two workgroups (8 waves) per CU; carries the PP_ATTN_DBG ablation variants.  PP_ATTN_KB=32:
 // 32-key tiles, <= 128 VGPRs, four workgroups per CU -- measured identical (347 vs 346 us at N = 4096): doubling the
 // occupancy hides nothing, the SIMD is issue-bound (~230 instructions per wave-tile at ~4 cycles + 14 MFMA at 32).
-template <int KB, int DBG>
+template <int KB, int DBG, int EDT>
 static int launch_pipe(const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt, void* o, int ldo,
                        int batch, int heads, int nq, int nk, float sl2, hipStream_t st) {
   using C = PCfg<40, KB>;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_pipe_kernel<40, KB, DBG>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_pipe_kernel<40, KB, DBG, EDT>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS) != hipSuccess) {
       pp_set_last_error("hipFuncSetAttribute(attention pipe)", hipGetLastError());
       return PP_ERR_LAUNCH;
@@ -362,29 +364,33 @@ static int launch_pipe(const void* q, int ldq, const void* k, int ldk, const voi
     attr_set = true;
   }
   const dim3 grid((nq + QW * NW - 1) / (QW * NW), heads, batch), block(256);
-  hipLaunchKernelGGL((attn_pipe_kernel<40, KB, DBG>), grid, block, C::LDS, st, (const uint16_t*)q, ldq, (const uint16_t*)k,
+  hipLaunchKernelGGL((attn_pipe_kernel<40, KB, DBG, EDT>), grid, block, C::LDS, st, (const uint16_t*)q, ldq, (const uint16_t*)k,
                      ldk, (const uint16_t*)vt, ldvt, (uint16_t*)o, ldo, heads, nq, nk, sl2);
   PP_CHECK_LAUNCH("attn_pipe_kernel");
   return PP_OK;
 }
 
 int pp_attention_pipe_launch(const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt, void* o, int ldo,
-                             int batch, int heads, int nq, int nk, int d, float sl2, hipStream_t st) {
+                             int batch, int heads, int nq, int nk, int d, float sl2, int dtype, hipStream_t st) {
   static const int kb = [] { const char* e = getenv("PP_ATTN_KB"); return e ? atoi(e) : 64; }();
   static const int dbg = [] { const char* e = getenv("PP_ATTN_DBG"); return e ? atoi(e) : 0; }();
   if (d != 40 || nk % kb != 0 || nk < 4 * kb) return PP_ERR_UNSUPPORTED;
 #define PP_ARGS q, ldq, k, ldk, vt, ldvt, o, ldo, batch, heads, nq, nk, sl2, st
-  if (kb == 32) return launch_pipe<32, 0>(PP_ARGS);
+  if (dtype == PP_DT_F16) {      // fp16: the shipping configuration only (the ablation variants are bf16 experiments)
+    if (kb != 64 || dbg != 0) return PP_ERR_UNSUPPORTED;
+    return launch_pipe<64, 0, PP_DT_F16>(PP_ARGS);
+  }
+  if (kb == 32) return launch_pipe<32, 0, PP_DT_BF16>(PP_ARGS);
   if (kb != 64) return PP_ERR_BAD_ARG;
   switch (dbg) {
-    case 0: return launch_pipe<64, 0>(PP_ARGS);
-    case 1: return launch_pipe<64, 1>(PP_ARGS);
-    case 2: return launch_pipe<64, 2>(PP_ARGS);
-    case 4: return launch_pipe<64, 4>(PP_ARGS);
-    case 8: return launch_pipe<64, 8>(PP_ARGS);
-    case 12: return launch_pipe<64, 12>(PP_ARGS);
-    case 13: return launch_pipe<64, 13>(PP_ARGS);
-    case 15: return launch_pipe<64, 15>(PP_ARGS);
+    case 0: return launch_pipe<64, 0, PP_DT_BF16>(PP_ARGS);
+    case 1: return launch_pipe<64, 1, PP_DT_BF16>(PP_ARGS);
+    case 2: return launch_pipe<64, 2, PP_DT_BF16>(PP_ARGS);
+    case 4: return launch_pipe<64, 4, PP_DT_BF16>(PP_ARGS);
+    case 8: return launch_pipe<64, 8, PP_DT_BF16>(PP_ARGS);
+    case 12: return launch_pipe<64, 12, PP_DT_BF16>(PP_ARGS);
+    case 13: return launch_pipe<64, 13, PP_DT_BF16>(PP_ARGS);
+    case 15: return launch_pipe<64, 15, PP_DT_BF16>(PP_ARGS);
     default: return PP_ERR_BAD_ARG;
   }
 #undef PP_ARGS

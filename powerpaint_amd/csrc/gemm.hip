@@ -76,7 +76,7 @@ PP_DEVINL void ln_row_moments(const PPGemmArgs& a, int m, float& mean, float& rs
   rstd = rsqrtf(fmaxf(q * inv - mean * mean, 0.f) + a.ln_eps);
 }
 
-template <int BN>
+template <int BN, int EDT>
 PP_DEVINL void epilogue4(const PPGemmArgs& a, int m, int n, f32x4_t v) {
   // v holds columns n..n+3 of row m (fp32 accumulators)
   if (a.ln_stats) {
@@ -101,16 +101,16 @@ PP_DEVINL void epilogue4(const PPGemmArgs& a, int m, int n, f32x4_t v) {
   v *= a.scale;
   if (a.res1) {
     const u32x2_t r = *reinterpret_cast<const u32x2_t*>((const uint16_t*)a.res1 + (size_t)m * a.ldres1 + n);
-    v[0] += bflo(r[0]); v[1] += bfhi(r[0]); v[2] += bflo(r[1]); v[3] += bfhi(r[1]);
+    v[0] += E16<EDT>::lo(r[0]); v[1] += E16<EDT>::hi(r[0]); v[2] += E16<EDT>::lo(r[1]); v[3] += E16<EDT>::hi(r[1]);
   }
   if (a.res2) {
     const u32x2_t r = *reinterpret_cast<const u32x2_t*>((const uint16_t*)a.res2 + (size_t)m * a.ldres2 + n);
-    v[0] += bflo(r[0]); v[1] += bfhi(r[0]); v[2] += bflo(r[1]); v[3] += bfhi(r[1]);
+    v[0] += E16<EDT>::lo(r[0]); v[1] += E16<EDT>::hi(r[0]); v[2] += E16<EDT>::lo(r[1]); v[3] += E16<EDT>::hi(r[1]);
   }
   if (a.act == PP_ACT_GEGLU) {
     const float o0 = v[0] * gelu_fast_f(v[2]);
     const float o1 = v[1] * gelu_fast_f(v[3]);
-    *reinterpret_cast<uint32_t*>((uint16_t*)a.out + (size_t)m * a.ldo + (n >> 1)) = pack2bf(o0, o1);
+    *reinterpret_cast<uint32_t*>((uint16_t*)a.out + (size_t)m * a.ldo + (n >> 1)) = E16<EDT>::pack2(o0, o1);
     return;
   }
   if (a.act == PP_ACT_SILU) {
@@ -120,21 +120,22 @@ PP_DEVINL void epilogue4(const PPGemmArgs& a, int m, int n, f32x4_t v) {
     const int ncols = a.N - a.vt_col0;
     uint16_t* dst = (uint16_t*)a.out_vt + ((size_t)bidx * ncols + (n - a.vt_col0)) * a.vt_ld + rin;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) dst[(size_t)j * a.vt_ld] = f2bf(v[j]);
+    for (int j = 0; j < 4; ++j) dst[(size_t)j * a.vt_ld] = E16<EDT>::from_f(v[j]);
     return;
   }
   if (a.out_f32) {
     *reinterpret_cast<f32x4_t*>((float*)a.out + (size_t)m * a.ldo + n) = v;
   } else {
     u32x2_t o;
-    o[0] = pack2bf(v[0], v[1]);
-    o[1] = pack2bf(v[2], v[3]);
+    o[0] = E16<EDT>::pack2(v[0], v[1]);
+    o[1] = E16<EDT>::pack2(v[2], v[3]);
     *reinterpret_cast<u32x2_t*>((uint16_t*)a.out + (size_t)m * a.ldo + n) = o;
   }
 }
 
-template <int BM, int BN, int WM, int WN, int XMODE>
+template <int BM, int BN, int WM, int WN, int XMODE, int EDT>
 __global__ void __launch_bounds__(WM* WN * 64, 2) pp_gemm_kernel(const PPGemmArgs a, const GemmDerived d) {
+  typedef typename E16<EDT>::v8 v8_t;
   constexpr int T = WM * WN * 64;
   constexpr int MI = BM / WM / 16;
   constexpr int NI = BN / WN / 16;
@@ -300,18 +301,18 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) pp_gemm_kernel(const PPGemmArg
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int so = ((ks * 4 + fk) ^ fsw) << 4;
-      bf16x8_t xf[MI], wf[NI];
+      v8_t xf[MI], wf[NI];
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi)
-        xf[mi] = *reinterpret_cast<const bf16x8_t*>(xs + (xrow0 + mi * 16) * 128 + so);
+        xf[mi] = *reinterpret_cast<const v8_t*>(xs + (xrow0 + mi * 16) * 128 + so);
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni)
-        wf[ni] = *reinterpret_cast<const bf16x8_t*>(ws + (wrow0 + ni * 16) * 128 + so);
+        wf[ni] = *reinterpret_cast<const v8_t*>(ws + (wrow0 + ni * 16) * 128 + so);
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
-          acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
+          acc[ni][mi] = E16<EDT>::mfma16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
     }
 
     if (more) store_tile(cur ^ 1);
@@ -341,7 +342,7 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) pp_gemm_kernel(const PPGemmArg
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
       const int n = n_base + ni * 16;
-      if (m < a.M && n < a.N) epilogue4<BN>(a, m, n, acc[ni][mi]);
+      if (m < a.M && n < a.N) epilogue4<BN, EDT>(a, m, n, acc[ni][mi]);
     }
   }
 }
@@ -369,9 +370,10 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) pp_gemm_kernel(const PPGemmArg
 //     MFMAs of tile t while waves 4-7 read their fragments of tile t and issue the refill DMAs, then the roles swap
 //     (two raw barriers per K step, group 1 enters the loop one barrier late).  In the lock-step loop both waves of a
 //     SIMD sit in barrier / bookkeeping / LDS-latency at the same time and the matrix pipe idles ~1/3 of every K step.
-template <int BM, int BN, int WM, int WN, int XMODE, int NS, int EPI, bool DMAI = false, bool PP = false>
+template <int BM, int BN, int WM, int WN, int XMODE, int NS, int EPI, bool DMAI, bool PP, int EDT>
 __global__ void __launch_bounds__(WM* WN * 64, (PP ? 2 : ((BM / WM / 16) * (BN / WN / 16) <= 10 ? 4 : 2)))
 pp_gemm_kernel_v2(const PPGemmArgs a, const GemmDerived d) {   // 2nd bound = waves / SIMD the register budget must allow
+  typedef typename E16<EDT>::v8 v8_t;
   constexpr bool LNF = EPI == 1 || EPI == 2;
   constexpr bool GNS = EPI == 4;
   constexpr int T = WM * WN * 64;
@@ -420,9 +422,9 @@ pp_gemm_kernel_v2(const PPGemmArgs a, const GemmDerived d) {   // 2nd bound = wa
   // ablation switches (tools/gemm_ablate.py): 1 no refill, 2 no MFMA, 4 no epilogue, 8 no s_setprio.  The ping-pong loop
   // honours them only in a -DPP_GEMM_DBG build (seven branches per K step otherwise ride in its read phase).
 #ifdef PP_GEMM_DBG
-  const int dbg = a.reserved[0];
+  const int dbg = a.dbg;
 #else
-  const int dbg = PP ? 0 : a.reserved[0];
+  const int dbg = PP ? 0 : a.dbg;
 #endif
 
   // lane -> (row within the wave's 8-row strip, k-slot it must FETCH so that its lane-linear LDS position is swizzled)
@@ -749,14 +751,14 @@ pp_gemm_kernel_v2(const PPGemmArgs a, const GemmDerived d) {   // 2nd bound = wa
       if (nstage >= NS) nstage -= NS;
       const bool refill = !(dbg & 1);
       if (refill) PP_ISSUE_BEGIN(nstage);
-      bf16x8_t xf[2][MI], wf[2][NI];
+      v8_t xf[2][MI], wf[2][NI];
       constexpr int NR = 2 * (MI + NI);
 #pragma unroll
       for (int r = 0; r < NR; ++r) {
         const int ks = r / (MI + NI), j = r % (MI + NI);
         const int so = ((ks * 4 + fk) ^ fsw) << 4;
-        if (j < NI) wf[ks][j < NI ? j : 0] = *reinterpret_cast<const bf16x8_t*>(ws + (wrow0 + j * 16) * 128 + so);
-        else xf[ks][j >= NI ? j - NI : 0] = *reinterpret_cast<const bf16x8_t*>(xs + (xrow0 + (j - NI) * 16) * 128 + so);
+        if (j < NI) wf[ks][j < NI ? j : 0] = *reinterpret_cast<const v8_t*>(ws + (wrow0 + j * 16) * 128 + so);
+        else xf[ks][j >= NI ? j - NI : 0] = *reinterpret_cast<const v8_t*>(xs + (xrow0 + (j - NI) * 16) * 128 + so);
         // piece k goes after read number ceil((k + 1) * NR / (P + 1))
         if (refill) {
 #pragma unroll
@@ -781,7 +783,7 @@ pp_gemm_kernel_v2(const PPGemmArgs a, const GemmDerived d) {   // 2nd bound = wa
           for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
-              acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][ni], xf[ks][mi], acc[ni][mi], 0, 0, 0);
+              acc[ni][mi] = E16<EDT>::mfma16(wf[ks][ni], xf[ks][mi], acc[ni][mi], 0, 0, 0);
         if (!(dbg & 8)) __builtin_amdgcn_s_setprio(0);
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -813,16 +815,16 @@ pp_gemm_kernel_v2(const PPGemmArgs a, const GemmDerived d) {   // 2nd bound = wa
     if (!(dbg & 2)) {
       // all 2*(MI+NI) fragment reads of the tile are issued up front (the LDS latency of k-step 1 hides behind the MFMAs
       // of k-step 0 instead of serialising read -> wait -> 4 MFMAs -> read ...), then 2*MI*NI MFMAs back to back
-      bf16x8_t xf[2][MI], wf[2][NI];
+      v8_t xf[2][MI], wf[2][NI];
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         const int so = ((ks * 4 + fk) ^ fsw) << 4;
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni)
-          wf[ks][ni] = *reinterpret_cast<const bf16x8_t*>(ws + (wrow0 + ni * 16) * 128 + so);
+          wf[ks][ni] = *reinterpret_cast<const v8_t*>(ws + (wrow0 + ni * 16) * 128 + so);
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
-          xf[ks][mi] = *reinterpret_cast<const bf16x8_t*>(xs + (xrow0 + mi * 16) * 128 + so);
+          xf[ks][mi] = *reinterpret_cast<const v8_t*>(xs + (xrow0 + mi * 16) * 128 + so);
       }
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_setprio(1);      // co-resident waves in their load / epilogue phase yield the issue slots
@@ -838,7 +840,7 @@ pp_gemm_kernel_v2(const PPGemmArgs a, const GemmDerived d) {   // 2nd bound = wa
           for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) {
-              acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][ni], xf[ks][mi], acc[ni][mi], 0, 0, 0);
+              acc[ni][mi] = E16<EDT>::mfma16(wf[ks][ni], xf[ks][mi], acc[ni][mi], 0, 0, 0);
               const int idx = (ks * NI + ni) * MI + mi + 1;
               if (idx % per == 0 && idx / per <= P) {
                 __builtin_amdgcn_sched_barrier(0);
@@ -855,7 +857,7 @@ pp_gemm_kernel_v2(const PPGemmArgs a, const GemmDerived d) {   // 2nd bound = wa
           for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
-              acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][ni], xf[ks][mi], acc[ni][mi], 0, 0, 0);
+              acc[ni][mi] = E16<EDT>::mfma16(wf[ks][ni], xf[ks][mi], acc[ni][mi], 0, 0, 0);
       }
       __builtin_amdgcn_s_setprio(0);
     }
@@ -918,7 +920,7 @@ pp_gemm_kernel_v2(const PPGemmArgs a, const GemmDerived d) {   // 2nd bound = wa
           v = (v - cs * mr[0]) * mr[1];
         }
         v += bs;
-        *reinterpret_cast<uint32_t*>(smem + row * GLD + nl) = pack2bf(v[0] * gelu_fast_f(v[2]), v[1] * gelu_fast_f(v[3]));
+        *reinterpret_cast<uint32_t*>(smem + row * GLD + nl) = E16<EDT>::pack2(v[0] * gelu_fast_f(v[2]), v[1] * gelu_fast_f(v[3]));
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -1009,12 +1011,12 @@ pp_gemm_kernel_v2(const PPGemmArgs a, const GemmDerived d) {   // 2nd bound = wa
         if ((a.rows_per_batch & 7) == 0 && (a.vt_ld & 7) == 0 && m + 8 <= a.M) {
           u32x4_t o;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) o[j] = pack2bf((v[2 * j] + bsv) * a.scale, (v[2 * j + 1] + bsv) * a.scale);
+          for (int j = 0; j < 4; ++j) o[j] = E16<EDT>::pack2((v[2 * j] + bsv) * a.scale, (v[2 * j + 1] + bsv) * a.scale);
           *reinterpret_cast<u32x4_t*>(dst + rin) = o;
         } else {
           for (int j = 0; j < 8 && m + j < a.M; ++j) {
             const int bj = (m + j) / a.rows_per_batch, rj = (m + j) - bj * a.rows_per_batch;
-            ((uint16_t*)a.out_vt)[((size_t)bj * ncols + (n - a.vt_col0)) * a.vt_ld + rj] = f2bf((v[j] + bsv) * a.scale);
+            ((uint16_t*)a.out_vt)[((size_t)bj * ncols + (n - a.vt_col0)) * a.vt_ld + rj] = E16<EDT>::from_f((v[j] + bsv) * a.scale);
           }
         }
       }
@@ -1077,10 +1079,10 @@ pp_gemm_kernel_v2(const PPGemmArgs a, const GemmDerived d) {   // 2nd bound = wa
               }
               v0 *= a.scale;
               v1 *= a.scale;
-              v0[0] += bflo(r1[j][0]) + bflo(r2[j][0]); v0[1] += bfhi(r1[j][0]) + bfhi(r2[j][0]);
-              v0[2] += bflo(r1[j][1]) + bflo(r2[j][1]); v0[3] += bfhi(r1[j][1]) + bfhi(r2[j][1]);
-              v1[0] += bflo(r1[j][2]) + bflo(r2[j][2]); v1[1] += bfhi(r1[j][2]) + bfhi(r2[j][2]);
-              v1[2] += bflo(r1[j][3]) + bflo(r2[j][3]); v1[3] += bfhi(r1[j][3]) + bfhi(r2[j][3]);
+              v0[0] += E16<EDT>::lo(r1[j][0]) + E16<EDT>::lo(r2[j][0]); v0[1] += E16<EDT>::hi(r1[j][0]) + E16<EDT>::hi(r2[j][0]);
+              v0[2] += E16<EDT>::lo(r1[j][1]) + E16<EDT>::lo(r2[j][1]); v0[3] += E16<EDT>::hi(r1[j][1]) + E16<EDT>::hi(r2[j][1]);
+              v1[0] += E16<EDT>::lo(r1[j][2]) + E16<EDT>::lo(r2[j][2]); v1[1] += E16<EDT>::hi(r1[j][2]) + E16<EDT>::hi(r2[j][2]);
+              v1[2] += E16<EDT>::lo(r1[j][3]) + E16<EDT>::lo(r2[j][3]); v1[3] += E16<EDT>::hi(r1[j][3]) + E16<EDT>::hi(r2[j][3]);
               if (a.act == PP_ACT_SILU) {
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) { v0[jj] = silu_f(v0[jj]); v1[jj] = silu_f(v1[jj]); }
@@ -1091,13 +1093,13 @@ pp_gemm_kernel_v2(const PPGemmArgs a, const GemmDerived d) {   // 2nd bound = wa
                 *reinterpret_cast<f32x4_t*>(op + 4) = v1;
               } else {
                 u32x4_t o;
-                o[0] = pack2bf(v0[0], v0[1]); o[1] = pack2bf(v0[2], v0[3]);
-                o[2] = pack2bf(v1[0], v1[1]); o[3] = pack2bf(v1[2], v1[3]);
+                o[0] = E16<EDT>::pack2(v0[0], v0[1]); o[1] = E16<EDT>::pack2(v0[2], v0[3]);
+                o[2] = E16<EDT>::pack2(v1[0], v1[1]); o[3] = E16<EDT>::pack2(v1[2], v1[3]);
                 *reinterpret_cast<u32x4_t*>((uint16_t*)a.out + (size_t)m * a.ldo + n) = o;
                 if (GNS) {   // per-column moments of the values as stored, over this thread's rows of the pass
 #pragma unroll
                   for (int jj = 0; jj < 4; ++jj) {
-                    const float lo = bflo(o[jj]), hi = bfhi(o[jj]);
+                    const float lo = E16<EDT>::lo(o[jj]), hi = E16<EDT>::hi(o[jj]);
                     gcs[2 * jj] += lo; gcq[2 * jj] += lo * lo;
                     gcs[2 * jj + 1] += hi; gcq[2 * jj + 1] += hi * hi;
                   }
@@ -1106,7 +1108,7 @@ pp_gemm_kernel_v2(const PPGemmArgs a, const GemmDerived d) {   // 2nd bound = wa
                   float sm = 0.f, sq = 0.f;
 #pragma unroll
                   for (int jj = 0; jj < 4; ++jj) {
-                    const float lo = bflo(o[jj]), hi = bfhi(o[jj]);
+                    const float lo = E16<EDT>::lo(o[jj]), hi = E16<EDT>::hi(o[jj]);
                     sm += lo + hi;
                     sq += lo * lo + hi * hi;
                   }
@@ -1143,7 +1145,7 @@ pp_gemm_kernel_v2(const PPGemmArgs a, const GemmDerived d) {   // 2nd bound = wa
 // LEAN = the common conv / linear epilogue (bias, per-batch row vector, scale, two residuals, bf16 store) as straight,
 // short code: this kernel runs ~38 times per UNet forward with a cold instruction cache, where its duration (~30 us in
 // the rocprof trace against ~8 us back to back) is dominated by fetching its own instructions.
-template <bool LEAN>
+template <bool LEAN, int EDT>
 __global__ void __launch_bounds__(256) pp_splitk_reduce_kernel(const PPGemmArgs a, int splits) {
   const int n8 = a.N >> 3;
   const long long total = (long long)a.M * n8;
@@ -1181,20 +1183,20 @@ __global__ void __launch_bounds__(256) pp_splitk_reduce_kernel(const PPGemmArgs 
       }
       v0 *= a.scale;
       v1 *= a.scale;
-      v0[0] += bflo(r1[0]) + bflo(r2[0]); v0[1] += bfhi(r1[0]) + bfhi(r2[0]);
-      v0[2] += bflo(r1[1]) + bflo(r2[1]); v0[3] += bfhi(r1[1]) + bfhi(r2[1]);
-      v1[0] += bflo(r1[2]) + bflo(r2[2]); v1[1] += bfhi(r1[2]) + bfhi(r2[2]);
-      v1[2] += bflo(r1[3]) + bflo(r2[3]); v1[3] += bfhi(r1[3]) + bfhi(r2[3]);
+      v0[0] += E16<EDT>::lo(r1[0]) + E16<EDT>::lo(r2[0]); v0[1] += E16<EDT>::hi(r1[0]) + E16<EDT>::hi(r2[0]);
+      v0[2] += E16<EDT>::lo(r1[1]) + E16<EDT>::lo(r2[1]); v0[3] += E16<EDT>::hi(r1[1]) + E16<EDT>::hi(r2[1]);
+      v1[0] += E16<EDT>::lo(r1[2]) + E16<EDT>::lo(r2[2]); v1[1] += E16<EDT>::hi(r1[2]) + E16<EDT>::hi(r2[2]);
+      v1[2] += E16<EDT>::lo(r1[3]) + E16<EDT>::lo(r2[3]); v1[3] += E16<EDT>::hi(r1[3]) + E16<EDT>::hi(r2[3]);
       u32x4_t o;
-      o[0] = pack2bf(v0[0], v0[1]); o[1] = pack2bf(v0[2], v0[3]);
-      o[2] = pack2bf(v1[0], v1[1]); o[3] = pack2bf(v1[2], v1[3]);
+      o[0] = E16<EDT>::pack2(v0[0], v0[1]); o[1] = E16<EDT>::pack2(v0[2], v0[3]);
+      o[2] = E16<EDT>::pack2(v1[0], v1[1]); o[3] = E16<EDT>::pack2(v1[2], v1[3]);
       *reinterpret_cast<u32x4_t*>((uint16_t*)a.out + (size_t)m * a.ldo + n) = o;
     } else {
       f32x4_t v0 = p0[0], v1 = p1[0];
 #pragma unroll
       for (int s = 1; s < 8; ++s) { v0 += p0[s]; v1 += p1[s]; }
-      epilogue4<160>(a, m, n, v0);
-      epilogue4<160>(a, m, n + 4, v1);
+      epilogue4<160, EDT>(a, m, n, v0);
+      epilogue4<160, EDT>(a, m, n + 4, v1);
     }
   }
 }
@@ -1202,6 +1204,7 @@ __global__ void __launch_bounds__(256) pp_splitk_reduce_kernel(const PPGemmArgs 
 // Lean combine that also accumulates GroupNorm statistics: one block = 16 rows x 160 columns, 320 threads, thread =
 // (row, 8-column strip) -> every slab load of the block is in flight at once; the finished values go through an LDS
 // tile, the 160 column threads fold the 16 rows and feed the groups' integer slots (gn_column / gn_flush).
+template <int EDT>
 __global__ void __launch_bounds__(320) pp_splitk_reduce_gn_kernel(const PPGemmArgs a, int splits, int tiles_n) {
   constexpr int BN = 160, ROWS = 16, EC = BN / 8;
   __shared__ __attribute__((aligned(16))) float tile[ROWS][BN + 4];
@@ -1244,16 +1247,16 @@ __global__ void __launch_bounds__(320) pp_splitk_reduce_gn_kernel(const PPGemmAr
     }
     v0 *= a.scale;
     v1 *= a.scale;
-    v0[0] += bflo(r1[0]) + bflo(r2[0]); v0[1] += bfhi(r1[0]) + bfhi(r2[0]);
-    v0[2] += bflo(r1[1]) + bflo(r2[1]); v0[3] += bfhi(r1[1]) + bfhi(r2[1]);
-    v1[0] += bflo(r1[2]) + bflo(r2[2]); v1[1] += bfhi(r1[2]) + bfhi(r2[2]);
-    v1[2] += bflo(r1[3]) + bflo(r2[3]); v1[3] += bfhi(r1[3]) + bfhi(r2[3]);
+    v0[0] += E16<EDT>::lo(r1[0]) + E16<EDT>::lo(r2[0]); v0[1] += E16<EDT>::hi(r1[0]) + E16<EDT>::hi(r2[0]);
+    v0[2] += E16<EDT>::lo(r1[1]) + E16<EDT>::lo(r2[1]); v0[3] += E16<EDT>::hi(r1[1]) + E16<EDT>::hi(r2[1]);
+    v1[0] += E16<EDT>::lo(r1[2]) + E16<EDT>::lo(r2[2]); v1[1] += E16<EDT>::hi(r1[2]) + E16<EDT>::hi(r2[2]);
+    v1[2] += E16<EDT>::lo(r1[3]) + E16<EDT>::lo(r2[3]); v1[3] += E16<EDT>::hi(r1[3]) + E16<EDT>::hi(r2[3]);
     u32x4_t o;
-    o[0] = pack2bf(v0[0], v0[1]); o[1] = pack2bf(v0[2], v0[3]);
-    o[2] = pack2bf(v1[0], v1[1]); o[3] = pack2bf(v1[2], v1[3]);
+    o[0] = E16<EDT>::pack2(v0[0], v0[1]); o[1] = E16<EDT>::pack2(v0[2], v0[3]);
+    o[2] = E16<EDT>::pack2(v1[0], v1[1]); o[3] = E16<EDT>::pack2(v1[2], v1[3]);
     *reinterpret_cast<u32x4_t*>((uint16_t*)a.out + (size_t)m * a.ldo + n) = o;
-    w0 = f32x4_t{bflo(o[0]), bfhi(o[0]), bflo(o[1]), bfhi(o[1])};
-    w1 = f32x4_t{bflo(o[2]), bfhi(o[2]), bflo(o[3]), bfhi(o[3])};
+    w0 = f32x4_t{E16<EDT>::lo(o[0]), E16<EDT>::hi(o[0]), E16<EDT>::lo(o[1]), E16<EDT>::hi(o[1])};
+    w1 = f32x4_t{E16<EDT>::lo(o[2]), E16<EDT>::hi(o[2]), E16<EDT>::lo(o[3]), E16<EDT>::hi(o[3])};
   }
   *reinterpret_cast<f32x4_t*>(&tile[row][c8 * 8]) = w0;      // rows / columns past the edge contribute zeros
   *reinterpret_cast<f32x4_t*>(&tile[row][c8 * 8 + 4]) = w1;
@@ -1354,12 +1357,12 @@ Choice choose(const PPGemmArgs& a) {
   return c;
 }
 
-template <int BM, int BN, int WM, int WN, int XMODE>
+template <int BM, int BN, int WM, int WN, int XMODE, int EDT>
 int launch(const PPGemmArgs& a, int splitk, hipStream_t st) {
   constexpr int T = WM * WN * 64;
   constexpr int LDS = 2 * (BM + BN) * 128;
   static bool attr_set = false;
-  auto kern = pp_gemm_kernel<BM, BN, WM, WN, XMODE>;
+  auto kern = pp_gemm_kernel<BM, BN, WM, WN, XMODE, EDT>;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) !=
         hipSuccess) {
@@ -1383,9 +1386,9 @@ int launch(const PPGemmArgs& a, int splitk, hipStream_t st) {
     if (nb > 4096) nb = 4096;
     if (a.gn_acc[0] || a.gn_acc[1]) {
       const int tn = (a.N + 159) / 160;
-      hipLaunchKernelGGL(pp_splitk_reduce_gn_kernel, dim3(((a.M + 15) / 16) * tn), dim3(320), 0, st, a, splitk, tn);
-    } else if (reduce_lean_ok(a)) hipLaunchKernelGGL(pp_splitk_reduce_kernel<true>, dim3(nb), dim3(256), 0, st, a, splitk);
-    else hipLaunchKernelGGL(pp_splitk_reduce_kernel<false>, dim3(nb), dim3(256), 0, st, a, splitk);
+      hipLaunchKernelGGL(pp_splitk_reduce_gn_kernel<EDT>, dim3(((a.M + 15) / 16) * tn), dim3(320), 0, st, a, splitk, tn);
+    } else if (reduce_lean_ok(a)) hipLaunchKernelGGL((pp_splitk_reduce_kernel<true, EDT>), dim3(nb), dim3(256), 0, st, a, splitk);
+    else hipLaunchKernelGGL((pp_splitk_reduce_kernel<false, EDT>), dim3(nb), dim3(256), 0, st, a, splitk);
     PP_CHECK_LAUNCH("pp_splitk_reduce_kernel");
   }
   return PP_OK;
@@ -1409,27 +1412,27 @@ bool gemm_dma_interleave() {
   return v != 0;
 }
 
-template <int BM, int BN, int WM, int WN, int XMODE, int NS, int EPI = 0, bool PP = false>
+template <int BM, int BN, int WM, int WN, int XMODE, int NS, int EPI, bool PP, int EDT>
 int launch2(const PPGemmArgs& a, int splitk, hipStream_t st) {
   if constexpr (EPI == 0) {
-    if ((a.gn_acc[0] || a.gn_acc[1]) && splitk == 1) return launch2<BM, BN, WM, WN, XMODE, NS, 4, PP>(a, splitk, st);
+    if ((a.gn_acc[0] || a.gn_acc[1]) && splitk == 1) return launch2<BM, BN, WM, WN, XMODE, NS, 4, PP, EDT>(a, splitk, st);
   }
   if constexpr (XMODE == PP_X_PLAIN && EPI == 0) {
-    if (a.act == PP_ACT_GEGLU && splitk == 1) return launch2<BM, BN, WM, WN, XMODE, NS, 2, PP>(a, splitk, st);
-    if (a.ln_stats || a.row_stats_out) return launch2<BM, BN, WM, WN, XMODE, NS, 1, PP>(a, splitk, st);
+    if (a.act == PP_ACT_GEGLU && splitk == 1) return launch2<BM, BN, WM, WN, XMODE, NS, 2, PP, EDT>(a, splitk, st);
+    if (a.ln_stats || a.row_stats_out) return launch2<BM, BN, WM, WN, XMODE, NS, 1, PP, EDT>(a, splitk, st);
   }
   constexpr bool LNF = EPI == 1 || EPI == 2;
   constexpr int T = WM * WN * 64;
   constexpr int LDS = NS * (BM + BN) * 128 + (LNF ? 2048 + BM * 32 : 0);   // + epilogue-operand prefetch (LNF)
   static_assert(LDS <= 160 * 1024 || (LNF && NS > 2), "LDS budget");
   if constexpr (LDS > 160 * 1024) {   // 256x160 x 3 stages has no room for the prefetch: drop to 2 stages (lock-step)
-    return launch2<BM, BN, WM, WN, XMODE, 2, EPI, false>(a, splitk, st);
+    return launch2<BM, BN, WM, WN, XMODE, 2, EPI, false, EDT>(a, splitk, st);
   } else {
   static bool attr_set = false;
   // (2-stage pipelines need their single in-flight refill as early as possible: the spread costs them time)
-  auto kern = pp_gemm_kernel_v2<BM, BN, WM, WN, XMODE, NS, EPI, false, PP>;
+  auto kern = pp_gemm_kernel_v2<BM, BN, WM, WN, XMODE, NS, EPI, false, PP, EDT>;
   if constexpr (NS >= 3 && !PP) {
-    if (gemm_dma_interleave()) kern = pp_gemm_kernel_v2<BM, BN, WM, WN, XMODE, NS, EPI, true, false>;
+    if (gemm_dma_interleave()) kern = pp_gemm_kernel_v2<BM, BN, WM, WN, XMODE, NS, EPI, true, false, EDT>;
   }
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) !=
@@ -1454,9 +1457,9 @@ int launch2(const PPGemmArgs& a, int splitk, hipStream_t st) {
     if (nb > 4096) nb = 4096;
     if (a.gn_acc[0] || a.gn_acc[1]) {
       const int tn = (a.N + 159) / 160;
-      hipLaunchKernelGGL(pp_splitk_reduce_gn_kernel, dim3(((a.M + 15) / 16) * tn), dim3(320), 0, st, a, splitk, tn);
-    } else if (reduce_lean_ok(a)) hipLaunchKernelGGL(pp_splitk_reduce_kernel<true>, dim3(nb), dim3(256), 0, st, a, splitk);
-    else hipLaunchKernelGGL(pp_splitk_reduce_kernel<false>, dim3(nb), dim3(256), 0, st, a, splitk);
+      hipLaunchKernelGGL(pp_splitk_reduce_gn_kernel<EDT>, dim3(((a.M + 15) / 16) * tn), dim3(320), 0, st, a, splitk, tn);
+    } else if (reduce_lean_ok(a)) hipLaunchKernelGGL((pp_splitk_reduce_kernel<true, EDT>), dim3(nb), dim3(256), 0, st, a, splitk);
+    else hipLaunchKernelGGL((pp_splitk_reduce_kernel<false, EDT>), dim3(nb), dim3(256), 0, st, a, splitk);
     PP_CHECK_LAUNCH("pp_splitk_reduce_kernel");
   }
   return PP_OK;
@@ -1475,7 +1478,7 @@ bool gn_stats_supported(const PPGemmArgs& a) {
 }
 
 int validate(const PPGemmArgs& a) {
-  if (a.M <= 0 || a.N <= 0 || a.K <= 0) return PP_ERR_BAD_ARG;
+  if (a.M <= 0 || a.N <= 0 || a.K <= 0 || !pp_dt_ok(a.dtype)) return PP_ERR_BAD_ARG;
   if (a.K % 64 != 0 || a.N % 4 != 0) return PP_ERR_BAD_ARG;
   if (!a.x1 || !a.w || !a.out) return PP_ERR_BAD_ARG;
   if (a.x_mode == PP_X_PLAIN) {
@@ -1509,6 +1512,37 @@ int validate(const PPGemmArgs& a) {
   return PP_OK;
 }
 
+template <int EDT>
+int dispatch(const PPGemmArgs& a, const Choice& c, hipStream_t st) {
+  const bool conv = a.x_mode == PP_X_CONV3X3;
+  switch (c.tile) {
+    case PP_TILE_128x160:
+      return conv ? launch<128, 160, 2, 2, PP_X_CONV3X3, EDT>(a, c.splitk, st) : launch<128, 160, 2, 2, PP_X_PLAIN, EDT>(a, c.splitk, st);
+    case PP_TILE_64x160:
+      return conv ? launch<64, 160, 2, 2, PP_X_CONV3X3, EDT>(a, c.splitk, st) : launch<64, 160, 2, 2, PP_X_PLAIN, EDT>(a, c.splitk, st);
+    case PP_TILE_256x160:
+      return conv ? launch<256, 160, 4, 2, PP_X_CONV3X3, EDT>(a, c.splitk, st) : launch<256, 160, 4, 2, PP_X_PLAIN, EDT>(a, c.splitk, st);
+#define PP_V2(ID, BM_, WM_, NS_, PP_)                                                                     \
+    case ID:                                                                                             \
+      return conv ? launch2<BM_, 160, WM_, 2, PP_X_CONV3X3, NS_, 0, PP_, EDT>(a, c.splitk, st)           \
+                  : launch2<BM_, 160, WM_, 2, PP_X_PLAIN, NS_, 0, PP_, EDT>(a, c.splitk, st);
+      PP_V2(21, 128, 2, 2, false)
+      PP_V2(31, 128, 2, 3, false)
+      PP_V2(22, 64, 2, 2, false)
+      PP_V2(32, 64, 2, 3, false)
+      PP_V2(42, 64, 2, 4, false)
+      PP_V2(23, 256, 4, 2, false)
+      PP_V2(33, 256, 4, 3, false)
+      PP_V2(24, 128, 4, 2, false)   // 8-wave 128x160 (wave tile 32x80): 4 waves / SIMD with two co-resident blocks
+      PP_V2(53, 256, 4, 3, true)    // ping-pong 8-wave tiles (one block per CU)
+      PP_V2(44, 128, 4, 3, true)
+      PP_V2(54, 128, 4, 4, true)
+#undef PP_V2
+    default:
+      return PP_ERR_BAD_ARG;
+  }
+}
+
 }  // namespace
 
 extern "C" int pp_gemm_gn_stats_ok(const PPGemmArgs* args) {
@@ -1537,36 +1571,6 @@ extern "C" int pp_gemm_bf16(const PPGemmArgs* args, void* stream) {
   if ((a.row_stats_out || a.gn_acc[0] || a.gn_acc[1] || (a.x_mode == PP_X_CONV3X3 && a.c3 > 0)) && c.tile < 10)
     return PP_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
-  const bool conv = a.x_mode == PP_X_CONV3X3;
-  switch (c.tile) {
-    case PP_TILE_128x160:
-      return conv ? launch<128, 160, 2, 2, PP_X_CONV3X3>(a, c.splitk, st) : launch<128, 160, 2, 2, PP_X_PLAIN>(a, c.splitk, st);
-    case PP_TILE_64x160:
-      return conv ? launch<64, 160, 2, 2, PP_X_CONV3X3>(a, c.splitk, st) : launch<64, 160, 2, 2, PP_X_PLAIN>(a, c.splitk, st);
-    case PP_TILE_256x160:
-      return conv ? launch<256, 160, 4, 2, PP_X_CONV3X3>(a, c.splitk, st) : launch<256, 160, 4, 2, PP_X_PLAIN>(a, c.splitk, st);
-#define PP_V2(ID, BM_, WM_, NS_)                                                                          \
-    case ID:                                                                                             \
-      return conv ? launch2<BM_, 160, WM_, 2, PP_X_CONV3X3, NS_>(a, c.splitk, st)                        \
-                  : launch2<BM_, 160, WM_, 2, PP_X_PLAIN, NS_>(a, c.splitk, st);
-      PP_V2(21, 128, 2, 2)
-      PP_V2(31, 128, 2, 3)
-      PP_V2(22, 64, 2, 2)
-      PP_V2(32, 64, 2, 3)
-      PP_V2(42, 64, 2, 4)
-      PP_V2(23, 256, 4, 2)
-      PP_V2(33, 256, 4, 3)
-      PP_V2(24, 128, 4, 2)   // 8-wave 128x160 (wave tile 32x80): 4 waves / SIMD with two co-resident blocks
-#undef PP_V2
-#define PP_V3(ID, BM_, WM_, NS_)                                                                          \
-    case ID:                                                                                             \
-      return conv ? launch2<BM_, 160, WM_, 2, PP_X_CONV3X3, NS_, 0, true>(a, c.splitk, st)               \
-                  : launch2<BM_, 160, WM_, 2, PP_X_PLAIN, NS_, 0, true>(a, c.splitk, st);
-      PP_V3(53, 256, 4, 3)   // ping-pong 8-wave tiles (one block per CU)
-      PP_V3(44, 128, 4, 3)
-      PP_V3(54, 128, 4, 4)
-#undef PP_V3
-    default:
-      return PP_ERR_BAD_ARG;
-  }
+  if (a.dtype == PP_DT_F16) return dispatch<PP_DT_F16>(a, c, st);
+  return dispatch<PP_DT_BF16>(a, c, st);
 }

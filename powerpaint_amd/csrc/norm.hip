@@ -15,6 +15,7 @@ namespace {
 constexpr int GN_MAX_T = 512;
 
 // grid (nchunk, batch); block = S*P threads, S = C/8 slots, P pixel lanes
+template <int EDT>
 __global__ void __launch_bounds__(GN_MAX_T) gn_stats_kernel(const uint16_t* __restrict__ x1, int c1,
                                                            const uint16_t* __restrict__ x2, int c2, int hw, int groups,
                                                            int S, int P, float* __restrict__ partial) {
@@ -38,7 +39,7 @@ __global__ void __launch_bounds__(GN_MAX_T) gn_stats_kernel(const uint16_t* __re
   auto acc8 = [&](const u32x4_t v) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const float lo = bflo(v[j]), hi = bfhi(v[j]);
+      const float lo = E16<EDT>::lo(v[j]), hi = E16<EDT>::hi(v[j]);
       s[2 * j] += lo; q[2 * j] += lo * lo;
       s[2 * j + 1] += hi; q[2 * j + 1] += hi * hi;
     }
@@ -141,7 +142,7 @@ PP_DEVINL void gn_fold_acc(const long long* __restrict__ acc, int groups, int C,
 
 // grid (blocks, batch): flat over 16-B pieces of one batch item.  ACC: statistics come from the int64 accumulators
 // (`partial` then points at them) instead of the chunk partials of gn_stats_kernel.
-template <bool SILU, bool ACC>
+template <bool SILU, bool ACC, int EDT>
 __global__ void __launch_bounds__(256) gn_apply_kernel(const uint16_t* __restrict__ x1, int c1,
                                                       const uint16_t* __restrict__ x2, int c2, int hw,
                                                       const float* __restrict__ partial, int nchunk, int groups,
@@ -164,22 +165,22 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const uint16_t* __restric
     const f32x4_t a0 = *reinterpret_cast<const f32x4_t*>(sc + c), a1 = *reinterpret_cast<const f32x4_t*>(sc + c + 4);
     const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(sh + c), b1 = *reinterpret_cast<const f32x4_t*>(sh + c + 4);
     float r[8];
-    r[0] = bflo(v[0]) * a0[0] + b0[0]; r[1] = bfhi(v[0]) * a0[1] + b0[1];
-    r[2] = bflo(v[1]) * a0[2] + b0[2]; r[3] = bfhi(v[1]) * a0[3] + b0[3];
-    r[4] = bflo(v[2]) * a1[0] + b1[0]; r[5] = bfhi(v[2]) * a1[1] + b1[1];
-    r[6] = bflo(v[3]) * a1[2] + b1[2]; r[7] = bfhi(v[3]) * a1[3] + b1[3];
+    r[0] = E16<EDT>::lo(v[0]) * a0[0] + b0[0]; r[1] = E16<EDT>::hi(v[0]) * a0[1] + b0[1];
+    r[2] = E16<EDT>::lo(v[1]) * a0[2] + b0[2]; r[3] = E16<EDT>::hi(v[1]) * a0[3] + b0[3];
+    r[4] = E16<EDT>::lo(v[2]) * a1[0] + b1[0]; r[5] = E16<EDT>::hi(v[2]) * a1[1] + b1[1];
+    r[6] = E16<EDT>::lo(v[3]) * a1[2] + b1[2]; r[7] = E16<EDT>::hi(v[3]) * a1[3] + b1[3];
     if (SILU) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) r[j] = silu_f(r[j]);
     }
     u32x4_t o;
-    o[0] = pack2bf(r[0], r[1]); o[1] = pack2bf(r[2], r[3]); o[2] = pack2bf(r[4], r[5]); o[3] = pack2bf(r[6], r[7]);
+    o[0] = E16<EDT>::pack2(r[0], r[1]); o[1] = E16<EDT>::pack2(r[2], r[3]); o[2] = E16<EDT>::pack2(r[4], r[5]); o[3] = E16<EDT>::pack2(r[6], r[7]);
     *reinterpret_cast<u32x4_t*>(y + ((size_t)b * hw + p) * C + c) = o;
   }
 }
 
 // LayerNorm: one wave per row, <= 4 16-B pieces per lane (C <= 2048), two-pass statistics in registers.
-template <int NP>
+template <int NP, int EDT>
 __global__ void __launch_bounds__(256) layernorm_kernel(const uint16_t* __restrict__ x, int rows, int C,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        float eps, uint16_t* __restrict__ y) {
@@ -195,7 +196,7 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const uint16_t* __restri
     if (pc < S) {
       const u32x4_t u = *reinterpret_cast<const u32x4_t*>(x + (size_t)row * C + pc * 8);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { v[i][2 * j] = bflo(u[j]); v[i][2 * j + 1] = bfhi(u[j]); }
+      for (int j = 0; j < 4; ++j) { v[i][2 * j] = E16<EDT>::lo(u[j]); v[i][2 * j + 1] = E16<EDT>::hi(u[j]); }
     } else {
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[i][j] = 0.f;
@@ -228,7 +229,7 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const uint16_t* __restri
         r[4 + j] = (v[i][4 + j] - mean) * rstd * g1[j] + b1[j];
       }
       u32x4_t o;
-      o[0] = pack2bf(r[0], r[1]); o[1] = pack2bf(r[2], r[3]); o[2] = pack2bf(r[4], r[5]); o[3] = pack2bf(r[6], r[7]);
+      o[0] = E16<EDT>::pack2(r[0], r[1]); o[1] = E16<EDT>::pack2(r[2], r[3]); o[2] = E16<EDT>::pack2(r[4], r[5]); o[3] = E16<EDT>::pack2(r[6], r[7]);
       *reinterpret_cast<u32x4_t*>(y + (size_t)row * C + c) = o;
     }
   }
@@ -250,9 +251,9 @@ extern "C" size_t pp_groupnorm_workspace_bytes(int batch, int hw, int C) {
 }
 
 extern "C" int pp_groupnorm_stats(const void* x1, int c1, const void* x2, int c2, int batch, int hw, int groups,
-                                  float* workspace, void* stream) {
+                                  float* workspace, int dtype, void* stream) {
   const int C = c1 + c2;
-  if (!x1) return PP_ERR_BAD_ARG;
+  if (!x1 || !pp_dt_ok(dtype)) return PP_ERR_BAD_ARG;
   if (!workspace) return PP_ERR_WORKSPACE;
   if (c1 <= 0 || c1 % 8 || c2 % 8 || (c2 > 0 && !x2) || groups <= 0 || groups > 32 || C % groups) return PP_ERR_BAD_ARG;
   const int S = C / 8;
@@ -261,16 +262,18 @@ extern "C" int pp_groupnorm_stats(const void* x1, int c1, const void* x2, int c2
   if (P > 8) P = 8;
   const size_t lds = (size_t)P * C * 2 * sizeof(float);
   if (lds > 64 * 1024) return PP_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(gn_stats_kernel, dim3(gn_nchunk(hw), batch), dim3(S * P), lds, (hipStream_t)stream,
-                     (const uint16_t*)x1, c1, (const uint16_t*)x2, c2, hw, groups, S, P, workspace);
+  PP_DT_SWITCH(dtype, hipLaunchKernelGGL(gn_stats_kernel<EDT>, dim3(gn_nchunk(hw), batch), dim3(S * P), lds,
+                                         (hipStream_t)stream, (const uint16_t*)x1, c1, (const uint16_t*)x2, c2, hw, groups,
+                                         S, P, workspace));
   PP_CHECK_LAUNCH("gn_stats_kernel");
   return PP_OK;
 }
 
 extern "C" int pp_groupnorm_apply(const void* x1, int c1, const void* x2, int c2, int batch, int hw, int groups,
                                   float eps, const float* gamma, const float* beta, const float* workspace, int silu,
-                                  void* y, void* stream) {
-  if (!x1 || !workspace || !gamma || !beta || !y || c1 <= 0 || c1 % 8 || c2 % 8 || (c2 > 0 && !x2)) return PP_ERR_BAD_ARG;
+                                  void* y, int dtype, void* stream) {
+  if (!x1 || !workspace || !gamma || !beta || !y || c1 <= 0 || c1 % 8 || c2 % 8 || (c2 > 0 && !x2) || !pp_dt_ok(dtype))
+    return PP_ERR_BAD_ARG;
   const int C = c1 + c2;
   if (groups <= 0 || groups > 32 || C % groups) return PP_ERR_BAD_ARG;
   const long long total = (long long)hw * (C / 8);
@@ -281,19 +284,22 @@ extern "C" int pp_groupnorm_apply(const void* x1, int c1, const void* x2, int c2
   hipStream_t st = (hipStream_t)stream;
   const int nchunk = gn_nchunk(hw);
   if (silu)
-    hipLaunchKernelGGL((gn_apply_kernel<true, false>), dim3(nb, batch), dim3(256), lds, st, (const uint16_t*)x1, c1,
-                       (const uint16_t*)x2, c2, hw, workspace, nchunk, groups, eps, gamma, beta, (uint16_t*)y);
+    PP_DT_SWITCH(dtype, hipLaunchKernelGGL((gn_apply_kernel<true, false, EDT>), dim3(nb, batch), dim3(256), lds, st,
+                                           (const uint16_t*)x1, c1, (const uint16_t*)x2, c2, hw, workspace, nchunk, groups, eps,
+                                           gamma, beta, (uint16_t*)y));
   else
-    hipLaunchKernelGGL((gn_apply_kernel<false, false>), dim3(nb, batch), dim3(256), lds, st, (const uint16_t*)x1, c1,
-                       (const uint16_t*)x2, c2, hw, workspace, nchunk, groups, eps, gamma, beta, (uint16_t*)y);
+    PP_DT_SWITCH(dtype, hipLaunchKernelGGL((gn_apply_kernel<false, false, EDT>), dim3(nb, batch), dim3(256), lds, st,
+                                           (const uint16_t*)x1, c1, (const uint16_t*)x2, c2, hw, workspace, nchunk, groups, eps,
+                                           gamma, beta, (uint16_t*)y));
   PP_CHECK_LAUNCH("gn_apply_kernel");
   return PP_OK;
 }
 
 extern "C" int pp_groupnorm_apply_acc(const void* x1, int c1, const void* x2, int c2, int batch, int hw, int groups,
                                       float eps, const float* gamma, const float* beta, const int64_t* acc, int silu,
-                                      void* y, void* stream) {
-  if (!x1 || !acc || !gamma || !beta || !y || c1 <= 0 || c1 % 8 || c2 % 8 || (c2 > 0 && !x2)) return PP_ERR_BAD_ARG;
+                                      void* y, int dtype, void* stream) {
+  if (!x1 || !acc || !gamma || !beta || !y || c1 <= 0 || c1 % 8 || c2 % 8 || (c2 > 0 && !x2) || !pp_dt_ok(dtype))
+    return PP_ERR_BAD_ARG;
   const int C = c1 + c2;
   if (groups <= 0 || groups > 32 || C % groups) return PP_ERR_BAD_ARG;
   const long long total = (long long)hw * (C / 8);
@@ -304,29 +310,35 @@ extern "C" int pp_groupnorm_apply_acc(const void* x1, int c1, const void* x2, in
   hipStream_t st = (hipStream_t)stream;
   const float* accf = reinterpret_cast<const float*>(acc);
   if (silu)
-    hipLaunchKernelGGL((gn_apply_kernel<true, true>), dim3(nb, batch), dim3(256), lds, st, (const uint16_t*)x1, c1,
-                       (const uint16_t*)x2, c2, hw, accf, 0, groups, eps, gamma, beta, (uint16_t*)y);
+    PP_DT_SWITCH(dtype, hipLaunchKernelGGL((gn_apply_kernel<true, true, EDT>), dim3(nb, batch), dim3(256), lds, st,
+                                           (const uint16_t*)x1, c1, (const uint16_t*)x2, c2, hw, accf, 0, groups, eps,
+                                           gamma, beta, (uint16_t*)y));
   else
-    hipLaunchKernelGGL((gn_apply_kernel<false, true>), dim3(nb, batch), dim3(256), lds, st, (const uint16_t*)x1, c1,
-                       (const uint16_t*)x2, c2, hw, accf, 0, groups, eps, gamma, beta, (uint16_t*)y);
+    PP_DT_SWITCH(dtype, hipLaunchKernelGGL((gn_apply_kernel<false, true, EDT>), dim3(nb, batch), dim3(256), lds, st,
+                                           (const uint16_t*)x1, c1, (const uint16_t*)x2, c2, hw, accf, 0, groups, eps,
+                                           gamma, beta, (uint16_t*)y));
   PP_CHECK_LAUNCH("gn_apply_kernel(acc)");
   return PP_OK;
 }
 
 extern "C" int pp_layernorm(const void* x, int rows, int C, const float* gamma, const float* beta, float eps, void* y,
-                            void* stream) {
-  if (!x || !y || !gamma || !beta || rows <= 0 || C <= 0 || C % 8) return PP_ERR_BAD_ARG;
+                            int dtype, void* stream) {
+  if (!x || !y || !gamma || !beta || rows <= 0 || C <= 0 || C % 8 || !pp_dt_ok(dtype)) return PP_ERR_BAD_ARG;
   const int S = C / 8;
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid((rows + 3) / 4), block(256);
   if (S <= 64)
-    hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, st, (const uint16_t*)x, rows, C, gamma, beta, eps, (uint16_t*)y);
+    PP_DT_SWITCH(dtype, hipLaunchKernelGGL((layernorm_kernel<1, EDT>), grid, block, 0, st, (const uint16_t*)x, rows, C, gamma,
+                                           beta, eps, (uint16_t*)y));
   else if (S <= 128)
-    hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, st, (const uint16_t*)x, rows, C, gamma, beta, eps, (uint16_t*)y);
+    PP_DT_SWITCH(dtype, hipLaunchKernelGGL((layernorm_kernel<2, EDT>), grid, block, 0, st, (const uint16_t*)x, rows, C, gamma,
+                                           beta, eps, (uint16_t*)y));
   else if (S <= 192)
-    hipLaunchKernelGGL(layernorm_kernel<3>, grid, block, 0, st, (const uint16_t*)x, rows, C, gamma, beta, eps, (uint16_t*)y);
+    PP_DT_SWITCH(dtype, hipLaunchKernelGGL((layernorm_kernel<3, EDT>), grid, block, 0, st, (const uint16_t*)x, rows, C, gamma,
+                                           beta, eps, (uint16_t*)y));
   else if (S <= 256)
-    hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, st, (const uint16_t*)x, rows, C, gamma, beta, eps, (uint16_t*)y);
+    PP_DT_SWITCH(dtype, hipLaunchKernelGGL((layernorm_kernel<4, EDT>), grid, block, 0, st, (const uint16_t*)x, rows, C, gamma,
+                                           beta, eps, (uint16_t*)y));
   else
     return PP_ERR_UNSUPPORTED;
   PP_CHECK_LAUNCH("layernorm_kernel");

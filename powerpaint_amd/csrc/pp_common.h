@@ -27,6 +27,54 @@ PP_DEVINL uint32_t pack2bf(float lo, float hi) {   // one v_cvt_pk_bf16_f32
 PP_DEVINL float bflo(uint32_t u) { return __uint_as_float(u << 16); }
 PP_DEVINL float bfhi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
 
+// ---- the two 16-bit storage formats of the path.  DT follows the dtype codes of pp_hip.h: 1 = bf16, 2 = fp16 (the
+//      reference's default torch_dtype, /root/reference/app.py:548,559).  Accumulation is fp32 in both.
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+template <int DT>
+struct E16;
+template <>
+struct E16<PP_DT_BF16> {
+  typedef bf16x8_t v8;
+  static PP_DEVINL float to_f(uint16_t v) { return bf2f(v); }
+  static PP_DEVINL uint16_t from_f(float f) { return f2bf(f); }
+  static PP_DEVINL float lo(uint32_t u) { return bflo(u); }
+  static PP_DEVINL float hi(uint32_t u) { return bfhi(u); }
+  static PP_DEVINL uint32_t pack2(float lo, float hi) { return pack2bf(lo, hi); }
+  static PP_DEVINL f32x4_t mfma16(v8 a, v8 b, f32x4_t c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+  static PP_DEVINL f32x16_t mfma32(v8 a, v8 b, f32x16_t c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+  static PP_DEVINL f32x16_t mfma32(v8 a, v8 b, f32x16_t c, int, int, int) { return mfma32(a, b, c); }
+  static PP_DEVINL f32x4_t mfma16(v8 a, v8 b, f32x4_t c, int, int, int) { return mfma16(a, b, c); }
+};
+template <>
+struct E16<PP_DT_F16> {
+  typedef f16x8_t v8;
+  static PP_DEVINL float to_f(uint16_t v) { return (float)__builtin_bit_cast(_Float16, v); }
+  static PP_DEVINL uint16_t from_f(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }   // RNE (v_cvt_f16_f32)
+  static PP_DEVINL float lo(uint32_t u) { return to_f((uint16_t)(u & 0xffffu)); }
+  static PP_DEVINL float hi(uint32_t u) { return to_f((uint16_t)(u >> 16)); }
+  static PP_DEVINL uint32_t pack2(float lo, float hi) {
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2_t));
+  }
+  static PP_DEVINL f32x4_t mfma16(v8 a, v8 b, f32x4_t c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+  static PP_DEVINL f32x16_t mfma32(v8 a, v8 b, f32x16_t c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+  static PP_DEVINL f32x16_t mfma32(v8 a, v8 b, f32x16_t c, int, int, int) { return mfma32(a, b, c); }
+  static PP_DEVINL f32x4_t mfma16(v8 a, v8 b, f32x4_t c, int, int, int) { return mfma16(a, b, c); }
+};
+// host-side dispatch on the runtime dtype code: PP_DT_SWITCH(dt, kernel<..., EDT>(...)) with EDT a constant in BODY
+#define PP_DT_SWITCH(DTV, ...)                    \
+  do {                                            \
+    if ((DTV) == PP_DT_F16) {                     \
+      constexpr int EDT = PP_DT_F16;               \
+      __VA_ARGS__;                                \
+    } else {                                      \
+      constexpr int EDT = PP_DT_BF16;             \
+      __VA_ARGS__;                                \
+    }                                             \
+  } while (0)
+inline bool pp_dt_ok(int dt) { return dt == PP_DT_BF16 || dt == PP_DT_F16; }
+
 PP_DEVINL float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 PP_DEVINL float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 // Exact-erf GELU, x * Phi(x), with erfc from Abramowitz-Stegun 7.1.26 (|erf error| <= 1.5e-7, far below bf16 output

@@ -19,7 +19,7 @@ __global__ void timestep_embedding_kernel(const float* __restrict__ t_dev, int r
 }
 
 // ------------------------------------------------------------------------------------------ skinny linear (GEMV-like)
-template <int R>
+template <int R, int EDT>
 __global__ void __launch_bounds__(256) linear_skinny_kernel(const float* __restrict__ x, int rows, int K,
                                                            const uint16_t* __restrict__ w, const float* __restrict__ bias,
                                                            int N, float* __restrict__ out, int ldo, int act_in, int act_out) {
@@ -41,7 +41,7 @@ __global__ void __launch_bounds__(256) linear_skinny_kernel(const float* __restr
       const u32x4_t u = *reinterpret_cast<const u32x4_t*>(w + (size_t)n * K + pc * 8);
       float wv[8];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { wv[2 * j] = bflo(u[j]); wv[2 * j + 1] = bfhi(u[j]); }
+      for (int j = 0; j < 4; ++j) { wv[2 * j] = E16<EDT>::lo(u[j]); wv[2 * j + 1] = E16<EDT>::hi(u[j]); }
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         const float* xp = xs + r * K + pc * 8;
@@ -63,6 +63,7 @@ __global__ void __launch_bounds__(256) linear_skinny_kernel(const float* __restr
 
 // ------------------------------------------------------------------------------------------ direct 3x3 conv, cout % 8 == 0
 // thread = (pixel, 8 consecutive output channels); weights [3][3][cin][cout] so the 8 weights of a tap are one 16-B load
+template <int EDT>
 __global__ void __launch_bounds__(256) conv3x3_direct_kernel(const uint16_t* __restrict__ x, int batch, int hin, int win,
                                                             int cin, const uint16_t* __restrict__ w,
                                                             const float* __restrict__ bias, int cout, int stride,
@@ -88,12 +89,12 @@ __global__ void __launch_bounds__(256) conv3x3_direct_kernel(const uint16_t* __r
         const uint16_t* xp = x + (((size_t)b * hin + iy) * win + ix) * cin;
         const uint16_t* wp = w + ((size_t)(ky * 3 + kx) * cin) * cout + sl * 8;
         for (int ci = 0; ci < cin; ++ci) {
-          const float xv = bf2f(xp[ci]);
+          const float xv = E16<EDT>::to_f(xp[ci]);
           const u32x4_t u = *reinterpret_cast<const u32x4_t*>(wp + (size_t)ci * cout);
-          acc[0] = fmaf(xv, bflo(u[0]), acc[0]); acc[1] = fmaf(xv, bfhi(u[0]), acc[1]);
-          acc[2] = fmaf(xv, bflo(u[1]), acc[2]); acc[3] = fmaf(xv, bfhi(u[1]), acc[3]);
-          acc[4] = fmaf(xv, bflo(u[2]), acc[4]); acc[5] = fmaf(xv, bfhi(u[2]), acc[5]);
-          acc[6] = fmaf(xv, bflo(u[3]), acc[6]); acc[7] = fmaf(xv, bfhi(u[3]), acc[7]);
+          acc[0] = fmaf(xv, E16<EDT>::lo(u[0]), acc[0]); acc[1] = fmaf(xv, E16<EDT>::hi(u[0]), acc[1]);
+          acc[2] = fmaf(xv, E16<EDT>::lo(u[1]), acc[2]); acc[3] = fmaf(xv, E16<EDT>::hi(u[1]), acc[3]);
+          acc[4] = fmaf(xv, E16<EDT>::lo(u[2]), acc[4]); acc[5] = fmaf(xv, E16<EDT>::hi(u[2]), acc[5]);
+          acc[6] = fmaf(xv, E16<EDT>::lo(u[3]), acc[6]); acc[7] = fmaf(xv, E16<EDT>::hi(u[3]), acc[7]);
         }
       }
     }
@@ -101,22 +102,22 @@ __global__ void __launch_bounds__(256) conv3x3_direct_kernel(const uint16_t* __r
     if (add) {
       const u32x4_t r = *reinterpret_cast<const u32x4_t*>(add + o);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { acc[2 * j] += bflo(r[j]); acc[2 * j + 1] += bfhi(r[j]); }
+      for (int j = 0; j < 4; ++j) { acc[2 * j] += E16<EDT>::lo(r[j]); acc[2 * j + 1] += E16<EDT>::hi(r[j]); }
     }
     if (silu_out) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) acc[j] = silu_f(acc[j]);
     }
     u32x4_t ov;
-    ov[0] = pack2bf(acc[0], acc[1]); ov[1] = pack2bf(acc[2], acc[3]);
-    ov[2] = pack2bf(acc[4], acc[5]); ov[3] = pack2bf(acc[6], acc[7]);
+    ov[0] = E16<EDT>::pack2(acc[0], acc[1]); ov[1] = E16<EDT>::pack2(acc[2], acc[3]);
+    ov[2] = E16<EDT>::pack2(acc[4], acc[5]); ov[3] = E16<EDT>::pack2(acc[6], acc[7]);
     *reinterpret_cast<u32x4_t*>(out + o) = ov;
   }
 }
 
 // ------------------------------------------------------------------------------------------ 3x3 conv with tiny cout (conv_out)
 // one wave per output pixel; lanes split K = 9*cin (cin % 8 == 0); weights [cout][3][3][cin]; out fp32 NCHW
-template <int CO>
+template <int CO, int EDT>
 __global__ void __launch_bounds__(256) conv3x3_smallcout_kernel(const uint16_t* __restrict__ x, int batch, int h, int w_,
                                                                int cin, const uint16_t* __restrict__ w,
                                                                const float* __restrict__ bias, float* __restrict__ out) {
@@ -140,8 +141,8 @@ __global__ void __launch_bounds__(256) conv3x3_smallcout_kernel(const uint16_t* 
       const u32x4_t wv = *reinterpret_cast<const u32x4_t*>(w + ((size_t)c * 9 + tap) * cin + sl * 8);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        acc[c] = fmaf(bflo(xv[j]), bflo(wv[j]), acc[c]);
-        acc[c] = fmaf(bfhi(xv[j]), bfhi(wv[j]), acc[c]);
+        acc[c] = fmaf(E16<EDT>::lo(xv[j]), E16<EDT>::lo(wv[j]), acc[c]);
+        acc[c] = fmaf(E16<EDT>::hi(xv[j]), E16<EDT>::hi(wv[j]), acc[c]);
       }
     }
   }
@@ -159,6 +160,7 @@ PP_DEVINL float load_as_f32(const void* p, int dtype, size_t i) {
   return (float)(((const _Float16*)p)[i]);
 }
 
+template <int EDT>
 __global__ void __launch_bounds__(256) nchw_to_nhwc_kernel(const void* __restrict__ src, int dtype, int batch, int c,
                                                           int hw, int bmod, uint16_t* __restrict__ dst, int ldc, int c0) {
   const long long total = (long long)batch * hw;
@@ -166,10 +168,11 @@ __global__ void __launch_bounds__(256) nchw_to_nhwc_kernel(const void* __restric
     const int b = (int)(i / hw), p = (int)(i - (long long)b * hw);
     const int sb = bmod > 0 ? b % bmod : b;
     for (int j = 0; j < c; ++j)
-      dst[(size_t)i * ldc + c0 + j] = f2bf(load_as_f32(src, dtype, ((size_t)sb * c + j) * hw + p));
+      dst[(size_t)i * ldc + c0 + j] = E16<EDT>::from_f(load_as_f32(src, dtype, ((size_t)sb * c + j) * hw + p));
   }
 }
 
+template <int EDT>
 __global__ void __launch_bounds__(256) nhwc_to_nchw_kernel(const uint16_t* __restrict__ src, int batch, int c, int hw,
                                                           void* __restrict__ dst, int dtype) {
   const long long total = (long long)batch * c * hw;
@@ -178,12 +181,13 @@ __global__ void __launch_bounds__(256) nhwc_to_nchw_kernel(const uint16_t* __res
     const int ch = (int)((i / hw) % c);
     const int b = (int)(i / ((long long)hw * c));
     const uint16_t v = src[((size_t)b * hw + p) * c + ch];
-    if (dtype == 0) ((float*)dst)[i] = bf2f(v);
+    if (dtype == 0) ((float*)dst)[i] = E16<EDT>::to_f(v);
     else ((uint16_t*)dst)[i] = v;
   }
 }
 
 // ------------------------------------------------------------------------------------------ elementwise add (bf16)
+template <int EDT>
 __global__ void __launch_bounds__(256) add_bf16_kernel(const uint16_t* __restrict__ a, const uint16_t* __restrict__ b,
                                                       uint16_t* __restrict__ out, long long n8) {
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
@@ -191,7 +195,7 @@ __global__ void __launch_bounds__(256) add_bf16_kernel(const uint16_t* __restric
     const u32x4_t y = *reinterpret_cast<const u32x4_t*>(b + i * 8);
     u32x4_t o;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) o[j] = pack2bf(bflo(x[j]) + bflo(y[j]), bfhi(x[j]) + bfhi(y[j]));
+    for (int j = 0; j < 4; ++j) o[j] = E16<EDT>::pack2(E16<EDT>::lo(x[j]) + E16<EDT>::lo(y[j]), E16<EDT>::hi(x[j]) + E16<EDT>::hi(y[j]));
     *reinterpret_cast<u32x4_t*>(out + i * 8) = o;
   }
 }
@@ -349,82 +353,97 @@ extern "C" int pp_timestep_embedding(const float* t_dev, int rows, int dim, floa
 }
 
 extern "C" int pp_linear_skinny(const float* x, int rows, int K, const void* w, const float* bias, int N, float* out,
-                                int ldo, int act_in, int act_out, void* stream) {
-  if (!x || !w || !out || rows <= 0 || rows > 16 || K <= 0 || K % 8 || N <= 0) return PP_ERR_BAD_ARG;
+                                int ldo, int act_in, int act_out, int dtype, void* stream) {
+  if (!x || !w || !out || rows <= 0 || rows > 16 || K <= 0 || K % 8 || N <= 0 || !pp_dt_ok(dtype)) return PP_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)stream;
   int nb = (N + 3) / 4;
   if (nb > 2048) nb = 2048;
-#define PP_SKINNY(R)                                                                                              \
+#define PP_SKINNY(R, E)                                                                                           \
   do {                                                                                                            \
     const size_t lds = (size_t)(R) * K * 4;                                                                       \
     if (lds > 160 * 1024) return PP_ERR_UNSUPPORTED;                                                              \
     static size_t attr_lds = 0;                                                                                   \
     if (lds > 64 * 1024 && lds > attr_lds) {                                                                      \
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(linear_skinny_kernel<R>),                             \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(linear_skinny_kernel<R, E>),                          \
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {              \
         pp_set_last_error("hipFuncSetAttribute(linear_skinny)", hipGetLastError());                               \
         return PP_ERR_LAUNCH;                                                                                     \
       }                                                                                                           \
       attr_lds = lds;                                                                                             \
     }                                                                                                             \
-    hipLaunchKernelGGL(linear_skinny_kernel<R>, dim3(nb), dim3(256), lds, st, x, rows, K, (const uint16_t*)w, bias, \
-                       N, out, ldo, act_in, act_out);                                                             \
+    hipLaunchKernelGGL((linear_skinny_kernel<R, E>), dim3(nb), dim3(256), lds, st, x, rows, K, (const uint16_t*)w, \
+                       bias, N, out, ldo, act_in, act_out);                                                       \
   } while (0)
-  if (rows == 1) PP_SKINNY(1);
-  else if (rows <= 4) PP_SKINNY(4);
-  else if (rows <= 8) PP_SKINNY(8);
-  else PP_SKINNY(16);
+#define PP_SKINNY_R(E)            \
+  do {                            \
+    if (rows == 1) PP_SKINNY(1, E);    \
+    else if (rows <= 4) PP_SKINNY(4, E); \
+    else if (rows <= 8) PP_SKINNY(8, E); \
+    else PP_SKINNY(16, E);        \
+  } while (0)
+  if (dtype == PP_DT_F16) PP_SKINNY_R(PP_DT_F16);
+  else PP_SKINNY_R(PP_DT_BF16);
+#undef PP_SKINNY_R
 #undef PP_SKINNY
   PP_CHECK_LAUNCH("linear_skinny_kernel");
   return PP_OK;
 }
 
 extern "C" int pp_conv3x3_direct(const void* x, int batch, int hin, int win, int cin, const void* w, const float* bias,
-                                 int cout, int stride, int silu_out, const void* add, void* out, void* stream) {
-  if (!x || !w || !out || batch <= 0 || hin <= 0 || win <= 0 || cin <= 0 || cout <= 0 || cout % 8) return PP_ERR_BAD_ARG;
+                                 int cout, int stride, int silu_out, const void* add, void* out, int dtype,
+                                 void* stream) {
+  if (!x || !w || !out || batch <= 0 || hin <= 0 || win <= 0 || cin <= 0 || cout <= 0 || cout % 8 || !pp_dt_ok(dtype))
+    return PP_ERR_BAD_ARG;
   if (stride != 1 && stride != 2) return PP_ERR_BAD_ARG;
   const int hout = (hin + 2 - 3) / stride + 1, wout = (win + 2 - 3) / stride + 1;
   const long long total = (long long)batch * hout * wout * (cout / 8);
-  hipLaunchKernelGGL(conv3x3_direct_kernel, dim3(grid_for_host(total)), dim3(256), 0, (hipStream_t)stream,
-                     (const uint16_t*)x, batch, hin, win, cin, (const uint16_t*)w, bias, cout, stride, hout, wout,
-                     silu_out, (const uint16_t*)add, (uint16_t*)out);
+  PP_DT_SWITCH(dtype, hipLaunchKernelGGL(conv3x3_direct_kernel<EDT>, dim3(grid_for_host(total)), dim3(256), 0,
+                                         (hipStream_t)stream, (const uint16_t*)x, batch, hin, win, cin, (const uint16_t*)w,
+                                         bias, cout, stride, hout, wout, silu_out, (const uint16_t*)add, (uint16_t*)out));
   PP_CHECK_LAUNCH("conv3x3_direct_kernel");
   return PP_OK;
 }
 
 extern "C" int pp_conv3x3_smallcout(const void* x, int batch, int h, int w_, int cin, const void* w, const float* bias,
-                                    int cout, float* out_nchw, void* stream) {
-  if (!x || !w || !out_nchw || batch <= 0 || h <= 0 || w_ <= 0 || cin <= 0 || cin % 8) return PP_ERR_BAD_ARG;
+                                    int cout, float* out_nchw, int dtype, void* stream) {
+  if (!x || !w || !out_nchw || batch <= 0 || h <= 0 || w_ <= 0 || cin <= 0 || cin % 8 || !pp_dt_ok(dtype))
+    return PP_ERR_BAD_ARG;
   if (cout != 4) return PP_ERR_UNSUPPORTED;
   const long long npix = (long long)batch * h * w_;
-  hipLaunchKernelGGL(conv3x3_smallcout_kernel<4>, dim3((unsigned)((npix + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
-                     (const uint16_t*)x, batch, h, w_, cin, (const uint16_t*)w, bias, out_nchw);
+  PP_DT_SWITCH(dtype, hipLaunchKernelGGL((conv3x3_smallcout_kernel<4, EDT>), dim3((unsigned)((npix + 3) / 4)), dim3(256), 0,
+                                         (hipStream_t)stream, (const uint16_t*)x, batch, h, w_, cin, (const uint16_t*)w,
+                                         bias, out_nchw));
   PP_CHECK_LAUNCH("conv3x3_smallcout_kernel");
   return PP_OK;
 }
 
 extern "C" int pp_nchw_to_nhwc(const void* src, int src_dtype, int batch, int c, int hw, int src_batch_mod, void* dst,
-                               int ldc, int c0, void* stream) {
-  if (!src || !dst || batch <= 0 || c <= 0 || hw <= 0 || src_dtype < 0 || src_dtype > 2 || c0 < 0 || c0 + c > ldc)
+                               int ldc, int c0, int dtype, void* stream) {
+  if (!src || !dst || batch <= 0 || c <= 0 || hw <= 0 || src_dtype < 0 || src_dtype > 2 || c0 < 0 || c0 + c > ldc ||
+      !pp_dt_ok(dtype))
     return PP_ERR_BAD_ARG;
-  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for_host((long long)batch * hw)), dim3(256), 0, (hipStream_t)stream,
-                     src, src_dtype, batch, c, hw, src_batch_mod, (uint16_t*)dst, ldc, c0);
+  PP_DT_SWITCH(dtype, hipLaunchKernelGGL(nchw_to_nhwc_kernel<EDT>, dim3(grid_for_host((long long)batch * hw)), dim3(256), 0,
+                                         (hipStream_t)stream, src, src_dtype, batch, c, hw, src_batch_mod, (uint16_t*)dst,
+                                         ldc, c0));
   PP_CHECK_LAUNCH("nchw_to_nhwc_kernel");
   return PP_OK;
 }
 
-extern "C" int pp_nhwc_to_nchw(const void* src, int batch, int c, int hw, void* dst, int dst_dtype, void* stream) {
-  if (!src || !dst || batch <= 0 || c <= 0 || hw <= 0 || (dst_dtype != 0 && dst_dtype != 1)) return PP_ERR_BAD_ARG;
-  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_for_host((long long)batch * c * hw)), dim3(256), 0,
-                     (hipStream_t)stream, (const uint16_t*)src, batch, c, hw, dst, dst_dtype);
+extern "C" int pp_nhwc_to_nchw(const void* src, int batch, int c, int hw, void* dst, int dst_dtype, int dtype,
+                               void* stream) {
+  // dst_dtype: fp32, or the source's own 16-bit format (a plain re-layout)
+  if (!src || !dst || batch <= 0 || c <= 0 || hw <= 0 || !pp_dt_ok(dtype) || (dst_dtype != 0 && dst_dtype != dtype))
+    return PP_ERR_BAD_ARG;
+  PP_DT_SWITCH(dtype, hipLaunchKernelGGL(nhwc_to_nchw_kernel<EDT>, dim3(grid_for_host((long long)batch * c * hw)), dim3(256),
+                                         0, (hipStream_t)stream, (const uint16_t*)src, batch, c, hw, dst, dst_dtype));
   PP_CHECK_LAUNCH("nhwc_to_nchw_kernel");
   return PP_OK;
 }
 
-extern "C" int pp_add_bf16(const void* a, const void* b, void* out, long long n, void* stream) {
-  if (!a || !b || !out || n <= 0 || n % 8) return PP_ERR_BAD_ARG;
-  hipLaunchKernelGGL(add_bf16_kernel, dim3(grid_for_host(n / 8)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)a,
-                     (const uint16_t*)b, (uint16_t*)out, n / 8);
+extern "C" int pp_add_bf16(const void* a, const void* b, void* out, long long n, int dtype, void* stream) {
+  if (!a || !b || !out || n <= 0 || n % 8 || !pp_dt_ok(dtype)) return PP_ERR_BAD_ARG;
+  PP_DT_SWITCH(dtype, hipLaunchKernelGGL(add_bf16_kernel<EDT>, dim3(grid_for_host(n / 8)), dim3(256), 0, (hipStream_t)stream,
+                                         (const uint16_t*)a, (const uint16_t*)b, (uint16_t*)out, n / 8));
   PP_CHECK_LAUNCH("add_bf16_kernel");
   return PP_OK;
 }
@@ -524,6 +543,7 @@ extern "C" int pp_embed_splice(const void* table, const void* ext, const int32_t
 // run as two GEMMs around this kernel: its logits are kept in fp32, only the probabilities are rounded to bf16).
 // One 256-thread block per row, two passes over the (L2-resident) row: running (max, sum), then normalise + store.
 namespace {
+template <int EDT>
 __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ s, long long lds, int n,
                                                            float scale_log2e, uint16_t* __restrict__ p,
                                                            long long ldp) {
@@ -558,20 +578,20 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
   for (int i = tid; i < n4; i += 256) {
     const float4 v = reinterpret_cast<const float4*>(row)[i];
     uint2 o;
-    o.x = pack2bf(exp2f(v.x * scale_log2e - M) * inv, exp2f(v.y * scale_log2e - M) * inv);
-    o.y = pack2bf(exp2f(v.z * scale_log2e - M) * inv, exp2f(v.w * scale_log2e - M) * inv);
+    o.x = E16<EDT>::pack2(exp2f(v.x * scale_log2e - M) * inv, exp2f(v.y * scale_log2e - M) * inv);
+    o.y = E16<EDT>::pack2(exp2f(v.z * scale_log2e - M) * inv, exp2f(v.w * scale_log2e - M) * inv);
     reinterpret_cast<uint2*>(out)[i] = o;
   }
-  for (int i = (n4 << 2) + tid; i < n; i += 256) out[i] = f2bf(exp2f(row[i] * scale_log2e - M) * inv);
+  for (int i = (n4 << 2) + tid; i < n; i += 256) out[i] = E16<EDT>::from_f(exp2f(row[i] * scale_log2e - M) * inv);
 }
 }  // namespace
 
 extern "C" int pp_softmax_rows(const float* s, long long lds, int rows, int n, float scale, void* p, long long ldp,
-                               void* stream) {
-  if (!s || !p || rows <= 0 || n <= 0 || lds < n || ldp < n) return PP_ERR_BAD_ARG;
+                               int dtype, void* stream) {
+  if (!s || !p || rows <= 0 || n <= 0 || lds < n || ldp < n || !pp_dt_ok(dtype)) return PP_ERR_BAD_ARG;
   if ((lds & 3) || (ldp & 3) || ((uintptr_t)s & 15) || ((uintptr_t)p & 7)) return PP_ERR_BAD_ARG;
-  hipLaunchKernelGGL(softmax_rows_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, s, lds, n,
-                     scale * 1.44269504088896340736f, (uint16_t*)p, ldp);
+  PP_DT_SWITCH(dtype, hipLaunchKernelGGL(softmax_rows_kernel<EDT>, dim3(rows), dim3(256), 0, (hipStream_t)stream, s, lds, n,
+                                         scale * 1.44269504088896340736f, (uint16_t*)p, ldp));
   PP_CHECK_LAUNCH("softmax_rows_kernel");
   return PP_OK;
 }
@@ -583,6 +603,7 @@ extern "C" int pp_softmax_rows(const float* s, long long lds, int rows, int n, f
 namespace {
 constexpr int AS_D = 64, AS_MAXK = 128, AS_KS = AS_D + 2;   // K rows padded to 66 halves: lane j -> bank (33 j) mod 32
 
+template <int EDT>
 __global__ __launch_bounds__(256) void attn_small_kernel(const uint16_t* __restrict__ q, int ldq,
                                                          const uint16_t* __restrict__ k, int ldk,
                                                          const uint16_t* __restrict__ v, int ldv,
@@ -604,7 +625,7 @@ __global__ __launch_bounds__(256) void attn_small_kernel(const uint16_t* __restr
   __syncthreads();
   const int nkb = (nk + 63) >> 6;
   for (int i = wave; i < nq; i += 4) {
-    Qs[wave][lane] = bf2f(q[((size_t)b * nq + i) * ldq + h * AS_D + lane]);
+    Qs[wave][lane] = E16<EDT>::to_f(q[((size_t)b * nq + i) * ldq + h * AS_D + lane]);
     __builtin_amdgcn_wave_barrier();
     float sv[AS_MAXK / 64];
     float m = -INFINITY;
@@ -615,7 +636,7 @@ __global__ __launch_bounds__(256) void attn_small_kernel(const uint16_t* __restr
       if (jb < nkb && j < nk && (!causal || j <= i)) {
         float acc = 0.f;
 #pragma unroll 16
-        for (int c = 0; c < AS_D; ++c) acc += Qs[wave][c] * bf2f(Ks[j * AS_KS + c]);
+        for (int c = 0; c < AS_D; ++c) acc += Qs[wave][c] * E16<EDT>::to_f(Ks[j * AS_KS + c]);
         sv[jb] = acc * scale;
       }
       m = fmaxf(m, sv[jb]);
@@ -632,8 +653,8 @@ __global__ __launch_bounds__(256) void attn_small_kernel(const uint16_t* __restr
     __builtin_amdgcn_wave_barrier();
     float acc = 0.f;
     const int jend = causal ? (i + 1 < nk ? i + 1 : nk) : nk;
-    for (int j = 0; j < jend; ++j) acc += Ps[wave][j] * bf2f(Vs[j * AS_D + lane]);
-    o[((size_t)b * nq + i) * ldo + h * AS_D + lane] = f2bf(acc / l);
+    for (int j = 0; j < jend; ++j) acc += Ps[wave][j] * E16<EDT>::to_f(Vs[j * AS_D + lane]);
+    o[((size_t)b * nq + i) * ldo + h * AS_D + lane] = E16<EDT>::from_f(acc / l);
     __builtin_amdgcn_wave_barrier();
   }
 }
@@ -641,13 +662,14 @@ __global__ __launch_bounds__(256) void attn_small_kernel(const uint16_t* __restr
 
 extern "C" int pp_attention_small(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* o,
                                   int ldo, int batch, int heads, int nq, int nk, int d, float scale, int causal,
-                                  void* stream) {
-  if (!q || !k || !v || !o || batch <= 0 || heads <= 0 || nq <= 0 || nk <= 0) return PP_ERR_BAD_ARG;
+                                  int dtype, void* stream) {
+  if (!q || !k || !v || !o || batch <= 0 || heads <= 0 || nq <= 0 || nk <= 0 || !pp_dt_ok(dtype)) return PP_ERR_BAD_ARG;
   if (d != AS_D || nk > AS_MAXK) return PP_ERR_UNSUPPORTED;
   if ((ldk & 1) || (ldv & 1) || ((uintptr_t)k & 3) || ((uintptr_t)v & 3)) return PP_ERR_BAD_ARG;
   if (causal && nq != nk) return PP_ERR_BAD_ARG;
-  hipLaunchKernelGGL(attn_small_kernel, dim3(heads, batch), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)q, ldq,
-                     (const uint16_t*)k, ldk, (const uint16_t*)v, ldv, (uint16_t*)o, ldo, nq, nk, scale, causal);
+  PP_DT_SWITCH(dtype, hipLaunchKernelGGL(attn_small_kernel<EDT>, dim3(heads, batch), dim3(256), 0, (hipStream_t)stream,
+                                         (const uint16_t*)q, ldq, (const uint16_t*)k, ldk, (const uint16_t*)v, ldv,
+                                         (uint16_t*)o, ldo, nq, nk, scale, causal));
   PP_CHECK_LAUNCH("attn_small_kernel");
   return PP_OK;
 }

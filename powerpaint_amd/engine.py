@@ -197,10 +197,12 @@ class Plan:
 class Builder:
     """Appends launches to a Plan, allocating outputs / workspaces from an Arena."""
 
-    def __init__(self, arena: Arena, plan: Optional[Plan] = None):
+    def __init__(self, arena: Arena, plan: Optional[Plan] = None, dtype: torch.dtype = torch.bfloat16):
         self.arena = arena
         self.plan = plan or Plan()
         self.lib = L.lib()
+        self.dtype = dtype                # 16-bit storage format of activations / matrix weights
+        self.dt = L.dtype_code(dtype)     # ... as the C ABI's dtype code
         self.gemm_tile = 0       # tuning overrides (0 = auto)
         self.gemm_splitk = 0
         self.last_gemm = None    # PPGemmArgs of the most recent GEMM launch
@@ -229,6 +231,7 @@ class Builder:
             a.tile = self.gemm_tile
         if a.splitk == 0:
             a.splitk = self.gemm_splitk
+        a.dtype = self.dt
         ws = self.lib.pp_gemm_workspace_bytes(C.byref(a))
         if ws:
             a.workspace = self.alloc(ws)
@@ -311,13 +314,14 @@ class Builder:
         if acc:
             # the statistics arrive from the epilogues of the launches that produced x (and x2): no stats launch
             self.plan.add("groupnorm_apply", self.lib.pp_groupnorm_apply_acc, x.ptr, x.C, x2p, c2, x.B, hw, groups, eps,
-                          gamma, beta, acc, int(silu), out.ptr)
+                          gamma, beta, acc, int(silu), out.ptr, self.dt)
             return out
         m = self.mark()
         ws = self.alloc(self.lib.pp_groupnorm_workspace_bytes(x.B, hw, Ct))
-        self.plan.add("groupnorm_stats", self.lib.pp_groupnorm_stats, x.ptr, x.C, x2p, c2, x.B, hw, groups, ws)
+        self.plan.add("groupnorm_stats", self.lib.pp_groupnorm_stats, x.ptr, x.C, x2p, c2, x.B, hw, groups, ws,
+                      self.dt)
         self.plan.add("groupnorm_apply", self.lib.pp_groupnorm_apply, x.ptr, x.C, x2p, c2, x.B, hw, groups, eps,
-                      gamma, beta, ws, int(silu), out.ptr)
+                      gamma, beta, ws, int(silu), out.ptr, self.dt)
         self.release(m)
         return out
 
@@ -355,7 +359,7 @@ class Builder:
 
     def layernorm(self, x: int, rows: int, Cc: int, gamma: int, beta: int, eps: float = 1e-5) -> int:
         out = self.alloc(rows * Cc * 2)
-        self.plan.add("layernorm", self.lib.pp_layernorm, x, rows, Cc, gamma, beta, eps, out)
+        self.plan.add("layernorm", self.lib.pp_layernorm, x, rows, Cc, gamma, beta, eps, out, self.dt)
         return out
 
     def attention(self, q: int, ldq: int, k: int, ldk: int, vt: int, ldvt: int, B: int, heads: int, nq: int,
@@ -364,12 +368,12 @@ class Builder:
         if not out:
             out, ldo = self.alloc(B * nq * Cc * 2), Cc
         self.plan.add("attention", self.lib.pp_attention_fwd, q, ldq, k, ldk, vt, ldvt, out, ldo, B, heads, nq, nk,
-                      d, float(d) ** -0.5)
+                      d, float(d) ** -0.5, self.dt)
         self.plan.count("attention", 4.0 * B * heads * nq * nk * d)
         return out
 
     def add(self, a: int, b: int, out: int, n: int):
-        self.plan.add("add", self.lib.pp_add_bf16, a, b, out, n)
+        self.plan.add("add", self.lib.pp_add_bf16, a, b, out, n, self.dt)
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -416,8 +420,11 @@ class SDNet:
                  heads=8, cross_attention_dim=768, groups=32, eps=1e-5,
                  down_block_types=("CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "DownBlock2D"),
                  up_block_types=("UpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D"),
-                 conditioning_channels: int = 0, cond_embed_channels=(16, 32, 96, 256), out_channels: int = 4):
+                 conditioning_channels: int = 0, cond_embed_channels=(16, 32, 96, 256), out_channels: int = 4,
+                 dtype: torch.dtype = torch.bfloat16):
         assert kind in ("unet", "brushnet", "controlnet")
+        L.dtype_code(dtype)              # bf16 | fp16 (raises otherwise)
+        self.dtype = dtype
         self.kind = kind
         self.in_channels = in_channels
         self.conditioning_channels = conditioning_channels
@@ -579,7 +586,7 @@ class SDNet:
     def load_state_dict(self, sd: Dict[str, torch.Tensor], device, materialize: bool = True):
         """sd: diffusers-format state dict (fp32/any float, CPU or meta).  Packs into kernel layouts on `device`."""
         pk = ParamPack()
-        bf, f32 = torch.bfloat16, torch.float32
+        bf, f32 = self.dtype, torch.float32      # `bf`: the 16-bit storage format of matrix weights (bf16 or fp16)
 
         def W(k):
             return sd[k].float() if sd[k].device.type != "meta" else sd[k]
@@ -813,7 +820,8 @@ class SDNet:
                 ho, wo = (x.H - 1) // stride + 1, (x.W - 1) // stride + 1
                 o = pb.new_act(x.B, ho, wo, cout)
                 pb.plan.add("conv3x3_direct", lib.pp_conv3x3_direct, x.ptr, x.B, x.H, x.W, x.C,
-                            self.P[f"{ce}.{name}.weight"], self.P[f"{ce}.{name}.bias"], cout, stride, silu, None, o.ptr)
+                            self.P[f"{ce}.{name}.weight"], self.P[f"{ce}.{name}.bias"], cout, stride, silu, None, o.ptr,
+                            pb.dt)
                 return o
 
             e = dconv(cond, "conv_in", chans[0], 1, 1)
@@ -846,17 +854,17 @@ class SDNet:
         te = boc[0] * 4
         pb.plan.add("timestep_embedding", lib.pp_timestep_embedding, t_dev, 1, boc[0], tsin)
         pb.plan.add("linear_skinny", lib.pp_linear_skinny, tsin, 1, boc[0], P["time_embedding.linear_1.weight"],
-                    P["time_embedding.linear_1.bias"], te, t1, te, 0, L.PP_ACT_SILU)
+                    P["time_embedding.linear_1.bias"], te, t1, te, 0, L.PP_ACT_SILU, pb.dt)
         pb.plan.add("linear_skinny", lib.pp_linear_skinny, t1, 1, te, P["time_embedding.linear_2.weight"],
-                    P["time_embedding.linear_2.bias"], te, temb, te, 0, 0)
+                    P["time_embedding.linear_2.bias"], te, temb, te, 0, 0, pb.dt)
         pb.plan.add("linear_skinny", lib.pp_linear_skinny, temb, 1, te, P["temb_all.weight"], P["temb_all.bias"],
-                    self.temb_total, temb_all, self.temb_total, L.PP_ACT_SILU, 0)
+                    self.temb_total, temb_all, self.temb_total, L.PP_ACT_SILU, 0, pb.dt)
 
         # 2. conv_in
         def conv_in(add_ptr) -> Act:
             o = pb.new_act(B, H, W, boc[0])
             pb.plan.add("conv3x3_direct", lib.pp_conv3x3_direct, x_in.ptr, B, H, W, x_in.C, P["conv_in.weight"],
-                        P["conv_in.bias"], boc[0], 1, 0, add_ptr, o.ptr)
+                        P["conv_in.bias"], boc[0], 1, 0, add_ptr, o.ptr, pb.dt)
             pb.plan.count("conv_in", 2.0 * B * H * W * boc[0] * 9 * x_in.C)
             return o
 
@@ -949,6 +957,6 @@ class SDNet:
         h = pb.groupnorm(s, P["conv_norm_out.weight"], P["conv_norm_out.bias"], self.eps, True, groups=self.groups)
         eps = pb.alloc(B * self.out_channels * H * W * 4)
         pb.plan.add("conv_out", lib.pp_conv3x3_smallcout, h.ptr, B, H, W, boc[0], P["conv_out.weight"],
-                    P["conv_out.bias"], self.out_channels, eps)
+                    P["conv_out.bias"], self.out_channels, eps, pb.dt)
         pb.plan.count("conv_out", 2.0 * B * H * W * self.out_channels * 9 * boc[0])
         return {"eps": eps}

@@ -95,7 +95,13 @@ class PretrainedMixin:
         d = resolve_dir(pretrained_model_name_or_path, subfolder, revision=revision)
         cfg = read_config(d)
         cfg.update(kw)
-        model = cls(device=device, **cfg)               # torch_dtype is the caller's storage wish; the HIP path is bf16
+        # torch_dtype = the 16-bit format the network computes in (the reference's default is fp16, app.py:548,559) for
+        # the networks that take one (UNet / BrushNet / ControlNet); fp32 / None -> bf16; VAE and CLIP tower: bf16
+        import inspect
+        import torch
+        if torch_dtype in (torch.float16, torch.bfloat16) and "dtype" in inspect.signature(cls.__init__).parameters:
+            cfg["dtype"] = torch_dtype
+        model = cls(device=device, **cfg)
         sd = read_state_dict(find_weights(d))
         model.load_state_dict(sd, keep_state_dict=True) if _keeps(model) else model.load_state_dict(sd)
         return model
@@ -140,7 +146,8 @@ class PipelinePretrainedMixin:
             raise L.PPError(f"{f} not found: not a diffusers pipeline folder")
         with open(f) as fh:
             index = {k: v for k, v in json.load(fh).items() if not k.startswith("_")}
-        loaders = {"unet": lambda: PM.UNet2DConditionModel.from_pretrained(root, subfolder="unet", device=device),
+        loaders = {"unet": lambda: PM.UNet2DConditionModel.from_pretrained(root, subfolder="unet", device=device,
+                                                                           torch_dtype=torch_dtype),
                    "vae": lambda: PM.AutoencoderKL.from_pretrained(root, subfolder="vae", device=device),
                    "text_encoder": lambda: PM.CLIPTextModel.from_pretrained(root, subfolder="text_encoder", device=device),
                    "scheduler": lambda: load_scheduler(os.path.join(root, "scheduler"))}

@@ -26,14 +26,14 @@ class _HipModel(PretrainedMixin):
 
     def __init__(self, in_channels, block_out_channels, layers_per_block, attention_head_dim, cross_attention_dim,
                  norm_num_groups, norm_eps, down_block_types, up_block_types, device, dtype, **net_kw):
-        if dtype != torch.bfloat16:
-            raise L.PPError("the HIP path computes in bf16 (fp32 accumulate); pass dtype=torch.bfloat16")
+        L.dtype_code(dtype)      # bf16 or fp16 storage (fp32 accumulate either way); raises PPError for anything else
         if not isinstance(attention_head_dim, int):
             raise L.PPError("per-block attention_head_dim tuples are not supported (SD-1.5 uses 8 everywhere)")
         self._device = torch.device(device)
         self._dtype = dtype
         self.net = SDNet(self.kind, in_channels, block_out_channels, layers_per_block, attention_head_dim,
-                         cross_attention_dim, norm_num_groups, norm_eps, down_block_types, up_block_types, **net_kw)
+                         cross_attention_dim, norm_num_groups, norm_eps, down_block_types, up_block_types, dtype=dtype,
+                         **net_kw)
         self.rt = NetRuntime(self.net, self._device)
         self._sd = None
 

@@ -36,9 +36,9 @@ def groupnorm_apply_acc(x: torch.Tensor, acc: torch.Tensor, gamma, beta, eps: fl
     """GroupNorm(+SiLU) of concat(x, x2) from statistics accumulated by the producers (PPGemmArgs.gn_acc)."""
     B, H, W, C1 = x.shape
     C2 = x2.shape[3] if x2 is not None else 0
-    y = torch.empty(B, H, W, C1 + C2, dtype=torch.bfloat16, device=x.device)
+    y = torch.empty(B, H, W, C1 + C2, dtype=x.dtype, device=x.device)
     L.check(L.lib().pp_groupnorm_apply_acc(_p(x), C1, _p(x2), C2, B, H * W, groups, eps, _p(gamma), _p(beta), _p(acc),
-                                           int(silu), _p(y), _s()), "pp_groupnorm_apply_acc")
+                                           int(silu), _p(y), L.dtype_code(x.dtype), _s()), "pp_groupnorm_apply_acc")
     return y
 
 
@@ -64,12 +64,13 @@ def gemm(x: torch.Tensor, w: torch.Tensor, bias=None, x2=None, res1=None, res2=N
     a.res2, a.ldres2 = _p(res2), (res2.stride(0) if res2 is not None else N)
     a.scale, a.act = scale, act
     n_out = N // 2 if act == L.PP_ACT_GEGLU else (vt_col0 if vt_col0 else N)
-    out = torch.empty(M, n_out, dtype=torch.float32 if out_f32 else torch.bfloat16, device=x.device)
+    out = torch.empty(M, n_out, dtype=torch.float32 if out_f32 else x.dtype, device=x.device)
+    a.dtype = L.dtype_code(x.dtype)
     a.out, a.ldo, a.out_f32 = _p(out), n_out, int(out_f32)
     vt = None
     if vt_col0:
         nb = M // rows_per_batch
-        vt = torch.zeros(nb, N - vt_col0, rows_per_batch, dtype=torch.bfloat16, device=x.device)
+        vt = torch.zeros(nb, N - vt_col0, rows_per_batch, dtype=x.dtype, device=x.device)
         a.out_vt, a.vt_col0, a.vt_ld = _p(vt), vt_col0, rows_per_batch
     a.tile, a.splitk = tile, splitk
     _set_gn(a, gn, rows_per_batch)
@@ -97,8 +98,9 @@ def conv3x3(x: torch.Tensor, w: torch.Tensor, bias=None, stride: int = 1, up: bo
     cout = w.shape[0]
     hv, wv = (2 * H, 2 * W) if up else (H, W)
     ho, wo = (hv - 1) // stride + 1, (wv - 1) // stride + 1
-    out = torch.empty(B, ho, wo, cout, dtype=torch.bfloat16, device=x.device)
+    out = torch.empty(B, ho, wo, cout, dtype=x.dtype, device=x.device)
     a = L.PPGemmArgs()
+    a.dtype = L.dtype_code(x.dtype)
     C3 = x3.shape[3] if x3 is not None else 0
     C4 = x4.shape[3] if x4 is not None else 0
     a.M, a.N, a.K, a.x_mode = B * ho * wo, cout, 9 * (C1 + C2) + C3 + C4, L.PP_X_CONV3X3
@@ -126,17 +128,19 @@ def groupnorm(x: torch.Tensor, gamma, beta, eps: float, silu: bool, groups: int 
     C2 = x2.shape[3] if x2 is not None else 0
     Ct = C1 + C2
     ws = torch.empty(lib.pp_groupnorm_workspace_bytes(B, H * W, Ct) // 4, dtype=torch.float32, device=x.device)
-    y = torch.empty(B, H, W, Ct, dtype=torch.bfloat16, device=x.device)
-    L.check(lib.pp_groupnorm_stats(_p(x), C1, _p(x2), C2, B, H * W, groups, _p(ws), _s()), "pp_groupnorm_stats")
+    y = torch.empty(B, H, W, Ct, dtype=x.dtype, device=x.device)
+    dt = L.dtype_code(x.dtype)
+    L.check(lib.pp_groupnorm_stats(_p(x), C1, _p(x2), C2, B, H * W, groups, _p(ws), dt, _s()), "pp_groupnorm_stats")
     L.check(lib.pp_groupnorm_apply(_p(x), C1, _p(x2), C2, B, H * W, groups, eps, _p(gamma), _p(beta), _p(ws),
-                                   int(silu), _p(y), _s()), "pp_groupnorm_apply")
+                                   int(silu), _p(y), dt, _s()), "pp_groupnorm_apply")
     return y
 
 
 def layernorm(x: torch.Tensor, gamma, beta, eps: float = 1e-5):
     rows, Cc = x.shape
     y = torch.empty_like(x)
-    L.check(L.lib().pp_layernorm(_p(x), rows, Cc, _p(gamma), _p(beta), eps, _p(y), _s()), "pp_layernorm")
+    L.check(L.lib().pp_layernorm(_p(x), rows, Cc, _p(gamma), _p(beta), eps, _p(y), L.dtype_code(x.dtype), _s()),
+            "pp_layernorm")
     return y
 
 
@@ -144,7 +148,7 @@ def transpose_v(v: torch.Tensor, batch: int, nk: int, ldvt: Optional[int] = None
     """v [batch*nk, cols] (row stride v.stride(0)) -> vt [batch, cols, ldvt]."""
     cols = v.shape[1]
     ldvt = ldvt or (nk + 7) // 8 * 8
-    vt = torch.empty(batch, cols, ldvt, dtype=torch.bfloat16, device=v.device)
+    vt = torch.empty(batch, cols, ldvt, dtype=v.dtype, device=v.device)
     L.check(L.lib().pp_transpose_v(_p(v), v.stride(0), batch, nk, cols, _p(vt), ldvt, _s()), "pp_transpose_v")
     return vt
 
@@ -153,18 +157,19 @@ def attention_small(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, batch: in
                     causal: bool = False, scale: Optional[float] = None):
     """q [batch*nq, >=heads*64], k / v [batch*nk, ...] row-major bf16 (row strides from the tensors) -> o [batch*nq, heads*64]."""
     d = 64
-    o = torch.empty(batch * nq, heads * d, dtype=torch.bfloat16, device=q.device)
+    o = torch.empty(batch * nq, heads * d, dtype=q.dtype, device=q.device)
     L.check(L.lib().pp_attention_small(_p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(o), heads * d,
                                        batch, heads, nq, nk, d, scale if scale is not None else d ** -0.5, int(causal),
-                                       _s()), "pp_attention_small")
+                                       L.dtype_code(q.dtype), _s()), "pp_attention_small")
     return o
 
 
-def softmax_rows(s: torch.Tensor, scale: float = 1.0):
-    """fp32 logits [rows, n] (row stride s.stride(0)) -> bf16 softmax(scale * s) [rows, n]."""
+def softmax_rows(s: torch.Tensor, scale: float = 1.0, dtype=torch.bfloat16):
+    """fp32 logits [rows, n] (row stride s.stride(0)) -> 16-bit softmax(scale * s) [rows, n]."""
     rows, n = s.shape
-    p = torch.empty(rows, n, dtype=torch.bfloat16, device=s.device)
-    L.check(L.lib().pp_softmax_rows(_p(s), s.stride(0), rows, n, float(scale), _p(p), n, _s()), "pp_softmax_rows")
+    p = torch.empty(rows, n, dtype=dtype, device=s.device)
+    L.check(L.lib().pp_softmax_rows(_p(s), s.stride(0), rows, n, float(scale), _p(p), n, L.dtype_code(dtype), _s()),
+            "pp_softmax_rows")
     return p
 
 
@@ -172,10 +177,10 @@ def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, batch: int, he
               scale: Optional[float] = None):
     """q [batch*nq, >=heads*d] / k [batch*nk, ...] row-major bf16 (row strides taken from the tensors);
     vt [batch, heads*d, ldvt].  Returns o [batch*nq, heads*d]."""
-    o = torch.empty(batch * nq, heads * d, dtype=torch.bfloat16, device=q.device)
+    o = torch.empty(batch * nq, heads * d, dtype=q.dtype, device=q.device)
     L.check(L.lib().pp_attention_fwd(_p(q), q.stride(0), _p(k), k.stride(0), _p(vt), vt.stride(1), _p(o), heads * d,
-                                     batch, heads, nq, nk, d, scale if scale is not None else d ** -0.5, _s()),
-            "pp_attention_fwd")
+                                     batch, heads, nq, nk, d, scale if scale is not None else d ** -0.5,
+                                     L.dtype_code(q.dtype), _s()), "pp_attention_fwd")
     return o
 
 
@@ -184,9 +189,9 @@ def conv3x3_direct(x, w, bias, stride: int = 1, silu: bool = False, add=None):
     B, H, W, Cin = x.shape
     cout = w.shape[3]
     ho, wo = (H - 1) // stride + 1, (W - 1) // stride + 1
-    out = torch.empty(B, ho, wo, cout, dtype=torch.bfloat16, device=x.device)
+    out = torch.empty(B, ho, wo, cout, dtype=x.dtype, device=x.device)
     L.check(L.lib().pp_conv3x3_direct(_p(x), B, H, W, Cin, _p(w), _p(bias), cout, stride, int(silu), _p(add), _p(out),
-                                      _s()), "pp_conv3x3_direct")
+                                      L.dtype_code(x.dtype), _s()), "pp_conv3x3_direct")
     return out
 
 
@@ -194,33 +199,35 @@ def conv3x3_smallcout(x, w, bias):
     """x NHWC bf16 [B,H,W,Cin]; w bf16 [4, 9*Cin] -> fp32 NCHW [B,4,H,W]."""
     B, H, W, Cin = x.shape
     out = torch.empty(B, w.shape[0], H, W, dtype=torch.float32, device=x.device)
-    L.check(L.lib().pp_conv3x3_smallcout(_p(x), B, H, W, Cin, _p(w), _p(bias), w.shape[0], _p(out), _s()),
-            "pp_conv3x3_smallcout")
+    L.check(L.lib().pp_conv3x3_smallcout(_p(x), B, H, W, Cin, _p(w), _p(bias), w.shape[0], _p(out),
+                                         L.dtype_code(x.dtype), _s()), "pp_conv3x3_smallcout")
     return out
 
 
-def nchw_to_nhwc(src: torch.Tensor, batch: Optional[int] = None, ldc: Optional[int] = None, c0: int = 0, dst=None):
+def nchw_to_nhwc(src: torch.Tensor, batch: Optional[int] = None, ldc: Optional[int] = None, c0: int = 0, dst=None,
+                 dtype=torch.bfloat16):
     B, Cc, H, W = src.shape
     nb = batch or B
     ldc = ldc or Cc
     if dst is None:
-        dst = torch.zeros(nb, H, W, ldc, dtype=torch.bfloat16, device=src.device)
+        dst = torch.zeros(nb, H, W, ldc, dtype=dtype, device=src.device)
     src = src.contiguous()
     L.check(L.lib().pp_nchw_to_nhwc(_p(src), _DT[src.dtype], nb, Cc, H * W, B if nb != B else 0, _p(dst), ldc, c0,
-                                    _s()), "pp_nchw_to_nhwc")
+                                    L.dtype_code(dst.dtype), _s()), "pp_nchw_to_nhwc")
     return dst
 
 
 def nhwc_to_nchw(src: torch.Tensor, dtype=torch.float32):
     B, H, W, Cc = src.shape
     dst = torch.empty(B, Cc, H, W, dtype=dtype, device=src.device)
-    L.check(L.lib().pp_nhwc_to_nchw(_p(src), B, Cc, H * W, _p(dst), _DT[dtype], _s()), "pp_nhwc_to_nchw")
+    L.check(L.lib().pp_nhwc_to_nchw(_p(src), B, Cc, H * W, _p(dst), _DT[dtype], L.dtype_code(src.dtype), _s()),
+            "pp_nhwc_to_nchw")
     return dst
 
 
 def add(a: torch.Tensor, b: torch.Tensor):
     out = torch.empty_like(a)
-    L.check(L.lib().pp_add_bf16(_p(a), _p(b), _p(out), a.numel(), _s()), "pp_add_bf16")
+    L.check(L.lib().pp_add_bf16(_p(a), _p(b), _p(out), a.numel(), L.dtype_code(a.dtype), _s()), "pp_add_bf16")
     return out
 
 
@@ -234,6 +241,6 @@ def linear_skinny(x: torch.Tensor, w: torch.Tensor, bias=None, act_in: int = 0, 
     rows, K = x.shape
     N = w.shape[0]
     out = torch.empty(rows, N, dtype=torch.float32, device=x.device)
-    L.check(L.lib().pp_linear_skinny(_p(x), rows, K, _p(w), _p(bias), N, _p(out), N, act_in, act_out, _s()),
-            "pp_linear_skinny")
+    L.check(L.lib().pp_linear_skinny(_p(x), rows, K, _p(w), _p(bias), N, _p(out), N, act_in, act_out,
+                                     L.dtype_code(w.dtype), _s()), "pp_linear_skinny")
     return out

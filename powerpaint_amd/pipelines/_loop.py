@@ -100,7 +100,8 @@ class DenoiseLoop:
         for r in ([side_rt] if side_rt is not None else []) + [rt]:
             prog.add("step_select_t", lib.pp_step_select_t, ts.data_ptr(), step.data_ptr(), r.lay["t_dev"])
             x = r.lay["x_in"]
-            prog.add("nchw_to_nhwc", lib.pp_nchw_to_nhwc, src.data_ptr(), 0, Be, Cl, hw, mod, x.ptr, x.C, 0)
+            prog.add("nchw_to_nhwc", lib.pp_nchw_to_nhwc, src.data_ptr(), 0, Be, Cl, hw, mod, x.ptr, x.C, 0,
+                     L.dtype_code(r.net.dtype))
         if side_rt is not None:
             prog.calls += side_rt.step_plan.calls
             prog.flops += side_rt.step_plan.flops

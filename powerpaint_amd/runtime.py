@@ -36,7 +36,7 @@ class NetRuntime:
     # ------------------------------------------------------------------ build
     def _build(self, arena: Arena, B, H, W, nctx, cin_total, wiring, cond_hw, scale):
         net = self.net
-        pb_setup = Builder(arena)
+        pb_setup = Builder(arena, dtype=net.dtype)
         pb_setup.gemm_tile, pb_setup.gemm_splitk = self.gemm_tile, self.gemm_splitk
         lay = {}
         lay["t_dev"] = arena.alloc(256)
@@ -60,7 +60,7 @@ class NetRuntime:
                      for k, v in shapes.items()}
         lay["slots"] = slots
         net.build_setup(pb_setup, B, nctx, lay["ehs"], cond)
-        pb = Builder(arena)
+        pb = Builder(arena, dtype=net.dtype)
         pb.gemm_tile, pb.gemm_splitk = self.gemm_tile, self.gemm_splitk
         pb.gn_acc_base, pb.gn_acc_cap = lay["gn_acc"], gn_cap
         kw = {}
@@ -155,7 +155,7 @@ class NetRuntime:
         ident = (ehs.data_ptr(), ehs._version, tuple(ehs.shape))
         if not force and ident == self._ctx_id:
             return
-        dst = self.arena.view(self.lay["ehs"], (self.B, self.nctx, self.net.ctx_dim), torch.bfloat16)
+        dst = self.arena.view(self.lay["ehs"], (self.B, self.nctx, self.net.ctx_dim), self.net.dtype)
         dst.copy_(ehs.to(self.device))
         if self.net.kind != "controlnet" or self._cond_id is not None:
             self.setup_plan.run(_stream())
@@ -183,7 +183,7 @@ class NetRuntime:
         src = src.contiguous()
         nb = batch if batch is not None else src.shape[0]
         L.check(self.lib.pp_nchw_to_nhwc(src.data_ptr(), _DT[src.dtype], nb, src.shape[1], hw, batch_mod, dst_ptr, ldc,
-                                         c0, _stream()), "pp_nchw_to_nhwc")
+                                         c0, L.dtype_code(self.net.dtype), _stream()), "pp_nchw_to_nhwc")
 
     def load_input(self, parts: Sequence[Tuple[torch.Tensor, int]]):
         """parts: (NCHW tensor, channel offset); a tensor with half the batch is CFG-duplicated."""
@@ -223,7 +223,7 @@ class NetRuntime:
     # ------------------------------------------------------------------ outputs
     def act_as_nchw(self, a: Act) -> torch.Tensor:
         """Zero-copy NCHW-logical (channels_last strides) bf16 torch view of an arena activation."""
-        t = self.arena.view(a.ptr, (a.B, a.C, a.H, a.W), torch.bfloat16,
+        t = self.arena.view(a.ptr, (a.B, a.C, a.H, a.W), self.net.dtype,
                             strides=(a.H * a.W * a.C, 1, a.W * a.C, a.C))
         t._pp_nhwc_ptr = a.ptr
         return t

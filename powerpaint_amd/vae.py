@@ -198,7 +198,7 @@ class VAENet:
     def _direct(self, pb: Builder, x: Act, name: str, cout: int) -> Act:
         out = pb.new_act(x.B, x.H, x.W, cout)
         pb.plan.add("conv3x3_direct", pb.lib.pp_conv3x3_direct, x.ptr, x.B, x.H, x.W, x.C, self.P[name + ".weight"],
-                    self.P[name + ".bias"], cout, 1, 0, None, out.ptr)
+                    self.P[name + ".bias"], cout, 1, 0, None, out.ptr, pb.dt)
         return out
 
     def _resnet(self, pb: Builder, pre: str, x: Act, cout: int) -> Act:
@@ -238,7 +238,7 @@ class VAENet:
         for b in range(B):
             tok = b * n * Cc * 2
             pb.linear(q + tok, n, Cc, k + tok, n, out=s, ldo=n, out_f32=True, name="attn_qk")
-            pb.plan.add("softmax_rows", pb.lib.pp_softmax_rows, s, n, n, n, float(Cc) ** -0.5, p, n)
+            pb.plan.add("softmax_rows", pb.lib.pp_softmax_rows, s, n, n, n, float(Cc) ** -0.5, p, n, pb.dt)
             pb.linear(p, n, n, vt + b * Cc * n * 2, Cc, out=o + tok, ldo=Cc, name="attn_pv")
         pb.linear(o, x.rows, Cc, P[f"{pre}.to_out.0.weight"], Cc, P[f"{pre}.to_out.0.bias"], res1=x.ptr, out=out.ptr,
                   name="linear")
@@ -267,7 +267,7 @@ class VAENet:
         x = pb.groupnorm(x, P["decoder.conv_norm_out.weight"], P["decoder.conv_norm_out.bias"], EPS, True,
                          groups=self.groups)
         pb.plan.add("conv_out", pb.lib.pp_conv3x3_smallcout, x.ptr, x.B, x.H, x.W, x.C, P["decoder.conv_out.weight"],
-                    P["decoder.conv_out.bias"], 4, out_nchw)
+                    P["decoder.conv_out.bias"], 4, out_nchw, pb.dt)
         return (x.B, 4, x.H, x.W)
 
     def build_encode(self, pb: Builder, img: Act) -> Act:
@@ -329,11 +329,13 @@ class VAERuntime:
         x = x.contiguous()
         dt = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}[x.dtype]
         xin = self.lay["x_in"]
-        L.check(L.lib().pp_nchw_to_nhwc(x.data_ptr(), dt, B, Cc, H * W, 0, xin.ptr, 8, 0, stream), "pp_nchw_to_nhwc")
+        L.check(L.lib().pp_nchw_to_nhwc(x.data_ptr(), dt, B, Cc, H * W, 0, xin.ptr, 8, 0, L.PP_DT_BF16, stream),
+                "pp_nchw_to_nhwc")
         self.plan.run(stream)
         if self.direction == "decode":
             return self.arena.view(self.lay["img"], self.lay["shape"], torch.float32)
         m = self.lay["moments"]
         out = torch.empty(m.B, 8, m.H, m.W, dtype=torch.float32, device=self.device)
-        L.check(L.lib().pp_nhwc_to_nchw(m.ptr, m.B, 8, m.H * m.W, out.data_ptr(), 0, stream), "pp_nhwc_to_nchw")
+        L.check(L.lib().pp_nhwc_to_nchw(m.ptr, m.B, 8, m.H * m.W, out.data_ptr(), 0, L.PP_DT_BF16, stream),
+                "pp_nhwc_to_nchw")
         return out

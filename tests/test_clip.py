@@ -114,7 +114,8 @@ def test_attention_small_gpu(B, H, n, causal):
     assert torch.allclose(o.float(), want, atol=2e-2, rtol=2e-2)
     with pytest.raises(L.PPError):
         L.check(L.lib().pp_attention_small(q.data_ptr(), 1, k.data_ptr(), 2, v.data_ptr(), 2, o.data_ptr(), 1, 1, 1, 200,
-                                           200, 64, 0.125, 0, torch.cuda.current_stream().cuda_stream), "too long")
+                                           200, 64, 0.125, 0, L.PP_DT_BF16, torch.cuda.current_stream().cuda_stream),
+                "too long")
 
 
 @pytest.mark.gpu

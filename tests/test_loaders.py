@@ -32,19 +32,25 @@ def write_dir(d, config, sd, weights="diffusion_pytorch_model.safetensors", clas
 
 
 def test_unet_and_controlnet_from_pretrained(tmp_path):
-    ref = PM.UNet2DConditionModel(in_channels=9, device="cpu", **TINY)
+    ref = PM.UNet2DConditionModel(in_channels=9, device="cpu", dtype=torch.float16, **TINY)
     sd = {k: v.half() for k, v in ref.net.synthetic_state_dict(seed=3).items()}
     root = str(tmp_path / "sd-inpainting")
     write_dir(os.path.join(root, "unet"), dict(TINY, in_channels=9, out_channels=4, sample_size=64, act_fn="silu"), sd)
     m = PM.UNet2DConditionModel.from_pretrained(root, subfolder="unet", torch_dtype=torch.float16, device="cpu",
                                                 local_files_only=True)
     assert m.config.in_channels == 9 and m.config.block_out_channels == (320, 640)
+    assert m.dtype == torch.float16                  # torch_dtype=float16 (the reference's default) computes in fp16 ...
     ref.load_state_dict(sd)
     assert torch.equal(m.param_buffer(), ref.param_buffer())                 # same packed bytes
+    w = m.net.params.tensor("mid_block.resnets.0.conv1.weight")              # ... and an fp16 checkpoint is not re-rounded
+    assert w.dtype == torch.float16 and torch.equal(
+        w, sd["mid_block.resnets.0.conv1.weight"].permute(0, 2, 3, 1).reshape(w.shape))
+    mb = PM.UNet2DConditionModel.from_pretrained(root, subfolder="unet", device="cpu")      # default: bf16
+    assert mb.dtype == torch.bfloat16 and mb.param_buffer().numel() == m.param_buffer().numel()
     assert m._sd is not None                                                 # kept for BrushNetModel.from_unet
     # load_model: the safetensors.torch.load_model stand-in (strict by default, (missing, unexpected) returned)
     f = os.path.join(root, "unet", "diffusion_pytorch_model.safetensors")
-    fresh = PM.UNet2DConditionModel(in_channels=9, device="cpu", **TINY)
+    fresh = PM.UNet2DConditionModel(in_channels=9, device="cpu", dtype=torch.float16, **TINY)
     assert loaders.load_model(fresh, f) == ([], [])
     assert torch.equal(fresh.param_buffer(), ref.param_buffer())
     extra = dict(sd, **{"not.a.key": torch.zeros(1)})
