@@ -29,14 +29,18 @@ from powerpaint_amd import dist as ppdist  # noqa: E402
 MFMA_PEAK_TFLOPS = 2500.0        # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md (2495 TF measured)
 # algorithmic GFLOP per sample per forward at 64x64 latents (2*MAC of conv/linear/attention)
 GFLOP_PER_SAMPLE = {"unet9": 803.4, "unet4": 803.3, "brushnet": 826.2, "controlnet": 283.3}
+# ... at 32x32 / 128x128 latents (attention is quadratic in the token count, so not a plain area ratio)
+GFLOP_PER_SAMPLE_BY_LATENT = {32: {"unet9": 180.1, "unet4": 180.1, "brushnet": 185.8, "controlnet": 62.7},
+                              64: GFLOP_PER_SAMPLE,
+                              128: {"unet9": 4674.5, "unet4": 4674.0, "brushnet": 4765.5, "controlnet": 1717.1}}
 
 
-def build_pipeline(cfg, device, rank, world, net_kw=None):
+def build_pipeline(cfg, device, rank, world, net_kw=None, dtype=torch.bfloat16, scheduler=None):
     """Networks + pipeline of one rank.  Rank 0 creates the (random-init) weights; every other rank only lays out its
     packed parameter buffer (`meta=True` state dict, `materialize=False`) and receives the bytes in the one start-up
     broadcast.  `net_kw` overrides the architecture (tests run this function with a reduced network)."""
     from powerpaint_amd import models as PM, pipelines as PP, schedulers as PS
-    net_kw = dict(net_kw or {})
+    net_kw = dict(net_kw or {}, dtype=dtype)
     unet = PM.UNet2DConditionModel(in_channels=9 if cfg != "v2" else 4, device=device, **net_kw)
     side = None
     nets = [unet]
@@ -62,17 +66,18 @@ def build_pipeline(cfg, device, rank, world, net_kw=None):
     if on_gpu:
         torch.cuda.synchronize()
     bcast_s = time.perf_counter() - t0
+    sched = {"ddim": PS.DDIMScheduler, "dpm": PS.DPMSolverMultistepScheduler, "pndm": PS.PNDMScheduler,
+             "unipc": PS.UniPCMultistepScheduler}[scheduler or ("dpm" if cfg == "v2" else "ddim")]()
     if cfg == "v1":
-        pipe = PP.StableDiffusionInpaintPipeline(unet=unet, scheduler=PS.DDIMScheduler())
+        pipe = PP.StableDiffusionInpaintPipeline(unet=unet, scheduler=sched)
     elif cfg == "v2":
-        pipe = PP.StableDiffusionPowerPaintBrushNetPipeline(unet=unet, brushnet=side,
-                                                            scheduler=PS.DPMSolverMultistepScheduler())
+        pipe = PP.StableDiffusionPowerPaintBrushNetPipeline(unet=unet, brushnet=side, scheduler=sched)
     else:
-        pipe = PP.StableDiffusionControlNetInpaintPipeline(unet=unet, controlnet=side, scheduler=PS.DDIMScheduler())
+        pipe = PP.StableDiffusionControlNetInpaintPipeline(unet=unet, controlnet=side, scheduler=sched)
     return pipe, nets, bcast_s
 
 
-def synthetic_inputs(cfg, device, rank, per_gpu, lat_hw):
+def synthetic_inputs(cfg, device, rank, per_gpu, lat_hw, denoise_steps=50):
     """SURVEY.md section 8d seeds: generator keyed by the GLOBAL image index, generated on CPU in fp32."""
     h = w = lat_hw
     lat, mil, pos, neg, posU, negU, ctrl = [], [], [], [], [], [], []
@@ -90,7 +95,7 @@ def synthetic_inputs(cfg, device, rank, per_gpu, lat_hw):
     mask[:, :, h // 4: 3 * h // 4, w // 4: 3 * w // 4] = 1.0
     cat = lambda l: torch.cat(l).to(device)  # noqa: E731
     kw = dict(prompt_embeds=cat(pos), negative_prompt_embeds=cat(neg), latents=cat(lat), guidance_scale=7.5,
-              num_inference_steps=50, output_type="latent", return_dict=False)
+              num_inference_steps=denoise_steps, output_type="latent", return_dict=False)
     if cfg in ("v1", "controlnet"):
         kw.update(mask_latents=mask.to(device), masked_image_latents=cat(mil), height=h * 8, width=w * 8)
         if cfg == "controlnet":
@@ -125,72 +130,155 @@ def roofline_pass(pipe):
     # residual operands once (bf16 = 2 B, temb row vector fp32)
     from powerpaint_amd import _lib as L
     alg_bytes = 0.0
+    hbm_bytes = {}          # algorithmic bytes (elements read + written) of the HBM-bound kernels
     for fn, args, name in loop.program.calls:
+        if name == "groupnorm_apply":        # (x1, c1, x2, c2, batch, hw, ...): read + write of [batch][hw][c1 + c2] 16-bit
+            hbm_bytes[name] = hbm_bytes.get(name, 0.0) + 2.0 * 2.0 * args[4] * args[5] * (args[1] + args[3])
+        elif name == "cfg_sched_step":       # eps (2 x n) + latents r/w (+ scheduler state) in fp32: 20 B / latent element
+            hbm_bytes[name] = hbm_bytes.get(name, 0.0) + 20.0 * args[5]
         if name != "conv3x3":
             continue
         a = args[0]._obj
         if isinstance(a, L.PPGemmArgs):
             alg_bytes += 2.0 * a.batch * a.hin * a.win * (a.c1 + a.c2) + 2.0 * a.N * a.K + 2.0 * a.M * a.N
             alg_bytes += (2.0 * a.M * a.N if a.res1 else 0.0) + (2.0 * a.M * a.N if a.res2 else 0.0)
-    return per, flops, counts, alg_bytes
+    return per, flops, counts, alg_bytes, hbm_bytes
+
+
+TRAFFIC_PROFILE = "profiles/r02_hbm_traffic.json"         # tools/hbm_traffic.sh (two rocprofv3 --pmc passes of this bench)
+KERNEL_STATS_PROFILE = "profiles/r02_kernel_stats.txt"     # rocprofv3 --kernel-trace --stats of this bench (tools/gpu_round.sh)
 
 
 def measured_traffic():
-    """HBM bytes per 3x3 implicit-GEMM launch from the committed PMC passes (tools/hbm_traffic.sh -> profiles/; two
-    rocprofv3 --pmc runs of this benchmark cannot happen inside this process).  None if the profile is absent."""
-    path = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+    """HBM bytes per 3x3 implicit-GEMM launch from the committed PMC passes (two rocprofv3 --pmc runs of this benchmark
+    cannot happen inside this process).  None if the profile is absent."""
+    for rel in (TRAFFIC_PROFILE, "profiles/r01_hbm_traffic.json"):
+        try:
+            fam = json.load(open(os.path.join(ROOT, rel)))["families"]["conv3x3 implicit GEMM"]
+            return fam["bytes_per_launch"], rel
+        except Exception:
+            continue
+    return None, None
+
+
+def profiled_conv_launch_us():
+    """Average duration of the implicit-GEMM 3x3 kernels (template argument XMODE = 1 of pp_gemm_kernel_v2) in the
+    committed rocprofv3 --stats summary of this benchmark: the kernel-only time base of `roofline`."""
+    import re
     try:
-        fam = json.load(open(path))["families"]["conv3x3 implicit GEMM"]
-        return fam["bytes_per_launch"]
+        calls, total_ms = 0, 0.0
+        for line in open(os.path.join(ROOT, KERNEL_STATS_PROFILE)):
+            m = re.match(r"\s*(\d+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+.*pp_gemm_kernel_v2<\d+, 160, \d, 2, 1,", line)
+            if m:
+                calls += int(m.group(1))
+                total_ms += float(m.group(2))
+        return (total_ms / calls * 1e3) if calls else None
     except Exception:
         return None
 
 
-def cpu_baseline():
-    """The CPU oracle (kind 'port': plain-PyTorch fp32 restatement of the reference's diffusers path) timed on this
-    box's host cores on a BOUNDED sample of the same workload: ONE UNet forward of one image with CFG (batch 2) at
-    32x32 latents (256x256 px, BASELINE config 1's shape; 0.360 TFLOP), scaled to the 64x64-latent forward by the
-    algorithmic FLOP ratio (803.4 / 180.1 GFLOP per sample) and to 50 steps."""
-    from oracle import sd_modules as OM
-    cores = min(os.cpu_count() or 1, 64)        # more threads only add contention for these conv sizes
-    torch.set_num_threads(cores)
+def cpu_baseline(budget_s: float = 40.0):
+    """SURVEY.md section 8(d) "CPU reference timing": the CPU oracle (kind "port": the plain-PyTorch fp32 restatement of
+    the reference's diffusers path -- diffusers itself cannot be installed) on this box's host cores, BASELINE config 1
+    END TO END: ppt-v1 loop, 256x256 (latents 32x32), 10-step DDIM, CFG 7.5, batch 1 -- 20 UNet sample-forwards,
+    3.6 TFLOP, ~20 s on 64 threads.  Bounded: if the loop has not finished after `budget_s` seconds it is stopped after
+    the current step and the remaining steps are extrapolated (the sample string says so).  `value` is in the metric's
+    unit for the headline shape: the config-1 time scaled by the algorithmic FLOP ratio to one 512x512 / 50-step image
+    (803.4 / 180.1 per forward x 50 / 10 steps; "extrapolated"); `config1_images_per_s` is the unscaled figure."""
+    from oracle import loops as OL, schedulers as OS, sd_modules as OM
+    ncpu = os.cpu_count() or 1
+    torch.set_num_threads(min(ncpu, 8))
     with torch.device("meta"):
         o = OM.UNet2DConditionModel(in_channels=9)
-    o = o.to_empty(device="cpu")
+    o = o.to_empty(device="cpu").eval()
     g = torch.Generator("cpu").manual_seed(0)
+
+    class Stop(Exception):
+        pass
+
+    done = []
     with torch.no_grad():
         for n, p in o.named_parameters():
             if p.dim() == 1:
                 p.fill_(1.0) if ("norm" in n and n.endswith("weight")) else p.zero_()
             else:
                 p.normal_(0, (1.0 / p[0].numel()) ** 0.5, generator=g)
-        x = torch.randn(2, 9, 32, 32, generator=g)
-        e = torch.randn(2, 77, 768, generator=g)
-        o(x[:, :, :8, :8], 500, e)                    # touch weights / warm the thread pool
+        lat = torch.randn(1, 4, 32, 32, generator=g)
+        mil = torch.randn(1, 4, 32, 32, generator=g) * 0.5
+        mask = torch.zeros(1, 1, 32, 32)
+        mask[:, :, 8:24, 8:24] = 1.0
+        pe = torch.randn(2, 77, 768, generator=g)
+        o(torch.randn(2, 9, 8, 8, generator=g), 500, pe)                  # touch weights / warm the thread pool
+        # thread count: these conv sizes stop scaling early and many-core hosts get SLOWER with every core in use
+        # (measured: 2.1 s per forward on 64 threads of the GPU box against 0.5 s on 8 threads of the build box) --
+        # time one forward at 8 / 16 / 32 threads and keep the fastest
+        x9 = torch.randn(2, 9, 32, 32, generator=g)
+        best = None
+        for nt in sorted({min(ncpu, 8), min(ncpu, 16), min(ncpu, 32)}):
+            torch.set_num_threads(nt)
+            tt = time.perf_counter()
+            o(x9, 500, pe)
+            tt = time.perf_counter() - tt
+            if best is None or tt < best[0]:
+                best = (tt, nt)
+            if tt > 8.0:
+                break
+        cores = best[1]
+        torch.set_num_threads(cores)
         t0 = time.perf_counter()
-        o(x, 500, e)
-        dt = time.perf_counter() - t0
-    scale = 803.4 / 180.1
-    return {"value": 1.0 / (dt * scale * 50), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"1 UNet forward, 1 image with CFG (batch 2), 32x32 latents, fp32 torch CPU oracle: {dt:.2f} s; "
-                      f"scaled x{scale:.2f} (FLOP ratio to 64x64 latents) x50 steps"}
+
+        def hook(i, t, latents, eps):
+            done.append(time.perf_counter() - t0)
+            if done[-1] > budget_s and len(done) >= 2:
+                raise Stop()
+
+        try:
+            OL.loop_v1(o, OS.DDIMScheduler(), lat, torch.cat([mask] * 2), torch.cat([mil] * 2), pe, 10, 7.5, eps_hook=hook)
+            dt, how = time.perf_counter() - t0, "end to end"
+        except Stop:
+            dt = done[-1] / len(done) * 10
+            how = f"first {len(done)} of 10 steps timed ({done[-1]:.1f} s), the rest extrapolated"
+    scale = (803.4 / 180.1) * (50 / 10)
+    return {"value": 1.0 / (dt * scale), "unit": "images/s", "cores": cores, "kind": "port",
+            "config1_images_per_s": 1.0 / dt,
+            "sample": f"BASELINE config 1 (ppt-v1, 256x256, 10-step DDIM, CFG 7.5, batch 1; 3.6 TFLOP) on the fp32 torch CPU "
+                      f"oracle, {cores} threads, {how}: {dt:.1f} s; `value` extrapolated to one 512x512 / 50-step image by "
+                      f"the algorithmic FLOP ratio x{scale:.1f}"}
 
 
-def roofline_report(pipe, dump_launches=None) -> dict:
-    """`roofline` (dominant kernel = the implicit-GEMM 3x3 convolution launches of pp_gemm_kernel) and the per-kernel
-    tables, from one eager replay of the step program with a HIP event pair around every launch."""
-    per, flops, counts, alg_bytes = roofline_pass(pipe)
+HBM_PEAK_GBS = 6290.0            # measured float4 copy, /opt/skills/guides/MI355X_MICROARCH.md ("6.29 TB/s measured")
+
+
+def roofline_report(pipe, dump_launches=None, peak=MFMA_PEAK_TFLOPS, profile_matches=True) -> dict:
+    """`roofline` (dominant kernel = the implicit-GEMM 3x3 convolution launches of pp_gemm_kernel_v2) with BOTH time
+    bases: `frac_event` from a HIP event pair around every launch of one eager replay of the step program (includes the
+    launch gap), `frac_kernel` from the committed rocprofv3 --stats summary of this command (kernel-only average of the
+    XMODE = 1 instantiations; `frac` = that when the profile is present).  Plus per-kernel tables and the HBM-bound
+    kernels' GB/s against the measured 6.29 TB/s."""
+    per, flops, counts, alg_bytes, hbm_bytes = roofline_pass(pipe)
     k = "conv3x3"
-    ach = flops[k] / 1e12 / (per[k] * 1e-3)
-    out = {"roofline": {"bound": "mfma", "kernel": "pp_gemm_kernel<...,CONV3X3> (implicit-GEMM 3x3 conv)",
-                        "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": ach / MFMA_PEAK_TFLOPS, "traffic": measured_traffic(),
-                        "traffic_unit": "bytes / launch (2 x FETCH_SIZE + WRITE_SIZE, profiles/r01_hbm_traffic.json)",
-                        "launches_per_step": counts[k], "avg_launch_ms": per[k] / counts[k],
-                        "alg_flop_per_launch": flops[k] / counts[k],
+    ach_event = flops[k] / 1e12 / (per[k] * 1e-3)
+    prof_us = profiled_conv_launch_us() if profile_matches else None     # (the committed trace is of the headline command)
+    ach_kernel = (flops[k] / counts[k]) / (prof_us * 1e-6) / 1e12 if prof_us else None
+    traffic, traffic_src = measured_traffic() if profile_matches else (None, None)
+    ach = ach_kernel if ach_kernel else ach_event
+    out = {"roofline": {"bound": "mfma", "kernel": "pp_gemm_kernel_v2<...,XMODE=1,...> (implicit-GEMM 3x3 conv)",
+                        "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                        "achieved_event": ach_event, "frac_event": ach_event / peak,
+                        "achieved_kernel": ach_kernel, "frac_kernel": (ach_kernel / peak) if ach_kernel else None,
+                        "kernel_time_source": KERNEL_STATS_PROFILE if prof_us else None,
+                        "avg_launch_us_kernel": prof_us, "avg_launch_us_event": per[k] / counts[k] * 1e3,
+                        "traffic": traffic, "traffic_unit": "bytes / launch (2 x FETCH_SIZE + WRITE_SIZE)",
+                        "traffic_source": traffic_src,
+                        "launches_per_step": counts[k], "alg_flop_per_launch": flops[k] / counts[k],
                         "alg_bytes_per_launch": alg_bytes / counts[k]},
+           "hbm_kernels": {n: {"GB_per_s": round(b / (per[n] * 1e-3) / 1e9, 1),
+                               "frac_of_measured_peak": round(b / (per[n] * 1e-3) / 1e9 / HBM_PEAK_GBS, 3),
+                               "alg_MB_per_step": round(b / 1e6, 1), "launches": counts[n]}
+                           for n, b in hbm_bytes.items() if per.get(n)},
            "per_kernel_ms_per_denoise_step": {n: round(v, 4) for n, v in sorted(per.items(), key=lambda kv: -kv[1])},
-           "per_kernel_tflops": {n: round(flops[n] / 1e12 / (per[n] * 1e-3), 1) for n in flops if per.get(n)}}
+           "per_kernel_tflops": {n: round(flops[n] / 1e12 / (per[n] * 1e-3), 1) for n in flops if per.get(n)},
+           "launches_per_denoise_step": len(pipe._loop.program.calls)}
     if dump_launches:
         prog = pipe._loop.program
         json.dump([{"i": i, "what": prog.describe(i), "ms": prog.last_launch_ms[i]}
@@ -206,6 +294,10 @@ def main():
     ap.add_argument("--config", default="v1", choices=["v1", "v2", "controlnet"])
     ap.add_argument("--per-gpu", type=int, default=4)
     ap.add_argument("--latent", type=int, default=64)
+    ap.add_argument("--denoise-steps", type=int, default=50, help="scheduler steps per image (config 5: 30)")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"], help="16-bit compute format (config 5: fp16)")
+    ap.add_argument("--scheduler", default=None, choices=["ddim", "dpm", "pndm", "unipc"],
+                    help="default: ddim (v1, controlnet), dpm = DPM-Solver++(2M) (v2)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -218,9 +310,12 @@ def main():
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
 
-    pipe, nets, bcast_s = build_pipeline(args.config, device, rank, world)
+    dtype = torch.float16 if args.dtype == "fp16" else torch.bfloat16
+    pipe, nets, bcast_s = build_pipeline(args.config, device, rank, world, dtype=dtype, scheduler=args.scheduler)
     pipe.use_graph = not args.no_graph
-    kw = synthetic_inputs(args.config, device, rank, args.per_gpu, args.latent)
+    kw = synthetic_inputs(args.config, device, rank, args.per_gpu, args.latent, args.denoise_steps)
+    sched_name = {"ddim": "DDIM", "dpm": "DPMSolver++", "pndm": "PNDM", "unipc": "UniPC"}[
+        args.scheduler or ("dpm" if args.config == "v2" else "ddim")]
 
     for _ in range(args.warmup):
         pipe(**kw)
@@ -237,24 +332,29 @@ def main():
     if rank == 0:
         images = args.per_gpu * world * args.steps
         ms_per_step = dt / args.steps * 1e3
-        unet_steps = 50
-        gf = {"v1": GFLOP_PER_SAMPLE["unet9"], "v2": GFLOP_PER_SAMPLE["unet4"] + GFLOP_PER_SAMPLE["brushnet"],
-              "controlnet": GFLOP_PER_SAMPLE["unet9"] + GFLOP_PER_SAMPLE["controlnet"]}[args.config]
-        scale_hw = (args.latent / 64.0) ** 2 if args.latent != 64 else 1.0
-        tflop_step = gf * 2 * args.per_gpu * scale_hw / 1e3         # CFG doubles the batch
+        unet_steps = len(pipe.scheduler.timesteps)          # network evaluations per image (PNDM: denoise_steps + 1)
+        tab = GFLOP_PER_SAMPLE_BY_LATENT.get(args.latent)
+        if tab is not None:
+            gf = {"v1": tab["unet9"], "v2": tab["unet4"] + tab["brushnet"],
+                  "controlnet": tab["unet9"] + tab["controlnet"]}[args.config]
+            tflop_step = gf * 2 * args.per_gpu / 1e3                # CFG doubles the batch
+        else:                                                       # other sizes: the launch plan's own count (2 * MAC)
+            tflop_step = pipe._loop.program.flops / 1e12
         ms_denoise_step = ms_per_step / unet_steps
         px = args.latent * 8
         res = {
-            "metric": ("inpainted images/sec @512x512, 50-step DDIM CFG, batch4/GPU" if (px, args.per_gpu, args.config) == (512, 4, "v1")
-                       else f"inpainted images/sec @{px}x{px}, 50-step, batch{args.per_gpu}/GPU ({args.config})"),
+            "metric": ("inpainted images/sec @512x512, 50-step DDIM CFG, batch4/GPU"
+                       if (px, args.per_gpu, args.config, args.denoise_steps, sched_name) == (512, 4, "v1", 50, "DDIM")
+                       else f"inpainted images/sec @{px}x{px}, {args.denoise_steps}-step {sched_name}, "
+                            f"batch{args.per_gpu}/GPU ({args.config})"),
             "value": images / dt, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": {"v1": f"ppt-v1 SD1.5-inpaint UNet (9-ch in), {px}x{px}, 50-step DDIM, CFG=7.5, batch={args.per_gpu}/GPU",
-                                    "v2": f"ppt-v2 BrushNet + SD1.5 UNet, {px}x{px}, 50-step DPMSolver++, CFG=7.5, batch={args.per_gpu}/GPU",
-                                    "controlnet": f"ppt-v1 + ControlNet, {px}x{px}, 50-step DDIM, CFG=7.5, batch={args.per_gpu}/GPU"}[args.config],
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": {"v1": f"ppt-v1 SD1.5-inpaint UNet (9-ch in), {px}x{px}, {args.denoise_steps}-step {sched_name}, CFG=7.5, {args.dtype}, batch={args.per_gpu}/GPU",
+                                    "v2": f"ppt-v2 BrushNet + SD1.5 UNet, {px}x{px}, {args.denoise_steps}-step {sched_name}, CFG=7.5, {args.dtype}, batch={args.per_gpu}/GPU",
+                                    "controlnet": f"ppt-v1 + ControlNet, {px}x{px}, {args.denoise_steps}-step {sched_name}, CFG=7.5, {args.dtype}, batch={args.per_gpu}/GPU"}[args.config],
                        "global_batch": args.per_gpu * world, "latent": [4, args.latent, args.latent],
-                       "denoise_steps": unet_steps, "parallelism": f"dp{world} (image shards, no step collectives)",
+                       "denoise_steps": args.denoise_steps, "network_evaluations": unet_steps, "parallelism": f"dp{world} (image shards, no step collectives)",
                        "hipgraph": not args.no_graph, "weights": "random init (no checkpoints offline)",
                        "weight_broadcast_s": round(bcast_s, 4)},
             "ms_per_denoise_step": ms_denoise_step,
@@ -262,7 +362,8 @@ def main():
         }
         if not args.no_roofline:
             try:
-                res.update(roofline_report(pipe, args.dump_launches))
+                headline = (args.config, args.latent, args.per_gpu, args.dtype) == ("v1", 64, 4, "bf16")
+                res.update(roofline_report(pipe, args.dump_launches, profile_matches=headline))
             except Exception as e:      # the headline number must still be reported: keep the one JSON line
                 res["roofline"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_cpu_baseline:

@@ -24,6 +24,7 @@ namespace {
 
 struct GemmDerived {
   int tiles_m, tiles_n, kt_total, kt_per_split, ctiles;
+  int n_major;   // 1: consecutive tile ids walk the M tiles of one N tile (the blocks of an XCD share the W strip)
 };
 
 // GroupNorm statistics from an epilogue.  A pass / tile = up to 64 output rows of ONE batch item x the <= 160 columns
@@ -159,8 +160,17 @@ __global__ void __launch_bounds__(WM* WN * 64, 2) pp_gemm_kernel(const PPGemmArg
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
     lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  const int tile_m = lid / d.tiles_n;
-  const int tile_n = lid - tile_m * d.tiles_n;
+  // the blocks resident on one XCD take consecutive tile ids: M-major ids walk the N tiles of one M panel (the activation
+  // panel is fetched into that XCD's L2 once), N-major ids the M tiles of one N strip (small-M launches, where the
+  // weight strip is the big operand: every XCD would otherwise pull the whole matrix through the fabric)
+  int tile_m, tile_n;
+  if (d.n_major) {
+    tile_n = lid / d.tiles_m;
+    tile_m = lid - tile_n * d.tiles_m;
+  } else {
+    tile_m = lid / d.tiles_n;
+    tile_n = lid - tile_m * d.tiles_n;
+  }
   const int m_blk = tile_m * BM, n_blk = tile_n * BN;
   const int split = blockIdx.y;
   const int kt_begin = split * d.kt_per_split;
@@ -411,8 +421,17 @@ pp_gemm_kernel_v2(const PPGemmArgs a, const GemmDerived d) {   // 2nd bound = wa
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
     lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  const int tile_m = lid / d.tiles_n;
-  const int tile_n = lid - tile_m * d.tiles_n;
+  // the blocks resident on one XCD take consecutive tile ids: M-major ids walk the N tiles of one M panel (the activation
+  // panel is fetched into that XCD's L2 once), N-major ids the M tiles of one N strip (small-M launches, where the
+  // weight strip is the big operand: every XCD would otherwise pull the whole matrix through the fabric)
+  int tile_m, tile_n;
+  if (d.n_major) {
+    tile_n = lid / d.tiles_m;
+    tile_m = lid - tile_n * d.tiles_m;
+  } else {
+    tile_m = lid / d.tiles_n;
+    tile_n = lid - tile_m * d.tiles_n;
+  }
   const int m_blk = tile_m * BM, n_blk = tile_n * BN;
   const int split = blockIdx.y;
   const int kt_begin = split * d.kt_per_split;
@@ -1286,6 +1305,7 @@ struct Choice {
   int tile, splitk;
 };
 bool gemm_pingpong();
+bool gemm_n_major();
 
 // v2 (LDS-direct pipeline + staged 16-byte epilogue) needs 16-byte aligned rows on every tensor the epilogue touches
 bool v2_ok(const PPGemmArgs& a) {
@@ -1377,6 +1397,7 @@ int launch(const PPGemmArgs& a, int splitk, hipStream_t st) {
   d.kt_total = a.K / 64;
   d.kt_per_split = (d.kt_total + splitk - 1) / splitk;
   d.ctiles = (a.c1 + a.c2) / 64;
+  d.n_major = (gemm_n_major() && d.tiles_m < d.tiles_n && d.tiles_m <= 8) ? 1 : 0;
   dim3 grid(d.tiles_m * d.tiles_n, splitk, 1);
   hipLaunchKernelGGL(kern, grid, dim3(T), LDS, st, a, d);
   PP_CHECK_LAUNCH("pp_gemm_kernel");
@@ -1392,6 +1413,15 @@ int launch(const PPGemmArgs& a, int splitk, hipStream_t st) {
     PP_CHECK_LAUNCH("pp_splitk_reduce_kernel");
   }
   return PP_OK;
+}
+
+// PP_GEMM_NMAJOR=0|1: A/B switch for the N-major tile order of small-M launches (default 1)
+bool gemm_n_major() {
+  static const int v = [] {
+    const char* e = getenv("PP_GEMM_NMAJOR");
+    return e ? atoi(e) : 1;
+  }();
+  return v != 0;
 }
 
 // PP_GEMM_PP=0|1: A/B switch for the ping-pong tiles in the automatic choice (default 1)
@@ -1448,6 +1478,7 @@ int launch2(const PPGemmArgs& a, int splitk, hipStream_t st) {
   d.kt_total = a.K / 64;
   d.kt_per_split = (d.kt_total + splitk - 1) / splitk;
   d.ctiles = (a.c1 + a.c2) / 64;
+  d.n_major = (gemm_n_major() && d.tiles_m < d.tiles_n && d.tiles_m <= 8) ? 1 : 0;
   dim3 grid(d.tiles_m * d.tiles_n, splitk, 1);
   hipLaunchKernelGGL(kern, grid, dim3(T), LDS, st, a, d);
   PP_CHECK_LAUNCH("pp_gemm_kernel_v2");

@@ -212,10 +212,22 @@ class PipelineBase(PipelinePretrainedMixin):
             if negative_prompt_embeds is None:
                 if text_encoder is None:
                     raise ValueError("classifier-free guidance needs negative_prompt_embeds when no text encoder is set")
-                nA = negative_promptA if negative_promptA is not None else [""] * bs
-                nB = negative_promptB if negative_promptB is not None else nA
-                if isinstance(nA, str):
-                    nA, nB = [nA] * bs, [nB if isinstance(nB, str) else nB[0]] * bs
+                # pipeline_PowerPaint.py:441-460: `negative_prompt` IS negative_promptA -- when it is None BOTH
+                # unconditional prompts are "" (a lone negative_promptB is ignored), a str is used as given, a list must
+                # match the prompt's type and batch size
+                if negative_promptA is None:
+                    nA = nB = [""] * bs
+                elif promptA is not None and type(promptA) is not type(negative_promptA):
+                    raise TypeError(f"`negative_prompt` should be the same type to `prompt`, but got "
+                                    f"{type(negative_promptA)} != {type(promptA)}.")
+                elif isinstance(negative_promptA, str):
+                    nA, nB = [negative_promptA], [negative_promptB]
+                elif bs != len(negative_promptA):
+                    raise ValueError(f"`negative_prompt`: {negative_promptA} has batch size {len(negative_promptA)}, but "
+                                     f"`prompt`: {promptA} has batch size {bs}. Please make sure that passed "
+                                     "`negative_prompt` matches the batch size of `prompt`.")
+                else:
+                    nA, nB = negative_promptA, negative_promptB
                 eA = self._text_embeds(text_encoder, nA, device)
                 eB = self._text_embeds(text_encoder, nB, device)
                 negative_prompt_embeds = eA * t_nag + (1 - t_nag) * eB                     # :499

@@ -157,7 +157,8 @@ class StableDiffusionPowerPaintBrushNetPipeline(PipelineBase):
         n = len(timesteps)
         keep = [1.0 - float(i / n < control_guidance_start or (i + 1) / n > control_guidance_end) for i in range(n)]
         scales = [brushnet_conditioning_scale * k for k in keep]                              # :1370-1376,1405-1409
-        if self._loop is None or self._loop.scheduler is not self.scheduler or self._loop.unet is not self.unet:
+        if self._loop is None or self._loop.scheduler is not self.scheduler or self._loop.unet is not self.unet or \
+                self._loop.side is not self.brushnet:        # (a replaced component must not keep driving the old one)
             self._loop = DenoiseLoop(self.unet, self.scheduler, side=self.brushnet, side_kind="brushnet")
         self._loop.bind(shape, do_cfg, guidance_scale, prompt_embedsU, prompt_embeds_side=prompt_embeds,
                         side_static_inputs=[(conditioning_latents, self.unet.config.in_channels)],
@@ -166,7 +167,15 @@ class StableDiffusionPowerPaintBrushNetPipeline(PipelineBase):
         if callback is not None or callback_on_step_end is not None:
             def cb(i, t, lat):
                 if callback_on_step_end is not None:
-                    callback_on_step_end(self, i, t, {"latents": lat})
+                    ret = callback_on_step_end(self, i, t, {"latents": lat})
+                    # the reference lets the callback hand back replacements (:1455-1459); the loop owns `lat`, so new
+                    # latents are copied into it, anything else (prompt_embeds ...) is baked into the step program
+                    if isinstance(ret, dict):
+                        new = ret.get("latents", lat)
+                        if new is not lat:
+                            lat.copy_(new.to(lat.device, lat.dtype))
+                        if any(k != "latents" for k in ret):
+                            raise NotImplementedError("callback_on_step_end may only replace `latents` on the HIP path")
                 if callback is not None and i % callback_steps == 0:
                     callback(i, t, lat)
         out = self._loop.run(latents, n, use_graph=self.use_graph, callback=cb, timesteps=timesteps,

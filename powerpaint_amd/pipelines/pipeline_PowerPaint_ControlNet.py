@@ -98,7 +98,8 @@ class StableDiffusionControlNetInpaintPipeline(StableDiffusionInpaintPipeline):
         n = len(timesteps)
         keep = [1.0 - float(i / n < control_guidance_start or (i + 1) / n > control_guidance_end) for i in range(n)]
         scales = [controlnet_conditioning_scale * k for k in keep]
-        if self._loop is None or self._loop.scheduler is not self.scheduler or self._loop.unet is not self.unet:
+        if self._loop is None or self._loop.scheduler is not self.scheduler or self._loop.unet is not self.unet or \
+                self._loop.side is not self.controlnet:
             self._loop = DenoiseLoop(self.unet, self.scheduler, side=self.controlnet, side_kind="controlnet")
         self._loop.bind(shape, do_cfg, guidance_scale, prompt_embeds, prompt_embeds_side=prompt_embeds,
                         static_inputs=[(m, 4), (mil, 5)], controlnet_cond=control_image, side_scale=scales[0])
