@@ -119,6 +119,16 @@ PP_DEVINL void gn_fold_acc(const long long* __restrict__ acc, int groups, int C,
                            const float* __restrict__ gamma, const float* __restrict__ beta, int b, float* mean_s,
                            float* rstd_s, float* sc_s, float* sh_s) {
   const int tid = threadIdx.x;
+  // gamma / beta do not depend on the statistics: fetch them first (<= 8 channels per thread, C <= 2048) so that the
+  // accumulator round trip and the fp64 arithmetic are the only serial part
+  constexpr int PRE = 8;
+  float gpre[PRE], bpre[PRE];
+#pragma unroll
+  for (int k = 0; k < PRE; ++k) {
+    const int c = tid + k * 256;
+    gpre[k] = (c < C) ? gamma[c] : 0.f;
+    bpre[k] = (c < C) ? beta[c] : 0.f;
+  }
   if (tid < groups) {
     const double s = (double)acc[((size_t)b * groups + tid) * 2] * (1.0 / (double)PP_GN_SUM_SCALE);
     const double q = (double)acc[((size_t)b * groups + tid) * 2 + 1] * (1.0 / (double)PP_GN_SQ_SCALE);
@@ -131,7 +141,17 @@ PP_DEVINL void gn_fold_acc(const long long* __restrict__ acc, int groups, int C,
   }
   __syncthreads();
   const int cg = C / groups;
-  for (int c = tid; c < C; c += blockDim.x) {
+#pragma unroll
+  for (int k = 0; k < PRE; ++k) {
+    const int c = tid + k * 256;
+    if (c < C) {
+      const int gg = c / cg;
+      const float sc = rstd_s[gg] * gpre[k];
+      sc_s[c] = sc;
+      sh_s[c] = bpre[k] - mean_s[gg] * sc;
+    }
+  }
+  for (int c = tid + PRE * 256; c < C; c += 256) {
     const int gg = c / cg;
     const float sc = rstd_s[gg] * gamma[c];
     sc_s[c] = sc;
@@ -153,17 +173,12 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const uint16_t* __restric
   const int b = blockIdx.y;
   float* sc = tab;
   float* sh = tab + C;
-  if (ACC) gn_fold_acc(reinterpret_cast<const long long*>(partial), groups, C, hw, eps, gamma, beta, b, tab + 2 * C,
-                       tab + 2 * C + 64, sc, sh);
-  else gn_fold(partial, nchunk, groups, C, hw, eps, gamma, beta, b, tab + 2 * C, tab + 2 * C + 64, sc, sh);
-  const int total = hw * S;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
-    const int p = i / S;
-    const int c = (i - p * S) * 8;
-    const uint16_t* src = (c < c1) ? x1 + ((size_t)b * hw + p) * c1 + c : x2 + ((size_t)b * hw + p) * c2 + (c - c1);
-    const u32x4_t v = *reinterpret_cast<const u32x4_t*>(src);
-    const f32x4_t a0 = *reinterpret_cast<const f32x4_t*>(sc + c), a1 = *reinterpret_cast<const f32x4_t*>(sc + c + 4);
-    const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(sh + c), b1 = *reinterpret_cast<const f32x4_t*>(sh + c + 4);
+  auto fold = [&]() {
+    if (ACC) gn_fold_acc(reinterpret_cast<const long long*>(partial), groups, C, hw, eps, gamma, beta, b, tab + 2 * C,
+                         tab + 2 * C + 64, sc, sh);
+    else gn_fold(partial, nchunk, groups, C, hw, eps, gamma, beta, b, tab + 2 * C, tab + 2 * C + 64, sc, sh);
+  };
+  auto one = [&](const u32x4_t v, const f32x4_t a0, const f32x4_t a1, const f32x4_t b0, const f32x4_t b1) -> u32x4_t {
     float r[8];
     r[0] = E16<EDT>::lo(v[0]) * a0[0] + b0[0]; r[1] = E16<EDT>::hi(v[0]) * a0[1] + b0[1];
     r[2] = E16<EDT>::lo(v[1]) * a0[2] + b0[2]; r[3] = E16<EDT>::hi(v[1]) * a0[3] + b0[3];
@@ -174,8 +189,56 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const uint16_t* __restric
       for (int j = 0; j < 8; ++j) r[j] = silu_f(r[j]);
     }
     u32x4_t o;
-    o[0] = E16<EDT>::pack2(r[0], r[1]); o[1] = E16<EDT>::pack2(r[2], r[3]); o[2] = E16<EDT>::pack2(r[4], r[5]); o[3] = E16<EDT>::pack2(r[6], r[7]);
-    *reinterpret_cast<u32x4_t*>(y + ((size_t)b * hw + p) * C + c) = o;
+    o[0] = E16<EDT>::pack2(r[0], r[1]); o[1] = E16<EDT>::pack2(r[2], r[3]);
+    o[2] = E16<EDT>::pack2(r[4], r[5]); o[3] = E16<EDT>::pack2(r[6], r[7]);
+    return o;
+  };
+  if (S <= 256) {
+    // A thread keeps ONE 8-channel slot for the whole launch: its scale / shift live in registers, the per-piece index
+    // arithmetic is one add, and four independent 16-byte loads are in flight per lane (the old flat loop had one, a
+    // division per piece and four LDS reads: 1.9 TB/s on the 21 MB tensors of the 64x64 level).  256 / S pixel rows
+    // per block pass; the threads past R * S idle (<= 37 % at C = 1280, none of the hot 64x64-level shapes).
+    const int R = 256 / S;
+    const int tid = threadIdx.x;
+    const bool active = tid < R * S;
+    const int r = active ? tid / S : 0, c = active ? (tid - r * S) * 8 : 0;
+    const bool first = c < c1;
+    const uint16_t* src = first ? x1 + (size_t)b * hw * c1 + c : x2 + (size_t)b * hw * c2 + (c - c1);
+    const size_t ss = first ? c1 : c2;
+    uint16_t* dst = y + (size_t)b * hw * C + c;
+    const int step = gridDim.x * R;
+    int p = blockIdx.x * R + r;
+    // The first four rows' loads are issued BEFORE the statistics are folded: the fold is two dependent global round
+    // trips (accumulators, then gamma / beta) plus fp64 arithmetic, ~4 us during which nothing else was in flight --
+    // the launch cost ~13 us whatever the tensor size.
+    u32x4_t v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      v[k] = u32x4_t{0u, 0u, 0u, 0u};
+      if (active && p + k * step < hw) v[k] = *reinterpret_cast<const u32x4_t*>(src + (size_t)(p + k * step) * ss);
+    }
+    fold();
+    if (!active) return;
+    const f32x4_t a0 = *reinterpret_cast<const f32x4_t*>(sc + c), a1 = *reinterpret_cast<const f32x4_t*>(sc + c + 4);
+    const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(sh + c), b1 = *reinterpret_cast<const f32x4_t*>(sh + c + 4);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (p + k * step < hw) *reinterpret_cast<u32x4_t*>(dst + (size_t)(p + k * step) * C) = one(v[k], a0, a1, b0, b1);
+    for (p += 4 * step; p < hw; p += step)
+      *reinterpret_cast<u32x4_t*>(dst + (size_t)p * C) =
+          one(*reinterpret_cast<const u32x4_t*>(src + (size_t)p * ss), a0, a1, b0, b1);
+    return;
+  }
+  fold();
+  const int total = hw * S;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const int p = i / S;
+    const int c = (i - p * S) * 8;
+    const uint16_t* src = (c < c1) ? x1 + ((size_t)b * hw + p) * c1 + c : x2 + ((size_t)b * hw + p) * c2 + (c - c1);
+    const u32x4_t v = *reinterpret_cast<const u32x4_t*>(src);
+    const f32x4_t a0 = *reinterpret_cast<const f32x4_t*>(sc + c), a1 = *reinterpret_cast<const f32x4_t*>(sc + c + 4);
+    const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(sh + c), b1 = *reinterpret_cast<const f32x4_t*>(sh + c + 4);
+    *reinterpret_cast<u32x4_t*>(y + ((size_t)b * hw + p) * C + c) = one(v, a0, a1, b0, b1);
   }
 }
 
@@ -237,6 +300,16 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const uint16_t* __restri
 
 }  // namespace
 
+// workgroups per batch item of the apply kernel: with the fixed-slot mapping (C <= 2048) one pass of four pixel rows per
+// thread -- every load of the launch is in flight at once; else >= 8 pieces per thread (amortises the fold prologue)
+static int gn_apply_blocks(int hw, int C, long long total) {
+  const int S = C / 8;
+  int nb = S <= 256 ? (hw + (256 / S) * 4 - 1) / ((256 / S) * 4) : (int)((total + 256 * 8 - 1) / (256 * 8));
+  if (nb > 512) nb = 512;
+  if (nb < 1) nb = 1;
+  return nb;
+}
+
 static int gn_nchunk(int hw) {
   int c = hw / 16;
   if (c < 1) c = 1;
@@ -277,9 +350,7 @@ extern "C" int pp_groupnorm_apply(const void* x1, int c1, const void* x2, int c2
   const int C = c1 + c2;
   if (groups <= 0 || groups > 32 || C % groups) return PP_ERR_BAD_ARG;
   const long long total = (long long)hw * (C / 8);
-  int nb = (int)((total + 256 * 8 - 1) / (256 * 8));    // >= 8 pieces per thread: amortise the fold prologue
-  if (nb > 512) nb = 512;
-  if (nb < 1) nb = 1;
+  int nb = gn_apply_blocks(hw, C, total);
   const size_t lds = (size_t)(2 * C + 128) * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
   const int nchunk = gn_nchunk(hw);
@@ -303,9 +374,7 @@ extern "C" int pp_groupnorm_apply_acc(const void* x1, int c1, const void* x2, in
   const int C = c1 + c2;
   if (groups <= 0 || groups > 32 || C % groups) return PP_ERR_BAD_ARG;
   const long long total = (long long)hw * (C / 8);
-  int nb = (int)((total + 256 * 8 - 1) / (256 * 8));
-  if (nb > 512) nb = 512;
-  if (nb < 1) nb = 1;
+  int nb = gn_apply_blocks(hw, C, total);
   const size_t lds = (size_t)(2 * C + 128) * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
   const float* accf = reinterpret_cast<const float*>(acc);
