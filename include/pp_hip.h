@@ -6,7 +6,9 @@
  * reference *call site / module* whose device work it replaces.  Conventions for every entry:
  *   - `extern "C"`, plain pointers + sizes, no torch types;
  *   - all pointers are DEVICE pointers unless named `host_*`;
- *   - activations are bf16 (raw uint16 storage) in NHWC / [rows][channels] layout, parameters as documented;
+ *   - activations are 16-bit (raw uint16 storage; bf16 or fp16, selected per call by the `dtype` argument / field --
+ *     where a comment below says "bf16" read "the call's 16-bit format") in NHWC / [rows][channels] layout,
+ *     parameters as documented;
  *   - the last argument is a `hipStream_t` (passed as void*; torch.cuda.current_stream().cuda_stream);
  *   - returns PP_OK (0) or a negative PP_ERR_*; never throws, never allocates, never synchronises, keeps no
  *     pointer after return, is re-entrant per stream; workspaces are caller-provided and sized by *_workspace_bytes.

@@ -55,6 +55,24 @@ def test_gemm_plain(tile, M, N, K):
     check(out, ref, 2e-2, 1e-2, f"gemm tile{tile}")
 
 
+@pytest.mark.parametrize("tile", [33, 31] + PP_TILES)
+@pytest.mark.parametrize("K", [64, 128, 192])
+def test_gemm_short_k_pipeline_edges(tile, K):
+    """K of one to three 64-deep tiles: fewer tiles than pipeline stages (the prologue's look-ahead refills are all
+    past the end) and, for the ping-pong tiles, a loop of 1-3 iterations around the group stagger; ragged M and N."""
+    M, N = 300, 200
+    x, w = bf(rnd(M, K, seed=1)), bf(rnd(N, K, seed=2, scale=K ** -0.5))
+    bias = rnd(N, seed=3)
+    out = ops.gemm(x, w, bias=bias, tile=tile, splitk=1)
+    check(out, x.float() @ w.float().t() + bias, 2e-2, 1e-2, f"gemm K={K} tile{tile}")
+    B, H, C = 1, 8, 64                                   # conv with 9 single-tile taps + a one-tile 1x1 tail
+    xc, x3 = bf(rnd(B, H, H, C, seed=4)), bf(rnd(B, H, H, 64, seed=5))
+    wc = bf(rnd(160, 9 * C + 64, seed=6, scale=(9 * C + 64) ** -0.5))
+    oc = ops.conv3x3(xc, wc, None, x3=x3, tile=tile, splitk=1)
+    ref = conv_ref(xc, wc[:, :9 * C].contiguous(), None) + x3.float() @ wc[:, 9 * C:].float().t()
+    check(oc, ref, 2e-2, 1e-2, f"conv + tail, single-tile segments, tile{tile}")
+
+
 def test_gemm_transpose_detect():
     """A = I check with asymmetric W (guide rule: a symmetric B hides a row<->col swap)."""
     K = 320
