@@ -156,11 +156,15 @@ attn_fwd_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __restr
   float l_run = 0.f;
 
   // one 64-key tile: S^T = K Q^T, online softmax (per-lane row state), O^T += V^T P^T
+  // tail_tag: 0 full tile | 1 last tile, keys >= nk masked | 2 last tile with <= 32 live keys: only the first 32-key
+  // block is computed at all (the masked block would contribute exp2(-1e30 - m) = 0 exactly).  Cross-attention over
+  // 77 text tokens is one full tile + one 13-key tail: a quarter of its MFMA / exp work was spent on padding.
   auto tile = [&](const char* ks, const char* vs, int t0, auto tail_tag) {
-    constexpr bool TAIL = decltype(tail_tag)::value;
+    constexpr bool TAIL = decltype(tail_tag)::value != 0;
+    constexpr int JN = decltype(tail_tag)::value == 2 ? 1 : 2;
     f32x16_t sacc[2];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < JN; ++j) {
       const f32x16_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int s = 0; s < C::DS; ++s) {
@@ -170,7 +174,7 @@ attn_fwd_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __restr
     }
     float tmax = -1.0e30f;
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < JN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         if (TAIL) {   // keys >= nk exist only in the last tile
@@ -197,7 +201,7 @@ attn_fwd_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __restr
       }
       const f32x2_t c2 = {scale_log2e, scale_log2e}, nm2 = {-m_run, -m_run};
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < JN; ++j)
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
           const f32x2_t s2 = {sacc[j][r], sacc[j][r + 1]};
@@ -208,7 +212,7 @@ attn_fwd_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __restr
         }
     }
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < JN; ++j)
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         u32x4_t w;
@@ -221,7 +225,7 @@ attn_fwd_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __restr
     if constexpr (!MFMA_SUM) l_run += psum;
     // O^T += V^T P^T : key slot (half, jj) <-> key 16u + 4 half + jj (jj<4) | 16u + 8 + 4 half + jj-4
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < JN; ++j)
 #pragma unroll
       for (int u = 0; u < 2; ++u)
 #pragma unroll
@@ -241,8 +245,9 @@ attn_fwd_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __restr
     const bool more = t + 1 < ntiles;
     if (more) load_tile(t0 + KB);                       // global -> registers, in flight during the MFMAs below
     const char* ks = smem + (t & 1) * BUF;
-    if (t0 + KB > nk) tile(ks, ks + C::KBYTES, t0, std::true_type{});
-    else tile(ks, ks + C::KBYTES, t0, std::false_type{});
+    if (t0 + KB / 2 >= nk) tile(ks, ks + C::KBYTES, t0, std::integral_constant<int, 2>{});
+    else if (t0 + KB > nk) tile(ks, ks + C::KBYTES, t0, std::integral_constant<int, 1>{});
+    else tile(ks, ks + C::KBYTES, t0, std::integral_constant<int, 0>{});
     if (more) store_tile((t + 1) & 1);                  // the other buffer: last read two barriers ago
     __syncthreads();
   }

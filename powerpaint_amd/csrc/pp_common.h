@@ -88,7 +88,8 @@ PP_DEVINL float gelu_fast_f(float x) {
   p = __builtin_fmaf(t, p, 0.5f * -0.284496736f);
   p = __builtin_fmaf(t, p, 0.5f * 0.254829592f);
   const float q = p * t * __builtin_amdgcn_exp2f(x * x * (-0.5f * 1.44269504088896340736f));   // Phi(-|x|)
-  return x * (x >= 0.f ? 1.0f - q : q);
+  // x Phi(x) = x - x q (x >= 0) | x q (x < 0)  =  max(x, 0) - |x| q : two instructions instead of compare/select/sub/mul
+  return __builtin_fmaf(-ax, q, __builtin_fmaxf(x, 0.f));
 }
 
 // Buffer resource over [base, base+bytes): out-of-range voffset reads return 0 -> free zero padding for im2col.

@@ -389,6 +389,18 @@ def _conv_direct(w: torch.Tensor) -> torch.Tensor:
     return w.permute(2, 3, 1, 0)
 
 
+CIN_CHUNK = 64   # K chunk of the implicit-GEMM conv: one (tap, 64 channels) slice per main-loop step
+
+
+def _conv_igemm_cpad(w: torch.Tensor, cpad: int) -> torch.Tensor:
+    """conv_in ([Cout, 4|9, 3, 3]) for the implicit-GEMM kernel: input channels zero-padded to `cpad` (one 64-deep K
+    chunk per tap; the network input buffer carries the same zero channels), then the igemm layout."""
+    pad = cpad - w.shape[1]
+    if pad:
+        w = torch.cat([w, torch.zeros(w.shape[0], pad, 3, 3, dtype=w.dtype, device=w.device)], 1)
+    return _conv_igemm(w)
+
+
 def _geglu_interleave(w: torch.Tensor) -> torch.Tensor:
     """GEGLU proj rows [h(0..F) ; g(0..F)] -> groups of four rows (h_{2q}, h_{2q+1}, g_{2q}, g_{2q+1})."""
     F2 = w.shape[0]
@@ -428,6 +440,9 @@ class SDNet:
         self.kind = kind
         self.in_channels = in_channels
         self.conditioning_channels = conditioning_channels
+        # channels of the network input as conv_in sees it, and as the input buffer stores it (zero-padded: see build_step)
+        self.cin0 = in_channels + (conditioning_channels if kind == "brushnet" else 0)
+        self.cin_pad = _align(self.cin0, CIN_CHUNK)
         self.boc = tuple(block_out_channels)
         self.merge_shortcut = self._merge_shortcut_env and all(c % 64 == 0 for c in self.boc)
         self.L = layers_per_block
@@ -523,8 +538,7 @@ class SDNet:
             sp[name + ".weight"] = (c,)
             sp[name + ".bias"] = (c,)
 
-        cin0 = self.in_channels + (self.conditioning_channels if self.kind == "brushnet" else 0)
-        conv("conv_in_condition" if self.kind == "brushnet" else "conv_in", boc[0], cin0, 3)
+        conv("conv_in_condition" if self.kind == "brushnet" else "conv_in", boc[0], self.cin0, 3)
         lin("time_embedding.linear_1", te, boc[0])
         lin("time_embedding.linear_2", te, te)
         for pre, cin, cout in self._resnet_specs():
@@ -592,7 +606,7 @@ class SDNet:
             return sd[k].float() if sd[k].device.type != "meta" else sd[k]
 
         conv_in = "conv_in_condition" if self.kind == "brushnet" else "conv_in"
-        pk.add("conv_in.weight", _conv_direct(W(conv_in + ".weight")), bf)
+        pk.add("conv_in.weight", _conv_igemm_cpad(W(conv_in + ".weight"), self.cin_pad), bf)
         pk.add("conv_in.bias", W(conv_in + ".bias"), f32)
         for n in ("linear_1", "linear_2"):
             pk.add(f"time_embedding.{n}.weight", W(f"time_embedding.{n}.weight"), bf)
@@ -860,12 +874,15 @@ class SDNet:
         pb.plan.add("linear_skinny", lib.pp_linear_skinny, temb, 1, te, P["temb_all.weight"], P["temb_all.bias"],
                     self.temb_total, temb_all, self.temb_total, L.PP_ACT_SILU, 0, pb.dt)
 
-        # 2. conv_in
+        # 2. conv_in: the implicit-GEMM conv over the zero-padded input (4 / 9 real channels in one 64-deep K chunk per
+        # tap: 6x the algorithmic MACs, still 4x faster than the scalar direct conv at 64x64 -- 9 short K steps on the
+        # matrix cores -- and its epilogue carries the GroupNorm statistics of resnets.0.norm1 and the side-branch add)
+        if x_in.C != self.cin_pad:
+            raise L.PPError(f"network input buffer has {x_in.C} channels, conv_in expects {self.cin_pad} (zero-padded)")
+
         def conv_in(add_ptr) -> Act:
-            o = pb.new_act(B, H, W, boc[0])
-            pb.plan.add("conv3x3_direct", lib.pp_conv3x3_direct, x_in.ptr, B, H, W, x_in.C, P["conv_in.weight"],
-                        P["conv_in.bias"], boc[0], 1, 0, add_ptr, o.ptr, pb.dt)
-            pb.plan.count("conv_in", 2.0 * B * H * W * boc[0] * 9 * x_in.C)
+            o = pb.conv3x3(x_in, P["conv_in.weight"], boc[0], P["conv_in.bias"], res2=add_ptr or 0, name="conv3x3")
+            pb.plan.count("conv3x3", -2.0 * B * H * W * boc[0] * 9 * (x_in.C - self.cin0))   # (count the real MACs)
             return o
 
         if self.kind == "controlnet":

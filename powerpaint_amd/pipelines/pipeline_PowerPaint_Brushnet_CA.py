@@ -6,6 +6,7 @@ Additive keyword extension for synthetic / VAE-free operation: `conditioning_lat
 VAE latents of the masked image * scaling_factor concatenated with the latent-resolution mask, i.e. the tensor the
 reference builds at :1338-1345) and `prompt_embedsU=` / `negative_prompt_embedsU=` for the UNet's plain prompt.
 """
+import inspect
 from typing import Any, Callable, Dict, List, Optional, Union
 
 import torch
@@ -16,9 +17,15 @@ from .image_processor import VaeImageProcessor
 
 
 def retrieve_timesteps(scheduler, num_inference_steps=None, device=None, timesteps=None, **kwargs):
-    """pipeline_PowerPaint_Brushnet_CA.py:87-128."""
+    """pipeline_PowerPaint_Brushnet_CA.py:87-128: a custom `timesteps` list goes to schedulers whose `set_timesteps`
+    takes one and is a ValueError for the others -- which, as in diffusers 0.27, is all four of this package
+    (DDIM / DPM-Solver++ / PNDM / UniPC take a step count only)."""
     if timesteps is not None:
-        raise NotImplementedError("custom timestep lists are outside the accelerated hot path")
+        if "timesteps" not in set(inspect.signature(scheduler.set_timesteps).parameters.keys()):
+            raise ValueError(f"The current scheduler class {scheduler.__class__}'s `set_timesteps` does not support custom"
+                             f" timestep schedules. Please check whether you are using the correct scheduler.")
+        scheduler.set_timesteps(timesteps=timesteps, device=device, **kwargs)
+        return scheduler.timesteps, len(scheduler.timesteps)
     scheduler.set_timesteps(num_inference_steps, device=device, **kwargs)
     return scheduler.timesteps, num_inference_steps
 

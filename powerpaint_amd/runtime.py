@@ -44,7 +44,11 @@ class NetRuntime:
         # by the first launch of every step
         gn_cap = 96 * B * 32 * 2 * 8
         lay["gn_acc"] = arena.alloc(gn_cap)
-        lay["x_in"] = Act(arena.alloc(B * H * W * cin_total * 2), B, H, W, cin_total)
+        # network input, NHWC; the channels are zero-padded to one 64-deep K chunk (conv_in runs on the implicit-GEMM
+        # kernel).  The arena is zero-filled and nothing else ever writes the pad channels.
+        if cin_total != net.cin0:
+            raise L.PPError(f"{net.kind} takes {net.cin0} input channels, got {cin_total}")
+        lay["x_in"] = Act(arena.alloc(B * H * W * net.cin_pad * 2), B, H, W, net.cin_pad)
         lay["ehs"] = arena.alloc(B * nctx * net.ctx_dim * 2)
         cond = None
         if net.kind == "controlnet":

@@ -329,7 +329,12 @@ def test_layernorm(C):
 # ------------------------------------------------------------------------------------------------ attention
 @pytest.mark.parametrize("d,nq,nk", [(40, 256, 256), (80, 256, 256), (160, 64, 64), (40, 1024, 77), (80, 200, 77),
                                      (160, 256, 77), (40, 4096, 4096), (40, 200, 192), (40, 128, 128), (40, 64, 64),
-                                     (40, 1000, 960)])
+                                     (40, 1000, 960),
+                                     # key-tail paths of attn_fwd_kernel: a last tile with <= 32 live keys computes only
+                                     # its first 32-key block (77 = 64 + 13, 96 = 64 + exactly 32, 16 / 32: first tile),
+                                     # 33 / 97 / 100 keep the masked full tile
+                                     (40, 96, 96), (80, 64, 16), (160, 64, 32), (40, 64, 33), (80, 128, 97),
+                                     (40, 128, 100)])
 def test_attention(d, nq, nk):
     B, Hh = 2, 8
     C = Hh * d
@@ -398,8 +403,12 @@ def test_conv_direct(cin, cout, stride):
     check(out, F.silu(ref + add.float()), 2e-2, 1e-2, "conv direct")
 
 
-def test_conv_smallcout():
-    B, H, cin = 2, 16, 320
+@pytest.mark.parametrize("B,H,cin", [(2, 16, 320),      # UNet conv_out: the MFMA kernel (cin % 32 == 0)
+                                     (1, 6, 128),       # 36 pixels: a ragged last 16-pixel group; VAE decoder width
+                                     (3, 5, 32),        # one 32-deep step: three of the four waves contribute zeros
+                                     (1, 8, 416),       # 13 steps: a second load round with one live step
+                                     (2, 8, 24)])       # cin % 32 != 0: the scalar kernel
+def test_conv_smallcout(B, H, cin):
     x = bf(rnd(B, H, H, cin, seed=1))
     w = bf(rnd(4, cin, 3, 3, seed=2, scale=(9 * cin) ** -0.5))
     b = rnd(4, seed=3)
