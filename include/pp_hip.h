@@ -29,7 +29,7 @@ extern "C" {
 #define PP_ERR_LAUNCH (-3)       /* hipLaunchKernel / hipFuncSetAttribute failed                  */
 #define PP_ERR_WORKSPACE (-4)    /* workspace pointer null or too small                           */
 
-#define PP_ABI_VERSION 6
+#define PP_ABI_VERSION 7
 /* 16-bit storage format of activations and matrix weights ("dtype" arguments; the same codes pp_nchw_to_nhwc uses for
  * its source): bf16 or fp16 -- the reference's default is fp16 (/root/reference/app.py:548,559).  MFMA accumulation,
  * norm statistics, softmax, biases and latents are fp32 with either. */
@@ -255,6 +255,13 @@ int pp_add_bf16(const void* a, const void* b, void* out, long long n, int dtype,
  */
 int pp_cfg_sched_step(const float* eps2, int cfg, float guidance, float* latents, float* m_prev, int n, int kind,
                       const float* coef_table, const int32_t* step_dev, void* stream);
+/* Stochastic DDIM, `eta > 0` (the pipelines' `eta` argument, pipeline_PowerPaint.py:736-745 / 1023: it reaches
+ * `DDIMScheduler.step` only): after pp_cfg_sched_step of the same step,  latents += std_dev_t * noise  with
+ * std_dev_t = coef[step][4] of the kind-0 table (eta * sqrt((1-a_prev)/(1-a_t) * (1-a_t/a_prev)); column 3 then holds
+ * sqrt(1-a_prev-std_dev_t^2)) and `noise` fp32 [n] drawn by the host from the caller's generator, once per step. */
+int pp_ddim_variance_noise(float* latents, const float* noise, int n, const float* coef_table, const int32_t* step_dev,
+                           void* stream);
+
 /* t_out[0] = timesteps[step]; used at the top of a captured step.  advance: ++step. */
 int pp_step_select_t(const float* timesteps, const int32_t* step_dev, float* t_out, void* stream);
 int pp_step_advance(int32_t* step_dev, void* stream);

@@ -47,23 +47,39 @@ def blend_prompt_embeds(embA, embB, t: float):
 @torch.no_grad()
 def loop_v1(unet, scheduler, latents, mask, masked_image_latents, prompt_embeds, num_inference_steps: int,
             guidance_scale: float = 7.5, controlnet=None, control_image=None, controlnet_conditioning_scale=0.5,
-            eps_hook: Optional[Callable] = None, teacher_latents: Optional[List[torch.Tensor]] = None):
+            eps_hook: Optional[Callable] = None, teacher_latents: Optional[List[torch.Tensor]] = None,
+            t_start: int = 0, guess_mode: bool = False, eta: float = 0.0, generator=None):
     """ppt-v1 loop (optionally + ControlNet).  `mask`, `masked_image_latents`, `prompt_embeds`, `control_image`
     are already CFG-duplicated ([uncond, cond] order, pipeline_PowerPaint.py:516,703-706).
     `eps_hook(i, t, latents_in, noise_pred_2B)` lets tests record per-step tensors; `teacher_latents[i]`
-    (if given) replaces the loop-carried latents at step i (teacher forcing)."""
+    (if given) replaces the loop-carried latents at step i (teacher forcing).
+    t_start > 0 (`strength < 1`, get_timesteps :713-720): the loop runs over `scheduler.timesteps[t_start:]` and
+    `latents` is the already-noised init image (no init_noise_sigma scaling, :640-642).
+    guess_mode (pipeline_PowerPaint_ControlNet.py:1669-1702): the ControlNet sees the conditional half only
+    (`control_image` un-duplicated), the unconditional half of the UNet batch gets zero residuals.
+    eta / generator: `prepare_extra_step_kwargs` (:536-551) -- handed to `scheduler.step` iff its signature names them."""
+    import inspect
+    step_params = set(inspect.signature(scheduler.step).parameters)
+    extra = {k: v for k, v in (("eta", eta), ("generator", generator)) if k in step_params}
     scheduler.set_timesteps(num_inference_steps)
     do_cfg = guidance_scale > 1.0
-    latents = latents * scheduler.init_noise_sigma
-    for i, t in enumerate(scheduler.timesteps):
+    if t_start == 0:
+        latents = latents * scheduler.init_noise_sigma
+    for i, t in enumerate(scheduler.timesteps[t_start * scheduler.order:]):
         if teacher_latents is not None:
             latents = teacher_latents[i]
         x = torch.cat([latents] * 2) if do_cfg else latents
         x = scheduler.scale_model_input(x, t)
         kw = {}
         if controlnet is not None:
-            down, mid = controlnet(x, t, encoder_hidden_states=prompt_embeds, controlnet_cond=control_image,
-                                   conditioning_scale=controlnet_conditioning_scale, guess_mode=False)
+            half = guess_mode and do_cfg
+            cx = scheduler.scale_model_input(latents, t) if half else x
+            ce = prompt_embeds.chunk(2)[1] if half else prompt_embeds
+            down, mid = controlnet(cx, t, encoder_hidden_states=ce, controlnet_cond=control_image,
+                                   conditioning_scale=controlnet_conditioning_scale, guess_mode=guess_mode)
+            if half:
+                down = [torch.cat([torch.zeros_like(d), d]) for d in down]
+                mid = torch.cat([torch.zeros_like(mid), mid])
             kw = dict(down_block_additional_residuals=down, mid_block_additional_residual=mid)
         if unet.config.in_channels == 9:
             x = torch.cat([x, mask, masked_image_latents], dim=1)
@@ -73,7 +89,7 @@ def loop_v1(unet, scheduler, latents, mask, masked_image_latents, prompt_embeds,
         if do_cfg:
             u, c = noise_pred.chunk(2)
             noise_pred = u + guidance_scale * (c - u)
-        latents = scheduler.step(noise_pred, t, latents)[0]
+        latents = scheduler.step(noise_pred, t, latents, **extra)[0]
     return latents
 
 
@@ -81,8 +97,11 @@ def loop_v1(unet, scheduler, latents, mask, masked_image_latents, prompt_embeds,
 def loop_v2(unet, brushnet, scheduler, latents, conditioning_latents, prompt_embeds, prompt_embedsU,
             num_inference_steps: int, guidance_scale: float = 7.5, brushnet_conditioning_scale: float = 1.0,
             control_guidance_start: float = 0.0, control_guidance_end: float = 1.0,
-            eps_hook: Optional[Callable] = None, teacher_latents: Optional[List[torch.Tensor]] = None):
-    """ppt-v2 (BrushNet) loop.  conditioning_latents is [2B,5,h,w] (already CFG-duplicated)."""
+            eps_hook: Optional[Callable] = None, teacher_latents: Optional[List[torch.Tensor]] = None,
+            guess_mode: bool = False):
+    """ppt-v2 (BrushNet) loop.  conditioning_latents is [2B,5,h,w] (already CFG-duplicated); in guess_mode
+    (:1394-1425) [B,5,h,w]: BrushNet then sees the conditional half only and the unconditional half of the UNet batch
+    gets zero residuals."""
     scheduler.set_timesteps(num_inference_steps)
     do_cfg = guidance_scale > 1.0
     latents = latents * scheduler.init_noise_sigma
@@ -93,8 +112,15 @@ def loop_v2(unet, brushnet, scheduler, latents, conditioning_latents, prompt_emb
             latents = teacher_latents[i]
         x = torch.cat([latents] * 2) if do_cfg else latents
         x = scheduler.scale_model_input(x, t)
-        down, mid, up = brushnet(x, t, encoder_hidden_states=prompt_embeds, brushnet_cond=conditioning_latents,
-                                 conditioning_scale=brushnet_conditioning_scale * keep[i], guess_mode=False)
+        half = guess_mode and do_cfg
+        bx = scheduler.scale_model_input(latents, t) if half else x
+        be = prompt_embeds.chunk(2)[1] if half else prompt_embeds
+        down, mid, up = brushnet(bx, t, encoder_hidden_states=be, brushnet_cond=conditioning_latents,
+                                 conditioning_scale=brushnet_conditioning_scale * keep[i], guess_mode=guess_mode)
+        if half:
+            down = [torch.cat([torch.zeros_like(d), d]) for d in down]
+            mid = torch.cat([torch.zeros_like(mid), mid])
+            up = [torch.cat([torch.zeros_like(d), d]) for d in up]
         noise_pred = unet(x, t, encoder_hidden_states=prompt_embedsU, down_block_add_samples=list(down),
                           mid_block_add_sample=mid, up_block_add_samples=list(up))[0]
         if eps_hook is not None:

@@ -21,7 +21,7 @@ def sd_betas(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012) -> to
 
 
 class DDIMScheduler:
-    """eta=0, epsilon prediction, `leading` spacing, steps_offset=1, set_alpha_to_one=False, no clipping
+    """epsilon prediction, `leading` spacing, steps_offset=1, set_alpha_to_one=False, no clipping
     (the `runwayml/stable-diffusion-inpainting` scheduler config applied to DDIM)."""
     order = 1
     init_noise_sigma = 1.0
@@ -47,15 +47,22 @@ class DDIMScheduler:
         return sample
 
     def step(self, model_output, timestep, sample, eta: float = 0.0, generator=None, return_dict=False):
-        assert eta == 0.0
+        """DDIMScheduler.step of diffusers 0.27 (epsilon prediction, no clipping): eta > 0 adds
+        std_dev_t * randn_tensor(model_output.shape, generator) with std_dev_t = eta * sqrt(_get_variance(t, prev_t))."""
         t = int(timestep)
         prev_t = t - self.config.num_train_timesteps // self.num_inference_steps
         a_t = self.alphas_cumprod[t]
         a_prev = self.alphas_cumprod[prev_t] if prev_t >= 0 else self.final_alpha_cumprod
         beta_t = 1 - a_t
         x0 = (sample - beta_t ** 0.5 * model_output) / a_t ** 0.5
-        direction = (1 - a_prev) ** 0.5 * model_output
+        variance = ((1 - a_prev) / (1 - a_t)) * (1 - a_t / a_prev)
+        std_dev_t = eta * variance ** 0.5
+        direction = (1 - a_prev - std_dev_t ** 2) ** 0.5 * model_output
         prev = a_prev ** 0.5 * x0 + direction
+        if eta > 0:
+            gdev = generator.device if generator is not None else model_output.device
+            noise = torch.randn(model_output.shape, generator=generator, device=gdev, dtype=model_output.dtype)
+            prev = prev + std_dev_t * noise.to(model_output.device)
         return (prev,)
 
     def add_noise(self, x0, noise, timesteps):
@@ -216,6 +223,16 @@ class DPMSolverMultistepScheduler:
         return (prev,)
 
 
+    def add_noise(self, x0, noise, timesteps):
+        """diffusers 0.27 DPMSolverMultistepScheduler.add_noise: sigma of the schedule entry holding each timestep,
+        (alpha_t, sigma_t) from it."""
+        idx = [int((self.timesteps == int(t)).nonzero()[0]) for t in timesteps]
+        alpha_t, sigma_t = self._alpha_sigma(self.sigmas[idx].flatten().to(x0.dtype))
+        while alpha_t.dim() < x0.dim():
+            alpha_t, sigma_t = alpha_t.unsqueeze(-1), sigma_t.unsqueeze(-1)
+        return alpha_t * x0 + sigma_t * noise
+
+
 # ---------------------------------------------------------------------------------------
 # independent float64 closed forms (pins for the classes above and for the HIP step kernel)
 # ---------------------------------------------------------------------------------------
@@ -260,8 +277,8 @@ class UniPCMultistepScheduler:
         self.model_outputs = [None] * self.solver_order
         self.lower_order_nums = 0
         self.last_sample = None
-        self.step_index = 0
-        self.this_order = 1
+        self.step_index = None          # found from the first timestep `step` sees (`_init_step_index`): img2img-style
+        self.this_order = 1             # loops enter the schedule late (get_timesteps slices scheduler.timesteps)
 
     def scale_model_input(self, sample, timestep=None):
         return sample
@@ -334,6 +351,8 @@ class UniPCMultistepScheduler:
         return x_t_ - alpha_t * B_h * (corr_res + rhos_c[-1] * D1_t)
 
     def step(self, model_output, timestep, sample, generator=None, return_dict=False):
+        if self.step_index is None:
+            self.step_index = int((self.timesteps == int(timestep)).nonzero()[0])
         i = self.step_index
         use_corrector = i > 0 and (i - 1) not in self.disable_corrector and self.last_sample is not None
         alpha_t, sigma_t = self._alpha_sigma(self.sigmas[i])

@@ -73,6 +73,7 @@ SIGNATURES = {
     "pp_add_bf16": (C.c_int, [vp, vp, vp, C.c_longlong, C.c_int, vp]),
     "pp_cfg_sched_step": (C.c_int, [vp, C.c_int, f32, vp, vp, C.c_int, C.c_int, vp, vp, vp]),
     "pp_step_select_t": (C.c_int, [vp, vp, vp, vp]),
+    "pp_ddim_variance_noise": (C.c_int, [vp, vp, C.c_int, vp, vp, vp]),
     "pp_step_advance": (C.c_int, [vp, vp]),
     "pp_mask_prep": (C.c_int, [C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
 }
@@ -97,7 +98,7 @@ def lib():
             fn = getattr(l, name)
             fn.restype = res
             fn.argtypes = args
-        if l.pp_abi_version() != 6:
+        if l.pp_abi_version() != 7:
             raise PPError("libpp_hip.so ABI version mismatch")
         _lib = l
     return _lib

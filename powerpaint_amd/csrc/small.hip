@@ -341,7 +341,8 @@ __global__ void __launch_bounds__(256) cfg_sched_step_kernel(const float* __rest
     }
     const float xv = x[i];
     if (kind == 0) {
-      // DDIM eta=0: c0 = sqrt(1-a_t), c1 = sqrt(a_t), c2 = sqrt(a_prev), c3 = sqrt(1-a_prev)
+      // DDIM: c0 = sqrt(1-a_t), c1 = sqrt(a_t), c2 = sqrt(a_prev), c3 = sqrt(1-a_prev-std_dev_t^2)  (c4 = std_dev_t = 0
+      // at eta = 0; the variance noise of eta > 0 is added by pp_ddim_variance_noise)
       const float x0 = (xv - c0 * e) / c1;
       x[i] = c2 * x0 + c3 * e;
     } else {
@@ -353,6 +354,14 @@ __global__ void __launch_bounds__(256) cfg_sched_step_kernel(const float* __rest
       m_prev[i] = x0;
     }
   }
+}
+
+// stochastic DDIM (eta > 0): x += std_dev_t * z, std_dev_t = column 4 of the step's table row, z drawn by the host
+__global__ void __launch_bounds__(256) ddim_variance_noise_kernel(float* __restrict__ x, const float* __restrict__ z, int n,
+                                                                 const float* __restrict__ coef,
+                                                                 const int32_t* __restrict__ step_dev) {
+  const float sd = coef[(size_t)step_dev[0] * 8 + 4];
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) x[i] = x[i] + sd * z[i];
 }
 
 __global__ void step_select_t_kernel(const float* __restrict__ ts, const int32_t* __restrict__ step, float* __restrict__ t) {
@@ -521,6 +530,15 @@ extern "C" int pp_cfg_sched_step(const float* eps2, int cfg, float guidance, flo
   hipLaunchKernelGGL(cfg_sched_step_kernel, dim3(grid_for_host(n)), dim3(256), 0, (hipStream_t)stream, eps2, cfg,
                      guidance, latents, m_prev, n, kind, coef_table, step_dev);
   PP_CHECK_LAUNCH("cfg_sched_step_kernel");
+  return PP_OK;
+}
+
+extern "C" int pp_ddim_variance_noise(float* latents, const float* noise, int n, const float* coef_table,
+                                      const int32_t* step_dev, void* stream) {
+  if (!latents || !noise || !coef_table || !step_dev || n <= 0) return PP_ERR_BAD_ARG;
+  hipLaunchKernelGGL(ddim_variance_noise_kernel, dim3(grid_for_host(n)), dim3(256), 0, (hipStream_t)stream, latents, noise,
+                     n, coef_table, step_dev);
+  PP_CHECK_LAUNCH("ddim_variance_noise_kernel");
   return PP_OK;
 }
 

@@ -847,9 +847,13 @@ class SDNet:
     # ---------------------------------------------------------------- step plan
     def build_step(self, pb: Builder, x_in: Act, t_dev: int, add_down: Optional[List[int]] = None,
                    add_mid: int = 0, add_up: Optional[List[int]] = None, ctrl_down: Optional[List[int]] = None,
-                   ctrl_mid: int = 0, scale: float = 1.0) -> Dict[str, object]:
+                   ctrl_mid: int = 0, scale: float = 1.0, pad_uncond: bool = False) -> Dict[str, object]:
         """Append one forward pass.  x_in: NHWC bf16 input (already channel-concatenated).  Returns outputs:
-        unet -> {"eps": ptr fp32 NCHW}; brushnet -> {"down": [Act], "mid": Act, "up": [Act]}; controlnet likewise."""
+        unet -> {"eps": ptr fp32 NCHW}; brushnet -> {"down": [Act], "mid": Act, "up": [Act]}; controlnet likewise.
+        pad_uncond (side networks): the pipelines' guess mode runs the side branch on the conditional half of a CFG pair
+        only and hands the UNet `cat([zeros_like(d), d])` (pipeline_PowerPaint_Brushnet_CA.py:1421-1425,
+        pipeline_PowerPaint_ControlNet.py:1697-1702): the residuals are written into the second half of tensors with
+        twice the batch whose first half one launch per step zeroes."""
         P, lib = self.P, pb.lib
         B, H, W = x_in.B, x_in.H, x_in.W
         boc = self.boc
@@ -917,14 +921,20 @@ class SDNet:
         mid_res = add_mid if brush else (ctrl_mid if ctrl_down is not None else 0)
         s = self._resnet(pb, "mid_block.resnets.1", s, boc[-1], temb_all, res2=mid_res)
 
+        def zero_convs(feats: List[Act]) -> List[Act]:
+            specs = self._zero_conv_specs()
+            mult = 2 if pad_uncond else 1
+            outs = [pb.new_act(mult * f.B, f.H, f.W, c) for (_, c), f in zip(specs, feats)]
+            if pad_uncond:           # one zeroing launch over the whole (contiguous) block of padded outputs
+                end = outs[-1].ptr + outs[-1].rows * outs[-1].C * 2
+                pb.plan.add("zero_u64", lib.pp_zero_u64, outs[0].ptr, (end - outs[0].ptr + 7) // 8)
+            for (pre, c), f, o in zip(specs, feats, outs):
+                pb.linear(f.ptr, f.rows, c, P[pre + ".weight"], c, P[pre + ".bias"], scale=scale,
+                          out=o.ptr + (f.rows * c * 2 if pad_uncond else 0), name="zero_conv")
+            return outs
+
         if self.kind == "controlnet":
-            feats = skips + [s]
-            outs = []
-            for (pre, c), f in zip(self._zero_conv_specs(), feats):
-                o = pb.new_act(f.B, f.H, f.W, c)
-                pb.linear(f.ptr, f.rows, c, P[pre + ".weight"], c, P[pre + ".bias"], scale=scale, out=o.ptr,
-                          name="zero_conv")
-                outs.append(o)
+            outs = zero_convs(skips + [s])
             return {"down": outs[:-1], "mid": outs[-1]}
 
         if ctrl_down is not None:  # stock-UNet ControlNet residuals on the skip tensors (unet_2d_condition.py:1263-1272)
@@ -960,13 +970,7 @@ class SDNet:
                 brush_up.append(s)
 
         if self.kind == "brushnet":
-            feats = brush_down + [brush_mid] + brush_up
-            outs = []
-            for (pre, c), f in zip(self._zero_conv_specs(), feats):
-                o = pb.new_act(f.B, f.H, f.W, c)
-                pb.linear(f.ptr, f.rows, c, P[pre + ".weight"], c, P[pre + ".bias"], scale=scale, out=o.ptr,
-                          name="zero_conv")
-                outs.append(o)
+            outs = zero_convs(brush_down + [brush_mid] + brush_up)
             nd = len(brush_down)
             return {"down": outs[:nd], "mid": outs[nd], "up": outs[nd + 1:]}
 

@@ -180,11 +180,32 @@ class PipelineBase(PipelinePretrainedMixin):
         return dt if dt in (torch.float16, torch.bfloat16, torch.float32) else torch.float32
 
     def get_timesteps(self, num_inference_steps, strength, device):
-        """pipeline_PowerPaint.py:713-720."""
+        """pipeline_PowerPaint.py:713-720.  The schedulers of this package additionally learn where the loop enters
+        (`set_begin_index`): their per-step tables are indexed by a device-side step counter, not by timestep lookup."""
         init_timestep = min(int(num_inference_steps * strength), num_inference_steps)
         t_start = max(num_inference_steps - init_timestep, 0)
         timesteps = self.scheduler.timesteps[t_start * self.scheduler.order:]
+        if t_start and getattr(self.scheduler, "kind", -1) >= 0:
+            self.scheduler.set_begin_index(t_start * self.scheduler.order)
         return timesteps, num_inference_steps - t_start
+
+    def _initial_latents(self, shape, strength, timesteps, latents, init_image, generator, device, noise_dtype):
+        """prepare_latents (pipeline_PowerPaint.py:604-655): pure noise * init_noise_sigma at strength 1 (or when the
+        caller hands `latents`, which the reference then treats as the noise whatever the strength), otherwise the
+        VAE latents of the init image noised to the first timestep of the shortened schedule.  Draw order as in the
+        reference: the init image's posterior sample BEFORE the noise."""
+        if latents is not None:
+            return latents.to(device=device, dtype=torch.float32) * self.scheduler.init_noise_sigma
+        if strength == 1.0:
+            noise = randn_tensor(shape, generator=generator, device=device, dtype=noise_dtype)
+            return noise.to(torch.float32) * self.scheduler.init_noise_sigma
+        if init_image is None:
+            raise ValueError("Since strength < 1. initial latents are to be initialised as a combination of Image + "
+                             "Noise.However, either the image or the noise timestep has not been provided.")
+        image_latents = self._vae_encode(init_image.to(device=device, dtype=noise_dtype), generator)
+        noise = randn_tensor(shape, generator=generator, device=device, dtype=noise_dtype)
+        t0 = timesteps[:1].repeat(shape[0])
+        return self.scheduler.add_noise(image_latents.to(noise.dtype), noise, t0).to(torch.float32)
 
     # ---- text: promptA/promptB blended by `tradoff` (pipeline_PowerPaint.py:317-518)
     def _text_embeds(self, text_encoder, prompt: Union[str, List[str]], device):

@@ -21,7 +21,7 @@ import torch
 
 from .. import _lib as L
 from ..engine import Plan
-from ..schedulers import _SchedulerBase
+from ..schedulers import _SchedulerBase, variance_noise
 
 
 class DenoiseLoop:
@@ -39,8 +39,16 @@ class DenoiseLoop:
 
     # ------------------------------------------------------------------
     def bind(self, latents_shape, do_cfg: bool, guidance_scale: float, prompt_embeds, prompt_embeds_side=None,
-             static_inputs=(), side_static_inputs=(), controlnet_cond=None, side_scale: float = 1.0):
-        """Compile the per-step program.  latents_shape = (B, 4, h, w) of the *un-duplicated* latents."""
+             static_inputs=(), side_static_inputs=(), controlnet_cond=None, side_scale: float = 1.0,
+             guess_mode: bool = False, eta: float = 0.0, generator=None, noise_dtype=torch.float32):
+        """Compile the per-step program.  latents_shape = (B, 4, h, w) of the *un-duplicated* latents.
+        eta > 0 with this package's DDIM (the only scheduler whose `step` takes it, pipeline_PowerPaint.py:536-551):
+        the step program gains `latents += std_dev_t * z`; `run` draws z from `generator` before every step, in
+        `noise_dtype`, exactly where the reference's `scheduler.step` calls `randn_tensor`.
+        guess_mode (pipeline_PowerPaint_Brushnet_CA.py:1394-1425, pipeline_PowerPaint_ControlNet.py:1669-1702): the
+        side network sees only the conditional half of a CFG pair (its inputs -- `prompt_embeds_side`, conditioning
+        latents / control image -- arrive un-duplicated) with its residual scales log-spaced from 0.1 to 1; the
+        unconditional half of the UNet batch gets zeros."""
         dev = self.unet.device
         B, Cl, h, w = latents_shape
         Be = 2 * B if do_cfg else B
@@ -53,13 +61,32 @@ class DenoiseLoop:
         cin = self.unet.config.in_channels
         side_rt = None
         wiring_kw = {}
+        self._eta = float(eta) if (not self.foreign and sch.kind == 0) else 0.0
+        self._gen, self._noise_dtype = generator, noise_dtype
+        self._extra_step_kwargs = {}
+        if self.foreign:                                     # prepare_extra_step_kwargs for a duck-typed scheduler
+            import inspect
+            names = set(inspect.signature(sch.step).parameters)
+            self._extra_step_kwargs = {k: v for k, v in (("eta", eta), ("generator", generator)) if k in names}
+        else:
+            sch.set_eta(self._eta)
+        half = bool(guess_mode and do_cfg)                   # side network on the conditional half only
+        # guess mode scales the n residuals by logspace(-1, 0, n) * conditioning_scale (BrushNet_CA.py:905-928): `run`'s
+        # per-step scalar schedule is expanded the same way before it is patched into the zero-conv launches
+        self._guess_ramp = None
+        if guess_mode and self.side is not None and not self.side.config.global_pool_conditions:
+            self._guess_ramp = [float(v) for v in torch.logspace(-1, 0, len(self.side.net._zero_conv_specs()))]
+        Bs = B if half else Be
         if self.side is not None:
+            if half and prompt_embeds_side.shape[0] == Be:
+                prompt_embeds_side = prompt_embeds_side.chunk(2)[1]
             if self.side_kind == "brushnet":
-                side_rt = self.side.prepare((Be, Cl, h, w), prompt_embeds_side, side_scale, False)
+                side_rt = self.side.prepare((Bs, Cl, h, w), prompt_embeds_side, side_scale, bool(guess_mode), half)
                 d, m, u = self.side.outputs()
                 wiring_kw = dict(down_block_add_samples=d, mid_block_add_sample=m, up_block_add_samples=u)
             else:
-                side_rt = self.side.prepare((Be, Cl, h, w), prompt_embeds_side, controlnet_cond, side_scale, False)
+                side_rt = self.side.prepare((Bs, Cl, h, w), prompt_embeds_side, controlnet_cond, side_scale,
+                                            bool(guess_mode), half)
                 d, m = self.side.outputs()
                 wiring_kw = dict(down_block_additional_residuals=d, mid_block_additional_residual=m)
         rt = self.unet.prepare((Be, cin, h, w), prompt_embeds, **wiring_kw)
@@ -85,7 +112,7 @@ class DenoiseLoop:
             ts, step = sch.timesteps_f32(), sch.step_counter()
             mp = sch.m_prev(lat) if sch.kind >= 1 else None  # scheduler state: DPM m_{i-1}; PNDM history + saved sample
             kind, src = sch.kind, lat
-        key = (tuple(latents_shape), bool(do_cfg), float(guidance_scale), id(rt.step_plan),
+        key = (tuple(latents_shape), bool(do_cfg), bool(guess_mode), self._eta > 0, float(guidance_scale), id(rt.step_plan),
                id(side_rt.step_plan) if side_rt is not None else None, kind, ts.data_ptr(), step.data_ptr(),
                0 if self.foreign else sch.coef_table().data_ptr(), mp.data_ptr() if mp is not None else 0, src.data_ptr())
         if key == self._key and self.program is not None:
@@ -100,8 +127,9 @@ class DenoiseLoop:
         for r in ([side_rt] if side_rt is not None else []) + [rt]:
             prog.add("step_select_t", lib.pp_step_select_t, ts.data_ptr(), step.data_ptr(), r.lay["t_dev"])
             x = r.lay["x_in"]
-            prog.add("nchw_to_nhwc", lib.pp_nchw_to_nhwc, src.data_ptr(), 0, Be, Cl, hw, mod, x.ptr, x.C, 0,
-                     L.dtype_code(r.net.dtype))
+            nb_r = Bs if r is side_rt else Be                    # (guess mode: the side network takes `latents` as is)
+            prog.add("nchw_to_nhwc", lib.pp_nchw_to_nhwc, src.data_ptr(), 0, nb_r, Cl, hw, mod if nb_r != B else 0,
+                     x.ptr, x.C, 0, L.dtype_code(r.net.dtype))
         if side_rt is not None:
             prog.calls += side_rt.step_plan.calls
             prog.flops += side_rt.step_plan.flops
@@ -111,12 +139,22 @@ class DenoiseLoop:
             prog.add("cfg_sched_step", lib.pp_cfg_sched_step, rt.outputs["eps"], int(do_cfg), float(guidance_scale),
                      lat.data_ptr(), mp.data_ptr() if mp is not None else None, lat.numel(), sch.kind,
                      sch.coef_table().data_ptr(), step.data_ptr())
+            if self._eta > 0:
+                if getattr(self, "_var_noise", None) is None or tuple(self._var_noise.shape) != tuple(latents_shape):
+                    self._var_noise = torch.zeros(latents_shape, dtype=torch.float32, device=dev)
+                prog.add("ddim_variance_noise", lib.pp_ddim_variance_noise, lat.data_ptr(), self._var_noise.data_ptr(),
+                         lat.numel(), sch.coef_table().data_ptr(), step.data_ptr())
         prog.add("step_advance", lib.pp_step_advance, step.data_ptr())
         self.program = prog
         self.rt, self.side_rt = rt, side_rt
         self.graph = None
         self._keep = (ts, step, mp, lat)
         return self
+
+    def _side_scale(self, v):
+        """One entry of `run`'s scale schedule as the side runtime stores it (guess mode: the per-residual ramp)."""
+        ramp = getattr(self, "_guess_ramp", None)
+        return tuple(r * v for r in ramp) if ramp is not None else v
 
     def _scale_now(self):
         sc = getattr(self.side_rt, "_scale", None) if getattr(self, "side_rt", None) is not None else None
@@ -158,14 +196,18 @@ class DenoiseLoop:
             self._keep[2].zero_()
         self.latents.copy_(latents.to(self.latents.device, torch.float32))
         varying = scale_schedule is not None and len(set(scale_schedule)) > 1
-        if not varying and scale_schedule and self.side_rt is not None and self._scale_now() != scale_schedule[0]:
-            self.side_rt._patch_scale(scale_schedule[0])      # (a previous call may have left a windowed value behind)
+        if not varying and scale_schedule and self.side_rt is not None and \
+                self._scale_now() != self._side_scale(scale_schedule[0]):
+            self.side_rt._patch_scale(self._side_scale(scale_schedule[0]))   # (a previous call may have left a windowed value)
         if use_graph and not varying and (self.graph is None or self._graph_scale != self._scale_now()):
             self.capture()
         stream = torch.cuda.current_stream().cuda_stream
         for i in range(num_steps):
             if varying and self.side_rt is not None:
-                self.side_rt._patch_scale(scale_schedule[i])
+                self.side_rt._patch_scale(self._side_scale(scale_schedule[i]))
+            if self._eta > 0:         # this step's variance noise (stream-ordered before the step that consumes it)
+                self._var_noise.copy_(variance_noise(self._var_noise.shape, self._gen, self._var_noise.device,
+                                                     self._noise_dtype))
             if use_graph and not varying:
                 self.graph.replay()
             else:
@@ -189,7 +231,7 @@ class DenoiseLoop:
             x = sch.scale_model_input(lat, t) if hasattr(sch, "scale_model_input") else lat
             self._f_x.copy_(x)
             if varying and self.side_rt is not None:
-                self.side_rt._patch_scale(scale_schedule[i])
+                self.side_rt._patch_scale(self._side_scale(scale_schedule[i]))
             if use_graph and not varying:
                 if self.graph is None or self._graph_scale != self._scale_now():
                     self.capture()
@@ -201,7 +243,7 @@ class DenoiseLoop:
             if self._do_cfg:
                 eu, ec = eps.chunk(2)
                 eps = eu + self._g * (ec - eu)
-            lat = sch.step(eps, t, lat, return_dict=False)[0].to(torch.float32)
+            lat = sch.step(eps, t, lat, **self._extra_step_kwargs, return_dict=False)[0].to(torch.float32)
             if callback is not None:
                 callback(i, t, lat)
         self.latents.copy_(lat)

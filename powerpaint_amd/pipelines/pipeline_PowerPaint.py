@@ -8,7 +8,7 @@ from typing import Any, Callable, Dict, List, Optional, Union
 
 import torch
 
-from ._base import PipelineBase, hip_mask_prep, prepare_mask_and_masked_image, randn_tensor
+from ._base import PipelineBase, hip_mask_prep, prepare_mask_and_masked_image
 from ._loop import DenoiseLoop
 from .image_processor import VaeImageProcessor
 
@@ -76,8 +76,6 @@ class StableDiffusionInpaintPipeline(PipelineBase):
                  callback_steps: int = 1, cross_attention_kwargs: Optional[Dict[str, Any]] = None, task_class=None,
                  masked_image_latents: Optional[torch.FloatTensor] = None,
                  mask_latents: Optional[torch.FloatTensor] = None):
-        if eta != 0.0 or strength != 1.0:
-            raise NotImplementedError("eta != 0 / strength < 1 are outside the accelerated hot path")
         if task_class is not None:
             raise NotImplementedError("task_class is not used by the released checkpoints")
         height = height or self.unet.config.sample_size * self.vae_scale_factor
@@ -99,7 +97,8 @@ class StableDiffusionInpaintPipeline(PipelineBase):
         self.scheduler.set_timesteps(num_inference_steps, device=device)
         timesteps, num_inference_steps = self.get_timesteps(num_inference_steps, strength, device)
         if num_inference_steps < 1:
-            raise ValueError("num_inference_steps < 1 after adjusting by strength")
+            raise ValueError(f"After adjusting the num_inference_steps by strength parameter: {strength}, the number of "
+                             f"pipelinesteps is {num_inference_steps} which is < 1 and not appropriate for this pipeline.")
         nb = batch_size * num_images_per_prompt
         h, w = height // self.vae_scale_factor, width // self.vae_scale_factor
         num_channels_unet = self.unet.config.in_channels
@@ -108,18 +107,22 @@ class StableDiffusionInpaintPipeline(PipelineBase):
                                       "(pipeline_PowerPaint.py:965-975)")
         # 6. latents -- drawn BEFORE the masked-image posterior is sampled, in the prompt dtype, as the reference does
         #    (prepare_latents :930 precedes prepare_mask_latents :952): same seed / generator => same noise
+        #    strength < 1 (:604-655, 713-720, 919): enter the schedule late, start from the noised init image
         shape = (nb, 4, h, w)
-        if latents is None:
-            latents = randn_tensor(shape, generator=generator, device=device, dtype=self._noise_dtype(prompt_embeds))
-        latents = latents.to(device=device, dtype=torch.float32) * self.scheduler.init_noise_sigma
+        pixels = not (mask_latents is not None and masked_image_latents is not None)
+        mk = masked_image = init_image = None
+        if pixels:
+            mk, masked_image, init_image = prepare_mask_and_masked_image(image, mask, height, width, device,
+                                                                          return_image=True)
+        latents = self._initial_latents(shape, strength, timesteps, latents, init_image, generator, device,
+                                        self._noise_dtype(prompt_embeds))
         # 5./7. mask + masked-image latents
-        if mask_latents is not None and masked_image_latents is not None:
+        if not pixels:
             m = mask_latents.to(device=device, dtype=torch.float32)
             mil = masked_image_latents.to(device)
             if do_cfg and m.shape[0] == nb:
                 m, mil = torch.cat([m] * 2), torch.cat([mil] * 2)
         else:
-            mk, masked_image = prepare_mask_and_masked_image(image, mask, height, width, device)
             m, mil = self.prepare_mask_latents(mk, masked_image, nb, height, width, prompt_embeds.dtype, device,
                                                generator, do_cfg, masked_image_latents)
         if 4 + m.shape[1] + mil.shape[1] != num_channels_unet:
@@ -128,7 +131,8 @@ class StableDiffusionInpaintPipeline(PipelineBase):
         # 10. fused denoising loop
         if self._loop is None or self._loop.scheduler is not self.scheduler or self._loop.unet is not self.unet:
             self._loop = DenoiseLoop(self.unet, self.scheduler)
-        self._loop.bind(shape, do_cfg, guidance_scale, prompt_embeds, static_inputs=[(m, 4), (mil, 5)])
+        self._loop.bind(shape, do_cfg, guidance_scale, prompt_embeds, static_inputs=[(m, 4), (mil, 5)], eta=eta,
+                        generator=generator, noise_dtype=self._noise_dtype(prompt_embeds))
         cb = None
         if callback is not None:
             def cb(i, t, lat):

@@ -96,10 +96,6 @@ class StableDiffusionPowerPaintBrushNetPipeline(PipelineBase):
         callback_steps = kwargs.pop("callback_steps", 1)
         if ip_adapter_image is not None or ip_adapter_image_embeds is not None:
             raise NotImplementedError("IP-Adapter is outside the PowerPaint hot path (never enabled by app.py)")
-        if guess_mode:
-            raise NotImplementedError("guess_mode in the fused loop is not implemented (not used by app.py)")
-        if eta != 0.0:
-            raise NotImplementedError("eta != 0 is outside the accelerated hot path")
         if isinstance(control_guidance_start, list):
             control_guidance_start = control_guidance_start[0]
         if isinstance(control_guidance_end, list):
@@ -136,8 +132,8 @@ class StableDiffusionPowerPaintBrushNetPipeline(PipelineBase):
             msk = ip.preprocess(mask, height=height, width=width).to(device=device, dtype=torch.float32)
             img = img.repeat_interleave(nb // img.shape[0], dim=0)
             msk = msk.repeat_interleave(nb // msk.shape[0], dim=0)
-            if do_cfg:      # prepare_image (:949-950) duplicates BEFORE the VAE: the two CFG halves get their own
-                img, msk = torch.cat([img] * 2), torch.cat([msk] * 2)   # posterior samples (and the RNG advances 2x)
+            if do_cfg and not guess_mode:   # prepare_image (:949-950) duplicates BEFORE the VAE: the two CFG halves get
+                img, msk = torch.cat([img] * 2), torch.cat([msk] * 2)   # their own posterior samples (the RNG advances 2x)
             B0, C0, H0, W0 = msk.shape
             original_mask = hip_mask_prep(3, msk, None, (B0, 1, H0, W0), B0, C0, H0, W0)   # (mask.sum(1) < 0)  :1312
             height, width = img.shape[-2:]
@@ -152,8 +148,11 @@ class StableDiffusionPowerPaintBrushNetPipeline(PipelineBase):
             ml = hip_mask_prep(2, original_mask, None, (B0, 1, hl, wl), B0, 1, H0, W0, hl, wl)  # nearest  :1342-1344
             conditioning_latents = torch.cat([cl.float(), ml], 1)                            # :1345
         conditioning_latents = conditioning_latents.to(device)
-        if do_cfg and conditioning_latents.shape[0] == nb:
+        if do_cfg and not guess_mode and conditioning_latents.shape[0] == nb:
             conditioning_latents = torch.cat([conditioning_latents] * 2)
+        if do_cfg and guess_mode and conditioning_latents.shape[0] != nb:
+            raise ValueError("guess_mode runs BrushNet on the conditional half only: conditioning_latents must have "
+                             f"batch {nb}, got {conditioning_latents.shape[0]}")
         h, w = conditioning_latents.shape[-2:]
         timesteps, num_inference_steps = retrieve_timesteps(self.scheduler, num_inference_steps, device, timesteps)
         self._num_timesteps = len(timesteps)
@@ -169,7 +168,8 @@ class StableDiffusionPowerPaintBrushNetPipeline(PipelineBase):
             self._loop = DenoiseLoop(self.unet, self.scheduler, side=self.brushnet, side_kind="brushnet")
         self._loop.bind(shape, do_cfg, guidance_scale, prompt_embedsU, prompt_embeds_side=prompt_embeds,
                         side_static_inputs=[(conditioning_latents, self.unet.config.in_channels)],
-                        side_scale=scales[0])
+                        side_scale=scales[0], guess_mode=guess_mode, eta=eta, generator=generator,
+                        noise_dtype=self._noise_dtype(prompt_embeds))
         cb = None
         if callback is not None or callback_on_step_end is not None:
             def cb(i, t, lat):

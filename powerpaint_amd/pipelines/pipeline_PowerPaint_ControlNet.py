@@ -7,7 +7,7 @@ from typing import Any, Callable, Dict, List, Optional, Union
 
 import torch
 
-from ._base import PipelineBase, prepare_mask_and_masked_image, randn_tensor
+from ._base import PipelineBase, prepare_mask_and_masked_image
 from ._loop import DenoiseLoop
 from .image_processor import VaeImageProcessor
 from .pipeline_PowerPaint import StableDiffusionInpaintPipeline
@@ -51,8 +51,6 @@ class StableDiffusionControlNetInpaintPipeline(StableDiffusionInpaintPipeline):
                  control_guidance_end: Union[float, List[float]] = 1.0,
                  masked_image_latents: Optional[torch.FloatTensor] = None,
                  mask_latents: Optional[torch.FloatTensor] = None):
-        if eta != 0.0 or strength != 1.0 or guess_mode:
-            raise NotImplementedError("eta != 0 / strength < 1 / guess_mode are outside the accelerated hot path")
         if isinstance(control_guidance_start, list):
             control_guidance_start = control_guidance_start[0]
         if isinstance(control_guidance_end, list):
@@ -82,17 +80,21 @@ class StableDiffusionControlNetInpaintPipeline(StableDiffusionInpaintPipeline):
         timesteps, num_inference_steps = self.get_timesteps(num_inference_steps, strength, device)
         h, w = height // self.vae_scale_factor, width // self.vae_scale_factor
         # latents before the masked-image posterior sample (pipeline_PowerPaint_ControlNet.py:1614 precedes :1636)
+        # strength < 1 (:1601-1625): enter the schedule late, start from the noised init image
         shape = (nb, 4, h, w)
-        if latents is None:
-            latents = randn_tensor(shape, generator=generator, device=device, dtype=self._noise_dtype(prompt_embeds))
-        latents = latents.to(device=device, dtype=torch.float32) * self.scheduler.init_noise_sigma
-        if mask_latents is not None and masked_image_latents is not None:
+        pixels = not (mask_latents is not None and masked_image_latents is not None)
+        mk = masked_image = init_image = None
+        if pixels:
+            mk, masked_image, init_image = prepare_mask_and_masked_image(image, mask, height, width, device,
+                                                                          return_image=True)
+        latents = self._initial_latents(shape, strength, timesteps, latents, init_image, generator, device,
+                                        self._noise_dtype(prompt_embeds))
+        if not pixels:
             m = mask_latents.to(device=device, dtype=torch.float32)
             mil = masked_image_latents.to(device)
             if do_cfg and m.shape[0] == nb:
                 m, mil = torch.cat([m] * 2), torch.cat([mil] * 2)
         else:
-            mk, masked_image = prepare_mask_and_masked_image(image, mask, height, width, device)
             m, mil = self.prepare_mask_latents(mk, masked_image, nb, height, width, prompt_embeds.dtype, device,
                                                generator, do_cfg, masked_image_latents)
         n = len(timesteps)
@@ -102,7 +104,9 @@ class StableDiffusionControlNetInpaintPipeline(StableDiffusionInpaintPipeline):
                 self._loop.side is not self.controlnet:
             self._loop = DenoiseLoop(self.unet, self.scheduler, side=self.controlnet, side_kind="controlnet")
         self._loop.bind(shape, do_cfg, guidance_scale, prompt_embeds, prompt_embeds_side=prompt_embeds,
-                        static_inputs=[(m, 4), (mil, 5)], controlnet_cond=control_image, side_scale=scales[0])
+                        static_inputs=[(m, 4), (mil, 5)], controlnet_cond=control_image, side_scale=scales[0],
+                        guess_mode=guess_mode, eta=eta, generator=generator,
+                        noise_dtype=self._noise_dtype(prompt_embeds))
         cb = None
         if callback is not None:
             def cb(i, t, lat):

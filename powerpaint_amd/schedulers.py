@@ -31,6 +31,18 @@ _ONLY = {"prediction_type": ("epsilon",), "beta_schedule": ("scaled_linear",), "
          "timestep_spacing": ("leading", "linspace", "trailing")}
 
 
+def variance_noise(shape, generator, device, dtype) -> torch.Tensor:
+    """diffusers' `randn_tensor` for the per-step DDIM variance noise: drawn on the generator's device (a CPU generator
+    gives the same numbers whatever the compute device), returned as contiguous fp32 on `device`."""
+    gdev = generator.device if isinstance(generator, torch.Generator) else torch.device(device)
+    if isinstance(generator, (list, tuple)):
+        z = torch.cat([torch.randn((1,) + tuple(shape[1:]), generator=g, device=g.device, dtype=dtype).to(device)
+                       for g in generator])
+    else:
+        z = torch.randn(tuple(shape), generator=generator, device=gdev, dtype=dtype).to(device)
+    return z.to(torch.float32).contiguous()
+
+
 def _check_config(cls_name, cfg):
     for k, ok in _ONLY.items():
         if k in cfg and cfg[k] not in ok:
@@ -54,6 +66,26 @@ class _SchedulerBase:
         self._step_dev = None
         self._m_prev = None
         self._device = None
+        self._begin = 0
+
+    def set_begin_index(self, begin_index: int = 0):
+        """diffusers' `set_begin_index`: the loop enters the schedule at row `begin_index` (`strength < 1`: the pipelines'
+        `get_timesteps` hands `scheduler.timesteps[t_start:]` to the loop, pipeline_PowerPaint.py:713-720).  The
+        multistep warm-up restarts there -- first-order first step of DPM-Solver++, PLMS start-up, UniPC order ramp and
+        no corrector on the first step -- exactly what the library's step-index / counter logic does when the first
+        `step()` call carries a later timestep.  `set_timesteps` resets it to 0."""
+        if self.timesteps is None:
+            raise L.PPError("set_begin_index before set_timesteps")
+        if not 0 <= int(begin_index) < len(self._ts_host):
+            raise ValueError(f"begin_index {begin_index} outside the schedule of {len(self._ts_host)} entries")
+        self._begin = int(begin_index)
+        self._fill_table()
+        self.timesteps = self._ts_host.clone()
+        self._upload(self._device)
+
+    @property
+    def begin_index(self):
+        return self._begin
 
     @classmethod
     def from_config(cls, config, **kw):
@@ -78,11 +110,11 @@ class _SchedulerBase:
             if same:   # keep device addresses stable across calls so captured graphs stay valid
                 self._coef_dev.copy_(self._coef)
                 self._ts_dev.copy_(self.timesteps.to(torch.float32))
-                self._step_dev.zero_()
+                self._step_dev.fill_(self._begin)
             else:
                 self._coef_dev = self._coef.to(self._device).contiguous()
                 self._ts_dev = self.timesteps.to(self._device, torch.float32).contiguous()
-                self._step_dev = torch.zeros(1, dtype=torch.int32, device=self._device)
+                self._step_dev = torch.full((1,), self._begin, dtype=torch.int32, device=self._device)
             self.timesteps = self.timesteps.to(self._device)
         if self._m_prev is not None:
             self._m_prev.zero_()
@@ -106,7 +138,7 @@ class _SchedulerBase:
 
     def reset(self):
         if self._step_dev is not None:
-            self._step_dev.zero_()
+            self._step_dev.fill_(self._begin)
         if self._m_prev is not None:
             self._m_prev.zero_()
 
@@ -117,12 +149,18 @@ class _SchedulerBase:
             raise ValueError(f"timestep {t} is not in the schedule")
         return int(idx[0])
 
+    def set_eta(self, eta: float = 0.0):
+        """`eta` of the pipelines (pipeline_PowerPaint.py:736-745): only DDIM's step takes it, the other schedulers
+        ignore it -- as `prepare_extra_step_kwargs` never hands it to them."""
+        return self
+
     def step(self, model_output, timestep, sample, eta: float = 0.0, generator=None, return_dict: bool = True, **kw):
-        """x_t -> x_{t-1} on the HIP kernel (fp32 math).  Returns a NEW tensor in sample's dtype."""
-        if eta != 0.0:
-            raise NotImplementedError("eta != 0 (stochastic DDIM) is outside the hot path")
+        """x_t -> x_{t-1} on the HIP kernel (fp32 math).  Returns a NEW tensor in sample's dtype.  `eta` / `generator`:
+        stochastic DDIM (kind 0 only), the variance noise drawn like diffusers' `randn_tensor(model_output.shape, ...)`."""
         if not sample.is_cuda:
             raise L.PPError("scheduler.step needs CUDA tensors: the step runs in the HIP kernel, no CPU fallback")
+        if self.kind == 0 and float(eta) != self.eta:
+            self.set_eta(eta)
         i = self._index_of(timestep)
         x = sample.detach().to(torch.float32).contiguous().clone()
         e = model_output.detach().to(torch.float32).contiguous()
@@ -131,6 +169,11 @@ class _SchedulerBase:
         L.check(L.lib().pp_cfg_sched_step(e.data_ptr(), 0, 0.0, x.data_ptr(), mp.data_ptr() if mp is not None else None,
                                            x.numel(), self.kind, self._coef_dev.data_ptr(), step.data_ptr(),
                                            torch.cuda.current_stream().cuda_stream), "pp_cfg_sched_step")
+        if self.kind == 0 and self.eta > 0:
+            z = variance_noise(model_output.shape, generator, x.device, model_output.dtype)
+            L.check(L.lib().pp_ddim_variance_noise(x.data_ptr(), z.data_ptr(), x.numel(), self._coef_dev.data_ptr(),
+                                                    step.data_ptr(), torch.cuda.current_stream().cuda_stream),
+                    "pp_ddim_variance_noise")
         out = x.to(sample.dtype)
         if not return_dict:
             return (out,)
@@ -146,7 +189,7 @@ class _SchedulerBase:
 
 
 class DDIMScheduler(_SchedulerBase):
-    """eta = 0, epsilon prediction, `leading` spacing, steps_offset = 1, set_alpha_to_one = False, no clipping."""
+    """epsilon prediction, `leading` spacing, steps_offset = 1, set_alpha_to_one = False, no clipping; eta in [0, 1]."""
     kind = 0
 
     def __init__(self, num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, steps_offset=1,
@@ -157,6 +200,21 @@ class DDIMScheduler(_SchedulerBase):
         super().__init__(num_train_timesteps, beta_start, beta_end, steps_offset=steps_offset,
                          set_alpha_to_one=set_alpha_to_one, timestep_spacing="leading", prediction_type="epsilon")
         self.final_alpha_cumprod = torch.tensor(1.0) if set_alpha_to_one else self.alphas_cumprod[0]
+        self.eta = 0.0
+
+    def set_eta(self, eta: float = 0.0):
+        """Stochastic DDIM: std_dev_t = eta * sqrt(variance_t) enters the table (columns 3 and 4); the device table is
+        rewritten in place, so a captured step graph picks the new values up."""
+        if not 0.0 <= float(eta) <= 1.0:
+            raise ValueError(f"eta must be in [0, 1], got {eta}")
+        self.eta = float(eta)
+        if self.timesteps is not None:
+            self._fill_table()
+            self.timesteps = self._ts_host.clone()
+            begin = self._begin
+            self._upload(self._device)
+            self._begin = begin
+        return self
 
     def set_timesteps(self, num_inference_steps: int, device=None):
         T = self.config.num_train_timesteps
@@ -165,7 +223,15 @@ class DDIMScheduler(_SchedulerBase):
         ts = (np.arange(0, num_inference_steps) * ratio).round()[::-1].copy().astype(np.int64) + self.config.steps_offset
         self._ts_host = torch.from_numpy(ts)
         self.timesteps = self._ts_host.clone()
-        coef = torch.zeros(num_inference_steps, 8, dtype=torch.float32)
+        self._begin = 0
+        self._fill_table()
+        self._upload(device)
+
+    def _fill_table(self):
+        """(rows do not depend on where the loop enters: DDIM keeps no history)"""
+        ts, n = self._ts_host.numpy(), self.num_inference_steps
+        ratio = self.config.num_train_timesteps // n
+        coef = torch.zeros(n, 8, dtype=torch.float32)
         for i, t in enumerate(ts.tolist()):
             prev = t - ratio
             a_t = self.alphas_cumprod[t]
@@ -173,9 +239,12 @@ class DDIMScheduler(_SchedulerBase):
             coef[i, 0] = (1 - a_t) ** 0.5
             coef[i, 1] = a_t ** 0.5
             coef[i, 2] = a_p ** 0.5
-            coef[i, 3] = (1 - a_p) ** 0.5
+            # DDIMScheduler.step: variance = (1-a_prev)/(1-a_t) * (1-a_t/a_prev); std_dev_t = eta * sqrt(variance);
+            # direction coefficient sqrt(1-a_prev-std_dev_t^2); prev_sample += std_dev_t * noise (pp_ddim_variance_noise)
+            sd = self.eta * (((1 - a_p) / (1 - a_t)) * (1 - a_t / a_p)) ** 0.5
+            coef[i, 3] = (1 - a_p - sd ** 2) ** 0.5
+            coef[i, 4] = sd
         self._coef = coef
-        self._upload(device)
 
 
 def dpm_timesteps(T, n, spacing="linspace", steps_offset=0):
@@ -220,9 +289,14 @@ class DPMSolverMultistepScheduler(_SchedulerBase):
         self.sigmas = torch.from_numpy(np.concatenate([sig, [0.0]]).astype(np.float32))
         self._ts_host = torch.from_numpy(ts)
         self.timesteps = self._ts_host.clone()
-        n = num_inference_steps
+        self._begin = 0
+        self._fill_table()
+        self._upload(device)
+
+    def _fill_table(self):
+        n = self.num_inference_steps
         coef = torch.zeros(n, 8, dtype=torch.float32)
-        for i in range(n):
+        for i in range(self._begin, n):
             a_cur, s_cur = self._alpha_sigma(self.sigmas[i])
             a_t, sg_t = self._alpha_sigma(self.sigmas[i + 1])
             lam_t = torch.log(a_t) - torch.log(sg_t)
@@ -232,7 +306,7 @@ class DPMSolverMultistepScheduler(_SchedulerBase):
             coef[i, 0], coef[i, 1] = s_cur, a_cur
             coef[i, 2] = sg_t / s_cur
             coef[i, 3] = c3
-            first_order = (i == 0) or (i == n - 1)       # lower_order_nums < 1, lower_order_final (sigma_last = 0)
+            first_order = (i == self._begin) or (i == n - 1)   # lower_order_nums < 1, lower_order_final (sigma_last = 0)
             if not first_order:
                 a_s1, sg_s1 = self._alpha_sigma(self.sigmas[i - 1])
                 lam_s1 = torch.log(a_s1) - torch.log(sg_s1)
@@ -240,7 +314,6 @@ class DPMSolverMultistepScheduler(_SchedulerBase):
                 coef[i, 4] = 0.5 * c3
                 coef[i, 5] = 1.0 / r0
         self._coef = coef
-        self._upload(device)
 
 
 class PNDMScheduler(_SchedulerBase):
@@ -280,30 +353,39 @@ class PNDMScheduler(_SchedulerBase):
         plms = np.concatenate([ts[:-1], ts[-2:-1], ts[-1:]])[::-1].copy()
         self._ts_host = torch.from_numpy(plms)
         self.timesteps = self._ts_host.clone()
+        self._begin = 0
+        self._fill_table()
+        self._upload(device)
+
+    def _fill_table(self):
+        """One row per evaluation, keyed on the evaluation COUNT since the loop entered the schedule (the library's
+        `counter`): entered late (`set_begin_index`), the second call is still treated as the repeat evaluation."""
+        plms = self._ts_host.numpy()
+        ratio = self.config.num_train_timesteps // self.num_inference_steps
         rows = len(plms)
         coef = torch.zeros(rows, 16, dtype=torch.float32)
         n_hist, head = 0, 0                       # stored predictions so far, ring slot of the next push
-        for k, t in enumerate(plms.tolist()):
+        for k, t in enumerate(plms.tolist()[self._begin:]):
+            r = self._begin + k
             slot = lambda back: float((head - back) % 4)          # noqa: E731  (slot of the prediction `back` pushes ago)
             if k == 1:
                 # second evaluation at the repeated timestep: redo the first transfer from the saved sample with the
                 # average of the two predictions; this prediction is not stored
                 a, b = self._transfer(t + ratio, t)
-                coef[k, :6] = torch.tensor([0.5, 0.5, 0.0, 0.0, a, b])
-                coef[k, 6:9] = torch.tensor([slot(1), slot(1), slot(1)])
-                coef[k, 9], coef[k, 10], coef[k, 11] = -1.0, 1.0, 0.0
+                coef[r, :6] = torch.tensor([0.5, 0.5, 0.0, 0.0, a, b])
+                coef[r, 6:9] = torch.tensor([slot(1), slot(1), slot(1)])
+                coef[r, 9], coef[r, 10], coef[r, 11] = -1.0, 1.0, 0.0
                 continue
             n_hist = min(n_hist + 1, 4)
             w = {1: (1.0, 0.0, 0.0, 0.0), 2: (1.5, -0.5, 0.0, 0.0), 3: (23 / 12, -16 / 12, 5 / 12, 0.0),
                  4: (55 / 24, -59 / 24, 37 / 24, -9 / 24)}[n_hist]
             a, b = self._transfer(t, t - ratio)
-            coef[k, :6] = torch.tensor([w[0], w[1], w[2], w[3], a, b])
-            coef[k, 6:9] = torch.tensor([slot(1), slot(2), slot(3)])      # h1, h2, h3 = previous pushes
-            coef[k, 9] = float(head)                                      # this prediction goes to ring slot `head`
-            coef[k, 10], coef[k, 11] = 0.0, (1.0 if k == 0 else 0.0)      # the first evaluation saves its input sample
+            coef[r, :6] = torch.tensor([w[0], w[1], w[2], w[3], a, b])
+            coef[r, 6:9] = torch.tensor([slot(1), slot(2), slot(3)])      # h1, h2, h3 = previous pushes
+            coef[r, 9] = float(head)                                      # this prediction goes to ring slot `head`
+            coef[r, 10], coef[r, 11] = 0.0, (1.0 if k == 0 else 0.0)      # the first evaluation saves its input sample
             head = (head + 1) % 4
         self._coef = coef
-        self._upload(device)
 
     def _index_of(self, timestep) -> int:
         """The repeated timestep is disambiguated by call order (a foreign loop calls step() once per entry)."""
@@ -398,14 +480,24 @@ class UniPCMultistepScheduler(_SchedulerBase):
         lam = np.log(alpha) - np.log(sigma)
         self._ts_host = torch.from_numpy(ts)
         self.timesteps = self._ts_host.clone()
+        self._grid_f64 = (alpha, sigma, lam)
+        self._begin = 0
+        self._fill_table()
+        self._upload(device)
+
+    def _fill_table(self):
+        alpha, sigma, lam = self._grid_f64
+        N, b0 = self.num_inference_steps, self._begin
         K = self.config.solver_order
         coef = np.zeros((N, 16), dtype=np.float64)
         lower, prev_order = 0, 1
-        for i in range(N):
+        for i in range(b0, N):
             c = coef[i]
             c[0], c[1] = sigma[i], alpha[i]
-            # ---- UniC: re-estimate x_i from x_{i-1} (order = the order the previous predictor ran at)
-            if i > 0 and (i - 1) not in self.config.disable_corrector:
+            # ---- UniC: re-estimate x_i from x_{i-1} (order = the order the previous predictor ran at); not on the step
+            # the loop enters at (the library's `last_sample is None`).  `disable_corrector` lists step indices of the
+            # full schedule, as the library's `step_index` does
+            if i > b0 and (i - 1) not in self.config.disable_corrector:
                 order = prev_order
                 h = lam[i] - lam[i - 1]
                 rks = np.array([(lam[i - (k + 1)] - lam[i - 1]) / h for k in range(1, order)] + [1.0])
@@ -439,7 +531,6 @@ class UniPCMultistepScheduler(_SchedulerBase):
             if lower < K:
                 lower += 1
         self._coef = torch.from_numpy(coef.astype(np.float32))
-        self._upload(device)
 
 
 SCHEDULERS = {"DDIMScheduler": DDIMScheduler, "DPMSolverMultistepScheduler": DPMSolverMultistepScheduler,

@@ -148,7 +148,87 @@ def main_cn():
     print("controlnet", out.shape, float(out.abs().max()))
 
 
+CALL_STRENGTH = dict(CALL, num_inference_steps=5, strength=0.6)
+DPM_SD15 = dict(timestep_spacing="leading", steps_offset=1)     # DPMSolverMultistepScheduler.from_config(<SD-1.5 config>)
+
+
+def main_strength():
+    """ref_pipeline_call_strength.pt: the v1 `__call__` with `strength = 0.6` and no `latents`
+    (pipeline_PowerPaint.py:604-655,713-720,906-944): the schedule is entered at entry 2 of 5, the initial latents are
+    the VAE posterior sample of the init image noised to that timestep (posterior sample, then noise, then the masked
+    image's posterior sample, all from one generator).  DPM-Solver++ so that the multistep warm-up restarts mid-schedule."""
+    from oracle import ref_pipeline
+    Pipe, _ = ref_pipeline.load_reference_pipeline_class()
+    tok, enc, unet, vae = components()
+    pipe = Pipe(vae=vae, text_encoder=enc, tokenizer=tok, unet=unet, scheduler=OS.DPMSolverMultistepScheduler(**DPM_SD15),
+                safety_checker=None, feature_extractor=None, requires_safety_checker=False)
+    img, mask, _ = inputs()
+    seen = []
+    with torch.no_grad():
+        out = pipe(image=img, mask=mask, generator=torch.Generator().manual_seed(5), output_type="latent",
+                   return_dict=False, callback=lambda i, t, l: seen.append((i, int(t), l.clone())), **CALL_STRENGTH)[0]
+    torch.save(dict(latents=out, steps=seen), os.path.join(HERE, "ref_pipeline_call_strength.pt"))
+    print("strength", out.shape, float(out.abs().max()), [s[:2] for s in seen])
+
+
+def main_guess():
+    """ref_pipeline_call_v2_guess.pt / ref_pipeline_call_cn_guess.pt: the BrushNet and ControlNet `__call__`s with
+    `guess_mode=True` under CFG (pipeline_PowerPaint_Brushnet_CA.py:1394-1425, pipeline_PowerPaint_ControlNet.py:
+    1669-1702): side network on the conditional half only (image / control image not duplicated, :949), residual scales
+    logspace(-1, 0, n), zeros for the unconditional half of the UNet batch."""
+    from oracle import ref_pipeline
+    Pipe = ref_pipeline.load_reference_brushnet_pipeline_class(OM.BrushNetModel)
+    tok, enc, unet, bn, vae = components_v2()
+    pipe = Pipe(vae=vae, text_encoder=enc, text_encoder_brushnet=enc, tokenizer=tok, unet=unet, brushnet=bn,
+                scheduler=OS.DPMSolverMultistepScheduler(), safety_checker=None, feature_extractor=None,
+                requires_safety_checker=False)
+    img, mask3, lat = inputs_v2()
+    torch.manual_seed(9)
+    with torch.no_grad():
+        out = pipe(image=img, mask=mask3, latents=lat.clone(), output_type="latent", return_dict=False, guess_mode=True,
+                   **CALL_V2)[0]
+    torch.save(dict(latents=out), os.path.join(HERE, "ref_pipeline_call_v2_guess.pt"))
+    print("v2 guess", out.shape, float(out.abs().max()))
+    Pipe = ref_pipeline.load_reference_controlnet_pipeline_class(OM.ControlNetModel)
+    tok, enc, unet, cn, vae = components_cn()
+    pipe = Pipe(vae=vae, text_encoder=enc, tokenizer=tok, unet=unet, controlnet=cn, scheduler=OS.DDIMScheduler(),
+                safety_checker=None, feature_extractor=None, requires_safety_checker=False)
+    img, mask, lat = inputs()
+    with torch.no_grad():
+        out = pipe(image=img, mask=mask, control_image=control_image(), latents=lat.clone(),
+                   generator=torch.Generator().manual_seed(5), output_type="latent", return_dict=False, guess_mode=True,
+                   **CALL_CN)[0]
+    torch.save(dict(latents=out), os.path.join(HERE, "ref_pipeline_call_cn_guess.pt"))
+    print("controlnet guess", out.shape, float(out.abs().max()))
+
+
+CALL_ETA = dict(CALL, eta=0.7)
+
+
+def main_eta():
+    """ref_pipeline_call_eta.pt: the v1 `__call__` with `eta = 0.7` on DDIM (pipeline_PowerPaint.py:536-551,1023): every
+    step adds std_dev_t * randn_tensor(noise_pred.shape, generator) -- the generator that has already produced the
+    masked image's posterior sample."""
+    from oracle import ref_pipeline
+    Pipe, _ = ref_pipeline.load_reference_pipeline_class()
+    tok, enc, unet, vae = components()
+    pipe = Pipe(vae=vae, text_encoder=enc, tokenizer=tok, unet=unet, scheduler=OS.DDIMScheduler(), safety_checker=None,
+                feature_extractor=None, requires_safety_checker=False)
+    img, mask, lat = inputs()
+    with torch.no_grad():
+        out = pipe(image=img, mask=mask, latents=lat.clone(), generator=torch.Generator().manual_seed(5),
+                   output_type="latent", return_dict=False, **CALL_ETA)[0]
+    torch.save(dict(latents=out), os.path.join(HERE, "ref_pipeline_call_eta.pt"))
+    print("eta", out.shape, float(out.abs().max()))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] in ("strength", "guess", "eta"):
+        {"strength": main_strength, "guess": main_guess, "eta": main_eta}[sys.argv[1]]()
+        sys.exit(0)
     main()
     main_v2()
     main_cn()
+    main_strength()
+    main_guess()
+    main_eta()

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
 def test_python_binding_covers_header():
     from powerpaint_amd import _lib
     assert sorted(_lib.SIGNATURES) == header_symbols()
-    assert _lib.lib().pp_abi_version() == 6
+    assert _lib.lib().pp_abi_version() == 7
 
 
 def test_gemm_args_struct_layout_matches_header():
@@ -54,6 +54,7 @@ def test_bad_args_are_rejected_without_a_gpu():
     assert lib.pp_gemm_workspace_bytes(ctypes.byref(a)) == 0
     assert lib.pp_attention_fwd(None, 0, None, 0, None, 0, None, 0, 1, 8, 64, 64, 40, 1.0, 1, None) == -1
     assert lib.pp_layernorm(None, 1, 320, None, None, 1e-5, None, 1, None) == -1
+    assert lib.pp_ddim_variance_noise(None, None, 16, None, None, None) == -1
     b = _lib.PPGemmArgs()
     b.M = b.N = b.K = 64
     b.dtype = 7                                                      # not bf16 / fp16

@@ -267,3 +267,193 @@ def test_hip_brushnet_pipeline_reproduces_the_reference_call():
     c = dict(M.CALL_V2)
     out = pipe(conditioning_latents=cond, latents=lat.cuda(), output_type="latent", return_dict=False, **c)[0]
     _close_latents(out, gold["latents"], "BrushNet pipeline vs the reference's own __call__")
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# signature-visible variants of the loops: strength < 1 (enter the schedule late from the noised init image) and
+# guess_mode (side network on the conditional half only), each frozen on the reference's OWN `__call__`
+# ------------------------------------------------------------------------------------------------------------------
+def _emb(tok, enc):
+    def emb(p):
+        ids = tok(p, padding="max_length", max_length=77, truncation=True, return_tensors="pt").input_ids
+        return enc(ids)[0]
+    return emb
+
+
+def test_oracle_loop_reproduces_the_reference_call_with_strength():
+    """`strength = 0.6`, 5 DPM-Solver++ steps -> entries 2..4 of the schedule, initial latents = add_noise(VAE posterior
+    sample of the init image, noise, t = 499) (pipeline_PowerPaint.py:604-655,713-720); draw order posterior sample,
+    noise, masked-image posterior sample."""
+    from oracle import loops as OL, schedulers as OS
+    import make_ref_pipeline_call as M
+    gold = torch.load(os.path.join(HERE, "golden", "ref_pipeline_call_strength.pt"), weights_only=False)
+    tok, enc, unet, vae = M.components()
+    img, mask, _ = M.inputs()
+    c, emb = M.CALL_STRENGTH, _emb(tok, enc)
+    with torch.no_grad():
+        pos = emb(c["promptA"]) * c["tradoff"] + (1 - c["tradoff"]) * emb(c["promptB"])
+        neg = emb(c["negative_promptA"]) * c["tradoff_nag"] + (1 - c["tradoff_nag"]) * emb(c["negative_promptB"])
+        sch = OS.DPMSolverMultistepScheduler(**M.DPM_SD15)
+        sch.set_timesteps(c["num_inference_steps"])
+        t_start = c["num_inference_steps"] - int(c["num_inference_steps"] * c["strength"])
+        assert sch.timesteps[t_start:].tolist() == [s[1] for s in gold["steps"]] == [499, 333, 167]
+        g = torch.Generator().manual_seed(5)
+        il = vae.encode(img).latent_dist.sample(g) * vae.config.scaling_factor
+        noise = torch.randn(1, 4, 16, 16, generator=g)
+        lat = sch.add_noise(il, noise, sch.timesteps[t_start:t_start + 1])
+        mil = vae.encode(img * (mask < 0.5)).latent_dist.sample(g) * vae.config.scaling_factor
+        m = torch.nn.functional.interpolate(mask, size=(16, 16))
+        out = OL.loop_v1(unet, sch, lat, torch.cat([m] * 2), torch.cat([mil] * 2), torch.cat([neg, pos]),
+                         c["num_inference_steps"], c["guidance_scale"], t_start=t_start)
+    assert torch.allclose(out, gold["latents"], atol=1e-4, rtol=1e-4)
+
+
+@pytest.mark.gpu
+def test_hip_pipeline_reproduces_the_reference_call_with_strength():
+    from powerpaint_amd import models as PM, pipelines as PP, schedulers as PS
+    import make_ref_pipeline_call as M
+    gold = torch.load(os.path.join(HERE, "golden", "ref_pipeline_call_strength.pt"), weights_only=False)
+    tok, enc, unet, vae = M.components()
+    img, mask, _ = M.inputs()
+    hu = PM.UNet2DConditionModel(in_channels=9, device="cuda", **M.TINY).load_state_dict(unet.state_dict())
+    hv = PM.AutoencoderKL(device="cuda", **M.VAE_CFG).load_state_dict(vae.state_dict())
+    he = PM.CLIPTextModel(device="cuda", vocab_size=enc.config.vocab_size, num_hidden_layers=1,
+                          eos_token_id=enc.config.eos_token_id)
+    he.load_state_dict(enc.state_dict())
+    pipe = PP.StableDiffusionInpaintPipeline(vae=hv, text_encoder=he, tokenizer=tok, unet=hu,
+                                             scheduler=PS.DPMSolverMultistepScheduler(**M.DPM_SD15))
+    seen = []
+    out = pipe(image=img, mask=mask, generator=torch.Generator().manual_seed(5), output_type="latent", return_dict=False,
+               callback=lambda i, t, l: seen.append(int(t)), **M.CALL_STRENGTH)[0]
+    assert seen == [499, 333, 167]
+    _close_latents(out, gold["latents"], "v1 pipeline, strength 0.6, vs the reference's own __call__")
+    # ... and the next full-strength call starts from the top of the schedule again
+    _, _, lat = M.inputs()
+    gold1 = torch.load(os.path.join(HERE, "golden", "ref_pipeline_call.pt"), weights_only=False)
+    pipe.scheduler = PS.DDIMScheduler()
+    out = pipe(image=img, mask=mask, latents=lat.cuda(), generator=torch.Generator().manual_seed(5), output_type="latent",
+               return_dict=False, **M.CALL)[0]
+    _close_latents(out, gold1["latents"], "v1 pipeline after a strength < 1 call")
+
+
+def test_oracle_loops_reproduce_the_reference_calls_in_guess_mode():
+    """guess_mode under CFG (pipeline_PowerPaint_Brushnet_CA.py:1394-1425, pipeline_PowerPaint_ControlNet.py:1669-1702)."""
+    from oracle import loops as OL, schedulers as OS
+    import make_ref_pipeline_call as M
+    gold = torch.load(os.path.join(HERE, "golden", "ref_pipeline_call_v2_guess.pt"), weights_only=False)
+    tok, enc, unet, bn, vae = M.components_v2()
+    img, mask3, lat = M.inputs_v2()
+    c, emb = M.CALL_V2, _emb(tok, enc)
+    with torch.no_grad():
+        pos = emb(c["promptA"]) * c["tradoff"] + (1 - c["tradoff"]) * emb(c["promptB"])
+        neg = emb(c["negative_promptA"]) * c["tradoff_nag"] + (1 - c["tradoff_nag"]) * emb(c["negative_promptB"])
+        peU = torch.cat([emb(c["negative_promptU"]), emb(c["promptU"])])
+        torch.manual_seed(9)
+        cl = vae.encode(img).latent_dist.sample() * vae.config.scaling_factor         # NOT duplicated (:949)
+        keep = (mask3.sum(1)[:, None] < 0).float()
+        cond = torch.cat([cl, torch.nn.functional.interpolate(keep, size=cl.shape[-2:])], 1)
+        out = OL.loop_v2(unet, bn, OS.DPMSolverMultistepScheduler(), lat, cond, torch.cat([neg, pos]), peU,
+                         c["num_inference_steps"], c["guidance_scale"], c["brushnet_conditioning_scale"], guess_mode=True)
+    assert torch.allclose(out, gold["latents"], atol=3e-4, rtol=1e-4)
+    gold = torch.load(os.path.join(HERE, "golden", "ref_pipeline_call_cn_guess.pt"), weights_only=False)
+    tok, enc, unet, cn, vae = M.components_cn()
+    img, mask, lat = M.inputs()
+    c, emb = M.CALL_CN, _emb(tok, enc)
+    with torch.no_grad():
+        pe = torch.cat([emb(c["negative_promptA"]), emb(c["promptA"])])
+        mil = vae.encode(img * (mask < 0.5)).latent_dist.sample(torch.Generator().manual_seed(5)) * vae.config.scaling_factor
+        m = torch.nn.functional.interpolate(mask, size=(16, 16))
+        out = OL.loop_v1(unet, OS.DDIMScheduler(), lat, torch.cat([m] * 2), torch.cat([mil] * 2), pe,
+                         c["num_inference_steps"], c["guidance_scale"], controlnet=cn, control_image=M.control_image(),
+                         controlnet_conditioning_scale=c["controlnet_conditioning_scale"], guess_mode=True)
+    assert torch.allclose(out, gold["latents"], atol=2e-4, rtol=1e-4)
+
+
+@pytest.mark.gpu
+def test_hip_side_pipelines_reproduce_the_reference_calls_in_guess_mode():
+    from powerpaint_amd import models as PM, pipelines as PP, schedulers as PS
+    import make_ref_pipeline_call as M
+    # ---- BrushNet
+    gold = torch.load(os.path.join(HERE, "golden", "ref_pipeline_call_v2_guess.pt"), weights_only=False)
+    tok, enc, unet, bn, vae = M.components_v2()
+    img, mask3, lat = M.inputs_v2()
+    hu = PM.UNet2DConditionModel(in_channels=4, device="cuda", **M.TINY).load_state_dict(unet.state_dict())
+    hb = PM.BrushNetModel(in_channels=4, conditioning_channels=5, device="cuda", **M.TINY).load_state_dict(bn.state_dict())
+    hv = PM.AutoencoderKL(device="cuda", **M.VAE_CFG).load_state_dict(vae.state_dict())
+    he = PM.CLIPTextModel(device="cuda", vocab_size=enc.config.vocab_size, num_hidden_layers=1,
+                          eos_token_id=enc.config.eos_token_id)
+    he.load_state_dict(enc.state_dict())
+    pipe = PP.StableDiffusionPowerPaintBrushNetPipeline(vae=hv, text_encoder=he, text_encoder_brushnet=he, tokenizer=tok,
+                                                        unet=hu, brushnet=hb, scheduler=PS.DPMSolverMultistepScheduler())
+    dist = hv.encode(img.cuda()).latent_dist
+    torch.manual_seed(9)
+    noise = torch.randn(dist.mean.shape)
+    cl = (dist.mean + dist.std * noise.cuda()) * hv.config.scaling_factor
+    keep = (mask3.sum(1)[:, None] < 0).float()
+    cond = torch.cat([cl, torch.nn.functional.interpolate(keep, size=cl.shape[-2:]).cuda()], 1)
+    out = pipe(conditioning_latents=cond, latents=lat.cuda(), output_type="latent", return_dict=False, guess_mode=True,
+               **M.CALL_V2)[0]
+    _close_latents(out, gold["latents"], "BrushNet pipeline, guess_mode, vs the reference's own __call__")
+    gold0 = torch.load(os.path.join(HERE, "golden", "ref_pipeline_call_v2.pt"), weights_only=False)
+    assert (gold["latents"] - gold0["latents"]).abs().max() > 1.0        # (the two modes are far apart: a real check)
+    # ---- ControlNet
+    gold = torch.load(os.path.join(HERE, "golden", "ref_pipeline_call_cn_guess.pt"), weights_only=False)
+    tok, enc, unet, cn, vae = M.components_cn()
+    img, mask, lat = M.inputs()
+    no_up = {k: v for k, v in M.TINY.items() if k != "up_block_types"}
+    hu = PM.UNet2DConditionModel(in_channels=9, device="cuda", **M.TINY).load_state_dict(unet.state_dict())
+    hc = PM.ControlNetModel(in_channels=4, device="cuda", **no_up).load_state_dict(cn.state_dict())
+    hv = PM.AutoencoderKL(device="cuda", **M.VAE_CFG).load_state_dict(vae.state_dict())
+    pipe = PP.StableDiffusionControlNetInpaintPipeline(vae=hv, text_encoder=he, tokenizer=tok, unet=hu, controlnet=hc,
+                                                       scheduler=PS.DDIMScheduler())
+    out = pipe(image=img, mask=mask, control_image=M.control_image(), latents=lat.cuda(),
+               generator=torch.Generator().manual_seed(5), output_type="latent", return_dict=False, guess_mode=True,
+               **M.CALL_CN)[0]
+    _close_latents(out, gold["latents"], "ControlNet pipeline, guess_mode, vs the reference's own __call__")
+
+
+def test_oracle_loop_reproduces_the_reference_call_with_eta():
+    """Stochastic DDIM: the loop's per-step variance noise comes from the generator that sampled the masked image's
+    posterior (tests/golden/ref_pipeline_call_eta.pt, eta = 0.7)."""
+    from oracle import loops as OL, schedulers as OS
+    import make_ref_pipeline_call as M
+    gold = torch.load(os.path.join(HERE, "golden", "ref_pipeline_call_eta.pt"), weights_only=False)
+    gold0 = torch.load(os.path.join(HERE, "golden", "ref_pipeline_call.pt"), weights_only=False)
+    assert (gold["latents"] - gold0["latents"]).abs().max() > 0.5
+    tok, enc, unet, vae = M.components()
+    img, mask, lat = M.inputs()
+    c, emb = M.CALL_ETA, _emb(tok, enc)
+    with torch.no_grad():
+        pos = emb(c["promptA"]) * c["tradoff"] + (1 - c["tradoff"]) * emb(c["promptB"])
+        neg = emb(c["negative_promptA"]) * c["tradoff_nag"] + (1 - c["tradoff_nag"]) * emb(c["negative_promptB"])
+        g = torch.Generator().manual_seed(5)
+        mil = vae.encode(img * (mask < 0.5)).latent_dist.sample(g) * vae.config.scaling_factor
+        m = torch.nn.functional.interpolate(mask, size=(16, 16))
+        out = OL.loop_v1(unet, OS.DDIMScheduler(), lat, torch.cat([m] * 2), torch.cat([mil] * 2), torch.cat([neg, pos]),
+                         c["num_inference_steps"], c["guidance_scale"], eta=c["eta"], generator=g)
+    assert torch.allclose(out, gold["latents"], atol=1e-4, rtol=1e-4)
+
+
+@pytest.mark.gpu
+def test_hip_pipeline_reproduces_the_reference_call_with_eta():
+    from powerpaint_amd import models as PM, pipelines as PP, schedulers as PS
+    import make_ref_pipeline_call as M
+    gold = torch.load(os.path.join(HERE, "golden", "ref_pipeline_call_eta.pt"), weights_only=False)
+    tok, enc, unet, vae = M.components()
+    img, mask, lat = M.inputs()
+    hu = PM.UNet2DConditionModel(in_channels=9, device="cuda", **M.TINY).load_state_dict(unet.state_dict())
+    hv = PM.AutoencoderKL(device="cuda", **M.VAE_CFG).load_state_dict(vae.state_dict())
+    he = PM.CLIPTextModel(device="cuda", vocab_size=enc.config.vocab_size, num_hidden_layers=1,
+                          eos_token_id=enc.config.eos_token_id)
+    he.load_state_dict(enc.state_dict())
+    pipe = PP.StableDiffusionInpaintPipeline(vae=hv, text_encoder=he, tokenizer=tok, unet=hu, scheduler=PS.DDIMScheduler())
+    for use_graph in (True, False):                 # the noise buffer is refilled before every graph replay / eager step
+        pipe.use_graph = use_graph
+        out = pipe(image=img, mask=mask, latents=lat.cuda(), generator=torch.Generator().manual_seed(5),
+                   output_type="latent", return_dict=False, **M.CALL_ETA)[0]
+        _close_latents(out, gold["latents"], f"v1 pipeline, eta 0.7 (graph={use_graph}), vs the reference's own __call__")
+    # eta back to 0 on the same pipeline object: the deterministic golden again (table and step program rebuilt)
+    gold0 = torch.load(os.path.join(HERE, "golden", "ref_pipeline_call.pt"), weights_only=False)
+    out = pipe(image=img, mask=mask, latents=lat.cuda(), generator=torch.Generator().manual_seed(5), output_type="latent",
+               return_dict=False, **M.CALL)[0]
+    _close_latents(out, gold0["latents"], "v1 pipeline, eta back to 0")

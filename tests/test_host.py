@@ -78,6 +78,36 @@ def test_brushnet_wiring_changes_the_unet_plan():
     assert {a.res2 for a in res2} <= slots
 
 
+def test_guess_mode_output_layout_of_the_side_networks():
+    """pad_uncond (the pipelines' guess mode): residual tensors with twice the batch, the zero convs write the second
+    half, one extra zeroing launch covers all of them; the UNet refuses the flag."""
+    for kind, tot, nk in (("brushnet", 9, dict(conditioning_channels=5)), ("controlnet", 4, dict(conditioning_channels=3))):
+        kw = {k: v for k, v in TINY.items() if not (kind == "controlnet" and k == "up_block_types")}
+        net = SDNet(kind, 4, **kw, **nk)
+        net.load_state_dict(net.synthetic_state_dict(meta=True), "cpu", materialize=False)
+        rt = NetRuntime(net, "cpu")
+        rt.ensure(2, 16, 16, 77, tot, ("plain",), cond_hw=(128, 128))
+        plain = [c[2] for c in rt.step_plan.calls]
+        rt.ensure(2, 16, 16, 77, tot, ("plain",), cond_hw=(128, 128), pad_uncond=True)
+        names = [c[2] for c in rt.step_plan.calls]
+        assert len(names) == len(plain) + 1 and names.count("zero_u64") == plain.count("zero_u64") + 1
+        outs = rt.outputs["down"] + [rt.outputs["mid"]] + rt.outputs.get("up", [])
+        zc = [a for a in rt.step_plan.keep if a.scale is not None and any(a is c[1][0]._obj for c in rt.step_plan.calls
+                                                                         if c[2] == "zero_conv")]
+        assert len(zc) == len(outs) and all(o.B == 4 for o in outs)
+        for a, o in zip(zc, outs):
+            assert a.M == 2 * o.H * o.W and a.out == o.ptr + a.M * o.C * 2          # second half of the padded tensor
+        zi = names.index("zero_u64", 1)
+        fn, args, _ = rt.step_plan.calls[zi]
+        end = outs[-1].ptr + outs[-1].rows * outs[-1].C * 2
+        assert args[0] == outs[0].ptr and args[1] * 8 == end - outs[0].ptr
+        assert zi < names.index("zero_conv")
+    net = SDNet("unet", 4, **TINY)
+    net.load_state_dict(net.synthetic_state_dict(meta=True), "cpu", materialize=False)
+    with pytest.raises(Exception):
+        NetRuntime(net, "cpu").ensure(2, 16, 16, 77, 4, ("plain",), pad_uncond=True)
+
+
 def test_geglu_interleave_is_a_row_permutation():
     w = torch.arange(16 * 3, dtype=torch.float32).reshape(16, 3)
     p = _geglu_interleave(w)

@@ -501,6 +501,59 @@ def test_pndm_step_kernel_vs_oracle(N):
         check(xh.cpu(), xo, 1e-4 * max(1.0, float(xo.abs().max())), 1e-4, f"pndm evaluation {k}")
 
 
+def test_ddim_step_with_eta_vs_oracle():
+    """Stochastic DDIM through `scheduler.step(..., eta, generator)` (pp_cfg_sched_step + pp_ddim_variance_noise): same
+    CPU generator state -> same variance noise as the oracle's diffusers-protocol step; eta = 0 afterwards is
+    deterministic again."""
+    from oracle import schedulers as OS
+    from powerpaint_amd import schedulers as PS
+    o, h = OS.DDIMScheduler(), PS.DDIMScheduler()
+    o.set_timesteps(6)
+    h.set_timesteps(6, device=DEV)
+    g = torch.Generator("cpu").manual_seed(0)
+    x0 = torch.randn(2, 4, 8, 8, generator=g)
+    eps = [torch.randn(2, 4, 8, 8, generator=g) for _ in range(6)]
+    go, gh = torch.Generator("cpu").manual_seed(7), torch.Generator("cpu").manual_seed(7)
+    xo, xh = x0, x0.to(DEV)
+    for k, t in enumerate(o.timesteps):
+        eta = 0.8 if k < 4 else 0.0
+        xo = o.step(eps[k], t, xo, eta=eta, generator=go)[0]
+        xh = h.step(eps[k].to(DEV), t, xh, eta=eta, generator=gh, return_dict=False)[0]
+        check(xh.cpu(), xo, 1e-4 * max(1.0, float(xo.abs().max())), 1e-4, f"ddim eta step {k}")
+    assert torch.equal(torch.randn(3, generator=go), torch.randn(3, generator=gh))      # same number of draws
+    with pytest.raises(ValueError):
+        h.set_eta(1.5)
+
+
+@pytest.mark.parametrize("name,kw", [("DDIMScheduler", {}), ("DPMSolverMultistepScheduler", {}), ("PNDMScheduler", {}),
+                                     ("UniPCMultistepScheduler", dict(solver_order=3))])
+@pytest.mark.parametrize("N,begin", [(10, 4), (6, 5)])
+def test_schedulers_enter_the_schedule_late(name, kw, N, begin):
+    """`strength < 1` (pipeline_PowerPaint.py:713-720): the loop runs over `scheduler.timesteps[t_start:]`.  The oracle's
+    diffusers-protocol classes find their place from the first timestep they see and restart their warm-up there; the
+    product tables do the same after `set_begin_index` (first-order first step, PLMS start-up, UniPC order ramp)."""
+    from oracle import schedulers as OS
+    from powerpaint_amd import schedulers as PS
+    o, h = getattr(OS, name)(**kw), getattr(PS, name)(**kw)
+    o.set_timesteps(N)
+    h.set_timesteps(N, device=DEV)
+    h.set_begin_index(begin)
+    assert h.begin_index == begin and int(h.step_counter()) == begin
+    assert h.timesteps.cpu().tolist() == o.timesteps.tolist()          # the scheduler keeps the whole list
+    g = torch.Generator("cpu").manual_seed(0)
+    x0 = torch.randn(2, 4, 8, 8, generator=g)
+    ts = o.timesteps[begin:]
+    eps = [torch.randn(2, 4, 8, 8, generator=g) for _ in ts]
+    xo, xh = x0, x0.to(DEV)
+    h.reset()
+    for k, t in enumerate(ts):
+        xo = o.step(eps[k], t, xo)[0]
+        xh = h.step(eps[k].to(DEV), t, xh, return_dict=False)[0]
+        check(xh.cpu(), xo, 1e-4 * max(1.0, float(xo.abs().max())), 1e-4, f"{name} entered at {begin}: step {k}")
+    h.set_timesteps(N, device=DEV)                                      # ... and set_timesteps starts from the top again
+    assert h.begin_index == 0 and int(h.step_counter()) == 0
+
+
 @pytest.mark.parametrize("K,N,spacing,off", [(2, 10, "leading", 1), (3, 6, "linspace", 0), (1, 3, "trailing", 0)])
 def test_unipc_step_kernel_vs_oracle(K, N, spacing, off):
     """scheduler.step of the product UniPC (HIP kernel, kind 3: corrector + predictor as one linear form over the
