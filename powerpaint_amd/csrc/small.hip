@@ -153,60 +153,92 @@ __global__ void __launch_bounds__(256) conv3x3_smallcout_kernel(const uint16_t* 
   }
 }
 
-// The same conv on the matrix cores (cin % 32 == 0: the UNet's 320 -> 4 conv_out, the VAE decoder's 128 -> 3(4)):
+// The same conv on the matrix cores (cin % 32 == 0, cin <= 384: the UNet's 320 -> 4 conv_out, the VAE decoder's 128 -> 3(4)):
 //   D[cout 16 (4 live)][pixel 16] += W[cout][k 32] . X^T[k 32][pixel 16]      v_mfma_f32_16x16x32
-// A workgroup owns 16 consecutive output pixels; its four waves split every tap's channel range in 32-deep steps
-// (s = wave, wave + 4, ...), each lane fetching the 16 bytes of its (row, k-group) straight from global memory -- the
-// 23 KB of weights stay in L1 / L2, the activations are re-read nine times from L2 -- and the four partial tiles are
-// summed through LDS.  The scalar kernel above spends 72 VALU instructions per 16-byte piece on bf16 unpacking and FMAs
-// and re-reads the weights for every pixel (48 us at 64x64 x 8); here the arithmetic is 90 MFMAs per 16 pixels.
+// A workgroup owns 32 consecutive output pixels (two 16-pixel MFMA column groups that share every weight fragment); its
+// four waves split every tap's channel range in 32-deep steps (s = wave, wave + 4, ...), each lane fetching the 16
+// bytes of its (row, k-group) straight from global memory -- the 23 KB of weights stay in L1 / L2, the activations are
+// re-read nine times from L2 -- and the four partial tiles are summed through LDS.  1024 workgroups at 64x64 x 8: one
+// round on 256 CUs at four waves per SIMD (16-pixel workgroups needed 8 per CU, 7 fit: the tail round doubled the time).
 template <int EDT>
-__global__ void __launch_bounds__(256) conv3x3_cout4_mfma_kernel(const uint16_t* __restrict__ x, int batch, int h, int w_,
-                                                                int cin, const uint16_t* __restrict__ w,
-                                                                const float* __restrict__ bias, float* __restrict__ out) {
+__global__ void __launch_bounds__(256, 4) conv3x3_cout4_mfma_kernel(const uint16_t* __restrict__ x, int batch, int h,
+                                                                   int w_, int cin, const uint16_t* __restrict__ w,
+                                                                   const float* __restrict__ bias,
+                                                                   float* __restrict__ out) {
   using E = E16<EDT>;
   typedef typename E::v8 v8_t;
-  __shared__ f32x4_t part[4][16];
+  constexpr int PG = 2;                                // 16-pixel groups per workgroup
+  __shared__ f32x4_t part[4][PG][16];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int col = lane & 15, kg = lane >> 4;           // B column = pixel / A row = cout; k-group of 8 channels
   const long long npix = (long long)batch * h * w_;
-  const long long pix = (long long)blockIdx.x * 16 + col;
-  const bool pv = pix < npix;
-  const long long pc = pv ? pix : npix - 1;
-  const int ox = (int)(pc % w_), oy = (int)((pc / w_) % h), b = (int)(pc / ((long long)w_ * h));
-  const int steps = cin >> 5;
-  f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-  for (int tap = 0; tap < 9; ++tap) {
+  bool pv[PG];
+  int ox[PG], oy[PG];
+  size_t img[PG];                                      // element offset of the pixel's image
+#pragma unroll
+  for (int g = 0; g < PG; ++g) {
+    const long long pix = (long long)blockIdx.x * (16 * PG) + g * 16 + col;
+    pv[g] = pix < npix;
+    const long long pc = pv[g] ? pix : npix - 1;
+    ox[g] = (int)(pc % w_);
+    oy[g] = (int)((pc / w_) % h);
+    img[g] = (size_t)(pc / ((long long)w_ * h)) * h * w_;
+  }
+  const int steps = cin >> 5;                          // <= 12 (host-checked): at most three 32-deep steps per wave
+  f32x4_t acc[PG];
+#pragma unroll
+  for (int g = 0; g < PG; ++g) acc[g] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  // Addresses are clamped to something readable and the value is masked instead (no divergent loads, no branches), and
+  // the nine taps are software-pipelined by hand: tap t + 1's nine loads are in flight under tap t's six MFMAs.
+  uint32_t wm[3];
+  int sc[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int st = wave + 4 * j;
+    sc[j] = (st < steps ? st : 0) * 32;
+    wm[j] = (col < 4 && st < steps) ? 0xffffffffu : 0u;
+  }
+  u32x4_t xv[2][3][PG], wv[2][3];
+  uint32_t xm[2][PG];
+  auto load_tap = [&](int tap, int buf) {
     const int ky = tap / 3, kx = tap - ky * 3;
-    const int iy = oy + ky - 1, ix = ox + kx - 1;
-    const bool ok = pv && (unsigned)iy < (unsigned)h && (unsigned)ix < (unsigned)w_;
-    // (addresses are clamped to something readable and the value is zeroed instead: no divergent loads)
-    const uint16_t* xp = x + (((size_t)b * h + (ok ? iy : oy)) * w_ + (ok ? ix : ox)) * cin + kg * 8;
     const uint16_t* wp = w + ((size_t)(col & 3) * 9 + tap) * cin + kg * 8;
-    for (int s0 = wave; s0 < steps; s0 += 12) {        // three steps' loads in flight per wave (320 channels: one round)
-      u32x4_t xv[3], wv[3];
 #pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        const int st = s0 + 4 * j;
-        const int sc = st < steps ? st : s0;
-        xv[j] = *reinterpret_cast<const u32x4_t*>(xp + sc * 32);
-        wv[j] = *reinterpret_cast<const u32x4_t*>(wp + sc * 32);
-        if (!ok || st >= steps) xv[j] = u32x4_t{0u, 0u, 0u, 0u};
-        if (col >= 4) wv[j] = u32x4_t{0u, 0u, 0u, 0u};
-      }
+    for (int g = 0; g < PG; ++g) {
+      const int iy = oy[g] + ky - 1, ix = ox[g] + kx - 1;
+      const bool ok = pv[g] && (unsigned)iy < (unsigned)h && (unsigned)ix < (unsigned)w_;
+      xm[buf][g] = ok ? 0xffffffffu : 0u;
+      const uint16_t* xp = x + (img[g] + (size_t)(ok ? iy : oy[g]) * w_ + (ok ? ix : ox[g])) * cin + kg * 8;
 #pragma unroll
-      for (int j = 0; j < 3; ++j)
-        acc = E::mfma16(__builtin_bit_cast(v8_t, wv[j]), __builtin_bit_cast(v8_t, xv[j]), acc);
+      for (int j = 0; j < 3; ++j) xv[buf][j][g] = *reinterpret_cast<const u32x4_t*>(xp + sc[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) wv[buf][j] = *reinterpret_cast<const u32x4_t*>(wp + sc[j]);
+  };
+  load_tap(0, 0);
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) {
+    const int buf = tap & 1;
+    if (tap + 1 < 9) load_tap(tap + 1, buf ^ 1);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const u32x4_t wj = wv[buf][j] & wm[j];
+#pragma unroll
+      for (int g = 0; g < PG; ++g)
+        acc[g] = E::mfma16(__builtin_bit_cast(v8_t, wj), __builtin_bit_cast(v8_t, xv[buf][j][g] & xm[buf][g]), acc[g]);
     }
   }
-  if (lane < 16) part[wave][lane] = acc;               // lanes 0-15: couts 0-3 (registers) of pixel `lane`
+  if (lane < 16) {                                     // lanes 0-15: couts 0-3 (registers) of pixel `lane` of each group
+#pragma unroll
+    for (int g = 0; g < PG; ++g) part[wave][g][lane] = acc[g];
+  }
   __syncthreads();
-  if (threadIdx.x < 64) {                              // thread = (cout, pixel): 64-byte runs per output plane
-    const int r = threadIdx.x >> 4, p = threadIdx.x & 15;
-    const long long q = (long long)blockIdx.x * 16 + p;
+  if (threadIdx.x < 64 * PG) {                         // thread = (group, cout, pixel): 64-byte runs per output plane
+    const int g = threadIdx.x >> 6, r = (threadIdx.x >> 4) & 3, p = threadIdx.x & 15;
+    const long long q = (long long)blockIdx.x * (16 * PG) + g * 16 + p;
     if (q < npix) {
       const int qx = (int)(q % w_), qy = (int)((q / w_) % h), qb = (int)(q / ((long long)w_ * h));
-      const float sum = (part[0][p][r] + part[1][p][r]) + (part[2][p][r] + part[3][p][r]);
+      const float sum = (part[0][g][p][r] + part[1][g][p][r]) + (part[2][g][p][r] + part[3][g][p][r]);
       out[(((size_t)qb * 4 + r) * h + qy) * w_ + qx] = sum + (bias ? bias[r] : 0.f);
     }
   }
@@ -478,8 +510,8 @@ extern "C" int pp_conv3x3_smallcout(const void* x, int batch, int h, int w_, int
     return PP_ERR_BAD_ARG;
   if (cout != 4) return PP_ERR_UNSUPPORTED;
   const long long npix = (long long)batch * h * w_;
-  if (cin % 32 == 0) {
-    PP_DT_SWITCH(dtype, hipLaunchKernelGGL((conv3x3_cout4_mfma_kernel<EDT>), dim3((unsigned)((npix + 15) / 16)), dim3(256), 0,
+  if (cin % 32 == 0 && cin <= 384) {
+    PP_DT_SWITCH(dtype, hipLaunchKernelGGL((conv3x3_cout4_mfma_kernel<EDT>), dim3((unsigned)((npix + 31) / 32)), dim3(256), 0,
                                            (hipStream_t)stream, (const uint16_t*)x, batch, h, w_, cin, (const uint16_t*)w,
                                            bias, out_nchw));
     PP_CHECK_LAUNCH("conv3x3_cout4_mfma_kernel");

@@ -60,7 +60,7 @@ def main():
                 if variant == "rowstats":
                     a.row_stats_out = stats_out.data_ptr()
                 if variant == "noepi":
-                    a.reserved[0] = 4
+                    a.dbg = 4
                 t = time_launch(lib, a)
                 row.append(f"{t:6.1f}" if t else "   err")
             tf = 2.0 * M * N * Cc / 1e6

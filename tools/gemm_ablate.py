@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Ablation of the v2 GEMM kernel phases on a few shapes (debug switches in PPGemmArgs.reserved[0])."""
+"""Ablation of the v2 GEMM kernel phases on a few shapes (debug switches in PPGemmArgs.dbg)."""
 import ctypes as C
 import os
 import sys
@@ -28,7 +28,7 @@ def run(M, N, K, tile, sk, dbg, res=True, iters=20):
         a.res1, a.ldres1 = r.data_ptr(), N
     a.scale, a.out, a.ldo = 1.0, out.data_ptr(), N
     a.tile, a.splitk, a.workspace = tile, sk, ws.data_ptr()
-    a.reserved[0] = dbg
+    a.dbg = dbg
     st = torch.cuda.current_stream()
     for _ in range(3):
         L.check(lib.pp_gemm_bf16(C.byref(a), st.cuda_stream), "gemm")

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Phase decomposition of the v2 GEMM main loop on long-K shapes (PPGemmArgs.reserved[0] switches: 1 no DMA refill,
+"""Phase decomposition of the v2 GEMM main loop on long-K shapes (PPGemmArgs.dbg switches: 1 no DMA refill,
 2 no fragment reads / MFMA, 4 no epilogue).    python tools/gemm_phase.py"""
 import os
 import sys

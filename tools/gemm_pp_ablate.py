@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Phase ablation of the ping-pong GEMM (debug switches in PPGemmArgs.reserved[0]: 1 no refill DMA, 2 no MFMA,
+"""Phase ablation of the ping-pong GEMM (debug switches in PPGemmArgs.dbg: 1 no refill DMA, 2 no MFMA,
 4 no epilogue, 8 no s_setprio) on long-K shapes; interleaved rounds, median."""
 import os
 import sys
