@@ -28,9 +28,8 @@
 namespace {
 
 constexpr int QW = 32;   // queries per wave
-constexpr int NW = 4;    // waves per block
 
-template <int D, int KB>
+template <int D, int KB, int NW>     // NW = waves per block (4: two blocks per CU; 8: one, half the tile DMAs per query)
 struct PCfg {
   static constexpr int JB = KB / 32;                      // 32-key S^T blocks per tile
   static constexpr int DP = (D + 15) / 16 * 16;
@@ -58,17 +57,18 @@ constexpr float RESCALE_THR = 8.0f;
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-template <int D, int KB, int dbg, int EDT>
-__global__ void __launch_bounds__(256, (KB == 32 ? 4 : 2))
+template <int D, int KB, int dbg, int EDT, int NW>
+__global__ void __launch_bounds__(64 * NW, (KB == 32 ? 4 : 2))
 attn_pipe_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __restrict__ k, int ldk,
                  const uint16_t* __restrict__ vt, int ldvt, uint16_t* __restrict__ o, int ldo, int heads, int nq, int nk,
                  float scale_log2e) {
   // dbg (PP_ATTN_DBG, timing experiments only; results are garbage): 1 no MFMA, 2 no exp, 4 no tile DMA / barrier,
   // 8 no LDS fragment reads
-  using C = PCfg<D, KB>;
+  using C = PCfg<D, KB, NW>;
   using E = E16<EDT>;
   typedef typename E::v8 v8_t;
   constexpr int JB = C::JB;
+  constexpr int T = 64 * NW;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -79,10 +79,10 @@ attn_pipe_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __rest
   const int ntiles = nk / KB;
 
   // ---- LDS init: V^T ring all zero (ring slot NVB-1 is read by stage 0 with P = 0; 0 x garbage could be NaN), ones row
-  for (int i = tid; i < C::NVB * C::VTILE / 16; i += 256)
+  for (int i = tid; i < C::NVB * C::VTILE / 16; i += T)
     *reinterpret_cast<u32x4_t*>(smem + C::VBASE + i * 16) = u32x4_t{0u, 0u, 0u, 0u};
   __syncthreads();
-  for (int i = tid; i < C::NVB * (KB / 2); i += 256) {
+  for (int i = tid; i < C::NVB * (KB / 2); i += T) {
     const int bufi = i / (KB / 2), w = i - bufi * (KB / 2);
     *reinterpret_cast<uint32_t*>(smem + C::VBASE + bufi * C::VTILE + (C::VROWS - 1) * C::VS + w * 4) = E::pack2(1.0f, 1.0f);
   }
@@ -350,22 +350,22 @@ attn_pipe_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __rest
 // Default: 64-key tiles, two workgroups (8 waves) per CU; carries the PP_ATTN_DBG ablation variants.  PP_ATTN_KB=32:
 // 32-key tiles, <= 128 VGPRs, four workgroups per CU -- measured identical (347 vs 346 us at N = 4096): doubling the
 // occupancy hides nothing, the SIMD is issue-bound (~230 instructions per wave-tile at ~4 cycles + 14 MFMA at 32).
-template <int KB, int DBG, int EDT>
+template <int KB, int DBG, int EDT, int NW = 4>
 static int launch_pipe(const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt, void* o, int ldo,
                        int batch, int heads, int nq, int nk, float sl2, hipStream_t st) {
-  using C = PCfg<40, KB>;
+  using C = PCfg<40, KB, NW>;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_pipe_kernel<40, KB, DBG, EDT>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_pipe_kernel<40, KB, DBG, EDT, NW>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS) != hipSuccess) {
       pp_set_last_error("hipFuncSetAttribute(attention pipe)", hipGetLastError());
       return PP_ERR_LAUNCH;
     }
     attr_set = true;
   }
-  const dim3 grid((nq + QW * NW - 1) / (QW * NW), heads, batch), block(256);
-  hipLaunchKernelGGL((attn_pipe_kernel<40, KB, DBG, EDT>), grid, block, C::LDS, st, (const uint16_t*)q, ldq, (const uint16_t*)k,
-                     ldk, (const uint16_t*)vt, ldvt, (uint16_t*)o, ldo, heads, nq, nk, sl2);
+  const dim3 grid((nq + QW * NW - 1) / (QW * NW), heads, batch), block(64 * NW);
+  hipLaunchKernelGGL((attn_pipe_kernel<40, KB, DBG, EDT, NW>), grid, block, C::LDS, st, (const uint16_t*)q, ldq,
+                     (const uint16_t*)k, ldk, (const uint16_t*)vt, ldvt, (uint16_t*)o, ldo, heads, nq, nk, sl2);
   PP_CHECK_LAUNCH("attn_pipe_kernel");
   return PP_OK;
 }
@@ -380,6 +380,8 @@ int pp_attention_pipe_launch(const void* q, int ldq, const void* k, int ldk, con
     if (kb != 64 || dbg != 0) return PP_ERR_UNSUPPORTED;
     return launch_pipe<64, 0, PP_DT_F16>(PP_ARGS);
   }
+  static const int nw = [] { const char* e = getenv("PP_ATTN_NW"); return e ? atoi(e) : 4; }();   // experiment: 8
+  if (nw == 8 && kb == 64 && dbg == 0) return launch_pipe<64, 0, PP_DT_BF16, 8>(PP_ARGS);
   if (kb == 32) return launch_pipe<32, 0, PP_DT_BF16>(PP_ARGS);
   if (kb != 64) return PP_ERR_BAD_ARG;
   switch (dbg) {
