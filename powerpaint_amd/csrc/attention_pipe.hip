@@ -20,6 +20,8 @@
 //   * V^T is stored with natural key order, each PV A-fragment is two ds_read_b64 (keys 4h..4h+3 and 8+4h..8+4h+3 of the
 //     16-key block = exactly the keys of the S^T accumulator registers this lane packed into its B-fragment);
 //   * the softmax denominator comes out of the PV MFMAs: V^T row 63 is all ones.
+//   * round 2: a wave owns 32 * QB queries.  QB = 2 on 32-key tiles does the same 14 MFMAs per stage with 7 fragment
+//     reads instead of 14 (the LDS is 45 % index-active + 18 % conflict cycles at QB = 1) and half the tile DMAs per query.
 // Restrictions (the host falls back to attn_fwd_kernel otherwise): d == 40, nk % 64 == 0.
 #include <cstdlib>
 
@@ -27,7 +29,7 @@
 
 namespace {
 
-constexpr int QW = 32;   // queries per wave
+// queries per wave = 32 * QB (template parameter): QB = 2 lets every K / V^T fragment read from LDS feed two MFMAs
 
 template <int D, int KB, int NW>     // NW = waves per block (4: two blocks per CU; 8: one, half the tile DMAs per query)
 struct PCfg {
@@ -57,8 +59,8 @@ constexpr float RESCALE_THR = 8.0f;
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-template <int D, int KB, int dbg, int EDT, int NW>
-__global__ void __launch_bounds__(64 * NW, (KB == 32 ? 4 : 2))
+template <int D, int KB, int dbg, int EDT, int NW, int QB>
+__global__ void __launch_bounds__(64 * NW, (KB == 32 && QB == 1 ? 4 : 2))
 attn_pipe_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __restrict__ k, int ldk,
                  const uint16_t* __restrict__ vt, int ldvt, uint16_t* __restrict__ o, int ldo, int heads, int nq, int nk,
                  float scale_log2e) {
@@ -69,6 +71,7 @@ attn_pipe_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __rest
   typedef typename E::v8 v8_t;
   constexpr int JB = C::JB;
   constexpr int T = 64 * NW;
+  constexpr int QW = 32 * QB;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -90,16 +93,17 @@ attn_pipe_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __rest
   __syncthreads();
 
   // ---- Q fragments (B operand): lane = query qi, k-slot = 8*half + jj  ->  Q[q0+qi][16 s + 8 half + jj]
-  u32x4_t qraw[C::DS];
-  {
-    const int qrow = q0 + qi;
+  u32x4_t qraw[QB][C::DS];
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    const int qrow = q0 + 32 * qb + qi;
     const uint16_t* qp = q + ((size_t)b * nq + (qrow < nq ? qrow : 0)) * ldq + h * D;
 #pragma unroll
     for (int s = 0; s < C::DS; ++s) {
       const int dc = 16 * s + 8 * half;
       u32x4_t v = {0u, 0u, 0u, 0u};
       if (qrow < nq && dc < D) v = *reinterpret_cast<const u32x4_t*>(qp + dc);
-      qraw[s] = v;
+      qraw[qb][s] = v;
     }
   }
 
@@ -159,25 +163,29 @@ attn_pipe_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __rest
     vring = vring + 1 == C::NVB ? 0 : vring + 1;
   };
 
-  f32x16_t oacc[C::DT];
+  f32x16_t oacc[QB][C::DT];
 #pragma unroll
-  for (int t = 0; t < C::DT; ++t)
+  for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) oacc[t][r] = 0.f;
-  float m_run = -1.0e30f;   // running max, log2 domain
-  float alpha = 1.0f;       // deferred O rescale factor of the previous stage
-  bool pend = false;        // wave-uniform: alpha != 1 somewhere
+    for (int t = 0; t < C::DT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[qb][t][r] = 0.f;
+  float m_run[QB], alpha[QB];   // running max (log2 domain) / deferred O rescale factor of the previous stage, per q-block
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) { m_run[qb] = -1.0e30f; alpha[qb] = 1.0f; }
+  bool pend = false;            // wave-uniform: some alpha != 1 somewhere
 
   // plain (non-interleaved) pieces: prologue S(0) and the drain PV
-  auto qk = [&](const char* ks, f32x16_t (&sn)[JB]) {
+  auto qk = [&](const char* ks, f32x16_t (&sn)[QB][JB]) {
 #pragma unroll
     for (int j = 0; j < JB; ++j) {
       const f32x16_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int s = 0; s < C::DS; ++s) {
         const v8_t kf = *reinterpret_cast<const v8_t*>(ks + (32 * j + qi) * C::KS + (2 * s + half) * 16);
-        sn[j] = E::mfma32(kf, __builtin_bit_cast(v8_t, qraw[s]), s == 0 ? zero : sn[j],
-                                                        0, 0, 0);
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb)
+          sn[qb][j] = E::mfma32(kf, __builtin_bit_cast(v8_t, qraw[qb][s]), s == 0 ? zero : sn[qb][j], 0, 0, 0);
       }
     }
   };
@@ -188,21 +196,26 @@ attn_pipe_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __rest
     const u32x4_t w = {lo[0], lo[1], hi[0], hi[1]};
     return __builtin_bit_cast(v8_t, w);
   };
-  auto pv = [&](const char* vs, const v8_t (&pp)[JB][2]) {
+  auto pv = [&](const char* vs, const v8_t (&pp)[QB][JB][2]) {
 #pragma unroll
     for (int j = 0; j < JB; ++j)
 #pragma unroll
       for (int u = 0; u < 2; ++u)
 #pragma unroll
-        for (int dt = 0; dt < C::DT; ++dt)
-          oacc[dt] = E::mfma32(vfrag(vs, j, u, dt), pp[j][u], oacc[dt], 0, 0, 0);
+        for (int dt = 0; dt < C::DT; ++dt) {
+          const v8_t vf = vfrag(vs, j, u, dt);
+#pragma unroll
+          for (int qb = 0; qb < QB; ++qb) oacc[qb][dt] = E::mfma32(vf, pp[qb][j][u], oacc[qb][dt], 0, 0, 0);
+        }
   };
 
   // stage t: consumes S(t) (sc) and P(t-1) (pp); produces S(t+1) (sn) and P(t) (pc).
-  // The body is choreographed by hand: NM = 2*DS + 4*DT MFMAs, one per slot; every slot also carries its share of the
-  // softmax VALU work and the LDS fragment reads of the MFMA two slots ahead.  sched_barrier(0) between slots keeps the
-  // compiler from regrouping (left alone it emits all MFMAs back to back, then the VALU block: zero overlap).
-  auto stage = [&](int t, const f32x16_t (&sc)[JB], f32x16_t (&sn)[JB], v8_t (&pc)[JB][2], const v8_t (&pp)[JB][2]) {
+  // The body is choreographed by hand: NM = QB * JB * (DS + 2 DT) MFMAs, one per slot; every slot also carries its share of
+  // the softmax VALU work, and every QB-th slot the LDS read of the fragment FDF fragments ahead (a fragment feeds the QB
+  // consecutive MFMAs of the wave's q-blocks).  sched_barrier(0) between slots keeps the compiler from regrouping (left
+  // alone it emits all MFMAs back to back, then the VALU block: zero overlap).
+  auto stage = [&](int t, const f32x16_t (&sc)[QB][JB], f32x16_t (&sn)[QB][JB], v8_t (&pc)[QB][JB][2],
+                   const v8_t (&pp)[QB][JB][2]) {
     if (!(dbg & 4)) {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::LPW) : "memory");   // tile t+1 (issued two stages ago) has landed
     asm volatile("s_barrier" ::: "memory");                         // ... for every wave; stage t-1 reads are done
@@ -210,93 +223,108 @@ attn_pipe_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __rest
     }
     if (pend) {                                                     // deferred rescale: after PV(t-2), before PV(t-1)
 #pragma unroll
-      for (int dt = 0; dt < C::DT; ++dt)
+      for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+        for (int dt = 0; dt < C::DT; ++dt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) oacc[qb][dt][r] *= alpha[qb];
     }
     const char* ks = smem + kread * C::KTILE;            // K(t+1)
     const char* vs = smem + C::VBASE + vread * C::VTILE; // V(t-1)
     kread = kread + 1 == C::NKB ? 0 : kread + 1;
     vread = vread + 1 == C::NVB ? 0 : vread + 1;
-    constexpr int NQK = JB * C::DS, NM = NQK + JB * 2 * C::DT;
-    constexpr int FD = (dbg >> 4) ? (dbg >> 4) : 2;   // fragment prefetch distance in slots (experiment: dbg / 16)
-    constexpr int MAXSLOTS = 2 * JB;             // slots carrying the running-max phase (8 scores each)
-    constexpr int NES = 8 * JB;                  // exp steps (2 scores each)
+    constexpr int NKF = JB * C::DS, NF = NKF + JB * 2 * C::DT;   // K fragments / all fragments of a stage
+    constexpr int NQK = NKF * QB, NM = NF * QB;                  // QK^T slots / all slots
+    constexpr int FDF = (dbg >> 4) ? (dbg >> 4) : (QB == 1 ? 2 : 1);   // fragment prefetch distance, in fragments
+    //                                       (= two slots either way; QB = 2 with FDF 2 measured the same)
+    constexpr int SB = QB * JB;                  // 32 x 32 score blocks per stage
+    constexpr int MAXSLOTS = 2 * SB;             // slots carrying the running-max phase (8 scores each)
+    constexpr int NES = 8 * SB;                  // exp steps (2 scores each)
     constexpr int ESLOTS = NM - MAXSLOTS;        // slots carrying them
-    v8_t frag[NM];
-    auto fetch = [&](int f) {
-      if (dbg & 8) { frag[f] = __builtin_bit_cast(v8_t, qraw[0]); return; }
-      if (f < NQK) {
-        const int j = f / C::DS, sidx = f % C::DS;
-        frag[f] = *reinterpret_cast<const v8_t*>(ks + (32 * j + qi) * C::KS + (2 * sidx + half) * 16);
+    v8_t frag[NF];
+    auto fetch = [&](int k) {
+      if (dbg & 8) { frag[k] = __builtin_bit_cast(v8_t, qraw[0][0]); return; }
+      if (k < NKF) {
+        const int j = k / C::DS, sidx = k % C::DS;
+        frag[k] = *reinterpret_cast<const v8_t*>(ks + (32 * j + qi) * C::KS + (2 * sidx + half) * 16);
       } else {
-        const int g = f - NQK, ju = g / C::DT, dt = g % C::DT;
-        frag[f] = vfrag(vs, ju >> 1, ju & 1, dt);
+        const int g = k - NKF, ju = g / C::DT, dt = g % C::DT;
+        frag[k] = vfrag(vs, ju >> 1, ju & 1, dt);
       }
     };
 #pragma unroll
-    for (int f = 0; f < FD; ++f) fetch(f);
-    float tmax = -1.0e30f;
-    f32x2_t c2 = {scale_log2e, scale_log2e}, nm2 = {0.f, 0.f};
-    u32x4_t w[JB][2];
+    for (int k = 0; k < FDF; ++k) fetch(k);
+    float tmax[QB];
+    f32x2_t c2 = {scale_log2e, scale_log2e}, nm2[QB];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) { tmax[qb] = -1.0e30f; nm2[qb] = f32x2_t{0.f, 0.f}; }
+    u32x4_t w[QB][JB][2];
+    bool any = false;
     int es = 0;                                  // exp steps done (compile-time after unrolling)
 #pragma unroll
     for (int f = 0; f < NM; ++f) {
-      if (f + FD < NM) fetch(f + FD);
+      const int k = f / QB, qb = f % QB;         // fragment of this slot, q-block it multiplies
+      if (qb == 0 && k + FDF < NF) fetch(k + FDF);
       if (dbg & 1) {
-        asm volatile("" ::"v"(frag[f]));
-      } else if (f < NQK) {
-        const int j = f / C::DS, sidx = f % C::DS;
+        asm volatile("" ::"v"(frag[k]));
+      } else if (k < NKF) {
+        const int j = k / C::DS, sidx = k % C::DS;
         const f32x16_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        sn[j] = E::mfma32(frag[f], __builtin_bit_cast(v8_t, qraw[sidx]),
-                                                        sidx == 0 ? zero : sn[j], 0, 0, 0);
+        sn[qb][j] = E::mfma32(frag[k], __builtin_bit_cast(v8_t, qraw[qb][sidx]), sidx == 0 ? zero : sn[qb][j], 0, 0, 0);
       } else {
-        const int g = f - NQK, ju = g / C::DT, dt = g % C::DT;
-        oacc[dt] = E::mfma32(frag[f], pp[ju >> 1][ju & 1], oacc[dt], 0, 0, 0);
+        const int g = k - NKF, ju = g / C::DT, dt = g % C::DT;
+        oacc[qb][dt] = E::mfma32(frag[k], pp[qb][ju >> 1][ju & 1], oacc[qb][dt], 0, 0, 0);
       }
-      if (f < MAXSLOTS) {                        // running max over this lane's 32 scores, 8 per slot
-        const int j = f >> 1, r0 = (f & 1) * 8;
+      if (f < MAXSLOTS) {                        // running max over a lane's 16 scores of one block, 8 per slot
+        const int sb = f >> 1, mq = sb / JB, mj = sb % JB, r0 = (f & 1) * 8;
 #pragma unroll
-        for (int r = r0; r < r0 + 8; r += 2) tmax = __builtin_fmaxf(__builtin_fmaxf(tmax, sc[j][r]), sc[j][r + 1]);
-        if (f == MAXSLOTS - 1) {
-          tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-          const float ts = tmax * scale_log2e;
-          const bool need = !__all(ts - m_run <= RESCALE_THR);
-          const float m_new = need ? fmaxf(m_run, ts) : m_run;
-          alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-          pend = need;
-          m_run = m_new;
-          nm2 = f32x2_t{-m_new, -m_new};
+        for (int r = r0; r < r0 + 8; r += 2)
+          tmax[mq] = __builtin_fmaxf(__builtin_fmaxf(tmax[mq], sc[mq][mj][r]), sc[mq][mj][r + 1]);
+        if (mj == JB - 1 && (f & 1)) {           // last block of q-block mq: its row maximum is complete
+          const float tm = fmaxf(tmax[mq], __shfl_xor(tmax[mq], 32, 64));
+          const float ts = tm * scale_log2e;
+          const bool need = !__all(ts - m_run[mq] <= RESCALE_THR);
+          const float m_new = need ? fmaxf(m_run[mq], ts) : m_run[mq];
+          alpha[mq] = __builtin_amdgcn_exp2f(m_run[mq] - m_new);
+          any = any || need;
+          m_run[mq] = m_new;
+          nm2[mq] = f32x2_t{-m_new, -m_new};
         }
+        if (f == MAXSLOTS - 1) pend = any;
       } else {                                   // exp steps: 2 scores each (pk_fma, 2 x exp2, cvt_pk)
-        const int k = f - MAXSLOTS;
-        const int upto = (NES * (k + 1) + ESLOTS - 1) / ESLOTS;
+        const int kk = f - MAXSLOTS;
+        const int upto = (NES * (kk + 1) + ESLOTS - 1) / ESLOTS;
 #pragma unroll
         for (; es < upto; ++es) {
-          const int j = es >> 3, u = (es >> 2) & 1, e = es & 3;
-          const f32x2_t s2 = {sc[j][8 * u + 2 * e], sc[j][8 * u + 2 * e + 1]};
-          const f32x2_t e2 = __builtin_elementwise_fma(s2, c2, nm2);
-          w[j][u][e] = (dbg & 2) ? E::pack2(e2[0], e2[1]) : E::pack2(__builtin_amdgcn_exp2f(e2[0]), __builtin_amdgcn_exp2f(e2[1]));
-          asm volatile("" ::"v"(w[j][u][e]));    // P(t) is only consumed next stage: keep LLVM from sinking the exps there
+          const int sb = es >> 3, eq = sb / JB, ej = sb % JB, u = (es >> 2) & 1, e = es & 3;
+          const f32x2_t s2 = {sc[eq][ej][8 * u + 2 * e], sc[eq][ej][8 * u + 2 * e + 1]};
+          const f32x2_t e2 = __builtin_elementwise_fma(s2, c2, nm2[eq]);
+          w[eq][ej][u][e] = (dbg & 2) ? E::pack2(e2[0], e2[1])
+                                      : E::pack2(__builtin_amdgcn_exp2f(e2[0]), __builtin_amdgcn_exp2f(e2[1]));
+          asm volatile("" ::"v"(w[eq][ej][u][e]));   // P(t) is only consumed next stage: keep LLVM from sinking the exps there
         }
       }
       __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
-    for (int j = 0; j < JB; ++j)
+    for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
-      for (int u = 0; u < 2; ++u) pc[j][u] = __builtin_bit_cast(v8_t, w[j][u]);
+      for (int jj = 0; jj < JB; ++jj)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) pc[qb][jj][u] = __builtin_bit_cast(v8_t, w[qb][jj][u]);
   };
 
-  f32x16_t sA[JB], sB[JB];
-  v8_t pA[JB][2], pB[JB][2];
+  f32x16_t sA[QB][JB], sB[QB][JB];
+  v8_t pA[QB][JB][2], pB[QB][JB][2];
 #pragma unroll
-  for (int j = 0; j < JB; ++j)
+  for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      pA[j][u] = __builtin_bit_cast(v8_t, u32x4_t{0u, 0u, 0u, 0u});
-      pB[j][u] = pA[j][u];
-    }
+    for (int jj = 0; jj < JB; ++jj)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        pA[qb][jj][u] = __builtin_bit_cast(v8_t, u32x4_t{0u, 0u, 0u, 0u});
+        pB[qb][jj][u] = pA[qb][jj][u];
+      }
 
   issue();
   issue();
@@ -313,9 +341,11 @@ attn_pipe_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __rest
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (pend) {
 #pragma unroll
-    for (int dt = 0; dt < C::DT; ++dt)
+    for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+      for (int dt = 0; dt < C::DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[qb][dt][r] *= alpha[qb];
   }
   {
     const char* vs = smem + C::VBASE + ((ntiles - 1) % C::NVB) * C::VTILE;
@@ -324,23 +354,26 @@ attn_pipe_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __rest
   }
 
   // ---- epilogue: denominator = O^T row VROWS-1 (tile DT-1, r = 15, lane half 1)
-  const float l_tot = __shfl(oacc[C::DT - 1][15], qi + 32, 64);
-  const float inv = 1.0f / l_tot;
-  const int qrow = q0 + qi;
-  if (qrow < nq) {
-    uint16_t* op = o + ((size_t)b * nq + qrow) * ldo + h * D;
 #pragma unroll
-    for (int dt = 0; dt < C::DT; ++dt)
+  for (int qb = 0; qb < QB; ++qb) {
+    const float l_tot = __shfl(oacc[qb][C::DT - 1][15], qi + 32, 64);
+    const float inv = 1.0f / l_tot;
+    const int qrow = q0 + 32 * qb + qi;
+    if (qrow < nq) {
+      uint16_t* op = o + ((size_t)b * nq + qrow) * ldo + h * D;
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int dc = dt * 32 + 8 * g + 4 * half;
-        if (dc < D) {
-          u32x2_t w;
-          w[0] = E::pack2(oacc[dt][4 * g + 0] * inv, oacc[dt][4 * g + 1] * inv);
-          w[1] = E::pack2(oacc[dt][4 * g + 2] * inv, oacc[dt][4 * g + 3] * inv);
-          *reinterpret_cast<u32x2_t*>(op + dc) = w;
+      for (int dt = 0; dt < C::DT; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int dc = dt * 32 + 8 * g + 4 * half;
+          if (dc < D) {
+            u32x2_t w;
+            w[0] = E::pack2(oacc[qb][dt][4 * g + 0] * inv, oacc[qb][dt][4 * g + 1] * inv);
+            w[1] = E::pack2(oacc[qb][dt][4 * g + 2] * inv, oacc[qb][dt][4 * g + 3] * inv);
+            *reinterpret_cast<u32x2_t*>(op + dc) = w;
+          }
         }
-      }
+    }
   }
 }
 
@@ -350,21 +383,21 @@ attn_pipe_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __rest
 // Default: 64-key tiles, two workgroups (8 waves) per CU; carries the PP_ATTN_DBG ablation variants.  PP_ATTN_KB=32:
 // 32-key tiles, <= 128 VGPRs, four workgroups per CU -- measured identical (347 vs 346 us at N = 4096): doubling the
 // occupancy hides nothing, the SIMD is issue-bound (~230 instructions per wave-tile at ~4 cycles + 14 MFMA at 32).
-template <int KB, int DBG, int EDT, int NW = 4>
+template <int KB, int DBG, int EDT, int NW = 4, int QB = 1>
 static int launch_pipe(const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt, void* o, int ldo,
                        int batch, int heads, int nq, int nk, float sl2, hipStream_t st) {
   using C = PCfg<40, KB, NW>;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_pipe_kernel<40, KB, DBG, EDT, NW>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_pipe_kernel<40, KB, DBG, EDT, NW, QB>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS) != hipSuccess) {
       pp_set_last_error("hipFuncSetAttribute(attention pipe)", hipGetLastError());
       return PP_ERR_LAUNCH;
     }
     attr_set = true;
   }
-  const dim3 grid((nq + QW * NW - 1) / (QW * NW), heads, batch), block(64 * NW);
-  hipLaunchKernelGGL((attn_pipe_kernel<40, KB, DBG, EDT, NW>), grid, block, C::LDS, st, (const uint16_t*)q, ldq,
+  const dim3 grid((nq + 32 * QB * NW - 1) / (32 * QB * NW), heads, batch), block(64 * NW);
+  hipLaunchKernelGGL((attn_pipe_kernel<40, KB, DBG, EDT, NW, QB>), grid, block, C::LDS, st, (const uint16_t*)q, ldq,
                      (const uint16_t*)k, ldk, (const uint16_t*)vt, ldvt, (uint16_t*)o, ldo, heads, nq, nk, sl2);
   PP_CHECK_LAUNCH("attn_pipe_kernel");
   return PP_OK;
@@ -376,11 +409,20 @@ int pp_attention_pipe_launch(const void* q, int ldq, const void* k, int ldk, con
   static const int dbg = [] { const char* e = getenv("PP_ATTN_DBG"); return e ? atoi(e) : 0; }();
   if (d != 40 || nk % kb != 0 || nk < 4 * kb) return PP_ERR_UNSUPPORTED;
 #define PP_ARGS q, ldq, k, ldk, vt, ldvt, o, ldo, batch, heads, nq, nk, sl2, st
+  static const int nw = [] { const char* e = getenv("PP_ATTN_NW"); return e ? atoi(e) : 4; }();   // experiment: 8
+  // 64 queries per wave on 32-key tiles (QB = 2: every K / V^T fragment read from LDS feeds two MFMAs, half the tile DMAs
+  // per query): 319 us against 338 us at N = 4096 hot, -0.5 % on the UNet step.  Needs two 256-query workgroups per CU
+  // to be worth it; PP_ATTN_QB=1|2 forces the choice.
+  static const int qbk = [] { const char* e = getenv("PP_ATTN_QB"); return e ? atoi(e) : 0; }();
+  const long long wg2 = (long long)batch * heads * ((nq + 255) / 256);
+  if (dbg == 0 && kb == 64 && nw == 4 && (qbk == 2 || (qbk == 0 && wg2 >= 512))) {
+    if (dtype == PP_DT_F16) return launch_pipe<32, 0, PP_DT_F16, 4, 2>(PP_ARGS);
+    return launch_pipe<32, 0, PP_DT_BF16, 4, 2>(PP_ARGS);
+  }
   if (dtype == PP_DT_F16) {      // fp16: the shipping configuration only (the ablation variants are bf16 experiments)
     if (kb != 64 || dbg != 0) return PP_ERR_UNSUPPORTED;
     return launch_pipe<64, 0, PP_DT_F16>(PP_ARGS);
   }
-  static const int nw = [] { const char* e = getenv("PP_ATTN_NW"); return e ? atoi(e) : 4; }();   // experiment: 8
   if (nw == 8 && kb == 64 && dbg == 0) return launch_pipe<64, 0, PP_DT_BF16, 8>(PP_ARGS);
   if (kb == 32) return launch_pipe<32, 0, PP_DT_BF16>(PP_ARGS);
   if (kb != 64) return PP_ERR_BAD_ARG;
