@@ -21,6 +21,7 @@ class BrushNetModel(_HipModel):
                  up_block_types=SD15_UP, block_out_channels=(320, 640, 1280, 1280), layers_per_block: int = 2,
                  norm_num_groups: int = 32, norm_eps: float = 1e-5, cross_attention_dim: int = 768,
                  attention_head_dim: int = 8, device="cuda", dtype=torch.bfloat16, **unused):
+        self._extra_config = unused         # validated in the base constructor (check_fixed_config)
         super().__init__(in_channels, block_out_channels, layers_per_block, attention_head_dim, cross_attention_dim,
                          norm_num_groups, norm_eps, down_block_types, up_block_types, device, dtype,
                          conditioning_channels=conditioning_channels)

@@ -13,6 +13,40 @@ SD15_DOWN = ("CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock
 SD15_UP = ("UpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D")
 
 
+# config.json keys of the diffusers SD-1.5 family that change the arithmetic and that the compiled networks fix at one
+# value: a checkpoint whose config says otherwise must be REFUSED (a swallowed key would load, run and give wrong images)
+_FIXED_CONFIG = {
+    "act_fn": ("silu",), "use_linear_projection": (False,), "class_embed_type": (None,), "num_class_embeds": (None,),
+    "upcast_attention": (False,), "resnet_time_scale_shift": ("default",), "only_cross_attention": (False,),
+    "dual_cross_attention": (False,), "addition_embed_type": (None,), "time_cond_proj_dim": (None,),
+    "time_embedding_type": ("positional",), "timestep_post_act": (None,), "time_embedding_act_fn": (None,),
+    "time_embedding_dim": (None,), "conv_in_kernel": (3,), "conv_out_kernel": (3,),
+    "mid_block_type": ("UNetMidBlock2DCrossAttn",), "transformer_layers_per_block": (1,),
+    "reverse_transformer_layers_per_block": (None,), "encoder_hid_dim": (None,), "encoder_hid_dim_type": (None,),
+    "flip_sin_to_cos": (True,), "freq_shift": (0,), "mid_block_scale_factor": (1, 1.0), "downsample_padding": (1,),
+    "num_attention_heads": (None,), "center_input_sample": (False,), "dropout": (0, 0.0), "attention_type": ("default",),
+    "cross_attention_norm": (None,), "class_embeddings_concat": (False,), "resnet_skip_time_act": (False,),
+    "resnet_out_scale_factor": (1, 1.0), "mid_block_only_cross_attention": (None,), "addition_time_embed_dim": (None,),
+    "projection_class_embeddings_input_dim": (None,), "controlnet_conditioning_channel_order": ("rgb",),
+    "brushnet_conditioning_channel_order": ("rgb",), "global_pool_conditions": (False,),
+    "addition_embed_type_num_heads": (64,),
+}
+
+
+def check_fixed_config(cls_name: str, extra: dict):
+    """Constructor keyword arguments the model does not name (the rest of a diffusers config.json): keys of
+    `_FIXED_CONFIG` must carry the value the HIP networks are compiled for; bookkeeping keys ("_class_name", ...) and
+    unknown keys pass (newer diffusers versions add options whose defaults keep the SD-1.5 arithmetic)."""
+    for k, v in extra.items():
+        if k.startswith("_") or k not in _FIXED_CONFIG:
+            continue
+        if isinstance(v, list):
+            v = tuple(v)
+        if v not in _FIXED_CONFIG[k]:
+            raise L.PPError(f"{cls_name}: config {k}={v!r} is not implemented on the HIP path "
+                            f"(supported: {', '.join(repr(x) for x in _FIXED_CONFIG[k])})")
+
+
 class Output(SimpleNamespace):
     """return_dict=True container (attribute access like diffusers BaseOutput)."""
 
@@ -27,6 +61,7 @@ class _HipModel(PretrainedMixin):
     def __init__(self, in_channels, block_out_channels, layers_per_block, attention_head_dim, cross_attention_dim,
                  norm_num_groups, norm_eps, down_block_types, up_block_types, device, dtype, **net_kw):
         L.dtype_code(dtype)      # bf16 or fp16 storage (fp32 accumulate either way); raises PPError for anything else
+        check_fixed_config(type(self).__name__, getattr(self, "_extra_config", {}))
         if not isinstance(attention_head_dim, int):
             raise L.PPError("per-block attention_head_dim tuples are not supported (SD-1.5 uses 8 everywhere)")
         self._device = torch.device(device)

@@ -210,3 +210,23 @@ def test_pipeline_from_pretrained(tmp_path):
     with pytest.raises(L.PPError):
         PP.StableDiffusionInpaintPipeline.from_pretrained(root, device="cpu", unet=pipe.unet, vae=pipe.vae,
                                                           text_encoder=pipe.text_encoder)
+
+
+def test_model_constructors_refuse_config_values_they_do_not_implement():
+    """a diffusers config.json key the compiled networks fix at one value (use_linear_projection,
+    class_embed_type, upcast_attention, act_fn ...) is an error when it carries another one, not a silently dropped
+    keyword; the SD-1.5 values, bookkeeping keys and unknown (newer) keys pass."""
+    from powerpaint_amd import _lib as L
+    from powerpaint_amd import models as PM
+    tiny = dict(block_out_channels=(320, 640), layers_per_block=1, down_block_types=("CrossAttnDownBlock2D", "DownBlock2D"),
+                up_block_types=("UpBlock2D", "CrossAttnUpBlock2D"), device="cpu")
+    ok = dict(_class_name="UNet2DConditionModel", _diffusers_version="0.27.0", act_fn="silu", use_linear_projection=False,
+              class_embed_type=None, upcast_attention=False, mid_block_type="UNetMidBlock2DCrossAttn", dropout=0.0,
+              some_future_option=1)
+    PM.UNet2DConditionModel(in_channels=9, **tiny, **ok)
+    for bad in (dict(use_linear_projection=True), dict(class_embed_type="timestep"), dict(act_fn="gelu"),
+                dict(upcast_attention=True), dict(resnet_time_scale_shift="scale_shift"), dict(transformer_layers_per_block=2)):
+        for cls, kw in ((PM.UNet2DConditionModel, dict(in_channels=9)), (PM.BrushNetModel, {}), (PM.ControlNetModel, {})):
+            t = {k: v for k, v in tiny.items() if not (cls is PM.ControlNetModel and k == "up_block_types")}
+            with pytest.raises(L.PPError):
+                cls(**kw, **t, **bad)
