@@ -129,6 +129,71 @@ __global__ void kmo(float* out, int iters) {
   out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + p0[0] + p1[0] + p2[1] + p3[1] + s;
 }
 
+// The same body as kmo with the MFMA accumulators in ACCUMULATION registers (AGPR C / D operands): does the softmax-type
+// VALU work overlap better with an in-flight 32x32 MFMA when the 16-register accumulator stays off the VGPR ports?
+// NV8 = number of 4-instruction VALU groups per MFMA (1: 4 ops per MFMA as in kmo; 2: 8 ops, the attention slot).
+template <int OP, int NM, bool AG, int NV8>
+__global__ void kma(float* out, int iters) {
+  float a0 = threadIdx.x * 1e-3f, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+  bf8 x, y;
+  for (int i = 0; i < 8; ++i) { x[i] = (__bf16)(a0 + i); y[i] = (__bf16)(a1 - i); }
+  f16v acc0 = {0}, acc1 = {0};
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        if (NM) {
+          if (AG) {
+            if (hh == 0) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc0) : "v"(x), "v"(y));
+            else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc1) : "v"(x), "v"(y));
+          } else {
+            if (hh == 0) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc0) : "v"(x), "v"(y));
+            else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc1) : "v"(x), "v"(y));
+          }
+        }
+#pragma unroll
+        for (int g = 0; g < NV8; ++g) {
+          if (OP == 0) asm volatile("v_exp_f32 %0, %0\n v_exp_f32 %1, %1\n v_exp_f32 %2, %2\n v_exp_f32 %3, %3" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+          if (OP == 1) asm volatile("v_fma_f32 %0, %0, %0, %0\n v_fma_f32 %1, %1, %1, %1\n v_fma_f32 %2, %2, %2, %2\n v_fma_f32 %3, %3, %3, %3" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+          if (OP == 3) asm volatile("v_max3_f32 %0, %0, %1, %2\n v_max3_f32 %1, %1, %2, %3\n v_max3_f32 %2, %2, %3, %0\n v_max3_f32 %3, %3, %0, %1" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+          if (OP == 8) asm volatile("v_fma_f32 %0, %4, %5, %0\n v_exp_f32 %1, %6\n v_max3_f32 %2, %2, %7, %4\n v_cvt_pk_bf16_f32 %3, %5, %6"   // the attention mix, 8 distinct sources
+                                    : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(a4), "v"(a5), "v"(a6), "v"(a7));
+        }
+      }
+    }
+  }
+  float s = 0;
+  for (int i = 0; i < 16; ++i) s += acc0[i] + acc1[i];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + s;
+}
+
+template <int OP, int NV8>
+void runa(const char* name, float* d) {
+  const int iters = 20000;
+  for (int cfg = 0; cfg < 3; ++cfg)          // 0: VALU alone, 1: + MFMA (VGPR accumulators), 2: + MFMA (AGPR accumulators)
+    for (int wps = 1; wps <= 2; wps *= 2) {
+      dim3 grid(256), block(256 * wps);
+      hipEvent_t e0, e1;
+      hipEventCreate(&e0); hipEventCreate(&e1);
+      auto go = [&](int it) {
+        if (cfg == 0) hipLaunchKernelGGL((kma<OP, 0, false, NV8>), grid, block, 0, 0, d, it);
+        else if (cfg == 1) hipLaunchKernelGGL((kma<OP, 1, false, NV8>), grid, block, 0, 0, d, it);
+        else hipLaunchKernelGGL((kma<OP, 1, true, NV8>), grid, block, 0, 0, d, it);
+      };
+      go(100);
+      hipEventRecord(e0);
+      go(iters);
+      hipEventRecord(e1);
+      hipEventSynchronize(e1);
+      float ms;
+      hipEventElapsedTime(&ms, e0, e1);
+      const double ns = ms * 1e6 / ((double)iters * 4 * wps);
+      printf("2 x (mfma + %d x %-14s) %-22s waves/SIMD=%d  %.1f ns per body per wave slot (2 mfma alone = 33)\n", 4 * NV8, name,
+             cfg == 0 ? "VALU alone" : cfg == 1 ? "+ mfma, VGPR acc" : "+ mfma, AGPR acc", wps, ns);
+    }
+}
+
 template <int OP>
 void runo(const char* name, float* d) {
   const int iters = 20000;
@@ -191,5 +256,10 @@ int main() {
   runo<2>("v_pk_fma_f32", d);
   runo<3>("v_max3_f32", d);
   runo<4>("v_cvt_pk_bf16_f32", d);
+  runa<1, 1>("v_fma_f32", d);
+  runa<0, 1>("v_exp_f32", d);
+  runa<8, 1>("softmax mix", d);
+  runa<8, 2>("softmax mix", d);
+  runa<1, 2>("v_fma_f32", d);
   return 0;
 }
