@@ -1,5 +1,6 @@
 #!/bin/bash
-# attention: QK^T MFMA chains of the two 32-key blocks interleaved (PP_ATTN_ILV=1, new default) against block order (0)
+# attention: QK^T MFMA chains of the two 32-key blocks interleaved (PP_ATTN_ILV) against block order.  The switch lived
+# only in the experiment build: no effect, reverted (profiles/r02_rejected_experiments.txt, item 11).
 set -u
 cd "$(dirname "$0")/.."
 O=gpurun_out/r02i

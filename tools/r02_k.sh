@@ -1,4 +1,5 @@
 #!/bin/bash
+# 64-query attention waves (PP_ATTN_QB=2) with 4- and 8-wave workgroups against the 32-query kernel
 set -u
 cd "$(dirname "$0")/.."
 PP_ATTN_QB=2 PP_ATTN_NW=8 timeout 600 python -m pytest tests/test_ops_gpu.py -q -p no:cacheprovider -k "attention" 2>&1 | tail -1

@@ -1,4 +1,6 @@
 #!/bin/bash
+# A/B of one attention switch given as $1 (PP_ATTN_EARLY, PP_ATTN_PAIR: experiment builds only, both reverted --
+# profiles/r02_rejected_experiments.txt, item 13; PP_ATTN_QB / PP_ATTN_NW exist in the product)
 set -u
 cd "$(dirname "$0")/.."
 V=${1:-PP_ATTN_EARLY}

@@ -1,4 +1,5 @@
 #!/bin/bash
+# the 4-wave 256x160 GEMM tile (id 63, experiment build only: profiles/r02_rejected_experiments.txt, item 14)
 set -u
 cd "$(dirname "$0")/.."
 O=gpurun_out/r02n
