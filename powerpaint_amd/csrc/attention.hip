@@ -45,11 +45,11 @@ struct Cfg {
 
 constexpr float RESCALE_THR = 8.0f;   // defer the O rescale while the running max grows by < 2^8 (log2 domain)
 
-template <int D, int EDT>
-__global__ void __launch_bounds__(256, (D <= 80 ? 2 : 1))
+template <int D, int EDT, bool QR>     // QR: the K / V-reuse loop over query blocks (its own instantiation: the loop-carried
+__global__ void __launch_bounds__(256, (D <= 80 ? 2 : 1))   // state costs registers the d = 80 / 160 kernels do not have)
 attn_fwd_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __restrict__ k, int ldk,
                 const uint16_t* __restrict__ vt, int ldvt, uint16_t* __restrict__ o, int ldo, int heads, int nq, int nk,
-                float scale_log2e) {
+                float scale_log2e, int qrep) {
   using C = Cfg<D>;
   using E = E16<EDT>;
   typedef typename E::v8 v8_t;
@@ -61,7 +61,12 @@ attn_fwd_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __restr
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = blockIdx.y, b = blockIdx.z;
-  const int q0 = blockIdx.x * (QW * NW) + wave * QW;
+  // qrep > 1 (cross-attention at 64x64: nk <= 2 tiles, thousands of workgroups): a workgroup serves qrep blocks of 128
+  // queries in turn.  After the first block both LDS buffers hold the whole K / V^T of this (batch, head): the later
+  // blocks recompute from LDS with no tile loads and no barriers -- the K / V round trip (the longest latency hop of
+  // this short kernel) is paid once per qrep blocks and the launch has 1 / qrep of the workgroups.
+  const int reps = QR ? qrep : 1;
+  int q0 = blockIdx.x * (QW * NW * reps) + wave * QW;
   const int qi = lane & 31, half = lane >> 5;
 
   if constexpr (MFMA_SUM) {   // padding rows of the V^T tile (both buffers), written once: row D all ones, the rest zero
@@ -75,17 +80,20 @@ attn_fwd_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __restr
 
   // ---- Q fragments (B operand): lane = query qi, k-slot = 8*half + jj  ->  Q[q0+qi][16 s + 8 half + jj]
   u32x4_t qraw[C::DS];
-  {
-    const int qrow = q0 + qi;
-    const uint16_t* qp = q + ((size_t)b * nq + (qrow < nq ? qrow : 0)) * ldq + h * D;
-#pragma unroll
-    for (int s = 0; s < C::DS; ++s) {
-      const int dc = 16 * s + 8 * half;
-      u32x4_t v = {0u, 0u, 0u, 0u};
-      if (qrow < nq && dc < D) v = *reinterpret_cast<const u32x4_t*>(qp + dc);
-      qraw[s] = v;
-    }
-  }
+  // (macros, not lambdas: a lambda that captures the loop-carried q0 / the tile lambda by reference makes LLVM keep the
+  //  closure -- and everything it points to -- in scratch memory)
+#define PP_LOAD_Q()                                                                                     \
+  do {                                                                                                  \
+    const int qrow_ = q0 + qi;                                                                          \
+    const uint16_t* qp_ = q + ((size_t)b * nq + (qrow_ < nq ? qrow_ : 0)) * ldq + h * D;                \
+    _Pragma("unroll") for (int s_ = 0; s_ < C::DS; ++s_) {                                              \
+      const int dc_ = 16 * s_ + 8 * half;                                                               \
+      u32x4_t v_ = {0u, 0u, 0u, 0u};                                                                    \
+      if (qrow_ < nq && dc_ < D) v_ = *reinterpret_cast<const u32x4_t*>(qp_ + dc_);                     \
+      qraw[s_] = v_;                                                                                    \
+    }                                                                                                   \
+  } while (0)
+  PP_LOAD_Q();
 
   // ---- tile loads: per-piece voffsets are constants; the walk over key tiles is SCALAR arithmetic on the buffer
   // descriptors (base += tile, size shrinks), and rows past the end of K fall outside the descriptor -> zeros.
@@ -236,20 +244,37 @@ attn_fwd_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __restr
   };
 
   const int ntiles = (nk + KB - 1) / KB;
+#define PP_RUN_TILE(T_)                                                                          \
+  do {                                                                                           \
+    const int t0_ = (T_) * KB;                                                                   \
+    const char* ks_ = smem + ((T_) & 1) * BUF;                                                   \
+    if (t0_ + KB / 2 >= nk) tile(ks_, ks_ + C::KBYTES, t0_, std::integral_constant<int, 2>{});   \
+    else if (t0_ + KB > nk) tile(ks_, ks_ + C::KBYTES, t0_, std::integral_constant<int, 1>{});   \
+    else tile(ks_, ks_ + C::KBYTES, t0_, std::integral_constant<int, 0>{});                      \
+  } while (0)
   load_tile(0);
   store_tile(0);
   __syncthreads();
 
-  for (int t = 0; t < ntiles; ++t) {
-    const int t0 = t * KB;
-    const bool more = t + 1 < ntiles;
-    if (more) load_tile(t0 + KB);                       // global -> registers, in flight during the MFMAs below
-    const char* ks = smem + (t & 1) * BUF;
-    if (t0 + KB / 2 >= nk) tile(ks, ks + C::KBYTES, t0, std::integral_constant<int, 2>{});
-    else if (t0 + KB > nk) tile(ks, ks + C::KBYTES, t0, std::integral_constant<int, 1>{});
-    else tile(ks, ks + C::KBYTES, t0, std::integral_constant<int, 0>{});
-    if (more) store_tile((t + 1) & 1);                  // the other buffer: last read two barriers ago
-    __syncthreads();
+  for (int rep = 0; rep < reps; ++rep) {
+  if (rep == 0) {
+    for (int t = 0; t < ntiles; ++t) {
+      const bool more = t + 1 < ntiles;
+      if (more) load_tile(t * KB + KB);                   // global -> registers, in flight during the MFMAs below
+      PP_RUN_TILE(t);
+      if (more) store_tile((t + 1) & 1);                  // the other buffer: last read two barriers ago
+      __syncthreads();
+    }
+  } else {                                                // (host: qrep > 1 only with ntiles <= 2 -- both tiles are in LDS)
+    q0 += QW * NW;
+    PP_LOAD_Q();
+#pragma unroll
+    for (int t = 0; t < C::DT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[t][r] = 0.f;
+    m_run = -1.0e30f;
+    l_run = 0.f;
+    for (int t = 0; t < ntiles; ++t) PP_RUN_TILE(t);
   }
 
   // ---- epilogue: lane = query qi; rows (dcols) = dt*32 + (r&3) + 8 (r>>2) + 4 half
@@ -280,6 +305,9 @@ attn_fwd_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __restr
         }
       }
   }
+  }   // rep
+#undef PP_LOAD_Q
+#undef PP_RUN_TILE
 }
 
 // [rows = b*nk + t][cols] (row stride ld) -> vt[b][col][t] (row stride ldvt), pad columns t in [nk, ldvt) zeroed.
@@ -308,16 +336,31 @@ static int launch_attn(const void* q, int ldq, const void* k, int ldk, const voi
   constexpr int LDS = 2 * (Cfg<D>::KBYTES + Cfg<D>::VBYTES);
   static bool attr_set = false;
   if (!attr_set && LDS > 64 * 1024) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<D, EDT>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<D, EDT, false>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
       pp_set_last_error("hipFuncSetAttribute(attention)", hipGetLastError());
       return PP_ERR_LAUNCH;
     }
     attr_set = true;
   }
-  const dim3 grid((nq + QW * NW - 1) / (QW * NW), heads, batch), block(256);
-  hipLaunchKernelGGL((attn_fwd_kernel<D, EDT>), grid, block, LDS, st, (const uint16_t*)q, ldq, (const uint16_t*)k, ldk,
-                     (const uint16_t*)vt, ldvt, (uint16_t*)o, ldo, heads, nq, nk, sl2);
+  static_assert(D > 40 || LDS <= 64 * 1024, "the d = 40 kernels run with the default dynamic LDS limit");
+  // K / V reuse over query blocks (see the kernel): only where the keys fit the two LDS buffers and the launch would
+  // otherwise be >= 4 rounds of workgroups (two 4-wave workgroups per CU).  PP_ATTN_QREP=1|2 forces it (A/B, tests).
+  static const int qrep_env = [] { const char* e = getenv("PP_ATTN_QREP"); return e ? atoi(e) : 0; }();
+  const long long wgs = (long long)((nq + QW * NW - 1) / (QW * NW)) * heads * batch;
+  int qrep = (D == 40 && nk <= 2 * KB && wgs >= 2048) ? 2 : 1;
+  if (D == 40 && (qrep_env == 1 || qrep_env == 2)) qrep = (nk <= 2 * KB) ? qrep_env : 1;
+  const dim3 grid((nq + QW * NW * qrep - 1) / (QW * NW * qrep), heads, batch), block(256);
+  if constexpr (D == 40) {
+    if (qrep > 1) {
+      hipLaunchKernelGGL((attn_fwd_kernel<D, EDT, true>), grid, block, LDS, st, (const uint16_t*)q, ldq, (const uint16_t*)k,
+                         ldk, (const uint16_t*)vt, ldvt, (uint16_t*)o, ldo, heads, nq, nk, sl2, qrep);
+      PP_CHECK_LAUNCH("attn_fwd_kernel");
+      return PP_OK;
+    }
+  }
+  hipLaunchKernelGGL((attn_fwd_kernel<D, EDT, false>), grid, block, LDS, st, (const uint16_t*)q, ldq, (const uint16_t*)k,
+                     ldk, (const uint16_t*)vt, ldvt, (uint16_t*)o, ldo, heads, nq, nk, sl2, 1);
   PP_CHECK_LAUNCH("attn_fwd_kernel");
   return PP_OK;
 }
