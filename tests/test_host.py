@@ -108,6 +108,28 @@ def test_guess_mode_output_layout_of_the_side_networks():
         NetRuntime(net, "cpu").ensure(2, 16, 16, 77, 4, ("plain",), pad_uncond=True)
 
 
+def test_conv_in_is_packed_for_the_implicit_gemm_over_a_padded_input():
+    """conv_in (4 / 9 input channels) runs on the implicit-GEMM kernel: weights [Cout][tap][64] with zeros in the pad
+    channels, the network input buffer 64 channels wide, no direct-conv launch in the plan."""
+    torch.manual_seed(0)
+    o = OM.UNet2DConditionModel(in_channels=9, **TINY)
+    net = SDNet("unet", 9, **TINY).load_state_dict(o.state_dict(), "cpu")
+    assert (net.cin0, net.cin_pad) == (9, 64)
+    w = net.params.tensor("conv_in.weight")
+    assert w.shape == (320, 9 * 64) and w.dtype == torch.bfloat16
+    w = w.view(320, 3, 3, 64)
+    assert torch.equal(w[..., :9], o.conv_in.weight.permute(0, 2, 3, 1).to(torch.bfloat16))
+    assert torch.count_nonzero(w[..., 9:]) == 0
+    rt = NetRuntime(net, "cpu")
+    rt.ensure(2, 16, 16, 77, 9, ("plain",))
+    assert rt.lay["x_in"].C == 64
+    first = next(a for a in rt.step_plan.keep if a.x_mode == 1)
+    assert (first.c1, first.N, first.K, first.M) == (64, 320, 9 * 64, 2 * 16 * 16) and first.x1 == rt.lay["x_in"].ptr
+    assert first.gn_acc[0]                                    # ... and its epilogue carries resnets.0.norm1's statistics
+    with pytest.raises(Exception):
+        rt.ensure(2, 16, 16, 77, 4, ("plain",))               # a 4-channel input for the 9-channel network
+
+
 def test_geglu_interleave_is_a_row_permutation():
     w = torch.arange(16 * 3, dtype=torch.float32).reshape(16, 3)
     p = _geglu_interleave(w)
