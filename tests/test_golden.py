@@ -457,3 +457,39 @@ def test_hip_pipeline_reproduces_the_reference_call_with_eta():
     out = pipe(image=img, mask=mask, latents=lat.cuda(), generator=torch.Generator().manual_seed(5), output_type="latent",
                return_dict=False, **M.CALL)[0]
     _close_latents(out, gold0["latents"], "v1 pipeline, eta back to 0")
+
+
+def test_product_prepare_latents_for_strength_matches_the_reference_draw_order():
+    """CPU half of the `strength < 1` path: the product's `get_timesteps` + `_initial_latents` over the oracle VAE (duck
+    typed) reproduce the initial latents the reference's `prepare_latents` built inside the frozen call -- posterior
+    sample of the init image first, then the noise, `scheduler.add_noise` at the first timestep of the shortened schedule
+    -- and leave the generator where the reference leaves it (the masked image's posterior sample comes next)."""
+    from oracle import schedulers as OS
+    from powerpaint_amd import schedulers as PS
+    from powerpaint_amd.pipelines._base import PipelineBase
+    import make_ref_pipeline_call as M
+    _, _, _, vae = M.components()
+    img, mask, _ = M.inputs()
+    c = M.CALL_STRENGTH
+    pb = PipelineBase.__new__(PipelineBase)
+    pb.vae, pb.scheduler = vae, PS.DPMSolverMultistepScheduler(**M.DPM_SD15)
+    pb.scheduler.set_timesteps(c["num_inference_steps"])
+    ts, n = pb.get_timesteps(c["num_inference_steps"], c["strength"], "cpu")
+    assert (n, ts.tolist(), pb.scheduler.begin_index) == (3, [499, 333, 167], 2)
+    g = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        lat = pb._initial_latents((1, 4, 16, 16), c["strength"], ts, None, img, g, "cpu", torch.float32)
+        after = torch.randn(3, generator=g)
+        # the reference's own sequence on the oracle parts
+        g2 = torch.Generator().manual_seed(5)
+        il = vae.encode(img).latent_dist.sample(g2) * vae.config.scaling_factor
+        noise = torch.randn(1, 4, 16, 16, generator=g2)
+        o = OS.DPMSolverMultistepScheduler(**M.DPM_SD15)
+        o.set_timesteps(c["num_inference_steps"])
+        ref = o.add_noise(il, noise, o.timesteps[2:3])
+    assert torch.allclose(lat, ref, atol=1e-5, rtol=1e-5) and torch.equal(after, torch.randn(3, generator=g2))
+    # latents handed in: the reference treats them as the noise whatever the strength (:646-648)
+    given = torch.randn(1, 4, 16, 16)
+    assert torch.equal(pb._initial_latents((1, 4, 16, 16), 0.6, ts, given, img, g, "cpu", torch.float32), given)
+    with pytest.raises(ValueError):
+        pb._initial_latents((1, 4, 16, 16), 0.6, ts, None, None, g, "cpu", torch.float32)
