@@ -387,3 +387,23 @@ def test_check_inputs_error_behaviour_matches_reference():
         assert got == want, (p, h, w, s, cb, ng, pe, ne, got, want)
         n_ok += got == "ok"
     assert 0 < n_ok < len(rows)
+
+
+def test_retrieve_timesteps_follows_the_reference():
+    """pipeline_PowerPaint_Brushnet_CA.py:87-128: a custom list reaches schedulers whose `set_timesteps` names
+    `timesteps`; the four fused schedulers (like diffusers 0.27's) do not -> the reference's ValueError."""
+    from powerpaint_amd import schedulers as PS
+    from powerpaint_amd.pipelines.pipeline_PowerPaint_Brushnet_CA import retrieve_timesteps
+    for cls in (PS.DDIMScheduler, PS.DPMSolverMultistepScheduler, PS.PNDMScheduler, PS.UniPCMultistepScheduler):
+        s = cls()
+        ts, n = retrieve_timesteps(s, 5, None)
+        assert n == 5 and len(ts) == len(s.timesteps)
+        with pytest.raises(ValueError, match="does not support custom"):
+            retrieve_timesteps(s, None, None, timesteps=[999, 500, 1])
+
+    class Custom:
+        def set_timesteps(self, num_inference_steps=None, device=None, timesteps=None):
+            self.timesteps = torch.tensor(timesteps)
+
+    ts, n = retrieve_timesteps(Custom(), None, None, timesteps=[9, 5, 1])
+    assert n == 3 and ts.tolist() == [9, 5, 1]
