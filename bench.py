@@ -145,14 +145,56 @@ def roofline_pass(pipe):
     return per, flops, counts, alg_bytes, hbm_bytes
 
 
-TRAFFIC_PROFILE = "profiles/r02_hbm_traffic.json"         # tools/hbm_traffic.sh (two rocprofv3 --pmc passes of this bench)
-KERNEL_STATS_PROFILE = "profiles/r02_kernel_stats.txt"     # rocprofv3 --kernel-trace --stats of this bench (tools/gpu_round.sh)
+TRAFFIC_PROFILE = "profiles/r03_hbm_traffic.json"         # tools/hbm_traffic.sh (two rocprofv3 --pmc passes of this bench)
+KERNEL_STATS_PROFILE = "profiles/r03_kernel_stats.txt"     # rocprofv3 --kernel-trace --stats of this bench (tools/gpu_round.sh)
+
+
+def lib_sha16() -> str:
+    """sha256 prefix of the libpp_hip.so this process runs: a committed profile names the build it was taken from."""
+    import hashlib
+    from powerpaint_amd import _lib as L
+    try:
+        return hashlib.sha256(open(L.LIB_PATH, "rb").read()).hexdigest()[:16]
+    except OSError:
+        return ""
+
+
+def family_replay_us(pipe, names, reps: int = 20):
+    """LIVE kernel time of one launch family: the family's launches of the step program (C-ABI calls, i.e. a split-K
+    GEMM together with its combine launch) are captured into a hipGraph of their own and that graph is replayed `reps`
+    times between ONE HIP event pair on the launch stream.  No event sits between kernels, nothing is subtracted:
+    (elapsed / reps) is the wall time the device spends on the family, launch boundaries included, with each launch
+    reading the arena addresses and weights it reads in the real step.  Returns (us per replay, number of launches)."""
+    from powerpaint_amd.engine import Plan
+    loop = pipe._loop
+    sub = Plan()
+    sub.calls = [c for c in loop.program.calls if c[2] in names]
+    if not sub.calls:
+        return None, 0
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        sub.run(side.cuda_stream)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        sub.run(torch.cuda.current_stream().cuda_stream)
+    g.replay()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e3, len(sub.calls)
 
 
 def measured_traffic():
     """HBM bytes per 3x3 implicit-GEMM launch from the committed PMC passes (two rocprofv3 --pmc runs of this benchmark
     cannot happen inside this process).  None if the profile is absent."""
-    for rel in (TRAFFIC_PROFILE, "profiles/r01_hbm_traffic.json"):
+    for rel in (TRAFFIC_PROFILE, "profiles/r02_hbm_traffic.json"):
         try:
             fam = json.load(open(os.path.join(ROOT, rel)))["families"]["conv3x3 implicit GEMM"]
             return fam["bytes_per_launch"], rel
@@ -162,19 +204,26 @@ def measured_traffic():
 
 
 def profiled_conv_launch_us():
-    """Average duration of the implicit-GEMM 3x3 kernels (template argument XMODE = 1 of pp_gemm_kernel_v2) in the
-    committed rocprofv3 --stats summary of this benchmark: the kernel-only time base of `roofline`."""
+    """Average duration of the implicit-GEMM 3x3 kernels (template argument XMODE = 1 of pp_gemm_kernel_v2, plus the
+    split-K combine launches that finish them) in the committed rocprofv3 --stats summary of this benchmark, and the
+    build that summary was taken from (`# lib_sha16:` header line).  -> (us per conv launch, lib sha) or (None, None)."""
     import re
-    try:
-        calls, total_ms = 0, 0.0
-        for line in open(os.path.join(ROOT, KERNEL_STATS_PROFILE)):
-            m = re.match(r"\s*(\d+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+.*pp_gemm_kernel_v2<\d+, 160, \d, 2, 1,", line)
-            if m:
-                calls += int(m.group(1))
-                total_ms += float(m.group(2))
-        return (total_ms / calls * 1e3) if calls else None
-    except Exception:
-        return None
+    for rel in (KERNEL_STATS_PROFILE, "profiles/r02_kernel_stats.txt"):
+        try:
+            calls, total_ms, sha = 0, 0.0, None
+            for line in open(os.path.join(ROOT, rel)):
+                m = re.match(r"#\s*lib_sha16:\s*(\w+)", line)
+                if m:
+                    sha = m.group(1)
+                m = re.match(r"\s*(\d+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+.*pp_gemm_kernel_v2<\d+, 160, \d, 2, 1,", line)
+                if m:
+                    calls += int(m.group(1))
+                    total_ms += float(m.group(2))
+            if calls:
+                return total_ms / calls * 1e3, sha, rel
+        except Exception:
+            continue
+    return None, None, None
 
 
 def cpu_baseline(budget_s: float = 40.0):
@@ -250,35 +299,69 @@ HBM_PEAK_GBS = 6290.0            # measured float4 copy, /opt/skills/guides/MI35
 
 
 def roofline_report(pipe, dump_launches=None, peak=MFMA_PEAK_TFLOPS, profile_matches=True) -> dict:
-    """`roofline` (dominant kernel = the implicit-GEMM 3x3 convolution launches of pp_gemm_kernel_v2) with BOTH time
-    bases: `frac_event` from a HIP event pair around every launch of one eager replay of the step program (includes the
-    launch gap), `frac_kernel` from the committed rocprofv3 --stats summary of this command (kernel-only average of the
-    XMODE = 1 instantiations; `frac` = that when the profile is present).  Plus per-kernel tables and the HBM-bound
-    kernels' GB/s against the measured 6.29 TB/s."""
+    """`roofline` of the dominant kernel family (the implicit-GEMM 3x3 convolution launches of pp_gemm_kernel_v2 with
+    their split-K combines).  `achieved` / `frac` are a LIVE measurement of this run: the family's launches replayed as
+    their own hipGraph between one HIP event pair (`family_replay_us`).  Next to it: `frac_event` (an event pair around
+    every launch of an eager step: includes the eager launch gap) and `frac_profile` (kernel-only average of the
+    committed rocprofv3 --stats summary, valid only for the build named in that file).  `hbm_roofline`: the plain
+    linear / 1x1 launches (K <= 1280, below the MFMA ridge) and the GroupNorm apply against the measured 6.29 TB/s."""
+    from powerpaint_amd import _lib as L
     per, flops, counts, alg_bytes, hbm_bytes = roofline_pass(pipe)
     k = "conv3x3"
     ach_event = flops[k] / 1e12 / (per[k] * 1e-3)
-    prof_us = profiled_conv_launch_us() if profile_matches else None     # (the committed trace is of the headline command)
-    ach_kernel = (flops[k] / counts[k]) / (prof_us * 1e-6) / 1e12 if prof_us else None
+    live_us, n_live = family_replay_us(pipe, ("conv3x3",))
+    ach_live = flops[k] / 1e12 / (live_us * 1e-6)
+    prof_us, prof_sha, prof_src = profiled_conv_launch_us() if profile_matches else (None, None, None)
+    ach_prof = (flops[k] / counts[k]) / (prof_us * 1e-6) / 1e12 if prof_us else None
     traffic, traffic_src = measured_traffic() if profile_matches else (None, None)
-    ach = ach_kernel if ach_kernel else ach_event
-    out = {"roofline": {"bound": "mfma", "kernel": "pp_gemm_kernel_v2<...,XMODE=1,...> (implicit-GEMM 3x3 conv)",
-                        "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+    sha = lib_sha16()
+    out = {"roofline": {"bound": "mfma", "kernel": "pp_gemm_kernel_v2<...,XMODE=1,...> (implicit-GEMM 3x3 conv) + split-K combines",
+                        "achieved": ach_live, "peak": peak, "unit": "TFLOP/s", "frac": ach_live / peak,
+                        "time_base": "live: the family's launches replayed as their own hipGraph between one HIP event "
+                                     "pair in this run (launch boundaries and split-K combines included)",
+                        "avg_launch_us": live_us / n_live,
                         "achieved_event": ach_event, "frac_event": ach_event / peak,
-                        "achieved_kernel": ach_kernel, "frac_kernel": (ach_kernel / peak) if ach_kernel else None,
-                        "kernel_time_source": KERNEL_STATS_PROFILE if prof_us else None,
-                        "avg_launch_us_kernel": prof_us, "avg_launch_us_event": per[k] / counts[k] * 1e3,
+                        "avg_launch_us_event": per[k] / counts[k] * 1e3,
+                        "frac_profile": (ach_prof / peak) if ach_prof else None, "avg_launch_us_profile": prof_us,
+                        "profile_source": prof_src, "profile_lib_sha16": prof_sha, "lib_sha16": sha,
+                        "profile_is_this_build": bool(prof_sha) and prof_sha == sha,
                         "traffic": traffic, "traffic_unit": "bytes / launch (2 x FETCH_SIZE + WRITE_SIZE)",
                         "traffic_source": traffic_src,
                         "launches_per_step": counts[k], "alg_flop_per_launch": flops[k] / counts[k],
-                        "alg_bytes_per_launch": alg_bytes / counts[k]},
-           "hbm_kernels": {n: {"GB_per_s": round(b / (per[n] * 1e-3) / 1e9, 1),
-                               "frac_of_measured_peak": round(b / (per[n] * 1e-3) / 1e9 / HBM_PEAK_GBS, 3),
-                               "alg_MB_per_step": round(b / 1e6, 1), "launches": counts[n]}
-                           for n, b in hbm_bytes.items() if per.get(n)},
-           "per_kernel_ms_per_denoise_step": {n: round(v, 4) for n, v in sorted(per.items(), key=lambda kv: -kv[1])},
-           "per_kernel_tflops": {n: round(flops[n] / 1e12 / (per[n] * 1e-3), 1) for n in flops if per.get(n)},
-           "launches_per_denoise_step": len(pipe._loop.program.calls)}
+                        "alg_bytes_per_launch": alg_bytes / counts[k]}}
+    # ---- HBM-side families, live
+    hbm = {}
+    lin_bytes, lin_n = 0.0, 0
+    for fn, args, name in pipe._loop.program.calls:
+        a = getattr(args[0], "_obj", None) if args else None
+        if name in ("linear", "conv1x1") and isinstance(a, L.PPGemmArgs):
+            # algorithmic bytes: X once, W once, output once, residual operands once (16-bit), row moments ignored
+            out_cols = a.N
+            lin_bytes += 2.0 * a.M * a.K + 2.0 * a.N * a.K + 2.0 * a.M * out_cols
+            lin_bytes += (2.0 * a.M * a.N if a.res1 else 0.0) + (2.0 * a.M * a.N if a.res2 else 0.0)
+            lin_n += 1
+    for fam, names, nbytes in (("linear + conv1x1 (plain GEMMs)", ("linear", "conv1x1"), lin_bytes),
+                               ("groupnorm_apply", ("groupnorm_apply",), hbm_bytes.get("groupnorm_apply", 0.0))):
+        us, n = family_replay_us(pipe, names)
+        if us:
+            gbs = nbytes / (us * 1e-6) / 1e9
+            hbm[fam] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(gbs / HBM_PEAK_GBS, 4), "launches": n, "avg_launch_us": round(us / n, 2),
+                        "alg_MB_per_step": round(nbytes / 1e6, 1), "time_base": "live hipGraph replay of the family"}
+            if fam.startswith("linear"):
+                fl = flops.get("linear", 0.0) + flops.get("conv1x1", 0.0)
+                hbm[fam]["tflops"] = round(fl / 1e12 / (us * 1e-6), 1)
+    out["hbm_roofline"] = hbm
+    fam_us = {}
+    for fam in ("attention", "linear_geglu"):
+        us, n = family_replay_us(pipe, (fam,))
+        if us:
+            fam_us[fam] = {"us_per_step": round(us, 1), "launches": n,
+                           "tflops": round(flops.get(fam, 0.0) / 1e12 / (us * 1e-6), 1)}
+    out["mfma_families_live"] = fam_us
+    out["per_kernel_ms_per_denoise_step"] = {n: round(v, 4) for n, v in sorted(per.items(), key=lambda kv: -kv[1])}
+    out["per_kernel_tflops"] = {n: round(flops[n] / 1e12 / (per[n] * 1e-3), 1) for n in flops if per.get(n)}
+    out["launches_per_denoise_step"] = len(pipe._loop.program.calls)
     if dump_launches:
         prog = pipe._loop.program
         json.dump([{"i": i, "what": prog.describe(i), "ms": prog.last_launch_ms[i]}
@@ -302,16 +385,24 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--dump-launches", default=None, help="write per-launch HIP-event timings of one step (JSON)")
+    ap.add_argument("--dist-timeout", type=float, default=180.0,
+                    help="N > 1: seconds the RCCL rendezvous / first all-reduce / weight broadcast may take before the "
+                         "rank exits with a message naming the stuck stage (0 = wait forever)")
     args = ap.parse_args()
 
-    rank, world, local = ppdist.init_from_env()
+    rank, world, local = ppdist.init_from_env(timeout_s=args.dist_timeout)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N > 1")
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
 
     dtype = torch.float16 if args.dtype == "fp16" else torch.bfloat16
-    pipe, nets, bcast_s = build_pipeline(args.config, device, rank, world, dtype=dtype, scheduler=args.scheduler)
+    with ppdist.Watchdog(args.dist_timeout if world > 1 else 0.0, "weight broadcast (build_pipeline)"):
+        pipe, nets, bcast_s = build_pipeline(args.config, device, rank, world, dtype=dtype, scheduler=args.scheduler)
+    rank_log = ppdist.gather_strings(f"rank {rank}: {ppdist.device_identity(local)}; weight_broadcast_s {bcast_s:.3f}")
+    if rank == 0 and world > 1:
+        for line in rank_log:
+            print(line, file=sys.stderr, flush=True)
     pipe.use_graph = not args.no_graph
     kw = synthetic_inputs(args.config, device, rank, args.per_gpu, args.latent, args.denoise_steps)
     sched_name = {"ddim": "DDIM", "dpm": "DPMSolver++", "pndm": "PNDM", "unipc": "UniPC"}[
@@ -356,7 +447,7 @@ def main():
                        "global_batch": args.per_gpu * world, "latent": [4, args.latent, args.latent],
                        "denoise_steps": args.denoise_steps, "network_evaluations": unet_steps, "parallelism": f"dp{world} (image shards, no step collectives)",
                        "hipgraph": not args.no_graph, "weights": "random init (no checkpoints offline)",
-                       "weight_broadcast_s": round(bcast_s, 4)},
+                       "weight_broadcast_s": round(bcast_s, 4), "ranks": rank_log},
             "ms_per_denoise_step": ms_denoise_step,
             "unet_step_mfma_util": tflop_step / (ms_denoise_step * 1e-3) / MFMA_PEAK_TFLOPS,
         }

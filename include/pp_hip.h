@@ -29,7 +29,7 @@ extern "C" {
 #define PP_ERR_LAUNCH (-3)       /* hipLaunchKernel / hipFuncSetAttribute failed                  */
 #define PP_ERR_WORKSPACE (-4)    /* workspace pointer null or too small                           */
 
-#define PP_ABI_VERSION 7
+#define PP_ABI_VERSION 8
 /* 16-bit storage format of activations and matrix weights ("dtype" arguments; the same codes pp_nchw_to_nhwc uses for
  * its source): bf16 or fp16 -- the reference's default is fp16 (/root/reference/app.py:548,559).  MFMA accumulation,
  * norm statistics, softmax, biases and latents are fp32 with either. */
@@ -197,6 +197,20 @@ int pp_layernorm(const void* x, int rows, int C, const float* gamma, const float
  */
 int pp_attention_fwd(const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt, void* o, int ldo,
                      int batch, int heads, int nq, int nk, int d, float scale, int dtype, void* stream);
+/* The same op with the kernel named explicitly (since ABI v8; op-level parity tests address every shipping kernel,
+ * the pipelines use PP_ATTN_AUTO = what pp_attention_fwd picks):
+ *   PP_ATTN_PHASED   attn_fwd_kernel   (three-phase, every head dim / key count)
+ *   PP_ATTN_PIPE_Q32 attn_pipe_kernel  (software-pipelined, 32 queries per wave, 64-key tiles; d = 40, nk % 64 == 0, nk >= 256)
+ *   PP_ATTN_PIPE_Q64 attn_pipe_kernel  (64 queries per wave on 32-key tiles; same shapes; AUTO takes it when
+ *                                       batch * heads * ceil(nq / 256) >= 512, i.e. the 64x64 and 128x128 latents)
+ * A named kernel that does not cover the shape returns PP_ERR_UNSUPPORTED. */
+#define PP_ATTN_AUTO 0
+#define PP_ATTN_PHASED 1
+#define PP_ATTN_PIPE_Q32 2
+#define PP_ATTN_PIPE_Q64 3
+int pp_attention_fwd_variant(const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt, void* o, int ldo,
+                             int batch, int heads, int nq, int nk, int d, float scale, int dtype, int variant,
+                             void* stream);
 /* [rows = b*nk + t][cols] bf16 (row stride ld) -> vt[b][col][t] (row stride ldvt).  Used for the cross-attention V
  * (computed once per call: encoder_hidden_states are step-invariant) and as the unfused fallback for self-attention. */
 int pp_transpose_v(const void* v, int ld, int batch, int nk, int cols, void* vt, int ldvt, void* stream);

@@ -109,8 +109,14 @@ class Attention(nn.Module):
         q = self.to_q(x).view(B, N, self.heads, -1).transpose(1, 2)
         k = self.to_k(c).view(B, c.shape[1], self.heads, -1).transpose(1, 2)
         v = self.to_v(c).view(B, c.shape[1], self.heads, -1).transpose(1, 2)
-        s = torch.matmul(q, k.transpose(-1, -2)) / math.sqrt(q.shape[-1])
-        o = torch.matmul(torch.softmax(s, dim=-1), v)
+        # softmax is row-wise, so evaluating it per block of queries is the same arithmetic per row; it only keeps the
+        # score matrix of the 16384-token self-attention (BASELINE config 5: 2 x 8 x 16384^2 fp32 = 17 GB) out of RAM
+        step = N if N * c.shape[1] <= (1 << 24) else max(1, (1 << 24) // c.shape[1])
+        outs = []
+        for i in range(0, N, step):
+            s = torch.matmul(q[:, :, i:i + step], k.transpose(-1, -2)) / math.sqrt(q.shape[-1])
+            outs.append(torch.matmul(torch.softmax(s, dim=-1), v))
+        o = outs[0] if len(outs) == 1 else torch.cat(outs, 2)
         o = o.transpose(1, 2).reshape(B, N, -1)
         return self.to_out[0](o)
 

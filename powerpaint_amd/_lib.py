@@ -13,6 +13,8 @@ PP_X_PLAIN, PP_X_CONV3X3 = 0, 1
 PP_ACT_NONE, PP_ACT_GEGLU, PP_ACT_SILU = 0, 1, 2
 PP_TILE_AUTO, PP_TILE_128x160, PP_TILE_64x160, PP_TILE_256x160 = 0, 1, 2, 3
 PP_DT_F32, PP_DT_BF16, PP_DT_F16 = 0, 1, 2      # dtype codes of the C ABI (include/pp_hip.h)
+PP_ATTN_AUTO, PP_ATTN_PHASED, PP_ATTN_PIPE_Q32, PP_ATTN_PIPE_Q64 = 0, 1, 2, 3   # pp_attention_fwd_variant
+ABI_VERSION = 8                                  # PP_ABI_VERSION of include/pp_hip.h this binding was written against
 PP_ERR = {0: "PP_OK", -1: "PP_ERR_BAD_ARG", -2: "PP_ERR_UNSUPPORTED", -3: "PP_ERR_LAUNCH", -4: "PP_ERR_WORKSPACE"}
 
 vp, i32, f32, sz = C.c_void_p, C.c_int32, C.c_float, C.c_size_t
@@ -64,6 +66,8 @@ SIGNATURES = {
     "pp_layernorm": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, f32, vp, C.c_int, vp]),
     "pp_attention_fwd": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_int, C.c_int, f32, C.c_int, vp]),
+    "pp_attention_fwd_variant": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int,
+                                           C.c_int, C.c_int, f32, C.c_int, C.c_int, vp]),
     "pp_transpose_v": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp]),
     "pp_conv3x3_direct": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, vp,
                                     vp, C.c_int, vp]),
@@ -98,7 +102,7 @@ def lib():
             fn = getattr(l, name)
             fn.restype = res
             fn.argtypes = args
-        if l.pp_abi_version() != 7:
+        if l.pp_abi_version() != ABI_VERSION:
             raise PPError("libpp_hip.so ABI version mismatch")
         _lib = l
     return _lib

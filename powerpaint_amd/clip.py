@@ -67,6 +67,9 @@ class CLIPTextNet:
         x = pb.alloc(rows * Cc * 2)
         for b in range(B):                                   # + position embedding (rows 0..n-1 of the table)
             pb.add(x_in + b * n * Cc * 2, P["pos"], x + b * n * Cc * 2, n * Cc)
+        # transformers' `hidden_states`: the embeddings and every layer's output BEFORE final_layer_norm; all of them
+        # are persistent arena tensors, so `output_hidden_states=True` (clip_skip) costs nothing extra
+        self.hidden = [x]
         for i in range(self.n_layers):
             p = f"encoder.layers.{i}"
             nxt = pb.alloc(rows * Cc * 2)
@@ -84,6 +87,7 @@ class CLIPTextNet:
             pb.linear(f, rows, self.F, P[f"{p}.fc2.weight"], Cc, P[f"{p}.fc2.bias"], res1=mid, out=nxt, name="linear")
             pb.release(m)
             x = nxt
+            self.hidden.append(x)
         return pb.layernorm(x, rows, Cc, P["final_layer_norm.weight"], P["final_layer_norm.bias"], self.eps)
 
 
@@ -107,7 +111,14 @@ class CLIPRuntime:
         self._build(dry, B, n)
         self.arena = Arena(_align(dry.peak, 4096), self.device)
         self.x_in, self.out, self.plan = self._build(self.arena, B, n)
+        self.hidden = list(self.net.hidden)
         self.key = (B, n)
+
+    def hidden_states(self):
+        """transformers' `hidden_states` of the last `run` (embeddings + one tensor per layer, pre final_layer_norm), as
+        copies (the arena is overwritten by the next call)."""
+        B, n = self.key
+        return tuple(self.arena.view(p, (B, n, self.net.C), torch.bfloat16).clone() for p in self.hidden)
 
     def run(self, tok_emb: torch.Tensor) -> torch.Tensor:
         """tok_emb [B, n, C] (any float dtype, on the device) -> last_hidden_state [B, n, C] bf16 (arena view)."""

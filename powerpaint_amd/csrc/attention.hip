@@ -346,7 +346,7 @@ static int launch_attn(const void* q, int ldq, const void* k, int ldk, const voi
   static_assert(D > 40 || LDS <= 64 * 1024, "the d = 40 kernels run with the default dynamic LDS limit");
   // K / V reuse over query blocks (see the kernel): only where the keys fit the two LDS buffers and the launch would
   // otherwise be >= 4 rounds of workgroups (two 4-wave workgroups per CU).  PP_ATTN_QREP=1|2 forces it (A/B, tests).
-  static const int qrep_env = [] { const char* e = getenv("PP_ATTN_QREP"); return e ? atoi(e) : 0; }();
+  static const int qrep_env = pp_lab_env("PP_ATTN_QREP", 0);
   const long long wgs = (long long)((nq + QW * NW - 1) / (QW * NW)) * heads * batch;
   int qrep = (D == 40 && nk <= 2 * KB && wgs >= 2048) ? 2 : 1;
   if (D == 40 && (qrep_env == 1 || qrep_env == 2)) qrep = (nk <= 2 * KB) ? qrep_env : 1;
@@ -367,22 +367,22 @@ static int launch_attn(const void* q, int ldq, const void* k, int ldk, const voi
 
 // attention_pipe.hip: software-pipelined kernel for the hot self-attention shapes (PP_ERR_UNSUPPORTED otherwise)
 int pp_attention_pipe_launch(const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt, void* o, int ldo,
-                             int batch, int heads, int nq, int nk, int d, float sl2, int dtype, hipStream_t st);
+                             int batch, int heads, int nq, int nk, int d, float sl2, int dtype, int variant,
+                             hipStream_t st);
 
-extern "C" int pp_attention_fwd(const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt, void* o,
-                                int ldo, int batch, int heads, int nq, int nk, int d, float scale, int dtype,
-                                void* stream) {
+extern "C" int pp_attention_fwd_variant(const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt, void* o,
+                                        int ldo, int batch, int heads, int nq, int nk, int d, float scale, int dtype,
+                                        int variant, void* stream) {
   if (!q || !k || !vt || !o || batch <= 0 || heads <= 0 || nq <= 0 || nk <= 0 || !pp_dt_ok(dtype)) return PP_ERR_BAD_ARG;
   if (ldq % 8 || ldk % 8 || ldvt % 8 || ldo % 4 || ldvt < nk) return PP_ERR_BAD_ARG;
+  if (variant < PP_ATTN_AUTO || variant > PP_ATTN_PIPE_Q64) return PP_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)stream;
   const float sl2 = scale * 1.4426950408889634f;
-  static const bool use_pipe = [] {   // PP_ATTN_PIPE=0: A/B measurements against the three-phase kernel
-    const char* e = getenv("PP_ATTN_PIPE");
-    return !(e && e[0] == '0');
-  }();
+  bool use_pipe = variant != PP_ATTN_PHASED;
+  if (variant == PP_ATTN_AUTO && pp_lab_env("PP_ATTN_PIPE", 1) == 0) use_pipe = false;   // (lab: A/B against the phased kernel)
   if (use_pipe) {
-    const int rc = pp_attention_pipe_launch(q, ldq, k, ldk, vt, ldvt, o, ldo, batch, heads, nq, nk, d, sl2, dtype, st);
-    if (rc != PP_ERR_UNSUPPORTED) return rc;
+    const int rc = pp_attention_pipe_launch(q, ldq, k, ldk, vt, ldvt, o, ldo, batch, heads, nq, nk, d, sl2, dtype, variant, st);
+    if (rc != PP_ERR_UNSUPPORTED || variant != PP_ATTN_AUTO) return rc;
   }
   switch (d) {
     case 40: PP_DT_SWITCH(dtype, return (launch_attn<40, EDT>(q, ldq, k, ldk, vt, ldvt, o, ldo, batch, heads, nq, nk, sl2, st)));
@@ -390,6 +390,13 @@ extern "C" int pp_attention_fwd(const void* q, int ldq, const void* k, int ldk, 
     case 160: PP_DT_SWITCH(dtype, return (launch_attn<160, EDT>(q, ldq, k, ldk, vt, ldvt, o, ldo, batch, heads, nq, nk, sl2, st)));
     default: return PP_ERR_UNSUPPORTED;
   }
+}
+
+extern "C" int pp_attention_fwd(const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt, void* o,
+                                int ldo, int batch, int heads, int nq, int nk, int d, float scale, int dtype,
+                                void* stream) {
+  return pp_attention_fwd_variant(q, ldq, k, ldk, vt, ldvt, o, ldo, batch, heads, nq, nk, d, scale, dtype, PP_ATTN_AUTO,
+                                  stream);
 }
 
 extern "C" int pp_transpose_v(const void* v, int ld, int batch, int nk, int cols, void* vt, int ldvt, void* stream) {

@@ -403,39 +403,46 @@ static int launch_pipe(const void* q, int ldq, const void* k, int ldk, const voi
   return PP_OK;
 }
 
+// variant (PP_ATTN_* of pp_hip.h): AUTO picks by shape; PIPE_Q32 / PIPE_Q64 force the 32- / 64-queries-per-wave kernel
+// (PP_ERR_UNSUPPORTED when the shape is outside it) -- the parity tests address each shipping kernel by name.
 int pp_attention_pipe_launch(const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt, void* o, int ldo,
-                             int batch, int heads, int nq, int nk, int d, float sl2, int dtype, hipStream_t st) {
-  static const int kb = [] { const char* e = getenv("PP_ATTN_KB"); return e ? atoi(e) : 64; }();
-  static const int dbg = [] { const char* e = getenv("PP_ATTN_DBG"); return e ? atoi(e) : 0; }();
-  if (d != 40 || nk % kb != 0 || nk < 4 * kb) return PP_ERR_UNSUPPORTED;
+                             int batch, int heads, int nq, int nk, int d, float sl2, int dtype, int variant,
+                             hipStream_t st) {
 #define PP_ARGS q, ldq, k, ldk, vt, ldvt, o, ldo, batch, heads, nq, nk, sl2, st
-  static const int nw = [] { const char* e = getenv("PP_ATTN_NW"); return e ? atoi(e) : 4; }();   // experiment: 8
+  // both tile sizes need whole tiles and at least four of them (three look-ahead issues + the prologue)
+  if (d != 40 || nk % 64 != 0 || nk < 4 * 64) return PP_ERR_UNSUPPORTED;
+#ifdef PP_LAB
+  // timing experiments (tools/attn_ablate.py, tools/attn_pmc.sh): PP_ATTN_KB=32 32-key tiles at 4 workgroups per CU,
+  // PP_ATTN_NW=8 one 8-wave workgroup per CU, PP_ATTN_DBG ablation masks (results are garbage), PP_ATTN_QB=1|2
+  const int kb = pp_lab_env("PP_ATTN_KB", 64), dbg = pp_lab_env("PP_ATTN_DBG", 0), nw = pp_lab_env("PP_ATTN_NW", 4);
+  const int qbk = pp_lab_env("PP_ATTN_QB", 0);
+  if (variant == PP_ATTN_AUTO && qbk) variant = qbk == 2 ? PP_ATTN_PIPE_Q64 : PP_ATTN_PIPE_Q32;
+  if (dtype == PP_DT_BF16 && (kb != 64 || dbg != 0 || nw != 4)) {
+    if (nw == 8 && kb == 64 && dbg == 0) return launch_pipe<64, 0, PP_DT_BF16, 8>(PP_ARGS);
+    if (kb == 32) return launch_pipe<32, 0, PP_DT_BF16>(PP_ARGS);
+    if (kb != 64) return PP_ERR_BAD_ARG;
+    switch (dbg) {
+      case 1: return launch_pipe<64, 1, PP_DT_BF16>(PP_ARGS);
+      case 2: return launch_pipe<64, 2, PP_DT_BF16>(PP_ARGS);
+      case 4: return launch_pipe<64, 4, PP_DT_BF16>(PP_ARGS);
+      case 8: return launch_pipe<64, 8, PP_DT_BF16>(PP_ARGS);
+      case 12: return launch_pipe<64, 12, PP_DT_BF16>(PP_ARGS);
+      case 13: return launch_pipe<64, 13, PP_DT_BF16>(PP_ARGS);
+      case 15: return launch_pipe<64, 15, PP_DT_BF16>(PP_ARGS);
+      default: return PP_ERR_BAD_ARG;
+    }
+  }
+#endif
   // 64 queries per wave on 32-key tiles (QB = 2: every K / V^T fragment read from LDS feeds two MFMAs, half the tile DMAs
   // per query): 319 us against 338 us at N = 4096 hot, -0.5 % on the UNet step.  Needs two 256-query workgroups per CU
-  // to be worth it; PP_ATTN_QB=1|2 forces the choice.
-  static const int qbk = [] { const char* e = getenv("PP_ATTN_QB"); return e ? atoi(e) : 0; }();
+  // to be worth it.
   const long long wg2 = (long long)batch * heads * ((nq + 255) / 256);
-  if (dbg == 0 && kb == 64 && nw == 4 && (qbk == 2 || (qbk == 0 && wg2 >= 512))) {
+  const bool q64 = variant == PP_ATTN_PIPE_Q64 || (variant == PP_ATTN_AUTO && wg2 >= 512);
+  if (q64) {
     if (dtype == PP_DT_F16) return launch_pipe<32, 0, PP_DT_F16, 4, 2>(PP_ARGS);
     return launch_pipe<32, 0, PP_DT_BF16, 4, 2>(PP_ARGS);
   }
-  if (dtype == PP_DT_F16) {      // fp16: the shipping configuration only (the ablation variants are bf16 experiments)
-    if (kb != 64 || dbg != 0) return PP_ERR_UNSUPPORTED;
-    return launch_pipe<64, 0, PP_DT_F16>(PP_ARGS);
-  }
-  if (nw == 8 && kb == 64 && dbg == 0) return launch_pipe<64, 0, PP_DT_BF16, 8>(PP_ARGS);
-  if (kb == 32) return launch_pipe<32, 0, PP_DT_BF16>(PP_ARGS);
-  if (kb != 64) return PP_ERR_BAD_ARG;
-  switch (dbg) {
-    case 0: return launch_pipe<64, 0, PP_DT_BF16>(PP_ARGS);
-    case 1: return launch_pipe<64, 1, PP_DT_BF16>(PP_ARGS);
-    case 2: return launch_pipe<64, 2, PP_DT_BF16>(PP_ARGS);
-    case 4: return launch_pipe<64, 4, PP_DT_BF16>(PP_ARGS);
-    case 8: return launch_pipe<64, 8, PP_DT_BF16>(PP_ARGS);
-    case 12: return launch_pipe<64, 12, PP_DT_BF16>(PP_ARGS);
-    case 13: return launch_pipe<64, 13, PP_DT_BF16>(PP_ARGS);
-    case 15: return launch_pipe<64, 15, PP_DT_BF16>(PP_ARGS);
-    default: return PP_ERR_BAD_ARG;
-  }
+  if (dtype == PP_DT_F16) return launch_pipe<64, 0, PP_DT_F16>(PP_ARGS);
+  return launch_pipe<64, 0, PP_DT_BF16>(PP_ARGS);
 #undef PP_ARGS
 }

@@ -440,10 +440,12 @@ pp_gemm_kernel_v2(const PPGemmArgs a, const GemmDerived d) {   // 2nd bound = wa
   const int nkt = kt_end - kt_begin;
   // ablation switches (tools/gemm_ablate.py): 1 no refill, 2 no MFMA, 4 no epilogue, 8 no s_setprio.  The ping-pong loop
   // honours them only in a -DPP_GEMM_DBG build (seven branches per K step otherwise ride in its read phase).
-#ifdef PP_GEMM_DBG
+#if defined(PP_LAB) && defined(PP_GEMM_DBG)
   const int dbg = a.dbg;
-#else
+#elif defined(PP_LAB)
   const int dbg = PP ? 0 : a.dbg;
+#else
+  constexpr int dbg = 0;      // shipping build: one code path (PPGemmArgs.dbg is ignored)
 #endif
 
   // lane -> (row within the wave's 8-row strip, k-slot it must FETCH so that its lane-linear LDS position is swizzled)
@@ -1415,30 +1417,21 @@ int launch(const PPGemmArgs& a, int splitk, hipStream_t st) {
   return PP_OK;
 }
 
-// PP_GEMM_NMAJOR=0|1: A/B switch for the N-major tile order of small-M launches (default 1)
+// (lab build) PP_GEMM_NMAJOR=0|1: A/B switch for the N-major tile order of small-M launches (default 1)
 bool gemm_n_major() {
-  static const int v = [] {
-    const char* e = getenv("PP_GEMM_NMAJOR");
-    return e ? atoi(e) : 1;
-  }();
+  static const int v = pp_lab_env("PP_GEMM_NMAJOR", 1);
   return v != 0;
 }
 
-// PP_GEMM_PP=0|1: A/B switch for the ping-pong tiles in the automatic choice (default 1)
+// (lab build) PP_GEMM_PP=0|1: A/B switch for the ping-pong tiles in the automatic choice (default 1)
 bool gemm_pingpong() {
-  static const int v = [] {
-    const char* e = getenv("PP_GEMM_PP");
-    return e ? atoi(e) : 1;
-  }();
+  static const int v = pp_lab_env("PP_GEMM_PP", 1);
   return v != 0;
 }
 
-// PP_GEMM_DMAI=0|1: tile refills as one DMA burst after the barrier (0) or spread over the MFMA burst (1, default)
+// (lab build) PP_GEMM_DMAI=0|1: tile refills as one DMA burst after the barrier (0) or spread over the MFMA burst (1, default)
 bool gemm_dma_interleave() {
-  static const int v = [] {
-    const char* e = getenv("PP_GEMM_DMAI");
-    return e ? atoi(e) : 1;
-  }();
+  static const int v = pp_lab_env("PP_GEMM_DMAI", 1);
   return v != 0;
 }
 
@@ -1460,10 +1453,14 @@ int launch2(const PPGemmArgs& a, int splitk, hipStream_t st) {
   } else {
   static bool attr_set = false;
   // (2-stage pipelines need their single in-flight refill as early as possible: the spread costs them time)
+#ifdef PP_LAB
   auto kern = pp_gemm_kernel_v2<BM, BN, WM, WN, XMODE, NS, EPI, false, PP, EDT>;
   if constexpr (NS >= 3 && !PP) {
     if (gemm_dma_interleave()) kern = pp_gemm_kernel_v2<BM, BN, WM, WN, XMODE, NS, EPI, true, false, EDT>;
   }
+#else
+  auto kern = pp_gemm_kernel_v2<BM, BN, WM, WN, XMODE, NS, EPI, (NS >= 3 && !PP), PP, EDT>;
+#endif
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) !=
         hipSuccess) {

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "pp_hip.h"
 
@@ -108,6 +109,18 @@ PP_DEVINL float wave_max(float v) {
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
   return v;
 }
+
+// Lab switches.  The shipping library has ONE code path per op: environment-variable A/B switches, the ablation
+// instantiations of the kernels and the `dbg` fields exist only in a -DPP_LAB build (`make EXTRA=-DPP_LAB`, what the
+// measurement scripts under tools/ use).  pp_lab_env() is a compile-time constant otherwise.
+#ifdef PP_LAB
+inline int pp_lab_env(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+#else
+constexpr int pp_lab_env(const char*, int dflt) { return dflt; }
+#endif
 
 // Host-side error plumbing (pp_api.cpp)
 void pp_set_last_error(const char* what, hipError_t e);

@@ -14,8 +14,42 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
-    """(rank, world_size, local_rank); initialises torch.distributed when WORLD_SIZE > 1."""
+class Watchdog:
+    """`with Watchdog(seconds, what):` -- if the block has not finished after `seconds`, print a clear message naming
+    the stuck stage and the rank, and end the process (exit code 3).  A hung RCCL bootstrap or first collective (wrong
+    MASTER_ADDR, a peer that died, IPC handles refused) otherwise blocks every rank forever and the launcher's own
+    timeout says nothing about where.  seconds <= 0 disables it."""
+
+    def __init__(self, seconds: float, what: str):
+        self.seconds, self.what, self.timer = seconds, what, None
+
+    def _fire(self):
+        import sys
+        rank, world = os.environ.get("RANK", "0"), os.environ.get("WORLD_SIZE", "1")
+        sys.stderr.write(f"[powerpaint_amd.dist] rank {rank}/{world}: '{self.what}' did not finish within "
+                         f"{self.seconds:.0f} s -- giving up (MASTER_ADDR={os.environ.get('MASTER_ADDR')}, "
+                         f"MASTER_PORT={os.environ.get('MASTER_PORT')}, "
+                         f"HSA_ENABLE_IPC_MODE_LEGACY={os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')})\n")
+        sys.stderr.flush()
+        os._exit(3)
+
+    def __enter__(self):
+        if self.seconds and self.seconds > 0:
+            import threading
+            self.timer = threading.Timer(self.seconds, self._fire)
+            self.timer.daemon = True
+            self.timer.start()
+        return self
+
+    def __exit__(self, *exc):
+        if self.timer is not None:
+            self.timer.cancel()
+        return False
+
+
+def init_from_env(backend: Optional[str] = None, timeout_s: float = 0.0) -> Tuple[int, int, int]:
+    """(rank, world_size, local_rank); initialises torch.distributed when WORLD_SIZE > 1.  `timeout_s` > 0: the
+    rendezvous and a first 4-byte all-reduce must finish within that time or the process exits with a message."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -27,8 +61,42 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
             torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        kw = {}
+        if timeout_s and timeout_s > 0:
+            import datetime
+            kw["timeout"] = datetime.timedelta(seconds=float(timeout_s))
+        with Watchdog(timeout_s, f"torch.distributed init_process_group(backend={backend})"):
+            dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
+        with Watchdog(timeout_s, f"first all-reduce over {backend}"):
+            t = torch.ones(1, device=torch.device("cuda", local) if backend == "nccl" else "cpu")
+            dist.all_reduce(t)
+            if backend == "nccl":
+                torch.cuda.synchronize()
+            if int(t.item()) != world:
+                raise RuntimeError(f"first all-reduce returned {t.item()} on a world of {world}")
     return rank, world, local
+
+
+def device_identity(local: int) -> str:
+    """'name | pci <bus id> | <GB> GB' of this rank's GPU (bench.py logs it per rank for N > 1)."""
+    if not torch.cuda.is_available():
+        return "cpu"
+    p = torch.cuda.get_device_properties(local)
+    bus = ""
+    for attr in ("pci_bus_id", "pci_device_id", "pci_domain_id"):
+        if hasattr(p, attr):
+            bus += f"{attr.split('_')[1]}={getattr(p, attr)} "
+    uuid = getattr(p, "uuid", "")
+    return f"cuda:{local} {p.name} | pci {bus.strip() or '?'} | uuid {uuid} | {p.total_memory / 2 ** 30:.0f} GiB"
+
+
+def gather_strings(s: str) -> List[str]:
+    """Every rank's string on every rank (start-up logging)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return [s]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, s)
+    return out
 
 
 def shard_range(global_batch: int, rank: int, world: int) -> range:

@@ -28,8 +28,14 @@ def _align(x: int, a: int = ALIGN) -> int:
 
 
 # ------------------------------------------------------------------------------------------------------------------
-# PP_GN_EPILOGUE=0: every GroupNorm keeps its own statistics launch (A/B measurements, bisecting)
-GN_STATS_IN_EPILOGUE = os.environ.get("PP_GN_EPILOGUE", "1") != "0"
+def _lab_switch(name: str) -> bool:
+    """A/B switches of the launch-plan compiler (measurement scripts, bisecting).  They are honoured only when PP_LAB=1
+    is set as well: the product has one code path, and a stray PP_* variable in a user's environment changes nothing."""
+    return not (os.environ.get("PP_LAB") == "1" and os.environ.get(name, "1") == "0")
+
+
+# (lab) PP_GN_EPILOGUE=0: every GroupNorm keeps its own statistics launch
+GN_STATS_IN_EPILOGUE = _lab_switch("PP_GN_EPILOGUE")
 
 
 class Arena:
@@ -421,12 +427,12 @@ class SDNet:
     """
 
     # BasicTransformerBlock.norm1/2/3 folded into the GEMMs on either side (no LayerNorm launch, no normalised copy in
-    # HBM).  PP_FOLD_LN=0 keeps the stand-alone pp_layernorm launches (A/B measurements, bisecting).
-    fold_ln = os.environ.get("PP_FOLD_LN", "1") != "0"
-    # FeedForward.net[2] and Transformer2DModel.proj_out composed into one GEMM (PP_MERGE_FF2=0: two launches)
-    merge_ff2_proj_out = os.environ.get("PP_MERGE_FF2", "1") != "0"
-    # ResnetBlock2D.conv_shortcut merged into conv2 as a 1x1 K tail (needs 64-channel multiples; PP_MERGE_SHORTCUT=0 off)
-    _merge_shortcut_env = os.environ.get("PP_MERGE_SHORTCUT", "1") != "0"
+    # HBM).  (lab) PP_FOLD_LN=0 keeps the stand-alone pp_layernorm launches (A/B measurements, bisecting).
+    fold_ln = _lab_switch("PP_FOLD_LN")
+    # FeedForward.net[2] and Transformer2DModel.proj_out composed into one GEMM ((lab) PP_MERGE_FF2=0: two launches)
+    merge_ff2_proj_out = _lab_switch("PP_MERGE_FF2")
+    # ResnetBlock2D.conv_shortcut merged into conv2 as a 1x1 K tail (needs 64-channel multiples; (lab) PP_MERGE_SHORTCUT=0 off)
+    _merge_shortcut_env = _lab_switch("PP_MERGE_SHORTCUT")
 
     def __init__(self, kind: str, in_channels: int, block_out_channels=(320, 640, 1280, 1280), layers_per_block=2,
                  heads=8, cross_attention_dim=768, groups=32, eps=1e-5,

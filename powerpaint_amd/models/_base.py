@@ -81,6 +81,26 @@ class _HipModel(PretrainedMixin):
         return self._device
 
     def to(self, *a, **k):
+        """`.to(device)` / `.to(same dtype)` are no-ops (the packed parameter buffer lives on the device it was loaded
+        to, in the model's 16-bit format).  A DIFFERENT dtype or device cannot be honoured after packing and is refused:
+        silently ignoring `.to(torch.float16)` on a bf16 network would hand bf16 bits to an fp16 consumer."""
+        want_dtype = k.get("dtype")
+        want_dev = k.get("device")
+        for v in a:
+            if isinstance(v, torch.dtype):
+                want_dtype = v
+            elif isinstance(v, (str, torch.device)):
+                want_dev = v
+            elif torch.is_tensor(v):
+                want_dtype, want_dev = v.dtype, v.device
+        if want_dtype is not None and want_dtype != self._dtype:
+            raise L.PPError(f"{type(self).__name__}.to({want_dtype}): the network was packed as {self._dtype}; build it "
+                            f"with dtype={want_dtype} (from_pretrained(torch_dtype=...)) instead")
+        if want_dev is not None:
+            d = torch.device(want_dev)
+            if d.type != self._device.type or (d.index is not None and self._device.index is not None
+                                               and d.index != self._device.index):
+                raise L.PPError(f"{type(self).__name__}.to({d}): the packed parameters live on {self._device}")
         return self
 
     def eval(self):

@@ -59,12 +59,25 @@ class _Embeddings(nn.Module):
         self.position_embedding = nn.Embedding(npos, c)
 
 
+class _FinalLayerNorm(nn.LayerNorm):
+    """`text_encoder.text_model.final_layer_norm(hidden)` is called by `encode_prompt(clip_skip=...)`
+    (/root/reference/powerpaint/pipelines/pipeline_PowerPaint_Brushnet_CA.py:547-552): same parameters and state-dict keys
+    as nn.LayerNorm, the arithmetic is the HIP `pp_layernorm` kernel for 16-bit device tensors."""
+
+    def forward(self, x):
+        if x.is_cuda and x.dtype in (torch.bfloat16, torch.float16):
+            from .. import ops
+            x2 = x.reshape(-1, x.shape[-1]).contiguous()
+            return ops.layernorm(x2, self.weight.float(), self.bias.float(), self.eps).view(x.shape)
+        return super().forward(x)
+
+
 class _TextTransformer(nn.Module):
     def __init__(self, cfg):
         super().__init__()
         self.embeddings = _Embeddings(cfg.vocab_size, cfg.max_position_embeddings, cfg.hidden_size)
         self.encoder = _Encoder(cfg.num_hidden_layers, cfg.hidden_size, cfg.intermediate_size, cfg.layer_norm_eps)
-        self.final_layer_norm = nn.LayerNorm(cfg.hidden_size, eps=cfg.layer_norm_eps)
+        self.final_layer_norm = _FinalLayerNorm(cfg.hidden_size, eps=cfg.layer_norm_eps)
 
 
 class CLIPTextModel(nn.Module, PretrainedMixin):
@@ -134,8 +147,8 @@ class CLIPTextModel(nn.Module, PretrainedMixin):
         if attention_mask is not None and not bool(torch.all(attention_mask == 1)):
             raise NotImplementedError("attention_mask with padding holes is outside the PowerPaint path (the pipelines "
                                       "pass none: pipeline_PowerPaint.py:400-409)")
-        if position_ids is not None or output_attentions or output_hidden_states:
-            raise NotImplementedError("position_ids / output_attentions / output_hidden_states are not used by the pipelines")
+        if position_ids is not None or output_attentions:
+            raise NotImplementedError("position_ids / output_attentions are not used by the pipelines")
         ids = input_ids.reshape(-1, input_ids.shape[-1])
         if ids.shape[1] > self.config.max_position_embeddings:
             raise ValueError(f"Sequence length must be less than max_position_embeddings (got `sequence length`: "
@@ -149,6 +162,13 @@ class CLIPTextModel(nn.Module, PretrainedMixin):
         else:
             pos = (ids.to(torch.int) == self.config.eos_token_id).int().argmax(dim=-1)
         pooled = last[torch.arange(last.shape[0], device=last.device), pos.to(last.device)]
+        if output_hidden_states:
+            # (embeddings, layer 1, ..., layer N) before final_layer_norm, as transformers returns them:
+            # `encode_prompt(clip_skip=k)` takes [-(k + 1)] and applies text_model.final_layer_norm itself
+            hs = tuple(h.to(self.dtype) for h in self._rt.hidden_states())
+            if not return_dict:
+                return (last, pooled, hs)
+            return Output(last_hidden_state=last, pooler_output=pooled, hidden_states=hs)
         if not return_dict:
             return (last, pooled)
         return Output(last_hidden_state=last, pooler_output=pooled)

@@ -41,7 +41,10 @@ class UNet2DConditionModel(_HipModel):
     # ------------------------------------------------------------------
     def _wiring(self, down_add, mid_add, up_add, ctrl_down, ctrl_mid):
         def ptrs(lst):
-            return [getattr(t, "_pp_nhwc_ptr", 0) for t in lst]
+            # zero-copy hand-off of a side network's NHWC arena tensor -- only when it is stored in THIS network's 16-bit
+            # format (a bf16 BrushNet feeding an fp16 UNet would have its bits reinterpreted); any other tensor goes
+            # through `load_residual`, which converts
+            return [getattr(t, "_pp_nhwc_ptr", 0) if t.dtype == self._dtype else 0 for t in lst]
 
         if down_add is not None and mid_add is not None and up_add is not None:
             return ("brushnet", {"down": ptrs(down_add), "mid": ptrs([mid_add]), "up": ptrs(up_add)})

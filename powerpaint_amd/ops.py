@@ -174,13 +174,15 @@ def softmax_rows(s: torch.Tensor, scale: float = 1.0, dtype=torch.bfloat16):
 
 
 def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, batch: int, heads: int, nq: int, nk: int, d: int,
-              scale: Optional[float] = None):
+              scale: Optional[float] = None, variant: int = L.PP_ATTN_AUTO):
     """q [batch*nq, >=heads*d] / k [batch*nk, ...] row-major bf16 (row strides taken from the tensors);
-    vt [batch, heads*d, ldvt].  Returns o [batch*nq, heads*d]."""
+    vt [batch, heads*d, ldvt].  Returns o [batch*nq, heads*d].  `variant` names the kernel (L.PP_ATTN_*): AUTO is what
+    the pipelines run; a named kernel raises PP_ERR_UNSUPPORTED on a shape it does not cover."""
     o = torch.empty(batch * nq, heads * d, dtype=q.dtype, device=q.device)
-    L.check(L.lib().pp_attention_fwd(_p(q), q.stride(0), _p(k), k.stride(0), _p(vt), vt.stride(1), _p(o), heads * d,
-                                     batch, heads, nq, nk, d, scale if scale is not None else d ** -0.5,
-                                     L.dtype_code(q.dtype), _s()), "pp_attention_fwd")
+    L.check(L.lib().pp_attention_fwd_variant(_p(q), q.stride(0), _p(k), k.stride(0), _p(vt), vt.stride(1), _p(o),
+                                             heads * d, batch, heads, nq, nk, d,
+                                             scale if scale is not None else d ** -0.5, L.dtype_code(q.dtype),
+                                             int(variant), _s()), "pp_attention_fwd")
     return o
 
 

@@ -77,6 +77,11 @@ class DenoiseLoop:
         if guess_mode and self.side is not None and not self.side.config.global_pool_conditions:
             self._guess_ramp = [float(v) for v in torch.logspace(-1, 0, len(self.side.net._zero_conv_specs()))]
         Bs = B if half else Be
+        if self.side is not None and self.side.dtype != self.unet.dtype:
+            # the fused loop hands the side network's residuals to the UNet as raw NHWC arena pointers, every step: both
+            # must store activations in the same 16-bit format (the reference raises a dtype error in its first conv)
+            raise L.PPError(f"{type(self.side).__name__} computes in {self.side.dtype}, the UNet in {self.unet.dtype}: "
+                            f"load both with the same torch_dtype")
         if self.side is not None:
             if half and prompt_embeds_side.shape[0] == Be:
                 prompt_embeds_side = prompt_embeds_side.chunk(2)[1]
@@ -222,6 +227,16 @@ class DenoiseLoop:
         (pipeline_PowerPaint.py:1018-1023)."""
         sch = self.scheduler
         tl = timesteps if timesteps is not None else sch.timesteps
+        # The timestep table the captured program indexes holds exactly the timesteps this run steps through: with
+        # `strength < 1` the pipelines hand over `scheduler.timesteps[t_start:]` (get_timesteps,
+        # pipeline_PowerPaint.py:713-720), and the networks must see those -- not the head of the full schedule that
+        # `bind` uploaded -- while `scheduler.step` receives the same values below.
+        tsv = torch.as_tensor(tl).detach().to(self._f_ts.device, torch.float32).reshape(-1)
+        if tsv.numel() > self._f_ts.numel():
+            raise L.PPError(f"{tsv.numel()} timesteps for a loop bound to a schedule of {self._f_ts.numel()}")
+        if num_steps > tsv.numel():
+            raise L.PPError(f"{num_steps} steps requested, {tsv.numel()} timesteps given")
+        self._f_ts[:tsv.numel()].copy_(tsv)
         self._f_step.zero_()
         lat = latents.to(self.latents.device, torch.float32).clone()
         varying = scale_schedule is not None and len(set(scale_schedule)) > 1

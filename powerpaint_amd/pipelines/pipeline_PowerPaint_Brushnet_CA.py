@@ -48,6 +48,13 @@ class StableDiffusionPowerPaintBrushNetPipeline(PipelineBase):
         return self._guidance_scale
 
     @property
+    def clip_skip(self):
+        """pipeline_PowerPaint_Brushnet_CA.py:1005-1007,1227: `__call__` records its `clip_skip` argument here and, like the
+        reference, does NOT pass it on to `encode_prompt` (:1268-1277) -- only a direct `encode_prompt(clip_skip=k)` call
+        selects an earlier hidden state."""
+        return getattr(self, "_clip_skip", None)
+
+    @property
     def do_classifier_free_guidance(self):
         return self._guidance_scale > 1 and self.unet.config.time_cond_proj_dim is None
 
@@ -57,7 +64,18 @@ class StableDiffusionPowerPaintBrushNetPipeline(PipelineBase):
         if prompt_embeds is None:
             if self.text_encoder is None:
                 raise ValueError("no text encoder registered: pass prompt_embedsU / negative_prompt_embedsU")
-            prompt_embeds = self._text_embeds(self.text_encoder, prompt, device)
+            if clip_skip is None:
+                prompt_embeds = self._text_embeds(self.text_encoder, prompt, device)
+            else:
+                # :537-552 -- the hidden state `clip_skip` layers before the last, then the tower's final LayerNorm.
+                # (Only a direct `encode_prompt(clip_skip=...)` call gets here: the reference's `__call__` stores its
+                # `clip_skip` argument in `self._clip_skip` (:1227) and never hands it to `encode_prompt` (:1268-1277),
+                # and this `__call__` does the same.)
+                tok = self.tokenizer
+                ids = tok(prompt, padding="max_length", max_length=tok.model_max_length, truncation=True,
+                          return_tensors="pt").input_ids
+                out = self.text_encoder(ids.to(device), output_hidden_states=True)
+                prompt_embeds = self.text_encoder.text_model.final_layer_norm(out[-1][-(clip_skip + 1)])
         bs, seq, _ = prompt_embeds.shape
         prompt_embeds = prompt_embeds.to(device).repeat(1, num_images_per_prompt, 1).view(bs * num_images_per_prompt, seq, -1)
         if do_cfg:
@@ -108,6 +126,7 @@ class StableDiffusionPowerPaintBrushNetPipeline(PipelineBase):
         if prompt is None and prompt_embeds is None:
             raise ValueError("Provide either `prompt` or `prompt_embeds`.")
         self._guidance_scale = guidance_scale
+        self._clip_skip = clip_skip                      # (:1227; recorded, not applied -- see the property)
         if prompt is not None and isinstance(prompt, str):
             batch_size = 1
         elif prompt is not None and isinstance(prompt, list):

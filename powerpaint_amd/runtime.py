@@ -120,6 +120,8 @@ class NetRuntime:
             return (w[0], tuple((k, tuple(v)) for k, v in sorted(w[1].items())))
 
         key = (B, H, W, nctx, cin_total, freeze(wiring), cond_hw, self.gemm_tile, self.gemm_splitk, bool(pad_uncond))
+        if isinstance(scale, (list, tuple)):
+            scale = tuple(float(v) for v in scale)       # (one representation: a list never equals the stored tuple)
         if key == self.key:
             if scale != self._scale:
                 self._patch_scale(scale)
@@ -147,7 +149,7 @@ class NetRuntime:
         vals = list(scale) if isinstance(scale, (list, tuple)) else [scale] * len(zc)
         for a, v in zip(zc, vals):
             a.scale = float(v)
-        self._scale = scale
+        self._scale = tuple(float(v) for v in scale) if isinstance(scale, (list, tuple)) else scale
         self.graph = None
 
     # ------------------------------------------------------------------ inputs

@@ -43,8 +43,12 @@ def variance_noise(shape, generator, device, dtype) -> torch.Tensor:
     return z.to(torch.float32).contiguous()
 
 
-def _check_config(cls_name, cfg):
+def _check_config(cls_name, cfg, keys=None):
+    """`keys`: restrict the check to the options the target class's diffusers constructor names (a donor config's other
+    keys never reach it in `from_config`)."""
     for k, ok in _ONLY.items():
+        if keys is not None and k not in keys:
+            continue
         if k in cfg and cfg[k] not in ok:
             raise L.PPError(f"{cls_name}: {k}={cfg[k]!r} is not implemented on the HIP path (supported: {ok})")
 
@@ -427,20 +431,37 @@ class UniPCMultistepScheduler(_SchedulerBase):
                          lower_order_final=lower_order_final, disable_corrector=list(disable_corrector),
                          timestep_spacing=timestep_spacing, steps_offset=steps_offset, predict_x0=predict_x0,
                          prediction_type=prediction_type)
+        _check_config("UniPCMultistepScheduler", dict(kw, prediction_type=prediction_type,
+                                                      lower_order_final=lower_order_final), self._CHECKED)
         if solver_order not in (1, 2, 3) or solver_type not in ("bh1", "bh2") or not predict_x0 or \
                 prediction_type != "epsilon":
             raise NotImplementedError("UniPC: solver_order 1-3, bh1 / bh2, predict_x0, epsilon prediction")
+
+    # arithmetic options of diffusers-0.27 `UniPCMultistepScheduler.__init__` that the fused step does not implement (a
+    # donor config's keys outside that constructor -- algorithm_type, euler_at_final, clip_sample ... -- never reach it;
+    # `solver_type` has its own rule below)
+    _CHECKED = ("prediction_type", "beta_schedule", "thresholding", "use_karras_sigmas", "trained_betas",
+                "final_sigmas_type", "lower_order_final")
 
     @classmethod
     def from_config(cls, config, **kw):
         """`UniPCMultistepScheduler.from_config(pipe.scheduler.config)` (app.py:197): the keys this class shares with
         the donor scheduler's config are taken over (betas, timestep_spacing, steps_offset), the rest keep defaults."""
         src = dict(config) if isinstance(config, dict) else dict(vars(config))
-        take = ("num_train_timesteps", "beta_start", "beta_end", "timestep_spacing", "steps_offset", "prediction_type")
+        # refuse what would change the arithmetic (beta_schedule, thresholding, Karras sigmas, trained_betas,
+        # final_sigmas_type ...) instead of dropping it: the donor's config is what app.py:197 hands over
+        _check_config(cls.__name__, {**src, **kw}, cls._CHECKED)
+        take = ("num_train_timesteps", "beta_start", "beta_end", "timestep_spacing", "steps_offset", "prediction_type",
+                "lower_order_final")
         args = {k: src[k] for k in take if k in src}
-        if src.get("solver_order") in (1, 2, 3) and "solver_type" in src and src["solver_type"] in ("bh1", "bh2"):
-            args["solver_order"], args["solver_type"] = src["solver_order"], src["solver_type"]
+        if src.get("solver_order") in (1, 2, 3):
+            args["solver_order"] = src["solver_order"]
+        # a donor's solver_type outside bh1 / bh2 (DPM-Solver's midpoint / heun, logrho) becomes bh2, as in diffusers
+        if src.get("solver_type") in ("bh1", "bh2"):
+            args["solver_type"] = src["solver_type"]
         args.update(kw)
+        if args.get("solver_type") in ("midpoint", "heun", "logrho"):
+            args["solver_type"] = "bh2"
         return cls(**args)
 
     def _grid(self, N):

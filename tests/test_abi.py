@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
 def test_python_binding_covers_header():
     from powerpaint_amd import _lib
     assert sorted(_lib.SIGNATURES) == header_symbols()
-    assert _lib.lib().pp_abi_version() == 7
+    assert _lib.lib().pp_abi_version() == _lib.ABI_VERSION
 
 
 def test_gemm_args_struct_layout_matches_header():

@@ -166,6 +166,39 @@ def test_clip_text_model_matches_transformers_gpu():
 
 
 @pytest.mark.gpu
+def test_clip_skip_hidden_states_match_transformers_gpu():
+    """`encode_prompt(clip_skip=k)` (pipeline_PowerPaint_Brushnet_CA.py:537-552): `output_hidden_states=True` returns the
+    embeddings + every layer's pre-final-LayerNorm state as transformers does, and the pipeline helper takes
+    [-(k + 1)] through `text_model.final_layer_norm` -- against the same recipe on transformers.CLIPTextModel."""
+    from powerpaint_amd.pipelines import StableDiffusionPowerPaintBrushNetPipeline
+    wrapper, G = tiny_tokenizer()
+    hf = hf_model(vocab=G["n_base"], layers=4, seed=5)
+    m = CLIPTextModel(device="cuda", vocab_size=G["n_base"], num_hidden_layers=4, eos_token_id=G["n_base"] - 1)
+    m.load_state_dict(hf.state_dict())
+    ids = wrapper(["a cat on a mat", "dog"], padding="max_length", max_length=77, truncation=True,
+                  return_tensors="pt").input_ids
+    with torch.no_grad():
+        ref = hf(ids, output_hidden_states=True)
+    out = m(ids.cuda(), output_hidden_states=True)
+    assert len(out.hidden_states) == len(ref.hidden_states) == 5
+    assert m(ids.cuda(), output_hidden_states=True, return_dict=False)[-1][2].shape == (2, 77, 768)
+    for i, (a, b) in enumerate(zip(out.hidden_states, ref.hidden_states)):
+        cos = F.cosine_similarity(a.float().cpu().flatten(), b.flatten(), dim=0).item()
+        assert cos >= 0.9995 and (a.float().cpu() - b).abs().max().item() <= 0.03 * max(1.0, b.abs().max().item()), (i, cos)
+    pipe = StableDiffusionPowerPaintBrushNetPipeline(text_encoder=m, tokenizer=wrapper)
+    hf_tm = getattr(hf, "text_model", hf)
+    for k in (1, 2):
+        got = pipe.encode_prompt(["a cat on a mat", "dog"], torch.device("cuda"), 1, False, clip_skip=k)
+        with torch.no_grad():
+            want = hf_tm.final_layer_norm(ref.hidden_states[-(k + 1)])
+        cos = F.cosine_similarity(got.float().cpu().flatten(), want.flatten(), dim=0).item()
+        assert got.shape == (2, 77, 768) and cos >= 0.9995, (k, cos)
+        assert (got.float().cpu() - want).abs().max().item() <= 0.03 * max(1.0, want.abs().max().item())
+    plain = pipe.encode_prompt(["a cat on a mat", "dog"], torch.device("cuda"), 1, False)
+    assert not torch.allclose(plain.float(), got.float(), atol=1e-2)         # clip_skip changes the embedding
+
+
+@pytest.mark.gpu
 def test_task_prompts_to_embeds_through_pipeline_helper_gpu():
     """add_task -> TokenizerWrapper -> HIP CLIPTextModel (spliced task tokens) -> blended prompt_embeds, against
     transformers' tower fed with the reference-rule embedding (oracle/task_tokens.py)."""

@@ -1,0 +1,236 @@
+"""-m gpu: oracle parity on the paths the benchmarks actually run ("close the parity holes").
+
+  * every SHIPPING attention kernel at its benchmark shape, named explicitly through `ops.attention(variant=...)`
+    (C ABI `pp_attention_fwd_variant`): the 64-queries-per-wave pipelined kernel at N = 4096 / batch 8 / bf16 (config 2-4,
+    the #1 line of the step trace) and at N = 16384 / batch 4 / fp16 (config 5), the 32-queries-per-wave kernel and the
+    three-phase kernel at N = 4096 -- all rows against fp32 attention;
+  * config 5: fp16 BrushNet -> UNet forward at 128x128 latents (1024x1024 outpainting, /root/reference/app.py:260-269,548)
+    for one CFG pair against the CPU oracle;
+  * config 4: full ControlNet -> UNet at 64x64 latents with a 512x512 control image
+    (pipeline_PowerPaint_ControlNet.py:1686-1694);
+  * config 2: a teacher-forced 10-step DDIM run at 64x64 through the FUSED loop (per-step epsilon and per-step
+    scheduler output against pipeline_PowerPaint.py:988-1041 restated by oracle/loops.py), and the free-running drift of
+    the same 10 steps.
+
+Gates sit at about twice the achieved error (numbers: profiles/r03_config_parity.txt, appended to
+gpurun_out/parity_r03.txt by every run).
+"""
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import loops as OL  # noqa: E402
+from oracle import schedulers as OS  # noqa: E402
+from oracle import sd_modules as OM  # noqa: E402
+from powerpaint_amd import _lib as L  # noqa: E402
+from powerpaint_amd import models as PM  # noqa: E402
+from powerpaint_amd import ops  # noqa: E402
+from powerpaint_amd import pipelines as PP  # noqa: E402
+from powerpaint_amd import schedulers as PS  # noqa: E402
+
+from test_models_gpu import DEV, bf16_weights_, close, gen  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def record(line: str):
+    print(line)
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "parity_r03.txt"), "a") as f:
+            f.write(line + "\n")
+    except OSError:
+        pass
+
+
+def measure(out, ref):
+    out, ref = out.float().cpu(), ref.float().cpu()
+    assert out.shape == ref.shape, (out.shape, ref.shape)
+    cos = F.cosine_similarity(out.flatten(), ref.flatten(), dim=0).item()
+    return cos, (out - ref).abs().max().item()
+
+
+def report(what, out, ref, cos_min, rel):
+    """Record the achieved numbers FIRST (a failing gate must still leave them in the log), then assert."""
+    cos, err = measure(out, ref)
+    record(f"[config parity] {what}: cosine {cos:.7f}  max-abs {err:.4g}  (max|ref| {float(ref.abs().max()):.4g})")
+    close(out, ref, what, cos_min=cos_min, rel=rel)
+    return cos, err
+
+
+def round_weights_(m, dtype):
+    with torch.no_grad():
+        for _, p in m.named_parameters():
+            if p.dim() >= 2:
+                p.copy_(p.to(dtype).float())
+    return m
+
+
+# ------------------------------------------------------------------------------------------------ attention kernels
+def sdpa_fp32_chunked(q, k, v, B, Hh, nq, nk, d):
+    """fp32 softmax(QK^T / sqrt d) V on the device, per batch item and per block of 2048 queries (the score matrix of
+    the 16384-token case would be 34 GB otherwise).  Plain torch matmul / softmax: the op-level truth."""
+    out = torch.empty(B * nq, Hh * d, dtype=torch.float32, device=q.device)
+    for b in range(B):
+        qh = q[b * nq:(b + 1) * nq].float().view(nq, Hh, d).transpose(0, 1)
+        kh = k[b * nk:(b + 1) * nk].float().view(nk, Hh, d).transpose(0, 1)
+        vh = v[b * nk:(b + 1) * nk].float().view(nk, Hh, d).transpose(0, 1)
+        for i in range(0, nq, 2048):
+            s = torch.matmul(qh[:, i:i + 2048], kh.transpose(1, 2)) * d ** -0.5
+            o = torch.matmul(torch.softmax(s, dim=-1), vh)
+            out[b * nq + i:b * nq + i + o.shape[1]] = o.transpose(0, 1).reshape(-1, Hh * d)
+    return out
+
+
+@pytest.mark.parametrize("dtype,B,n,variant,name", [
+    (torch.bfloat16, 8, 4096, L.PP_ATTN_PIPE_Q64, "attn_pipe_kernel<40, QB=2> bf16 N=4096 B=8 (config 2-4, as benchmarked)"),
+    (torch.float16, 4, 16384, L.PP_ATTN_PIPE_Q64, "attn_pipe_kernel<40, QB=2> fp16 N=16384 B=4 (config 5, as benchmarked)"),
+    (torch.float16, 8, 4096, L.PP_ATTN_PIPE_Q64, "attn_pipe_kernel<40, QB=2> fp16 N=4096 B=8"),
+    (torch.bfloat16, 2, 4096, L.PP_ATTN_PIPE_Q32, "attn_pipe_kernel<40, QB=1> bf16 N=4096 B=2"),
+    (torch.bfloat16, 2, 4096, L.PP_ATTN_PHASED, "attn_fwd_kernel<40> bf16 N=4096 B=2"),
+    (torch.bfloat16, 8, 4096, L.PP_ATTN_AUTO, "AUTO (what the pipelines run) bf16 N=4096 B=8"),
+])
+def test_attention_shipping_kernels_at_benchmark_shapes(dtype, B, n, variant, name):
+    Hh, d = 8, 40
+    C = Hh * d
+    g = torch.Generator("cpu").manual_seed(7)
+    q = torch.randn(B * n, C, generator=g).to(DEV, dtype)
+    k = torch.randn(B * n, C, generator=g).to(DEV, dtype)
+    v = torch.randn(B * n, C, generator=g).to(DEV, dtype)
+    vt = ops.transpose_v(v, B, n)
+    out = ops.attention(q, k, vt, B, Hh, n, n, d, variant=variant)
+    ref = sdpa_fp32_chunked(q, k, v, B, Hh, n, n, d)
+    err = (out.float() - ref).abs().max().item()
+    cos = F.cosine_similarity(out.float().flatten(), ref.flatten(), dim=0).item()
+    record(f"[config parity] {name}: max-abs {err:.4g} (max|ref| {ref.abs().max().item():.3g}), cosine {cos:.7f}, "
+           f"all {B * n} rows")
+    # averages of thousands of N(0,1) values: |ref| ~ 0.1; bf16 output rounding alone is 4e-4 there.  Achieved on
+    # MI355X: 1.1e-3 (bf16) / 2.4e-4 (fp16) -> gates at ~2x
+    atol = 2.5e-3 if dtype == torch.bfloat16 else 6e-4
+    assert torch.isfinite(out).all()
+    assert err <= atol and cos >= (0.9999 if dtype == torch.bfloat16 else 0.99999), (name, err, cos)
+    if variant == L.PP_ATTN_AUTO:      # AUTO at this shape IS the 64-query kernel: same bits
+        assert torch.equal(out, ops.attention(q, k, vt, B, Hh, n, n, d, variant=L.PP_ATTN_PIPE_Q64))
+
+
+def test_attention_named_kernel_refuses_shapes_outside_it():
+    B, Hh, d, n = 1, 8, 80, 256
+    q = torch.zeros(B * n, Hh * d, dtype=torch.bfloat16, device=DEV)
+    vt = ops.transpose_v(q, B, n)
+    for variant in (L.PP_ATTN_PIPE_Q32, L.PP_ATTN_PIPE_Q64):
+        with pytest.raises(L.PPError, match="UNSUPPORTED"):
+            ops.attention(q, q, vt, B, Hh, n, n, d, variant=variant)
+    ops.attention(q, q, vt, B, Hh, n, n, d, variant=L.PP_ATTN_PHASED)
+    with pytest.raises(L.PPError, match="BAD_ARG"):
+        ops.attention(q, q, vt, B, Hh, n, n, d, variant=9)
+
+
+# ------------------------------------------------------------------------------------------------ config 5
+def test_config5_fp16_brushnet_unet_128x128_vs_oracle():
+    """BASELINE config 5 at its real shape and dtype: ppt-v2-1 outpainting at 1024x1024 = 128x128 latents, fp16
+    (/root/reference/app.py:260-269,548): full-width BrushNet_CA -> 4-channel UNet for ONE CFG pair, self-attention over
+    16384 keys, against the fp32 CPU oracle on fp16-rounded weights (the oracle evaluates its softmax per block of
+    queries; ~19 TFLOP of host work)."""
+    H16 = torch.float16
+    torch.manual_seed(5)
+    ou = round_weights_(OM.UNet2DConditionModel(in_channels=4), H16).eval()
+    ob = round_weights_(OM.randomize_zero_convs(OM.BrushNetModel(in_channels=4, conditioning_channels=5)), H16).eval()
+    hu = PM.UNet2DConditionModel(in_channels=4, device=DEV, dtype=H16).load_state_dict(ou.state_dict())
+    hb = PM.BrushNetModel(in_channels=4, conditioning_channels=5, device=DEV, dtype=H16).load_state_dict(ob.state_dict())
+    hh = 128
+    x, e, eu = gen(2, 4, hh, hh, seed=51), gen(2, 77, 768, seed=52), gen(2, 77, 768, seed=53)
+    mask = torch.zeros(2, 1, hh, hh)
+    mask[:, :, :, : hh // 4] = 1.0                       # an outpainting band
+    cond = torch.cat([gen(2, 4, hh, hh, seed=54, scale=0.5), mask], 1)
+    with torch.no_grad():
+        dn, md, up = ob(x, 481, e, cond, conditioning_scale=1.0)
+        ref = ou(x, 481, eu, down_block_add_samples=list(dn), mid_block_add_sample=md, up_block_add_samples=list(up))[0]
+    hdn, hmd, hup = hb(x.to(DEV), 481, e.to(DEV), cond.to(DEV), conditioning_scale=1.0, return_dict=False)
+    worst = 1.0
+    for i, (a, b) in enumerate(zip(hdn + [hmd] + hup, list(dn) + [md] + list(up))):
+        cos, _ = close(a, b, f"config 5 BrushNet residual {i}", cos_min=0.9999, rel=1.5e-2)
+        worst = min(worst, cos)
+    record(f"[config parity] config 5 fp16 BrushNet 128x128: 28 residuals, worst cosine {worst:.7f}")
+    out = hu(x.to(DEV), 481, eu.to(DEV), down_block_add_samples=list(hdn), mid_block_add_sample=hmd,
+             up_block_add_samples=list(hup), return_dict=False)[0]
+    report("config 5 fp16 BrushNet -> UNet, 128x128 latents, one CFG pair", out, ref, cos_min=0.99999, rel=7.5e-3)
+
+
+# ------------------------------------------------------------------------------------------------ config 4
+def test_config4_controlnet_unet_64x64_512px_control_image():
+    """BASELINE config 4 at its real shape: full-width ControlNet on 64x64 latents with a 512x512 control image
+    (conditioning embedding at full resolution, 3 stride-2 stages), residuals into the 9-channel UNet."""
+    torch.manual_seed(6)
+    ou = bf16_weights_(OM.UNet2DConditionModel(in_channels=9)).eval()
+    oc = bf16_weights_(OM.randomize_zero_convs(OM.ControlNetModel(in_channels=4))).eval()
+    hu = PM.UNet2DConditionModel(in_channels=9, device=DEV).load_state_dict(ou.state_dict())
+    hc = PM.ControlNetModel(in_channels=4, device=DEV).load_state_dict(oc.state_dict())
+    x4, x9, e = gen(2, 4, 64, 64, seed=61), gen(2, 9, 64, 64, seed=62), gen(2, 77, 768, seed=63)
+    img = torch.rand(2, 3, 512, 512, generator=torch.Generator("cpu").manual_seed(64))
+    with torch.no_grad():
+        dn, md = oc(x4, 700, e, img, conditioning_scale=0.5)
+        ref = ou(x9, 700, e, down_block_additional_residuals=dn, mid_block_additional_residual=md)[0]
+    hdn, hmd = hc(x4.to(DEV), 700, e.to(DEV), img.to(DEV), conditioning_scale=0.5, return_dict=False)
+    worst = 1.0
+    for i, (a, b) in enumerate(zip(hdn + [hmd], list(dn) + [md])):
+        cos, _ = close(a, b, f"config 4 ControlNet residual {i}", cos_min=0.9995)
+        worst = min(worst, cos)
+    record(f"[config parity] config 4 ControlNet 64x64 (512x512 control image): 13 residuals, worst cosine {worst:.7f}")
+    out = hu(x9.to(DEV), 700, e.to(DEV), down_block_additional_residuals=hdn, mid_block_additional_residual=hmd,
+             return_dict=False)[0]
+    report("config 4 ControlNet -> UNet, 64x64 latents", out, ref, cos_min=0.9999, rel=2e-2)
+
+
+# ------------------------------------------------------------------------------------------------ config 2, multi-step
+def test_config2_teacher_forced_and_free_running_10_steps_64x64():
+    """SURVEY.md section 8(d) "teacher-forced ... same per step" at the real size: 10 DDIM steps (CFG 7.5) of the full
+    9-channel UNet at 64x64.  The oracle runs free; the product's FUSED loop (hipGraph replay: input assembly, UNet,
+    CFG combine + DDIM step in one launch program) is teacher-forced with the oracle's latents through the callback,
+    and BOTH its epsilon and its scheduler output are compared per step.  Then the same 10 steps free-running."""
+    torch.manual_seed(8)
+    o = bf16_weights_(OM.UNet2DConditionModel(in_channels=9)).eval()
+    h = PM.UNet2DConditionModel(in_channels=9, device=DEV).load_state_dict(o.state_dict())
+    B, hh, N = 1, 64, 10
+    lat = gen(B, 4, hh, hh, seed=81)
+    mask = torch.zeros(B, 1, hh, hh)
+    mask[:, :, 16:48, 16:48] = 1.0
+    mil = gen(B, 4, hh, hh, seed=82, scale=0.5)
+    pe = gen(2 * B, 77, 768, seed=83)
+    rec = []
+    ref_final = OL.loop_v1(o, OS.DDIMScheduler(), lat, torch.cat([mask] * 2), torch.cat([mil] * 2), pe, N, 7.5,
+                           eps_hook=lambda i, t, l, e: rec.append((l.clone(), e.clone(), int(t))))
+    lat_after = [rec[i + 1][0] for i in range(N - 1)] + [ref_final]
+    pipe = PP.StableDiffusionInpaintPipeline(unet=h, scheduler=PS.DDIMScheduler())
+    kw = dict(prompt_embeds=pe[B:].to(DEV), negative_prompt_embeds=pe[:B].to(DEV), height=hh * 8, width=hh * 8,
+              num_inference_steps=N, guidance_scale=7.5, latents=lat.to(DEV), mask_latents=mask.to(DEV),
+              masked_image_latents=mil.to(DEV), output_type="latent", return_dict=False)
+    worst = {"eps_cos": 1.0, "eps_err": 0.0, "lat_cos": 1.0, "lat_err": 0.0}
+
+    def teacher(i, t, latents):
+        assert int(t) == rec[i][2]
+        eps = pipe._loop.rt.eps_tensor()
+        ec, ee = measure(eps, rec[i][1])
+        lc, le = measure(latents, lat_after[i])
+        record(f"[config parity] config 2 teacher-forced step {i} (t={int(t)}): eps cosine {ec:.7f} max-abs {ee:.4g} "
+               f"(max|ref| {rec[i][1].abs().max().item():.3g}); latents cosine {lc:.7f} max-abs {le:.4g} "
+               f"(max|ref| {lat_after[i].abs().max().item():.3g})")
+        worst["eps_cos"], worst["eps_err"] = min(worst["eps_cos"], ec), max(worst["eps_err"], ee)
+        worst["lat_cos"], worst["lat_err"] = min(worst["lat_cos"], lc), max(worst["lat_err"], le)
+        close(eps, rec[i][1], f"teacher-forced eps step {i}", cos_min=0.9999, rel=2e-2)
+        close(latents, lat_after[i], f"teacher-forced scheduler output step {i}", cos_min=0.99999, rel=5e-3)
+        if i + 1 < N:
+            latents.copy_(lat_after[i].to(latents.device))          # teacher-force the next step of the fused loop
+
+    pipe(callback=teacher, callback_steps=1, **kw)
+    record(f"[config parity] config 2 teacher-forced 10 steps 64x64: worst eps cosine {worst['eps_cos']:.7f} / max-abs "
+           f"{worst['eps_err']:.4g}; worst latents cosine {worst['lat_cos']:.7f} / max-abs {worst['lat_err']:.4g}")
+    drift = []
+    out = pipe(callback=lambda i, t, l: drift.append((l.float().cpu() - lat_after[i]).abs().max().item()),
+               callback_steps=1, **kw)[0]
+    record("[config parity] config 2 free-running 10 steps 64x64, max-abs latent drift per step: "
+           + " ".join(f"{d:.4g}" for d in drift))
+    report("config 2 free-running 10 DDIM steps, 64x64, final latents", out, ref_final, cos_min=0.9998, rel=5e-2)

@@ -327,6 +327,22 @@ def test_hip_pipeline_reproduces_the_reference_call_with_strength():
                callback=lambda i, t, l: seen.append(int(t)), **M.CALL_STRENGTH)[0]
     assert seen == [499, 333, 167]
     _close_latents(out, gold["latents"], "v1 pipeline, strength 0.6, vs the reference's own __call__")
+    # a DUCK-TYPED scheduler (the oracle's class: not one of powerpaint_amd.schedulers, so `scheduler.step` runs as that
+    # object's own code) enters the schedule late too: the networks must see timesteps[t_start:], the same values
+    # `scheduler.step` receives (the loop's device timestep table held the HEAD of the schedule)
+    from oracle import schedulers as OS
+    duck = PP.StableDiffusionInpaintPipeline(vae=hv, text_encoder=he, tokenizer=tok, unet=hu,
+                                             scheduler=OS.DPMSolverMultistepScheduler(**M.DPM_SD15))
+    for use_graph in (True, False):
+        duck.use_graph = use_graph
+        seen2 = []
+        out2 = duck(image=img, mask=mask, generator=torch.Generator().manual_seed(5), output_type="latent",
+                    return_dict=False, callback=lambda i, t, l: seen2.append(int(t)), **M.CALL_STRENGTH)[0]
+        assert seen2 == [499, 333, 167]
+        assert [int(v) for v in duck._loop._f_ts[:3].cpu()] == [499, 333, 167]      # what the UNet was given
+        _close_latents(out2, gold["latents"], "v1 pipeline, duck-typed scheduler, strength 0.6")
+        cos = torch.nn.functional.cosine_similarity(out2.float().flatten(), out.float().flatten(), dim=0).item()
+        assert cos >= 0.9999, ("duck-typed vs fused at strength 0.6", cos)
     # ... and the next full-strength call starts from the top of the schedule again
     _, _, lat = M.inputs()
     gold1 = torch.load(os.path.join(HERE, "golden", "ref_pipeline_call.pt"), weights_only=False)

@@ -279,7 +279,8 @@ def _bench_worker(rank, world, port, q):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, root)
     import bench
-    r, w, _ = ppdist.init_from_env("gloo")
+    r, w, _ = ppdist.init_from_env("gloo", timeout_s=120.0)        # (the watchdog + first all-reduce path of bench.py)
+    assert ppdist.gather_strings(f"rank {r}") == ["rank 0", "rank 1"]
     out = []
     for cfg in ("v1", "v2", "controlnet"):
         pipe, nets, bcast_s = bench.build_pipeline(cfg, "cpu", r, w, net_kw=TINY)
@@ -328,6 +329,26 @@ def test_bench_startup_path_two_ranks_gloo():
     for i, cfg in ((1, "v1"), (3, "v2"), (5, "controlnet")):
         both = bench.synthetic_inputs(cfg, "cpu", 0, 4, 8)["latents"]    # world = 1 with the whole batch
         assert a[i] == float(both[:2].double().sum()) and b[i] == float(both[2:].double().sum())
+
+
+def test_distributed_watchdog_names_the_stuck_stage_and_exits():
+    """bench.py --gpus N must fail fast, not hang: a rank that waits for a peer that never arrives leaves within the
+    time-out with a message that names the stage."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import os, sys, time; sys.path.insert(0, %r)\n"
+            "from powerpaint_amd import dist as d\n"
+            "with d.Watchdog(0.5, 'first all-reduce over nccl'):\n"
+            "    time.sleep(30)\n" % root)
+    env = dict(os.environ, RANK="1", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="1")
+    t0 = __import__("time").time()
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert p.returncode == 3 and __import__("time").time() - t0 < 60
+    assert "rank 1/2" in p.stderr and "first all-reduce over nccl" in p.stderr and "MASTER_ADDR=127.0.0.1" in p.stderr
+    with ppdist.Watchdog(30.0, "fast block"):      # a block that finishes cancels the timer
+        pass
+    with ppdist.Watchdog(0.0, "disabled"):
+        pass
 
 
 def test_encode_prompt_matches_reference_method():
@@ -407,3 +428,50 @@ def test_retrieve_timesteps_follows_the_reference():
 
     ts, n = retrieve_timesteps(Custom(), None, None, timesteps=[9, 5, 1])
     assert n == 3 and ts.tolist() == [9, 5, 1]
+
+
+def test_model_to_refuses_what_it_cannot_honour_and_wiring_is_dtype_safe():
+    """`.to(other dtype)` on a packed network used to be silently ignored, and the zero-copy residual
+    hand-off reinterpreted a side network's bits when the two networks stored different 16-bit formats."""
+    from powerpaint_amd import _lib as L
+    from powerpaint_amd import models as PM
+    u = PM.UNet2DConditionModel(in_channels=4, device="cpu", dtype=torch.float16, **TINY)
+    assert u.to("cpu") is u and u.to(torch.float16) is u and u.to(dtype=torch.float16, device="cpu") is u
+    assert u.to(torch.zeros(1, dtype=torch.float16)) is u
+    with pytest.raises(L.PPError, match="packed as"):
+        u.to(torch.bfloat16)
+    with pytest.raises(L.PPError, match="packed as"):
+        u.to(dtype=torch.float32)
+    with pytest.raises(L.PPError, match="live on"):
+        u.to("cuda")
+    # wiring: a residual tensor stored in another format is never taken by pointer (it goes through the converting copy)
+    t16 = torch.zeros(1, 4, 2, 2, dtype=torch.float16)
+    tbf = torch.zeros(1, 4, 2, 2, dtype=torch.bfloat16)
+    t16._pp_nhwc_ptr, tbf._pp_nhwc_ptr = 1234, 5678
+    kind, ptrs = u._wiring([t16, tbf], t16, [tbf], None, None)
+    assert kind == "brushnet" and ptrs == {"down": [1234, 0], "mid": [1234], "up": [0]}
+
+
+def test_runtime_scale_schedule_representation_is_stable():
+    """guess mode hands `ensure` a LIST of per-residual scales; the stored form is a tuple, so an unchanged schedule must
+    compare equal (it used to re-patch every launch record and drop the captured graph on every bind)."""
+    from powerpaint_amd.runtime import NetRuntime
+    calls = []
+
+    class RT(NetRuntime):
+        def __init__(self):
+            self.key, self._scale, self.gemm_tile, self.gemm_splitk = None, 1.0, 0, 0
+
+        def _patch_scale(self, scale):
+            calls.append(scale)
+            self._scale = tuple(float(v) for v in scale) if isinstance(scale, (list, tuple)) else scale
+
+    rt = RT()
+    rt.key = (2, 8, 8, 77, 9, ("plain",), None, 0, 0, False)
+    rt.ensure(2, 8, 8, 77, 9, scale=[0.1, 0.5, 1.0])
+    rt.ensure(2, 8, 8, 77, 9, scale=[0.1, 0.5, 1.0])
+    rt.ensure(2, 8, 8, 77, 9, scale=(0.1, 0.5, 1.0))
+    assert len(calls) == 1
+    rt.ensure(2, 8, 8, 77, 9, scale=0.5)
+    rt.ensure(2, 8, 8, 77, 9, scale=0.5)
+    assert len(calls) == 2

@@ -112,3 +112,29 @@ def test_begin_index_is_validated():
         h.set_begin_index(5)
     h.set_begin_index(4)
     assert (h._coef[:4] == 0).all() and (h._coef[4] != 0).any()
+
+
+def test_unipc_from_config_refuses_what_it_cannot_compute():
+    """`UniPCMultistepScheduler.from_config(pipe.scheduler.config)` is the call app.py:197 makes: arithmetic options of
+    the donor config that the fused step does not implement must be REFUSED, not dropped; the donor's
+    non-UniPC keys (algorithm_type ...) never reach the class in diffusers and are ignored; a DPM-Solver solver_type
+    becomes bh2 as in diffusers."""
+    from powerpaint_amd import _lib as L
+    donor = PS.DPMSolverMultistepScheduler()
+    u = PS.UniPCMultistepScheduler.from_config(donor.config)
+    assert (u.config.solver_type, u.config.solver_order) == ("bh2", 2)
+    base = dict(vars(donor.config))
+    for bad in (dict(beta_schedule="linear"), dict(thresholding=True), dict(use_karras_sigmas=True),
+                dict(trained_betas=[0.1, 0.2]), dict(final_sigmas_type="sigma_min"), dict(prediction_type="v_prediction"),
+                dict(lower_order_final=False)):
+        with pytest.raises(L.PPError):
+            PS.UniPCMultistepScheduler.from_config({**base, **bad})
+        with pytest.raises(L.PPError):
+            PS.UniPCMultistepScheduler.from_config(base, **bad)
+        with pytest.raises(L.PPError):
+            PS.UniPCMultistepScheduler(**bad)
+    ok = PS.UniPCMultistepScheduler.from_config({**base, "solver_type": "heun", "algorithm_type": "sde-dpmsolver++",
+                                                 "euler_at_final": True})
+    assert ok.config.solver_type == "bh2"
+    assert PS.UniPCMultistepScheduler(solver_type="bh1").config.solver_type == "bh1"
+    assert PS.UniPCMultistepScheduler.from_config({**base, "solver_type": "bh1", "solver_order": 3}).config.solver_order == 3

@@ -1,7 +1,11 @@
 #!/usr/bin/env python
 """Turn a rocprofv3 (--kernel-trace --stats) rocpd SQLite database into a text kernel summary for profiles/."""
+import hashlib
+import os
 import sqlite3
 import sys
+
+LIB = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "powerpaint_amd", "libpp_hip.so")
 
 
 def main(db, out, title=""):
@@ -9,6 +13,10 @@ def main(db, out, title=""):
     rows = list(c.execute("select name, total_calls, total_duration, average, percentage from top_kernels"))
     with open(out, "w") as f:
         f.write(f"# rocprofv3 --kernel-trace --stats summary  {title}\n# source: {db}\n")
+        try:       # the build this trace was taken from (bench.py compares it with the library it runs)
+            f.write(f"# lib_sha16: {hashlib.sha256(open(LIB, 'rb').read()).hexdigest()[:16]}\n")
+        except OSError:
+            pass
         f.write(f"# {'calls':>7} {'total_ms':>11} {'avg_us':>10} {'pct':>6}  kernel\n")
         for name, calls, tot, avg, pct in rows:
             if len(name) > 150:
