@@ -66,7 +66,7 @@ class DDIMScheduler:
         return (prev,)
 
     def add_noise(self, x0, noise, timesteps):
-        a = self.alphas_cumprod[timesteps].to(x0.dtype)
+        a = self.alphas_cumprod[timesteps.cpu()].to(device=x0.device, dtype=x0.dtype)   # (diffusers moves its tables too)
         sa = (a ** 0.5).flatten()
         s1 = ((1 - a) ** 0.5).flatten()
         while sa.dim() < x0.dim():
@@ -227,7 +227,7 @@ class DPMSolverMultistepScheduler:
         """diffusers 0.27 DPMSolverMultistepScheduler.add_noise: sigma of the schedule entry holding each timestep,
         (alpha_t, sigma_t) from it."""
         idx = [int((self.timesteps == int(t)).nonzero()[0]) for t in timesteps]
-        alpha_t, sigma_t = self._alpha_sigma(self.sigmas[idx].flatten().to(x0.dtype))
+        alpha_t, sigma_t = self._alpha_sigma(self.sigmas[idx].flatten().to(device=x0.device, dtype=x0.dtype))
         while alpha_t.dim() < x0.dim():
             alpha_t, sigma_t = alpha_t.unsqueeze(-1), sigma_t.unsqueeze(-1)
         return alpha_t * x0 + sigma_t * noise
@@ -370,7 +370,7 @@ class UniPCMultistepScheduler:
         return (prev,)
 
     def add_noise(self, x0, noise, timesteps):
-        a = self.alphas_cumprod[timesteps.long()].to(x0.dtype)
+        a = self.alphas_cumprod[timesteps.long().cpu()].to(device=x0.device, dtype=x0.dtype)
         sa, s1 = (a ** 0.5).flatten(), ((1 - a) ** 0.5).flatten()
         while sa.dim() < x0.dim():
             sa, s1 = sa.unsqueeze(-1), s1.unsqueeze(-1)

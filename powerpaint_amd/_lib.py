@@ -8,6 +8,8 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpp_hip.so")
+if os.environ.get("PP_LAB") == "1" and os.environ.get("PP_LIB"):      # lab: A/B against a variant build (csrc/Makefile)
+    LIB_PATH = os.path.abspath(os.environ["PP_LIB"])
 
 PP_X_PLAIN, PP_X_CONV3X3 = 0, 1
 PP_ACT_NONE, PP_ACT_GEGLU, PP_ACT_SILU = 0, 1, 2

@@ -36,6 +36,19 @@ def bf16_weights_(m):
     return m
 
 
+def _record_achieved(what, cos, err, ref_max, cos_min, bound):
+    """Every comparison leaves its ACHIEVED numbers in gpurun_out/parity_achieved.txt (merged back from the GPU box):
+    the gates are set from these, at about twice the achieved error (profiles/r03_loop_parity.txt)."""
+    import os
+    try:
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(root, "gpurun_out", "parity_achieved.txt"), "a") as f:
+            f.write(f"{what}: cosine {cos:.7f} (gate {cos_min})  max-abs {err:.4g} (gate {bound:.4g})  max|ref| {ref_max:.4g}\n")
+    except OSError:
+        pass
+
+
 def close(out, ref, what, cos_min=0.999, rel=3e-2):
     out, ref = out.float().cpu(), ref.float().cpu()
     assert out.shape == ref.shape, (what, out.shape, ref.shape)
@@ -43,6 +56,7 @@ def close(out, ref, what, cos_min=0.999, rel=3e-2):
     cos = torch.nn.functional.cosine_similarity(out.flatten(), ref.flatten(), dim=0).item()
     err = (out - ref).abs().max().item()
     bound = rel * max(1.0, ref.abs().max().item())
+    _record_achieved(what, cos, err, ref.abs().max().item(), cos_min, bound)
     assert cos >= cos_min and err <= bound, f"{what}: cosine {cos:.6f}, max-abs {err:.4g} (bound {bound:.4g})"
     return cos, err
 
