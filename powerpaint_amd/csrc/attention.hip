@@ -191,7 +191,12 @@ attn_fwd_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __restr
         }
         tmax = fmaxf(tmax, sacc[j][r]);
       }
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    {   // cross-half row maximum through the VALU swap (lanes i <-> i + 32): no ds_bpermute round trip, no lgkmcnt drain
+        // (inline asm: see attn_pipe_kernel; s_nop 1 = the wait states between the VALU write and the swap)
+      float r0 = tmax, r1 = tmax;
+      asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 0" : "+v"(r0), "+v"(r1));
+      tmax = fmaxf(r0, r1);
+    }
     float psum = 0.f;
     v8_t pf[2][2];
     float p[2][16];

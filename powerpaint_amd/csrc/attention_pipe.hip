@@ -59,7 +59,14 @@ constexpr float RESCALE_THR = 8.0f;
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-template <int D, int KB, int dbg, int EDT, int NW, int QB>
+// OPT (round 3; bit mask, PP_ATTN_OPT_DEFAULT ships):
+//   1  the cross-half row maximum by v_permlane32_swap (VALU) instead of __shfl_xor(.., 32) = ds_bpermute_b32, whose
+//      `s_waitcnt lgkmcnt(0)` also drained the prefetched K / V^T fragment reads at the head of every stage;
+//   2  the exp argument as two scalar v_fma_f32 instead of one v_pk_fma_f32 (packed fp32 VALU does not overlap an
+//      in-flight MFMA on gfx950: MI355X_MICROARCH.md, "price of one filler beside MFMAs");
+//   4  fragment reads issued at the HEAD of a slot, two fragments ahead, fenced from the slot's VALU block (the
+//      compiler otherwise sinks the ds_read behind the slot's exps and the next MFMA waits the whole LDS latency).
+template <int D, int KB, int dbg, int EDT, int NW, int QB, int OPT>
 __global__ void __launch_bounds__(64 * NW, (KB == 32 && QB == 1 ? 4 : 2))
 attn_pipe_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __restrict__ k, int ldk,
                  const uint16_t* __restrict__ vt, int ldvt, uint16_t* __restrict__ o, int ldo, int heads, int nq, int nk,
@@ -235,7 +242,7 @@ attn_pipe_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __rest
     vread = vread + 1 == C::NVB ? 0 : vread + 1;
     constexpr int NKF = JB * C::DS, NF = NKF + JB * 2 * C::DT;   // K fragments / all fragments of a stage
     constexpr int NQK = NKF * QB, NM = NF * QB;                  // QK^T slots / all slots
-    constexpr int FDF = (dbg >> 4) ? (dbg >> 4) : (QB == 1 ? 2 : 1);   // fragment prefetch distance, in fragments
+    constexpr int FDF = (dbg >> 4) ? (dbg >> 4) : ((OPT & 4) ? 2 : (QB == 1 ? 2 : 1));   // fragment prefetch distance, in fragments
     //                                       (= two slots either way; QB = 2 with FDF 2 measured the same)
     constexpr int SB = QB * JB;                  // 32 x 32 score blocks per stage
     constexpr int MAXSLOTS = 2 * SB;             // slots carrying the running-max phase (8 scores each)
@@ -264,7 +271,10 @@ attn_pipe_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __rest
 #pragma unroll
     for (int f = 0; f < NM; ++f) {
       const int k = f / QB, qb = f % QB;         // fragment of this slot, q-block it multiplies
-      if (qb == 0 && k + FDF < NF) fetch(k + FDF);
+      if (qb == 0 && k + FDF < NF) {
+        fetch(k + FDF);
+        if (OPT & 4) __builtin_amdgcn_sched_barrier(0);   // the read leaves at the head of the slot
+      }
       if (dbg & 1) {
         asm volatile("" ::"v"(frag[k]));
       } else if (k < NKF) {
@@ -281,7 +291,19 @@ attn_pipe_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __rest
         for (int r = r0; r < r0 + 8; r += 2)
           tmax[mq] = __builtin_fmaxf(__builtin_fmaxf(tmax[mq], sc[mq][mj][r]), sc[mq][mj][r + 1]);
         if (mj == JB - 1 && (f & 1)) {           // last block of q-block mq: its row maximum is complete
-          const float tm = fmaxf(tmax[mq], __shfl_xor(tmax[mq], 32, 64));
+          float tm;
+          if (OPT & 1) {      // lanes i and i + 32 exchange through the VALU swap: no LDS round trip, no lgkmcnt drain.
+            // swap(x, x): the first result holds the low half's value in both halves, the second the high half's
+            // Inline asm on purpose: through __builtin_amdgcn_permlane32_swap hipcc (ROCm 7.2) returned the FIRST result
+            // in both elements here (a v_mov over the second register right after the swap: the low half's maximum only,
+            // visible as 1-ulp output differences because softmax is invariant to the reference value).  s_nop 1 = the two
+            // wait states between a VALU write of an operand and the swap (cdna_hip_programming.md, T21).
+            float r0 = tmax[mq], r1 = tmax[mq];
+            asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 0" : "+v"(r0), "+v"(r1));
+            tm = fmaxf(r0, r1);
+          } else {
+            tm = fmaxf(tmax[mq], __shfl_xor(tmax[mq], 32, 64));
+          }
           const float ts = tm * scale_log2e;
           const bool need = !__all(ts - m_run[mq] <= RESCALE_THR);
           const float m_new = need ? fmaxf(m_run[mq], ts) : m_run[mq];
@@ -298,7 +320,14 @@ attn_pipe_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __rest
         for (; es < upto; ++es) {
           const int sb = es >> 3, eq = sb / JB, ej = sb % JB, u = (es >> 2) & 1, e = es & 3;
           const f32x2_t s2 = {sc[eq][ej][8 * u + 2 * e], sc[eq][ej][8 * u + 2 * e + 1]};
-          const f32x2_t e2 = __builtin_elementwise_fma(s2, c2, nm2[eq]);
+          f32x2_t e2;
+          if (OPT & 2) {
+            float e0 = __builtin_fmaf(s2[0], scale_log2e, nm2[eq][0]), e1 = __builtin_fmaf(s2[1], scale_log2e, nm2[eq][1]);
+            asm volatile("" : "+v"(e0), "+v"(e1));        // (keeps LLVM's SLP vectoriser from re-packing the pair)
+            e2 = f32x2_t{e0, e1};
+          } else {
+            e2 = __builtin_elementwise_fma(s2, c2, nm2[eq]);
+          }
           w[eq][ej][u][e] = (dbg & 2) ? E::pack2(e2[0], e2[1])
                                       : E::pack2(__builtin_amdgcn_exp2f(e2[0]), __builtin_amdgcn_exp2f(e2[1]));
           asm volatile("" ::"v"(w[eq][ej][u][e]));   // P(t) is only consumed next stage: keep LLVM from sinking the exps there
@@ -383,13 +412,18 @@ attn_pipe_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __rest
 // Default: 64-key tiles, two workgroups (8 waves) per CU; carries the PP_ATTN_DBG ablation variants.  PP_ATTN_KB=32:
 // 32-key tiles, <= 128 VGPRs, four workgroups per CU -- measured identical (347 vs 346 us at N = 4096): doubling the
 // occupancy hides nothing, the SIMD is issue-bound (~230 instructions per wave-tile at ~4 cycles + 14 MFMA at 32).
-template <int KB, int DBG, int EDT, int NW = 4, int QB = 1>
+// shipping: 5 = VALU-swap maximum + early fragment reads (profiles/r03_attention_opt_ab.txt: 263 -> 249-252 us at
+// N = 4096 / batch 8, 1944 -> 1866 us at N = 16384 / batch 4, bit-identical output; bit 2 alone moved nothing)
+#ifndef PP_ATTN_OPT_DEFAULT
+#define PP_ATTN_OPT_DEFAULT 5
+#endif
+template <int KB, int DBG, int EDT, int NW = 4, int QB = 1, int OPT = PP_ATTN_OPT_DEFAULT>
 static int launch_pipe(const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt, void* o, int ldo,
                        int batch, int heads, int nq, int nk, float sl2, hipStream_t st) {
   using C = PCfg<40, KB, NW>;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_pipe_kernel<40, KB, DBG, EDT, NW, QB>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_pipe_kernel<40, KB, DBG, EDT, NW, QB, OPT>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS) != hipSuccess) {
       pp_set_last_error("hipFuncSetAttribute(attention pipe)", hipGetLastError());
       return PP_ERR_LAUNCH;
@@ -397,7 +431,7 @@ static int launch_pipe(const void* q, int ldq, const void* k, int ldk, const voi
     attr_set = true;
   }
   const dim3 grid((nq + 32 * QB * NW - 1) / (32 * QB * NW), heads, batch), block(64 * NW);
-  hipLaunchKernelGGL((attn_pipe_kernel<40, KB, DBG, EDT, NW, QB>), grid, block, C::LDS, st, (const uint16_t*)q, ldq,
+  hipLaunchKernelGGL((attn_pipe_kernel<40, KB, DBG, EDT, NW, QB, OPT>), grid, block, C::LDS, st, (const uint16_t*)q, ldq,
                      (const uint16_t*)k, ldk, (const uint16_t*)vt, ldvt, (uint16_t*)o, ldo, heads, nq, nk, sl2);
   PP_CHECK_LAUNCH("attn_pipe_kernel");
   return PP_OK;
@@ -438,6 +472,21 @@ int pp_attention_pipe_launch(const void* q, int ldq, const void* k, int ldk, con
   // to be worth it.
   const long long wg2 = (long long)batch * heads * ((nq + 255) / 256);
   const bool q64 = variant == PP_ATTN_PIPE_Q64 || (variant == PP_ATTN_AUTO && wg2 >= 512);
+#ifdef PP_LAB
+  if (q64 && dtype == PP_DT_BF16 && pp_lab_env("PP_ATTN_OPT", -1) >= 0) {      // A/B of the round-3 loop changes
+    switch (pp_lab_env("PP_ATTN_OPT", 0)) {
+      case 0: return launch_pipe<32, 0, PP_DT_BF16, 4, 2, 0>(PP_ARGS);
+      case 1: return launch_pipe<32, 0, PP_DT_BF16, 4, 2, 1>(PP_ARGS);
+      case 2: return launch_pipe<32, 0, PP_DT_BF16, 4, 2, 2>(PP_ARGS);
+      case 3: return launch_pipe<32, 0, PP_DT_BF16, 4, 2, 3>(PP_ARGS);
+      case 4: return launch_pipe<32, 0, PP_DT_BF16, 4, 2, 4>(PP_ARGS);
+      case 5: return launch_pipe<32, 0, PP_DT_BF16, 4, 2, 5>(PP_ARGS);
+      case 6: return launch_pipe<32, 0, PP_DT_BF16, 4, 2, 6>(PP_ARGS);
+      case 7: return launch_pipe<32, 0, PP_DT_BF16, 4, 2, 7>(PP_ARGS);
+      default: return PP_ERR_BAD_ARG;
+    }
+  }
+#endif
   if (q64) {
     if (dtype == PP_DT_F16) return launch_pipe<32, 0, PP_DT_F16, 4, 2>(PP_ARGS);
     return launch_pipe<32, 0, PP_DT_BF16, 4, 2>(PP_ARGS);
