@@ -189,7 +189,7 @@ def test_pipeline_v2_fp16_dpm_loop():
               negative_prompt_embedsU=peU[:B].to(DEV), conditioning_latents=cl.to(DEV), num_inference_steps=N,
               guidance_scale=7.5, latents=lat.to(DEV), output_type="latent", return_dict=False)
     out = pipe(**kw)[0]
-    close16(out, ref, "fp16 v2 free-running, 4 DPM-Solver++ steps", cos_min=0.9999, rel=2.5e-2)   # (bf16 gate: 0.995 / 0.1)
+    close16(out, ref, "fp16 v2 free-running, 4 DPM-Solver++ steps", cos_min=0.9999, rel=2.5e-2)   # (bf16 gate: 0.9997 / 4.5e-2)
     pipe.use_graph = False
     assert torch.equal(out, pipe(**kw)[0])
 

@@ -155,9 +155,7 @@ def test_hip_pipeline_reproduces_the_reference_call():
     out = pipe(image=img, mask=mask, latents=lat.cuda(), generator=torch.Generator().manual_seed(5), output_type="latent",
                return_dict=False, **M.CALL)[0]
     want = gold["latents"]
-    cos = torch.nn.functional.cosine_similarity(out.float().cpu().flatten(), want.flatten(), dim=0).item()
-    err = (out.float().cpu() - want).abs().max().item()
-    assert cos >= 0.995 and err <= 0.1 * max(1.0, want.abs().max().item()), (cos, err)
+    _close_latents(out, want, "v1 pipeline vs the reference's own __call__")
 
 
 def test_oracle_loop_v2_reproduces_the_reference_brushnet_call():
@@ -214,7 +212,9 @@ def test_oracle_loop_reproduces_the_reference_controlnet_call():
     assert torch.allclose(out, gold["latents"], atol=2e-4, rtol=1e-4)
 
 
-def _close_latents(out, want, what, cos_min=0.995, rel=0.1):
+def _close_latents(out, want, what, cos_min=0.9997, rel=4.5e-2):
+    """Free-running HIP pipeline against a frozen reference `__call__`: gates at twice the worst achieved error
+    (profiles/r03_parity_achieved.txt: cosine 0.99987, max-abs 2.2e-2 of max|ref|)."""
     cos = torch.nn.functional.cosine_similarity(out.float().cpu().flatten(), want.flatten(), dim=0).item()
     err = (out.float().cpu() - want).abs().max().item()
     from test_models_gpu import _record_achieved

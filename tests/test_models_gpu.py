@@ -3,7 +3,10 @@
 Tolerances (bf16 compute with fp32 accumulate vs an fp32 oracle, SURVEY.md section 8d "Parity gates"):
   UNet / BrushNet / ControlNet forward : cosine >= 0.999 and max-abs <= 3e-2 * max(1, max|ref|)
   teacher-forced loop                  : the same per step
-  free-running short loop              : cosine >= 0.995 on the final latents (error compounds; informational bound)
+  free-running short loop              : cosine >= 0.9997 and max-abs <= 4.5e-2 * max|ref| on the final latents -- twice the
+                                         worst error ACHIEVED on MI355X over every loop test (profiles/r03_parity_achieved.txt:
+                                         cosine 0.99986, 2.2e-2); every comparison appends its achieved numbers to
+                                         gpurun_out/parity_achieved.txt
 """
 import pytest
 import torch
@@ -200,7 +203,7 @@ def test_baseline_config1_256_ddim10_full_unet():
     out = pipe(prompt_embeds=pe[B:].to(DEV), negative_prompt_embeds=pe[:B].to(DEV), height=hh * 8, width=hh * 8,
                num_inference_steps=N, guidance_scale=7.5, latents=lat.to(DEV), mask_latents=mask.to(DEV),
                masked_image_latents=mil.to(DEV), output_type="latent", return_dict=False)[0]
-    close(out, ref, "config 1: 256x256, 10-step DDIM, full UNet", cos_min=0.995, rel=0.1)
+    close(out, ref, "config 1: 256x256, 10-step DDIM, full UNet", cos_min=0.9997, rel=4.5e-2)
 
 
 def _v1_inputs(B, h, w, seed=0):
@@ -233,7 +236,7 @@ def test_pipeline_v1_loop(kind, N):
     out_eager = pipe(callback=lambda i, t, l: seen.append((i, int(t), l.clone())), **kw)[0]
     evals = len(osch.timesteps)                                 # N, or N + 1 for PNDM (its second timestep repeats)
     assert [s[0] for s in seen] == list(range(evals)) and [s[1] for s in seen] == [int(t) for t in osch.timesteps]
-    close(out_eager, ref, f"v1 {kind} free-running", cos_min=0.995, rel=0.1)
+    close(out_eager, ref, f"v1 {kind} free-running", cos_min=0.9997, rel=4.5e-2)
     pipe.use_graph = True
     out_graph = pipe(**kw)[0]
     assert torch.equal(out_eager, out_graph), "hipGraph replay differs from eager replay"
@@ -282,14 +285,14 @@ def test_pipeline_v2_brushnet_loop():
               negative_prompt_embedsU=peU[:B].to(DEV), conditioning_latents=cl.to(DEV), num_inference_steps=N,
               guidance_scale=7.5, latents=lat.to(DEV), output_type="latent", return_dict=False)
     out = pipe(**kw)[0]
-    close(out, ref, "v2 free-running", cos_min=0.995, rel=0.1)
+    close(out, ref, "v2 free-running", cos_min=0.9997, rel=4.5e-2)
     pipe.use_graph = False
     assert torch.equal(out, pipe(**kw)[0])
     # control_guidance_end < 1 switches BrushNet off for the tail steps (scale patched per step, eager replay)
     ref2 = OL.loop_v2(ou, ob, OS.DPMSolverMultistepScheduler(), lat, torch.cat([cl] * 2), pe, peU, N, 7.5, 1.0,
                       control_guidance_end=0.5)
     out2 = pipe(control_guidance_end=0.5, **kw)[0]
-    close(out2, ref2, "v2 guidance window", cos_min=0.995, rel=0.1)
+    close(out2, ref2, "v2 guidance window", cos_min=0.9997, rel=4.5e-2)
 
 
 def test_pipeline_v2_brushnet_unipc():
@@ -311,7 +314,7 @@ def test_pipeline_v2_brushnet_unipc():
               negative_prompt_embedsU=peU[:B].to(DEV), conditioning_latents=cl.to(DEV), num_inference_steps=N,
               guidance_scale=7.5, latents=lat.to(DEV), output_type="latent", return_dict=False)
     out = pipe(**kw)[0]
-    close(out, ref, "v2 UniPC free-running", cos_min=0.995, rel=0.1)
+    close(out, ref, "v2 UniPC free-running", cos_min=0.9997, rel=4.5e-2)
     pipe.use_graph = False
     assert torch.equal(out, pipe(**kw)[0])
 
@@ -366,7 +369,7 @@ def test_pipeline_controlnet_loop():
     out = pipe(prompt_embeds=pe[B:].to(DEV), negative_prompt_embeds=pe[:B].to(DEV), control_image=img.to(DEV),
                height=hh * 8, width=hh * 8, num_inference_steps=N, guidance_scale=7.5, latents=lat.to(DEV),
                mask_latents=mask.to(DEV), masked_image_latents=mil.to(DEV), output_type="latent", return_dict=False)[0]
-    close(out, ref, "controlnet free-running", cos_min=0.995, rel=0.1)
+    close(out, ref, "controlnet free-running", cos_min=0.9997, rel=4.5e-2)
 
 
 def test_controlnet_scale_change_reaches_the_captured_graph():
@@ -454,7 +457,7 @@ def test_pipeline_v1_pixels_in_pixels_out_with_vae():
         ref = ov.decode(fin / ov.config.scaling_factor, return_dict=False)[0]
         ref = (ref / 2 + 0.5).clamp(0, 1)                    # image_processor.postprocess(output_type="pt")
     assert float(out.min()) >= 0.0 and float(out.max()) <= 1.0
-    close(out, ref, "pixels in -> pixels out", cos_min=0.995, rel=0.1)
+    close(out, ref, "pixels in -> pixels out", cos_min=0.9998, rel=0.07)     # (achieved 0.99994 / 3.4e-2 of the [-1, 1] range)
     pil = pipe(prompt_embeds=pe[B:].to(DEV), negative_prompt_embeds=pe[:B].to(DEV), image=img, mask=mask,
                height=side, width=side, num_inference_steps=N, guidance_scale=7.5, latents=lat.to(DEV),
                generator=torch.Generator("cpu").manual_seed(77)).images
