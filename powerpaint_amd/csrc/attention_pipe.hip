@@ -66,6 +66,10 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 //      in-flight MFMA on gfx950: MI355X_MICROARCH.md, "price of one filler beside MFMAs");
 //   4  fragment reads issued at the HEAD of a slot, two fragments ahead, fenced from the slot's VALU block (the
 //      compiler otherwise sinks the ds_read behind the slot's exps and the next MFMA waits the whole LDS latency).
+//   8  fewer issue slots per stage (the wave is instruction-issue bound: ~236 instructions per 32-key stage at ~5 cycles):
+//      the v_cvt_pk of an exp step is issued one step LATER (behind the next step's v_exp pair: no `s_nop` for the
+//      transcendental-result hazard, 13 per stage before), and the deferred-rescale factor exp2(m_old - m_new) is
+//      evaluated inside the (rare) rescale branch instead of on every stage.
 template <int D, int KB, int dbg, int EDT, int NW, int QB, int OPT>
 __global__ void __launch_bounds__(64 * NW, (KB == 32 && QB == 1 ? 4 : 2))
 attn_pipe_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __restrict__ k, int ldk,
@@ -179,7 +183,7 @@ attn_pipe_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __rest
       for (int r = 0; r < 16; ++r) oacc[qb][t][r] = 0.f;
   float m_run[QB], alpha[QB];   // running max (log2 domain) / deferred O rescale factor of the previous stage, per q-block
 #pragma unroll
-  for (int qb = 0; qb < QB; ++qb) { m_run[qb] = -1.0e30f; alpha[qb] = 1.0f; }
+  for (int qb = 0; qb < QB; ++qb) { m_run[qb] = -1.0e30f; alpha[qb] = (OPT & 8) ? 0.0f : 1.0f; }
   bool pend = false;            // wave-uniform: some alpha != 1 somewhere
 
   // plain (non-interleaved) pieces: prologue S(0) and the drain PV
@@ -230,11 +234,13 @@ attn_pipe_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __rest
     }
     if (pend) {                                                     // deferred rescale: after PV(t-2), before PV(t-1)
 #pragma unroll
-      for (int qb = 0; qb < QB; ++qb)
+      for (int qb = 0; qb < QB; ++qb) {
+        const float al = (OPT & 8) ? __builtin_amdgcn_exp2f(alpha[qb]) : alpha[qb];   // (OPT 8: alpha[] holds m_old - m_new)
 #pragma unroll
         for (int dt = 0; dt < C::DT; ++dt)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) oacc[qb][dt][r] *= alpha[qb];
+          for (int r = 0; r < 16; ++r) oacc[qb][dt][r] *= al;
+      }
     }
     const char* ks = smem + kread * C::KTILE;            // K(t+1)
     const char* vs = smem + C::VBASE + vread * C::VTILE; // V(t-1)
@@ -266,6 +272,7 @@ attn_pipe_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __rest
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) { tmax[qb] = -1.0e30f; nm2[qb] = f32x2_t{0.f, 0.f}; }
     u32x4_t w[QB][JB][2];
+    float pend0 = 0.f, pend1 = 0.f;              // (OPT 8) the exps whose pack is still to come
     bool any = false;
     int es = 0;                                  // exp steps done (compile-time after unrolling)
 #pragma unroll
@@ -307,7 +314,7 @@ attn_pipe_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __rest
           const float ts = tm * scale_log2e;
           const bool need = !__all(ts - m_run[mq] <= RESCALE_THR);
           const float m_new = need ? fmaxf(m_run[mq], ts) : m_run[mq];
-          alpha[mq] = __builtin_amdgcn_exp2f(m_run[mq] - m_new);
+          alpha[mq] = (OPT & 8) ? (m_run[mq] - m_new) : __builtin_amdgcn_exp2f(m_run[mq] - m_new);
           any = any || need;
           m_run[mq] = m_new;
           nm2[mq] = f32x2_t{-m_new, -m_new};
@@ -328,12 +335,29 @@ attn_pipe_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __rest
           } else {
             e2 = __builtin_elementwise_fma(s2, c2, nm2[eq]);
           }
-          w[eq][ej][u][e] = (dbg & 2) ? E::pack2(e2[0], e2[1])
-                                      : E::pack2(__builtin_amdgcn_exp2f(e2[0]), __builtin_amdgcn_exp2f(e2[1]));
-          asm volatile("" ::"v"(w[eq][ej][u][e]));   // P(t) is only consumed next stage: keep LLVM from sinking the exps there
+          if (OPT & 8) {
+            // this step's exps now, the PREVIOUS step's pack behind them (its exps are a step old: no hazard wait)
+            float x0 = __builtin_amdgcn_exp2f(e2[0]), x1 = __builtin_amdgcn_exp2f(e2[1]);
+            asm volatile("" : "+v"(x0), "+v"(x1));   // pinned here: P(t) is only consumed next stage
+            if (es > 0) {
+              const int ps = es - 1, psb = ps >> 3, pq = psb / JB, pj = psb % JB, pu = (ps >> 2) & 1, pe = ps & 3;
+              w[pq][pj][pu][pe] = E::pack2(pend0, pend1);
+              asm volatile("" ::"v"(w[pq][pj][pu][pe]));
+            }
+            pend0 = x0;
+            pend1 = x1;
+          } else {
+            w[eq][ej][u][e] = (dbg & 2) ? E::pack2(e2[0], e2[1])
+                                        : E::pack2(__builtin_amdgcn_exp2f(e2[0]), __builtin_amdgcn_exp2f(e2[1]));
+            asm volatile("" ::"v"(w[eq][ej][u][e]));   // P(t) is only consumed next stage: keep LLVM from sinking the exps there
+          }
         }
       }
       __builtin_amdgcn_sched_barrier(0);
+    }
+    if (OPT & 8) {                               // the last step's pack
+      constexpr int ps = NES - 1, psb = ps >> 3, pq = psb / JB, pj = psb % JB, pu = (ps >> 2) & 1, pe = ps & 3;
+      w[pq][pj][pu][pe] = E::pack2(pend0, pend1);
     }
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb)
@@ -370,11 +394,13 @@ attn_pipe_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __rest
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (pend) {
 #pragma unroll
-    for (int qb = 0; qb < QB; ++qb)
+    for (int qb = 0; qb < QB; ++qb) {
+      const float al = (OPT & 8) ? __builtin_amdgcn_exp2f(alpha[qb]) : alpha[qb];
 #pragma unroll
       for (int dt = 0; dt < C::DT; ++dt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) oacc[qb][dt][r] *= alpha[qb];
+        for (int r = 0; r < 16; ++r) oacc[qb][dt][r] *= al;
+    }
   }
   {
     const char* vs = smem + C::VBASE + ((ntiles - 1) % C::NVB) * C::VTILE;
@@ -483,6 +509,8 @@ int pp_attention_pipe_launch(const void* q, int ldq, const void* k, int ldk, con
       case 5: return launch_pipe<32, 0, PP_DT_BF16, 4, 2, 5>(PP_ARGS);
       case 6: return launch_pipe<32, 0, PP_DT_BF16, 4, 2, 6>(PP_ARGS);
       case 7: return launch_pipe<32, 0, PP_DT_BF16, 4, 2, 7>(PP_ARGS);
+      case 13: return launch_pipe<32, 0, PP_DT_BF16, 4, 2, 13>(PP_ARGS);
+      case 15: return launch_pipe<32, 0, PP_DT_BF16, 4, 2, 15>(PP_ARGS);
       default: return PP_ERR_BAD_ARG;
     }
   }

@@ -31,6 +31,8 @@ def retrieve_timesteps(scheduler, num_inference_steps=None, device=None, timeste
 
 
 class StableDiffusionPowerPaintBrushNetPipeline(PipelineBase):
+    _callback_tensor_inputs = ["latents", "prompt_embeds", "negative_prompt_embeds"]     # pipeline_PowerPaint_Brushnet_CA.py:177
+
     def __init__(self, vae=None, text_encoder=None, text_encoder_brushnet=None, tokenizer=None, unet=None,
                  brushnet=None, scheduler=None, safety_checker=None, feature_extractor=None, image_encoder=None,
                  requires_safety_checker: bool = False):
@@ -190,18 +192,37 @@ class StableDiffusionPowerPaintBrushNetPipeline(PipelineBase):
                         side_scale=scales[0], guess_mode=guess_mode, eta=eta, generator=generator,
                         noise_dtype=self._noise_dtype(prompt_embeds))
         cb = None
+        bad = [k for k in callback_on_step_end_tensor_inputs if k not in self._callback_tensor_inputs]
+        if bad:                                                                              # check_inputs, :775-780
+            raise ValueError(f"`callback_on_step_end_tensor_inputs` has to be in {self._callback_tensor_inputs}, but "
+                             f"found {bad}")
         if callback is not None or callback_on_step_end is not None:
+            state = {"prompt_embeds": prompt_embeds, "negative_prompt_embeds": negative_prompt_embeds}
+
             def cb(i, t, lat):
                 if callback_on_step_end is not None:
-                    ret = callback_on_step_end(self, i, t, {"latents": lat})
-                    # the reference lets the callback hand back replacements (:1455-1459); the loop owns `lat`, so new
-                    # latents are copied into it, anything else (prompt_embeds ...) is baked into the step program
+                    # :1451-1459 -- the callback sees the tensors it asked for and may hand back replacements:
+                    #   latents         the loop owns `lat`: new values are copied into it (the next replay reads it);
+                    #   prompt_embeds   in the reference's loop that name is BrushNet's context (`encoder_hidden_states=
+                    #                   prompt_embeds`, :1411-1419): the side network's hoisted cross-attention K / V^T are
+                    #                   recomputed in place (same arena addresses -> the captured step graph stays valid);
+                    #   negative_prompt_embeds   rebinds a local the reference never reads again: recorded only.
+                    kwargs = {k: (lat if k == "latents" else state[k]) for k in callback_on_step_end_tensor_inputs}
+                    ret = callback_on_step_end(self, i, t, kwargs)
                     if isinstance(ret, dict):
-                        new = ret.get("latents", lat)
+                        new = ret.pop("latents", lat)
                         if new is not lat:
                             lat.copy_(new.to(lat.device, lat.dtype))
-                        if any(k != "latents" for k in ret):
-                            raise NotImplementedError("callback_on_step_end may only replace `latents` on the HIP path")
+                        pe = ret.pop("prompt_embeds", state["prompt_embeds"])
+                        if pe is not state["prompt_embeds"]:
+                            if tuple(pe.shape) != tuple(state["prompt_embeds"].shape):
+                                raise ValueError(f"callback_on_step_end returned prompt_embeds of shape {tuple(pe.shape)}, "
+                                                 f"the loop was built for {tuple(state['prompt_embeds'].shape)}")
+                            state["prompt_embeds"] = pe
+                            side_rt = self._loop.side_rt
+                            ctx = pe.chunk(2)[1] if (guess_mode and do_cfg and pe.shape[0] == 2 * nb) else pe
+                            side_rt.set_context(ctx.to(device), force=True)
+                        state["negative_prompt_embeds"] = ret.pop("negative_prompt_embeds", state["negative_prompt_embeds"])
                 if callback is not None and i % callback_steps == 0:
                     callback(i, t, lat)
         out = self._loop.run(latents, n, use_graph=self.use_graph, callback=cb, timesteps=timesteps,

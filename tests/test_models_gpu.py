@@ -295,6 +295,53 @@ def test_pipeline_v2_brushnet_loop():
     close(out2, ref2, "v2 guidance window", cos_min=0.9997, rel=4.5e-2)
 
 
+def test_pipeline_v2_callback_on_step_end_replaces_prompt_embeds():
+    """`callback_on_step_end` may hand back `prompt_embeds` (pipeline_PowerPaint_Brushnet_CA.py:1451-1459): in the
+    reference's loop that local is BrushNet's `encoder_hidden_states`, so the side network must run on the new context from
+    the next step on -- with the captured step graph still valid (the hoisted K / V^T are recomputed in place).  Oracle:
+    the same loop with the embeds tensor swapped after step 1."""
+    torch.manual_seed(0)      # zero convs with std 0.2 and a 3x louder replacement context: the swap moves the final latents
+    ob = bf16_weights_(OM.randomize_zero_convs(OM.BrushNetModel(in_channels=4, conditioning_channels=5, **TINY), std=0.2)).eval()
+    hb = PM.BrushNetModel(in_channels=4, conditioning_channels=5, device=DEV, **TINY).load_state_dict(ob.state_dict())
+    ou, hu = make_tiny("unet", seed=1, in_channels=4)
+    B, hh, N = 1, 16, 4
+    lat = gen(B, 4, hh, hh, seed=0)
+    mask = torch.zeros(B, 1, hh, hh); mask[:, :, 4:12, 4:12] = 1.0
+    cl = torch.cat([gen(B, 4, hh, hh, seed=1, scale=0.5), mask], 1)
+    pe, peU, pe_new = gen(2 * B, 77, 768, seed=2), gen(2 * B, 77, 768, seed=3), gen(2 * B, 77, 768, seed=4, scale=3.0)
+    pe_run = pe.clone()
+
+    def swap(i, t, l, e):                      # (mutates the tensor the oracle loop keeps passing to BrushNet)
+        if i == 0:
+            pe_run.copy_(pe_new)
+
+    ref = OL.loop_v2(ou, ob, OS.DPMSolverMultistepScheduler(), lat, torch.cat([cl] * 2), pe_run, peU, N, 7.5, 1.0, eps_hook=swap)
+    plain = OL.loop_v2(ou, ob, OS.DPMSolverMultistepScheduler(), lat, torch.cat([cl] * 2), pe.clone(), peU, N, 7.5, 1.0)
+    assert (ref - plain).abs().max() > 0.1 * ref.abs().max()       # the swap moves the result by far more than the gate
+    pipe = PP.StableDiffusionPowerPaintBrushNetPipeline(unet=hu, brushnet=hb, scheduler=PS.DPMSolverMultistepScheduler())
+    kw = dict(prompt_embeds=pe[B:].to(DEV), negative_prompt_embeds=pe[:B].to(DEV), prompt_embedsU=peU[B:].to(DEV),
+              negative_prompt_embedsU=peU[:B].to(DEV), conditioning_latents=cl.to(DEV), num_inference_steps=N,
+              guidance_scale=7.5, latents=lat.to(DEV), output_type="latent", return_dict=False)
+    seen = []
+
+    def on_end(p, i, t, kwargs):
+        seen.append(sorted(kwargs))
+        assert tuple(kwargs["prompt_embeds"].shape) == (2 * B, 77, 768)
+        return {"prompt_embeds": pe_new.to(DEV)} if i == 0 else {}
+
+    for use_graph in (True, False):
+        pipe.use_graph = use_graph
+        out = pipe(callback_on_step_end=on_end, callback_on_step_end_tensor_inputs=["latents", "prompt_embeds"], **kw)[0]
+        close(out, ref, f"v2 callback_on_step_end swaps prompt_embeds (graph={use_graph})", cos_min=0.9997, rel=4.5e-2)
+    assert seen[0] == ["latents", "prompt_embeds"]
+    out_plain = pipe(**kw)[0]
+    close(out_plain, plain, "v2 after a callback run: the original context is back", cos_min=0.9997, rel=4.5e-2)
+    d_hip, d_ref = (out.float().cpu() - out_plain.float().cpu()).flatten(), (ref - plain).flatten()
+    assert torch.nn.functional.cosine_similarity(d_hip, d_ref, dim=0) > 0.99      # the EFFECT of the swap agrees
+    with pytest.raises(ValueError, match="callback_on_step_end_tensor_inputs"):
+        pipe(callback_on_step_end=on_end, callback_on_step_end_tensor_inputs=["latents", "image"], **kw)
+
+
 def test_pipeline_v2_brushnet_unipc():
     """What app.py:197 configures for ppt-v2: BrushNet + UNet under UniPCMultistepScheduler.from_config(<SD-1.5 config>)."""
     ob, hb = make_tiny("brushnet")
