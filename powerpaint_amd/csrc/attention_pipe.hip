@@ -24,6 +24,7 @@
 //     reads instead of 14 (the LDS is 45 % index-active + 18 % conflict cycles at QB = 1) and half the tile DMAs per query.
 // Restrictions (the host falls back to attn_fwd_kernel otherwise): d == 40, nk % 64 == 0.
 #include <cstdlib>
+#include <type_traits>
 
 #include "pp_common.h"
 
@@ -31,23 +32,26 @@ namespace {
 
 // queries per wave = 32 * QB (template parameter): QB = 2 lets every K / V^T fragment read from LDS feed two MFMAs
 
-template <int D, int KB, int NW>     // NW = waves per block (4: two blocks per CU; 8: one, half the tile DMAs per query)
+// SUBS (round 3): an LDS tile = SUBS stages of KB keys.  SUBS = 2 halves the barriers, counted waits, DMA issues and ring
+// updates per key (a stage keeps the registers of KB keys: S / P double buffers for 64 keys x 64 queries do not fit).
+template <int D, int KB, int NW, int SUBS = 1>     // NW = waves per block (4: two blocks per CU; 8: one, half the tile DMAs per query)
 struct PCfg {
-  static constexpr int JB = KB / 32;                      // 32-key S^T blocks per tile
+  static constexpr int KT = KB * SUBS;                    // keys per LDS tile
+  static constexpr int JB = KB / 32;                      // 32-key S^T blocks per stage
   static constexpr int DP = (D + 15) / 16 * 16;
   static constexpr int DS = DP / 16;
   static constexpr int VROWS = (D + 1 + 31) / 32 * 32;   // head-dim rows + the all-ones row, whole 32-row MFMA tiles
   static constexpr int DT = VROWS / 32;
   static constexpr int KSL = DP / 8 + 1;                 // 16-B slots per K row (odd)
   static constexpr int KS = KSL * 16;
-  static constexpr int KTILE = (KB * KS + 1023) / 1024 * 1024;   // whole DMA instructions (tail slots unused)
+  static constexpr int KTILE = (KT * KS + 1023) / 1024 * 1024;   // whole DMA instructions (tail slots unused)
   static constexpr int KI = KTILE / 1024;                // wave-wide DMA instructions per K tile
-  static constexpr int VSL = KB / 8 + 1;                 // 9 slots per V^T row
+  static constexpr int VSL = KT / 8 + 1;                 // 9 slots per V^T row (64 keys)
   static constexpr int VS = VSL * 16;
   static constexpr int VTILE = VROWS * VS;
   static constexpr int VI = (D * VS + 1023) / 1024;      // DMA instructions for the streamed rows [0, D)
   static constexpr int LPW = (KI + NW - 1) / NW + (VI + NW - 1) / NW;   // DMA instructions per wave per tile
-  static constexpr int NKB = 3, NVB = 5;                 // ring depths
+  static constexpr int NKB = SUBS == 1 ? 3 : 4, NVB = 5; // ring depths (SUBS = 2: tiles are issued three PAIRS of stages ahead)
   static constexpr int VBASE = NKB * KTILE;
   static constexpr int DUMMY = VBASE + NVB * VTILE;
   static constexpr int LDS = DUMMY + 1024;
@@ -66,6 +70,8 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 //      in-flight MFMA on gfx950: MI355X_MICROARCH.md, "price of one filler beside MFMAs");
 //   4  fragment reads issued at the HEAD of a slot, two fragments ahead, fenced from the slot's VALU block (the
 //      compiler otherwise sinks the ds_read behind the slot's exps and the next MFMA waits the whole LDS latency).
+//  16  64-key LDS tiles consumed as two 32-key stages (PCfg SUBS = 2): half the barriers / counted waits / DMA issues /
+//      ring updates per key.
 //   8  fewer issue slots per stage (the wave is instruction-issue bound: ~236 instructions per 32-key stage at ~5 cycles):
 //      the v_cvt_pk of an exp step is issued one step LATER (behind the next step's v_exp pair: no `s_nop` for the
 //      transcendental-result hazard, 13 per stage before), and the deferred-rescale factor exp2(m_old - m_new) is
@@ -77,7 +83,9 @@ attn_pipe_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __rest
                  float scale_log2e) {
   // dbg (PP_ATTN_DBG, timing experiments only; results are garbage): 1 no MFMA, 2 no exp, 4 no tile DMA / barrier,
   // 8 no LDS fragment reads
-  using C = PCfg<D, KB, NW>;
+  constexpr int SUBS = (OPT & 16) ? 2 : 1;
+  constexpr int KT = KB * SUBS;
+  using C = PCfg<D, KB, NW, SUBS>;
   using E = E16<EDT>;
   typedef typename E::v8 v8_t;
   constexpr int JB = C::JB;
@@ -96,8 +104,8 @@ attn_pipe_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __rest
   for (int i = tid; i < C::NVB * C::VTILE / 16; i += T)
     *reinterpret_cast<u32x4_t*>(smem + C::VBASE + i * 16) = u32x4_t{0u, 0u, 0u, 0u};
   __syncthreads();
-  for (int i = tid; i < C::NVB * (KB / 2); i += T) {
-    const int bufi = i / (KB / 2), w = i - bufi * (KB / 2);
+  for (int i = tid; i < C::NVB * (KT / 2); i += T) {
+    const int bufi = i / (KT / 2), w = i - bufi * (KT / 2);
     *reinterpret_cast<uint32_t*>(smem + C::VBASE + bufi * C::VTILE + (C::VROWS - 1) * C::VS + w * 4) = E::pack2(1.0f, 1.0f);
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -135,27 +143,27 @@ attn_pipe_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __rest
     if (i < LPK) {
       const int g = i * NW + wave;
       const int L = 64 * g + lane, r = L / C::KSL, p = L - r * C::KSL;
-      if (g < C::KI && r < KB && p < D / 8) off = (r * ldk + p * 8) * 2;
+      if (g < C::KI && r < KT && p < D / 8) off = (r * ldk + p * 8) * 2;
       rel[i] = g < C::KI ? g * 1024 : -1;
     } else {
       const int g = (i - LPK) * NW + wave;
       const int L = 64 * g + lane, r = L / C::VSL, p = L - r * C::VSL;
-      if (g < C::VI && r < D && p < KB / 8) off = (r * ldvt + p * 8) * 2;
+      if (g < C::VI && r < D && p < KT / 8) off = (r * ldvt + p * 8) * 2;
       rel[i] = g < C::VI ? g * 1024 : -1;
     }
     vo[i] = off;
   }
-  int kread = 1, vread = C::NVB - 1;        // ring slots stage t reads: K(t+1), V(t-1)
+  int kread = SUBS == 1 ? 1 : 0, vread = C::NVB - 1;   // ring slots stage 0 reads: K(1), V(-1)  (SUBS = 2: K(1) = 2nd half of tile 0)
   int kring = 0, vring = 0;                 // ring slots of the NEXT tile to issue
   int t_issue = 0;                          // its index
   // The descriptors never change: the tile advance is the scalar offset operand of the DMA (soffset is not part of the
   // range check, so dead lanes -- voffset out of range -- still read zeros), and the two look-ahead issues past the last
   // tile get a zero-sized descriptor.  ~20 SALU instructions per stage instead of ~45: the SIMD is issue-bound.
   const uint32_t kbytes = (uint32_t)((nk - 1) * ldk + D) * 2u, vbytes = (uint32_t)D * (uint32_t)ldvt * 2u;
-  const int kstep = KB * ldk * 2, vstep = KB * 2;
+  const int kstep = KT * ldk * 2, vstep = KT * 2;
   int ksoff = 0, vsoff = 0;
   auto issue = [&]() {
-    const bool live = t_issue < ntiles;
+    const bool live = t_issue * SUBS < ntiles;      // (t_issue counts LDS tiles)
     const __amdgpu_buffer_rsrc_t rs_k = make_rsrc(k_bh, live ? kbytes : 0u);
     const __amdgpu_buffer_rsrc_t rs_v = make_rsrc(vt_bh, live ? vbytes : 0u);
     char* kdst = smem + kring * C::KTILE;
@@ -225,9 +233,14 @@ attn_pipe_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __rest
   // the softmax VALU work, and every QB-th slot the LDS read of the fragment FDF fragments ahead (a fragment feeds the QB
   // consecutive MFMAs of the wave's q-blocks).  sched_barrier(0) between slots keeps the compiler from regrouping (left
   // alone it emits all MFMAs back to back, then the VALU block: zero overlap).
-  auto stage = [&](int t, const f32x16_t (&sc)[QB][JB], f32x16_t (&sn)[QB][JB], v8_t (&pc)[QB][JB][2],
+  auto stage = [&](auto sub_tag, const f32x16_t (&sc)[QB][JB], f32x16_t (&sn)[QB][JB], v8_t (&pc)[QB][JB][2],
                    const v8_t (&pp)[QB][JB][2]) {
-    if (!(dbg & 4)) {
+    constexpr int sub = decltype(sub_tag)::value;       // t & 1
+    // SUBS = 2: `sub` = t & 1 is a compile-time constant of the two stage instantiations (the loop is unrolled by two).
+    // Stage t reads K(t+1) and V(t-1): with 64-key tiles the even stage t = 2p reads the SECOND halves of K tile p and of
+    // V^T tile p-1, the odd stage the FIRST halves of K tile p+1 and V^T tile p.  Barrier, counted wait and the issue of
+    // tile p+3 happen once per pair, at the even stage.
+    if (!(dbg & 4) && (SUBS == 1 || sub == 0)) {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::LPW) : "memory");   // tile t+1 (issued two stages ago) has landed
     asm volatile("s_barrier" ::: "memory");                         // ... for every wave; stage t-1 reads are done
     issue();
@@ -244,8 +257,17 @@ attn_pipe_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __rest
     }
     const char* ks = smem + kread * C::KTILE;            // K(t+1)
     const char* vs = smem + C::VBASE + vread * C::VTILE; // V(t-1)
-    kread = kread + 1 == C::NKB ? 0 : kread + 1;
-    vread = vread + 1 == C::NVB ? 0 : vread + 1;
+    if constexpr (SUBS == 1) {
+      kread = kread + 1 == C::NKB ? 0 : kread + 1;
+      vread = vread + 1 == C::NVB ? 0 : vread + 1;
+    } else {
+      if (sub == 0) {        // even stage: second halves; both rings move on to the tiles the odd stage reads
+        ks += KB * C::KS;
+        vs += KB * 2;
+        kread = kread + 1 == C::NKB ? 0 : kread + 1;
+        vread = vread + 1 == C::NVB ? 0 : vread + 1;
+      }
+    }
     constexpr int NKF = JB * C::DS, NF = NKF + JB * 2 * C::DT;   // K fragments / all fragments of a stage
     constexpr int NQK = NKF * QB, NM = NF * QB;                  // QK^T slots / all slots
     constexpr int FDF = (dbg >> 4) ? (dbg >> 4) : ((OPT & 4) ? 2 : (QB == 1 ? 2 : 1));   // fragment prefetch distance, in fragments
@@ -387,8 +409,8 @@ attn_pipe_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __rest
   qk(smem, sA);                                                    // S(0)
 
   for (int t = 0; t < ntiles; t += 2) {
-    stage(t, sA, sB, pA, pB);
-    if (t + 1 < ntiles) stage(t + 1, sB, sA, pB, pA);
+    stage(std::integral_constant<int, 0>{}, sA, sB, pA, pB);
+    if (t + 1 < ntiles) stage(std::integral_constant<int, 1>{}, sB, sA, pB, pA);
   }
   // ---- drain: PV of the last tile
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -403,7 +425,7 @@ attn_pipe_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __rest
     }
   }
   {
-    const char* vs = smem + C::VBASE + ((ntiles - 1) % C::NVB) * C::VTILE;
+    const char* vs = smem + C::VBASE + (((ntiles - 1) / SUBS) % C::NVB) * C::VTILE + (SUBS == 2 ? KB * 2 : 0);   // V(ntiles-1)
     if (ntiles & 1) pv(vs, pA);
     else pv(vs, pB);
   }
@@ -438,15 +460,17 @@ attn_pipe_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __rest
 // Default: 64-key tiles, two workgroups (8 waves) per CU; carries the PP_ATTN_DBG ablation variants.  PP_ATTN_KB=32:
 // 32-key tiles, <= 128 VGPRs, four workgroups per CU -- measured identical (347 vs 346 us at N = 4096): doubling the
 // occupancy hides nothing, the SIMD is issue-bound (~230 instructions per wave-tile at ~4 cycles + 14 MFMA at 32).
-// shipping: 5 = VALU-swap maximum + early fragment reads (profiles/r03_attention_opt_ab.txt: 263 -> 249-252 us at
-// N = 4096 / batch 8, 1944 -> 1866 us at N = 16384 / batch 4, bit-identical output; bit 2 alone moved nothing)
+// shipping: 29 = VALU-swap maximum + early fragment reads + late v_cvt / lazy rescale factor + 64-key LDS tiles
+// (profiles/r03_attention_opt_ab.txt: 287 -> 254 us at N = 4096 / batch 8 on one box, 1981 -> 1869 us at N = 16384 / batch 4,
+// bit-identical output).  The 64-key tiles (bit 16) belong to the 32-key-stage kernels (QB = 2); the 64-key-stage kernel
+// (QB = 1) would need 128-key tiles and 143 KB of LDS per workgroup, so it keeps single-stage tiles.
 #ifndef PP_ATTN_OPT_DEFAULT
-#define PP_ATTN_OPT_DEFAULT 5
+#define PP_ATTN_OPT_DEFAULT 29
 #endif
-template <int KB, int DBG, int EDT, int NW = 4, int QB = 1, int OPT = PP_ATTN_OPT_DEFAULT>
+template <int KB, int DBG, int EDT, int NW = 4, int QB = 1, int OPT = (KB == 32 ? PP_ATTN_OPT_DEFAULT : (PP_ATTN_OPT_DEFAULT & ~16))>
 static int launch_pipe(const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt, void* o, int ldo,
                        int batch, int heads, int nq, int nk, float sl2, hipStream_t st) {
-  using C = PCfg<40, KB, NW>;
+  using C = PCfg<40, KB, NW, (OPT & 16) ? 2 : 1>;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_pipe_kernel<40, KB, DBG, EDT, NW, QB, OPT>),
@@ -510,6 +534,8 @@ int pp_attention_pipe_launch(const void* q, int ldq, const void* k, int ldk, con
       case 6: return launch_pipe<32, 0, PP_DT_BF16, 4, 2, 6>(PP_ARGS);
       case 7: return launch_pipe<32, 0, PP_DT_BF16, 4, 2, 7>(PP_ARGS);
       case 13: return launch_pipe<32, 0, PP_DT_BF16, 4, 2, 13>(PP_ARGS);
+      case 21: return launch_pipe<32, 0, PP_DT_BF16, 4, 2, 21>(PP_ARGS);
+      case 29: return launch_pipe<32, 0, PP_DT_BF16, 4, 2, 29>(PP_ARGS);
       case 15: return launch_pipe<32, 0, PP_DT_BF16, 4, 2, 15>(PP_ARGS);
       default: return PP_ERR_BAD_ARG;
     }

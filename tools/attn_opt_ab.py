@@ -9,7 +9,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from powerpaint_amd import ops  # noqa: E402
 
-OPTS = [int(x) for x in (sys.argv[1].split(",") if len(sys.argv) > 1 else "0,1,2,3,4,5,6,7".split(","))]
+OPTS = [int(x) for x in (sys.argv[1].split(",") if len(sys.argv) > 1 else "0,5,13,21,29".split(","))]
 for B, n in ((8, 4096), (4, 16384)):
     H, d = 8, 40
     C = H * d
