@@ -1890,11 +1890,24 @@ extern "C" size_t pp_gemm_workspace_bytes(const PPGemmArgs* args) {
   return c.splitk > 1 ? (size_t)c.splitk * args->M * args->N * sizeof(float) : 0;
 }
 
+#ifdef PP_LAB
+// geglu_ws.hip (lab build only): wave-specialised GEGLU GEMM, main loop of one tile beside the GELU epilogue of the
+// previous one.  Bit-identical to EPI = 2 but 15-50 % slower (profiles/r03_geglu_ws_ab.txt) -> PP_GEGLU_WS=1 opts in.
+bool pp_geglu_ws_ok(const PPGemmArgs& a);
+int pp_geglu_ws_launch(const PPGemmArgs& a, hipStream_t st);
+#endif
+
 extern "C" int pp_gemm_bf16(const PPGemmArgs* args, void* stream) {
   if (!args) return PP_ERR_BAD_ARG;
   const PPGemmArgs& a = *args;
   const int v = validate(a);
   if (v != PP_OK) return v;
+#ifdef PP_LAB
+  if (pp_lab_env("PP_GEGLU_WS", 0) && pp_geglu_ws_ok(a)) {
+    const int rc = pp_geglu_ws_launch(a, (hipStream_t)stream);
+    if (rc != PP_ERR_UNSUPPORTED) return rc;
+  }
+#endif
   const Choice c = choose(a);
   if (c.splitk > 1 && !a.workspace) return PP_ERR_WORKSPACE;
   if (c.tile > 10 && !v2_ok(a)) return PP_ERR_BAD_ARG;

@@ -573,3 +573,41 @@ def test_unipc_step_kernel_vs_oracle(K, N, spacing, off):
         xo = o.step(eps[k], t, xo)[0]
         xh = h.step(eps[k].to(DEV), t, xh, return_dict=False)[0]
         check(xh.cpu(), xo, 1e-4 * max(1.0, float(xo.abs().max())), 1e-4, f"unipc step {k}")
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("fold", [False, True])
+@pytest.mark.parametrize("M,C", [(32768, 320), (8192, 640), (2048, 1280), (65536, 320)])
+def test_geglu_wave_specialised_kernel(M, C, fold, dtype):
+    """LAB BUILD ONLY (PP_LAB=1 PP_LIB=.../libpp_hip_lab.so PP_GEGLU_WS=1; skipped on the shipping library, which does
+    not contain the kernel): pp_geglu_ws_kernel (geglu_ws.hip) against the tiled EPI = 2 kernel (an explicit tile id
+    keeps the launch on pp_gemm_kernel_v2): same MFMA operand order and fp32 epilogue arithmetic -> bit-identical; and
+    against fp32 torch on a row sample."""
+    import os
+    if not (os.environ.get("PP_LAB") == "1" and os.environ.get("PP_GEGLU_WS") == "1"):
+        pytest.skip("lab experiment: the shipping library has no wave-specialised GEGLU kernel")
+    from powerpaint_amd.engine import _geglu_interleave
+    N = 8 * C
+    x = (rnd(M, C, seed=1, scale=2.0) + 0.3).to(dtype).cuda()
+    w = _geglu_interleave(rnd(N, C, seed=2, scale=C ** -0.5)).to(dtype).contiguous().cuda()
+    b = _geglu_interleave(rnd(N, seed=3)).contiguous().cuda()
+    kw = {}
+    if fold:
+        xf = x.float()
+        tiles = C // 160
+        st = torch.stack([xf.reshape(M, tiles, 160).sum(-1), (xf * xf).reshape(M, tiles, 160).sum(-1)], -1).contiguous()
+        kw = dict(ln_stats=st, ln_colsum=w.float().sum(1).contiguous(), ln_dim=C)
+    new = ops.gemm(x, w, bias=b, act=L.PP_ACT_GEGLU, **kw)
+    old = ops.gemm(x, w, bias=b, act=L.PP_ACT_GEGLU, tile=24, **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(new, old), f"max diff {(new.float() - old.float()).abs().max().item():.3g}"
+    rows = torch.arange(0, M, 97, device="cuda")
+    xr = x[rows].float()
+    y = xr @ w.float().t()
+    if fold:
+        mean = xr.mean(-1, keepdim=True)
+        rstd = torch.rsqrt((xr * xr).mean(-1, keepdim=True) - mean * mean + 1e-5)
+        y = rstd * (y - mean * kw["ln_colsum"])
+    y = (y + b).reshape(len(rows), N // 4, 4)
+    ref = torch.stack([y[..., 0] * F.gelu(y[..., 2]), y[..., 1] * F.gelu(y[..., 3])], -1).reshape(len(rows), N // 2)
+    check(new[rows], ref, 3e-2, 1e-2, "wave-specialised GEGLU vs fp32")
