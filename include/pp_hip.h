@@ -29,7 +29,7 @@ extern "C" {
 #define PP_ERR_LAUNCH (-3)       /* hipLaunchKernel / hipFuncSetAttribute failed                  */
 #define PP_ERR_WORKSPACE (-4)    /* workspace pointer null or too small                           */
 
-#define PP_ABI_VERSION 8
+#define PP_ABI_VERSION 9
 /* 16-bit storage format of activations and matrix weights ("dtype" arguments; the same codes pp_nchw_to_nhwc uses for
  * its source): bf16 or fp16 -- the reference's default is fp16 (/root/reference/app.py:548,559).  MFMA accumulation,
  * norm statistics, softmax, biases and latents are fp32 with either. */
@@ -275,6 +275,16 @@ int pp_cfg_sched_step(const float* eps2, int cfg, float guidance, float* latents
  * sqrt(1-a_prev-std_dev_t^2)) and `noise` fp32 [n] drawn by the host from the caller's generator, once per step. */
 int pp_ddim_variance_noise(float* latents, const float* noise, int n, const float* coef_table, const int32_t* step_dev,
                            void* stream);
+
+/* ppt-v1 with a 4-channel (non-inpainting) UNet -- the `num_channels_unet == 4` branch of the loop body,
+ * pipeline_PowerPaint.py:1025-1039: after pp_cfg_sched_step of the same step
+ *     latents[b] = (1 - mask) * (a * image_latents + b * noise[b]) + mask * latents[b]
+ * with (a, b) = renoise_table[step] = (sqrt(abar), sqrt(1 - abar)) of the NEXT timestep (`scheduler.add_noise(
+ * init_latents_proper, noise, timesteps[i + 1])`), (1, 0) on the last step (the clean image latents are put back).
+ * fp32; latents / noise [batch][channels][hw], image_latents [channels][hw] and mask [hw] = the FIRST image's
+ * (`image_latents[:1]`, `mask[:1]` broadcast, as the reference does); renoise_table [steps][2]. */
+int pp_latent_blend(float* latents, const float* image_latents, const float* mask, const float* noise,
+                    const float* renoise_table, const int32_t* step_dev, int batch, int channels, int hw, void* stream);
 
 /* t_out[0] = timesteps[step]; used at the top of a captured step.  advance: ++step. */
 int pp_step_select_t(const float* timesteps, const int32_t* step_dev, float* t_out, void* stream);

@@ -48,7 +48,8 @@ def blend_prompt_embeds(embA, embB, t: float):
 def loop_v1(unet, scheduler, latents, mask, masked_image_latents, prompt_embeds, num_inference_steps: int,
             guidance_scale: float = 7.5, controlnet=None, control_image=None, controlnet_conditioning_scale=0.5,
             eps_hook: Optional[Callable] = None, teacher_latents: Optional[List[torch.Tensor]] = None,
-            t_start: int = 0, guess_mode: bool = False, eta: float = 0.0, generator=None):
+            t_start: int = 0, guess_mode: bool = False, eta: float = 0.0, generator=None, image_latents=None,
+            noise=None):
     """ppt-v1 loop (optionally + ControlNet).  `mask`, `masked_image_latents`, `prompt_embeds`, `control_image`
     are already CFG-duplicated ([uncond, cond] order, pipeline_PowerPaint.py:516,703-706).
     `eps_hook(i, t, latents_in, noise_pred_2B)` lets tests record per-step tensors; `teacher_latents[i]`
@@ -57,7 +58,10 @@ def loop_v1(unet, scheduler, latents, mask, masked_image_latents, prompt_embeds,
     `latents` is the already-noised init image (no init_noise_sigma scaling, :640-642).
     guess_mode (pipeline_PowerPaint_ControlNet.py:1669-1702): the ControlNet sees the conditional half only
     (`control_image` un-duplicated), the unconditional half of the UNet batch gets zero residuals.
-    eta / generator: `prepare_extra_step_kwargs` (:536-551) -- handed to `scheduler.step` iff its signature names them."""
+    eta / generator: `prepare_extra_step_kwargs` (:536-551) -- handed to `scheduler.step` iff its signature names them.
+    image_latents / noise: the `num_channels_unet == 4` branch (:1025-1036; ControlNet pipeline :1725-1736) -- after every
+    step the unmasked region becomes the FIRST image's latents noised to the next timestep (clean on the last step),
+    `mask[:1]` being the first row of the (CFG-duplicated) latent-resolution mask."""
     import inspect
     step_params = set(inspect.signature(scheduler.step).parameters)
     extra = {k: v for k, v in (("eta", eta), ("generator", generator)) if k in step_params}
@@ -65,7 +69,8 @@ def loop_v1(unet, scheduler, latents, mask, masked_image_latents, prompt_embeds,
     do_cfg = guidance_scale > 1.0
     if t_start == 0:
         latents = latents * scheduler.init_noise_sigma
-    for i, t in enumerate(scheduler.timesteps[t_start * scheduler.order:]):
+    timesteps = scheduler.timesteps[t_start * scheduler.order:]
+    for i, t in enumerate(timesteps):
         if teacher_latents is not None:
             latents = teacher_latents[i]
         x = torch.cat([latents] * 2) if do_cfg else latents
@@ -90,6 +95,11 @@ def loop_v1(unet, scheduler, latents, mask, masked_image_latents, prompt_embeds,
             u, c = noise_pred.chunk(2)
             noise_pred = u + guidance_scale * (c - u)
         latents = scheduler.step(noise_pred, t, latents, **extra)[0]
+        if unet.config.in_channels == 4 and image_latents is not None:
+            proper = image_latents[:1]
+            if i < len(timesteps) - 1:
+                proper = scheduler.add_noise(proper, noise, torch.tensor([timesteps[i + 1]]))
+            latents = (1 - mask[:1]) * proper + mask[:1] * latents
     return latents
 
 

@@ -396,6 +396,24 @@ __global__ void __launch_bounds__(256) ddim_variance_noise_kernel(float* __restr
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) x[i] = x[i] + sd * z[i];
 }
 
+// ppt-v1 with a 4-channel UNet (pipeline_PowerPaint.py:1025-1039): after the scheduler step the known region is put back,
+//   latents = (1 - m) * (a * x0 + b * noise) + m * latents,   (a, b) = row `step` of the re-noise table
+// (sqrt(abar), sqrt(1 - abar)) of the NEXT timestep, (1, 0) on the last step.  x0 [chw] and m [hw] are the first image's
+// latents / mask, broadcast over the batch as `image_latents[:1]` / `mask[:1]` are.
+__global__ void __launch_bounds__(256) latent_blend_kernel(float* __restrict__ x, const float* __restrict__ x0,
+                                                          const float* __restrict__ m, const float* __restrict__ z,
+                                                          const float* __restrict__ tab, const int32_t* __restrict__ step_dev,
+                                                          int chw, int hw, int n) {
+  const int r = step_dev[0];
+  const float a = tab[2 * r], b = tab[2 * r + 1];
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const int e = i % chw;
+    const float mk = m[e % hw];
+    const float proper = b == 0.f ? x0[e] : a * x0[e] + b * z[i];
+    x[i] = (1.f - mk) * proper + mk * x[i];
+  }
+}
+
 __global__ void step_select_t_kernel(const float* __restrict__ ts, const int32_t* __restrict__ step, float* __restrict__ t) {
   if (threadIdx.x == 0 && blockIdx.x == 0) t[0] = ts[step[0]];
 }
@@ -571,6 +589,18 @@ extern "C" int pp_ddim_variance_noise(float* latents, const float* noise, int n,
   hipLaunchKernelGGL(ddim_variance_noise_kernel, dim3(grid_for_host(n)), dim3(256), 0, (hipStream_t)stream, latents, noise,
                      n, coef_table, step_dev);
   PP_CHECK_LAUNCH("ddim_variance_noise_kernel");
+  return PP_OK;
+}
+
+extern "C" int pp_latent_blend(float* latents, const float* image_latents, const float* mask, const float* noise,
+                               const float* renoise_table, const int32_t* step_dev, int batch, int channels, int hw,
+                               void* stream) {
+  if (!latents || !image_latents || !mask || !noise || !renoise_table || !step_dev) return PP_ERR_BAD_ARG;
+  if (batch <= 0 || channels <= 0 || hw <= 0 || (long long)batch * channels * hw > 0x7fffffffLL) return PP_ERR_BAD_ARG;
+  const int n = batch * channels * hw;
+  hipLaunchKernelGGL(latent_blend_kernel, dim3(grid_for_host(n)), dim3(256), 0, (hipStream_t)stream, latents, image_latents,
+                     mask, noise, renoise_table, step_dev, channels * hw, hw, n);
+  PP_CHECK_LAUNCH("latent_blend_kernel");
   return PP_OK;
 }
 

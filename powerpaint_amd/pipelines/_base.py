@@ -189,23 +189,30 @@ class PipelineBase(PipelinePretrainedMixin):
             self.scheduler.set_begin_index(t_start * self.scheduler.order)
         return timesteps, num_inference_steps - t_start
 
-    def _initial_latents(self, shape, strength, timesteps, latents, init_image, generator, device, noise_dtype):
+    def _initial_latents(self, shape, strength, timesteps, latents, init_image, generator, device, noise_dtype,
+                         return_image_latents=False, return_all=False):
         """prepare_latents (pipeline_PowerPaint.py:604-655): pure noise * init_noise_sigma at strength 1 (or when the
         caller hands `latents`, which the reference then treats as the noise whatever the strength), otherwise the
         VAE latents of the init image noised to the first timestep of the shortened schedule.  Draw order as in the
-        reference: the init image's posterior sample BEFORE the noise."""
+        reference: the init image's posterior sample BEFORE the noise.  `return_image_latents` (a 4-channel UNet,
+        :927-928): the init image is encoded in every case.  return_all -> (latents, noise, image_latents | None)."""
+        image_latents = None
+        if return_image_latents or (latents is None and strength != 1.0):
+            if init_image is None:
+                raise ValueError("Since strength < 1. initial latents are to be initialised as a combination of Image + "
+                                 "Noise.However, either the image or the noise timestep has not been provided.")
+            image_latents = self._vae_encode(init_image.to(device=device, dtype=noise_dtype), generator)
         if latents is not None:
-            return latents.to(device=device, dtype=torch.float32) * self.scheduler.init_noise_sigma
-        if strength == 1.0:
+            noise = latents.to(device=device)
+            out = noise.to(torch.float32) * self.scheduler.init_noise_sigma
+        else:
             noise = randn_tensor(shape, generator=generator, device=device, dtype=noise_dtype)
-            return noise.to(torch.float32) * self.scheduler.init_noise_sigma
-        if init_image is None:
-            raise ValueError("Since strength < 1. initial latents are to be initialised as a combination of Image + "
-                             "Noise.However, either the image or the noise timestep has not been provided.")
-        image_latents = self._vae_encode(init_image.to(device=device, dtype=noise_dtype), generator)
-        noise = randn_tensor(shape, generator=generator, device=device, dtype=noise_dtype)
-        t0 = timesteps[:1].repeat(shape[0])
-        return self.scheduler.add_noise(image_latents.to(noise.dtype), noise, t0).to(torch.float32)
+            if strength == 1.0:
+                out = noise.to(torch.float32) * self.scheduler.init_noise_sigma
+            else:
+                t0 = timesteps[:1].repeat(shape[0])
+                out = self.scheduler.add_noise(image_latents.to(noise.dtype), noise, t0).to(torch.float32)
+        return (out, noise, image_latents) if return_all else out
 
     # ---- text: promptA/promptB blended by `tradoff` (pipeline_PowerPaint.py:317-518)
     def _text_embeds(self, text_encoder, prompt: Union[str, List[str]], device):

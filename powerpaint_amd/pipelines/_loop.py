@@ -7,6 +7,7 @@ pipeline_PowerPaint_Brushnet_CA.py:1384-1466, pipeline_PowerPaint_ControlNet.py:
     [BrushNet | ControlNet forward]                                   (own launch plan, residuals stay in HBM as NHWC)
     eps          <- UNet(x_in, t, ctx, residuals)
     latents      <- scheduler.step(eps_u + g (eps_c - eps_u), t, latents)   (pp_cfg_sched_step, fp32)
+    [latents     <- (1 - m) add_noise(x0, noise, t_next) + m latents]       (pp_latent_blend; ppt-v1 with a 4-channel UNet)
     step         <- step + 1                                          (pp_step_advance)
 No host->device traffic and no host synchronisation inside the loop.
 
@@ -40,8 +41,11 @@ class DenoiseLoop:
     # ------------------------------------------------------------------
     def bind(self, latents_shape, do_cfg: bool, guidance_scale: float, prompt_embeds, prompt_embeds_side=None,
              static_inputs=(), side_static_inputs=(), controlnet_cond=None, side_scale: float = 1.0,
-             guess_mode: bool = False, eta: float = 0.0, generator=None, noise_dtype=torch.float32):
+             guess_mode: bool = False, eta: float = 0.0, generator=None, noise_dtype=torch.float32, blend=None):
         """Compile the per-step program.  latents_shape = (B, 4, h, w) of the *un-duplicated* latents.
+        blend = (image_latents [1,4,h,w], mask [1,1,h,w], noise [B,4,h,w]): the `num_channels_unet == 4` branch of the
+        ppt-v1 loop body (pipeline_PowerPaint.py:1025-1039) -- after every scheduler step the unmasked region is
+        replaced by the init image's latents noised to the NEXT timestep.
         eta > 0 with this package's DDIM (the only scheduler whose `step` takes it, pipeline_PowerPaint.py:536-551):
         the step program gains `latents += std_dev_t * z`; `run` draws z from `generator` before every step, in
         `noise_dtype`, exactly where the reference's `scheduler.step` calls `randn_tensor`.
@@ -70,6 +74,17 @@ class DenoiseLoop:
             self._extra_step_kwargs = {k: v for k, v in (("eta", eta), ("generator", generator)) if k in names}
         else:
             sch.set_eta(self._eta)
+        self._blend = None
+        if blend is not None:
+            # loop-owned fp32 copies at stable addresses (a captured graph reads them); first image / first mask only
+            x0, mk, nz = blend
+            want = ((1, Cl, h, w), (1, 1, h, w), tuple(latents_shape))
+            bufs = getattr(self, "_blend_bufs", None)
+            if bufs is None or tuple(tuple(b.shape) for b in bufs) != want:
+                bufs = self._blend_bufs = tuple(torch.zeros(sh, dtype=torch.float32, device=dev) for sh in want)
+            for b_, v in zip(bufs, (x0[:1], mk[:1], nz)):
+                b_.copy_(v.to(device=dev, dtype=torch.float32).reshape(b_.shape))
+            self._blend = bufs
         half = bool(guess_mode and do_cfg)                   # side network on the conditional half only
         # guess mode scales the n residuals by logspace(-1, 0, n) * conditioning_scale (BrushNet_CA.py:905-928): `run`'s
         # per-step scalar schedule is expanded the same way before it is patched into the zero-conv launches
@@ -119,7 +134,9 @@ class DenoiseLoop:
             kind, src = sch.kind, lat
         key = (tuple(latents_shape), bool(do_cfg), bool(guess_mode), self._eta > 0, float(guidance_scale), id(rt.step_plan),
                id(side_rt.step_plan) if side_rt is not None else None, kind, ts.data_ptr(), step.data_ptr(),
-               0 if self.foreign else sch.coef_table().data_ptr(), mp.data_ptr() if mp is not None else 0, src.data_ptr())
+               0 if self.foreign else sch.coef_table().data_ptr(), mp.data_ptr() if mp is not None else 0, src.data_ptr(),
+               tuple(b.data_ptr() for b in self._blend) if self._blend is not None else None,
+               sch.renoise_table().data_ptr() if (self._blend is not None and not self.foreign) else 0)
         if key == self._key and self.program is not None:
             # The conditioning scale is a by-value argument of the zero-conv launches: `prepare` has patched the launch
             # records (eager runs see it), but a graph captured with another value still carries the old one.
@@ -149,6 +166,10 @@ class DenoiseLoop:
                     self._var_noise = torch.zeros(latents_shape, dtype=torch.float32, device=dev)
                 prog.add("ddim_variance_noise", lib.pp_ddim_variance_noise, lat.data_ptr(), self._var_noise.data_ptr(),
                          lat.numel(), sch.coef_table().data_ptr(), step.data_ptr())
+            if self._blend is not None:
+                x0, mk, nz = self._blend
+                prog.add("latent_blend", lib.pp_latent_blend, lat.data_ptr(), x0.data_ptr(), mk.data_ptr(), nz.data_ptr(),
+                         sch.renoise_table().data_ptr(), step.data_ptr(), B, Cl, hw)
         prog.add("step_advance", lib.pp_step_advance, step.data_ptr())
         self.program = prog
         self.rt, self.side_rt = rt, side_rt
@@ -259,6 +280,12 @@ class DenoiseLoop:
                 eu, ec = eps.chunk(2)
                 eps = eu + self._g * (ec - eu)
             lat = sch.step(eps, t, lat, **self._extra_step_kwargs, return_dict=False)[0].to(torch.float32)
+            if self._blend is not None:                       # pipeline_PowerPaint.py:1025-1039, with the scheduler's own add_noise
+                x0, mk, nz = self._blend
+                proper = x0
+                if i < len(tl) - 1:
+                    proper = sch.add_noise(x0, nz, torch.as_tensor(tl[i + 1]).reshape(1).to(x0.device)).to(torch.float32)
+                lat = (1 - mk) * proper + mk * lat
             if callback is not None:
                 callback(i, t, lat)
         self.latents.copy_(lat)

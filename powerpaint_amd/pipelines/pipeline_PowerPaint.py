@@ -102,9 +102,10 @@ class StableDiffusionInpaintPipeline(PipelineBase):
         nb = batch_size * num_images_per_prompt
         h, w = height // self.vae_scale_factor, width // self.vae_scale_factor
         num_channels_unet = self.unet.config.in_channels
-        if num_channels_unet != 9:
-            raise NotImplementedError("the ppt-v1 hot path is the 9-channel inpainting UNet "
-                                      "(pipeline_PowerPaint.py:965-975)")
+        if num_channels_unet not in (4, 9):
+            raise ValueError(f"The unet {type(self.unet).__name__} should have either 4 or 9 input channels, not "
+                             f"{num_channels_unet}.")                                     # pipeline_PowerPaint.py:976-979
+        four = num_channels_unet == 4      # plain text-to-image UNet: known region re-imposed every step (:1025-1036)
         # 6. latents -- drawn BEFORE the masked-image posterior is sampled, in the prompt dtype, as the reference does
         #    (prepare_latents :930 precedes prepare_mask_latents :952): same seed / generator => same noise
         #    strength < 1 (:604-655, 713-720, 919): enter the schedule late, start from the noised init image
@@ -114,8 +115,12 @@ class StableDiffusionInpaintPipeline(PipelineBase):
         if pixels:
             mk, masked_image, init_image = prepare_mask_and_masked_image(image, mask, height, width, device,
                                                                           return_image=True)
-        latents = self._initial_latents(shape, strength, timesteps, latents, init_image, generator, device,
-                                        self._noise_dtype(prompt_embeds))
+        if four and not pixels:
+            raise ValueError("a 4-channel UNet needs the init image (its latents are blended back every step): pass "
+                             "`image` and `mask`, not latent-space inputs")
+        latents, noise, image_latents = self._initial_latents(shape, strength, timesteps, latents, init_image, generator,
+                                                              device, self._noise_dtype(prompt_embeds),
+                                                              return_image_latents=four, return_all=True)
         # 5./7. mask + masked-image latents
         if not pixels:
             m = mask_latents.to(device=device, dtype=torch.float32)
@@ -125,14 +130,15 @@ class StableDiffusionInpaintPipeline(PipelineBase):
         else:
             m, mil = self.prepare_mask_latents(mk, masked_image, nb, height, width, prompt_embeds.dtype, device,
                                                generator, do_cfg, masked_image_latents)
-        if 4 + m.shape[1] + mil.shape[1] != num_channels_unet:
+        if not four and 4 + m.shape[1] + mil.shape[1] != num_channels_unet:
             raise ValueError("Incorrect configuration settings! mask / masked-image latents do not add up to "
                              f"unet.config.in_channels = {num_channels_unet}")
         # 10. fused denoising loop
         if self._loop is None or self._loop.scheduler is not self.scheduler or self._loop.unet is not self.unet:
             self._loop = DenoiseLoop(self.unet, self.scheduler)
-        self._loop.bind(shape, do_cfg, guidance_scale, prompt_embeds, static_inputs=[(m, 4), (mil, 5)], eta=eta,
-                        generator=generator, noise_dtype=self._noise_dtype(prompt_embeds))
+        self._loop.bind(shape, do_cfg, guidance_scale, prompt_embeds, static_inputs=[] if four else [(m, 4), (mil, 5)],
+                        eta=eta, generator=generator, noise_dtype=self._noise_dtype(prompt_embeds),
+                        blend=(image_latents, m, noise) if four else None)
         cb = None
         if callback is not None:
             def cb(i, t, lat):

@@ -87,8 +87,17 @@ class StableDiffusionControlNetInpaintPipeline(StableDiffusionInpaintPipeline):
         if pixels:
             mk, masked_image, init_image = prepare_mask_and_masked_image(image, mask, height, width, device,
                                                                           return_image=True)
-        latents = self._initial_latents(shape, strength, timesteps, latents, init_image, generator, device,
-                                        self._noise_dtype(prompt_embeds))
+        num_channels_unet = self.unet.config.in_channels
+        if num_channels_unet not in (4, 9):                                     # pipeline_PowerPaint_ControlNet.py:1251-1254
+            raise ValueError(f"The unet {type(self.unet).__name__} should have either 4 or 9 input channels, not "
+                             f"{num_channels_unet}.")
+        four = num_channels_unet == 4      # known region re-imposed after every step (:1613, 1725-1736)
+        if four and not pixels:
+            raise ValueError("a 4-channel UNet needs the init image (its latents are blended back every step): pass "
+                             "`image` and `mask`, not latent-space inputs")
+        latents, noise, image_latents = self._initial_latents(shape, strength, timesteps, latents, init_image, generator,
+                                                              device, self._noise_dtype(prompt_embeds),
+                                                              return_image_latents=four, return_all=True)
         if not pixels:
             m = mask_latents.to(device=device, dtype=torch.float32)
             mil = masked_image_latents.to(device)
@@ -104,9 +113,9 @@ class StableDiffusionControlNetInpaintPipeline(StableDiffusionInpaintPipeline):
                 self._loop.side is not self.controlnet:
             self._loop = DenoiseLoop(self.unet, self.scheduler, side=self.controlnet, side_kind="controlnet")
         self._loop.bind(shape, do_cfg, guidance_scale, prompt_embeds, prompt_embeds_side=prompt_embeds,
-                        static_inputs=[(m, 4), (mil, 5)], controlnet_cond=control_image, side_scale=scales[0],
-                        guess_mode=guess_mode, eta=eta, generator=generator,
-                        noise_dtype=self._noise_dtype(prompt_embeds))
+                        static_inputs=[] if four else [(m, 4), (mil, 5)], controlnet_cond=control_image,
+                        side_scale=scales[0], guess_mode=guess_mode, eta=eta, generator=generator,
+                        noise_dtype=self._noise_dtype(prompt_embeds), blend=(image_latents, m, noise) if four else None)
         cb = None
         if callback is not None:
             def cb(i, t, lat):

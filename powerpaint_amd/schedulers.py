@@ -110,7 +110,8 @@ class _SchedulerBase:
         self._device = torch.device(device) if device is not None else None
         if self._device is not None and self._device.type == "cuda":
             same = (self._coef_dev is not None and self._coef_dev.shape == self._coef.shape
-                    and self._coef_dev.device == self._device)
+                    and self._coef_dev.device.type == "cuda"
+                    and (self._device.index is None or self._coef_dev.device.index == self._device.index))
             if same:   # keep device addresses stable across calls so captured graphs stay valid
                 self._coef_dev.copy_(self._coef)
                 self._ts_dev.copy_(self.timesteps.to(torch.float32))
@@ -131,6 +132,24 @@ class _SchedulerBase:
 
     def step_counter(self) -> torch.Tensor:
         return self._step_dev
+
+    def renoise_table(self) -> torch.Tensor:
+        """[rows][2] fp32 on the scheduler's device, indexed by the step counter like the coefficient table: what
+        `add_noise(x0, noise, timesteps[i + 1])` multiplies x0 and the noise by AFTER step i -- (sqrt(abar), sqrt(1-abar))
+        of the next timestep, (1, 0) after the last one.  The ppt-v1 loop with a 4-channel UNet re-noises the known
+        region with it every step (pipeline_PowerPaint.py:1025-1039; pp_latent_blend)."""
+        ts = self._ts_host.long()
+        a = self.alphas_cumprod[ts[1:]].to(torch.float32)
+        tab = torch.stack([torch.cat([a ** 0.5, torch.ones(1)]), torch.cat([(1 - a) ** 0.5, torch.zeros(1)])], 1)
+        dev = self._device if self._device is not None else "cpu"
+        cur = getattr(self, "_renoise_dev", None)
+        want = torch.device(dev)
+        if cur is not None and cur.shape == tab.shape and cur.device.type == want.type and \
+                (want.index is None or cur.device.index == want.index):
+            cur.copy_(tab)            # (stable address: a captured step graph reads it)
+        else:
+            self._renoise_dev = tab.to(dev).contiguous()
+        return self._renoise_dev
 
     state_slots = 1          # fp32 copies of the latents the step kernel keeps between steps (DPM: 1, PNDM: 5)
 

@@ -222,9 +222,53 @@ def main_eta():
     print("eta", out.shape, float(out.abs().max()))
 
 
+CALL_4CH = dict(CALL, num_inference_steps=4)
+CALL_4CH_CN = dict(CALL_CN, num_inference_steps=4, strength=0.8)
+
+
+def components_4ch():
+    tok, enc, _, vae = components()
+    torch.manual_seed(37)
+    unet = bf16_(OM.UNet2DConditionModel(in_channels=4, **TINY)).eval()
+    return tok, enc, unet, vae
+
+
+def main_4ch():
+    """ref_pipeline_call_4ch.pt: the `num_channels_unet == 4` branch of the v1 and the ControlNet `__call__`s
+    (pipeline_PowerPaint.py:927-928,965-979,1025-1036; pipeline_PowerPaint_ControlNet.py:1612-1613,1725-1736): a plain
+    4-channel UNet sees only the latents; after every scheduler step the unmasked region is replaced by the init
+    image's latents noised to the next timestep.  No `latents` argument: init-image posterior sample, noise, masked-image
+    posterior sample come from one generator, in that order.  Case "v1": DDIM, strength 1; case "cn": ControlNet,
+    DPM-Solver++, strength 0.8 (schedule entered at entry 1 of 4, initial latents = noised init image)."""
+    from oracle import ref_pipeline
+    Pipe, _ = ref_pipeline.load_reference_pipeline_class()
+    tok, enc, unet, vae = components_4ch()
+    pipe = Pipe(vae=vae, text_encoder=enc, tokenizer=tok, unet=unet, scheduler=OS.DDIMScheduler(), safety_checker=None,
+                feature_extractor=None, requires_safety_checker=False)
+    img, mask, _ = inputs()
+    seen = []
+    with torch.no_grad():
+        out = pipe(image=img, mask=mask, generator=torch.Generator().manual_seed(5), output_type="latent",
+                   return_dict=False, callback=lambda i, t, l: seen.append((i, int(t), l.clone())), **CALL_4CH)[0]
+    Pipe = ref_pipeline.load_reference_controlnet_pipeline_class(OM.ControlNetModel)
+    _, _, _, cn, _ = components_cn()
+    pipe = Pipe(vae=vae, text_encoder=enc, tokenizer=tok, unet=unet, controlnet=cn,
+                scheduler=OS.DPMSolverMultistepScheduler(**DPM_SD15), safety_checker=None, feature_extractor=None,
+                requires_safety_checker=False)
+    seen_cn = []
+    with torch.no_grad():
+        out_cn = pipe(image=img, mask=mask, control_image=control_image(), generator=torch.Generator().manual_seed(6),
+                      output_type="latent", return_dict=False,
+                      callback=lambda i, t, l: seen_cn.append((i, int(t), l.clone())), **CALL_4CH_CN)[0]
+    torch.save(dict(latents=out, steps=seen, latents_cn=out_cn, steps_cn=seen_cn),
+               os.path.join(HERE, "ref_pipeline_call_4ch.pt"))
+    print("4ch", out.shape, float(out.abs().max()), [s[:2] for s in seen], "cn", float(out_cn.abs().max()),
+          [s[:2] for s in seen_cn])
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] in ("strength", "guess", "eta"):
-        {"strength": main_strength, "guess": main_guess, "eta": main_eta}[sys.argv[1]]()
+    if len(sys.argv) > 1 and sys.argv[1] in ("strength", "guess", "eta", "4ch"):
+        {"strength": main_strength, "guess": main_guess, "eta": main_eta, "4ch": main_4ch}[sys.argv[1]]()
         sys.exit(0)
     main()
     main_v2()
@@ -232,3 +276,4 @@ if __name__ == "__main__":
     main_strength()
     main_guess()
     main_eta()
+    main_4ch()

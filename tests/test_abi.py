@@ -55,6 +55,7 @@ def test_bad_args_are_rejected_without_a_gpu():
     assert lib.pp_attention_fwd(None, 0, None, 0, None, 0, None, 0, 1, 8, 64, 64, 40, 1.0, 1, None) == -1
     assert lib.pp_layernorm(None, 1, 320, None, None, 1e-5, None, 1, None) == -1
     assert lib.pp_ddim_variance_noise(None, None, 16, None, None, None) == -1
+    assert lib.pp_latent_blend(None, None, None, None, None, None, 1, 4, 256, None) == -1
     b = _lib.PPGemmArgs()
     b.M = b.N = b.K = 64
     b.dtype = 7                                                      # not bf16 / fp16

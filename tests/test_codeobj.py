@@ -60,7 +60,7 @@ def test_no_hot_kernel_uses_scratch_memory():
     assert len(ks) >= 200, len(ks)                      # five translation units, every template instantiation
     names = [n for n, _ in ks]
     for must in ("attn_pipe_kernel", "pp_gemm_kernel_v2", "gn_apply_kernel", "conv3x3_cout4_mfma_kernel",
-                 "cfg_sched_step_kernel", "ddim_variance_noise_kernel"):
+                 "cfg_sched_step_kernel", "ddim_variance_noise_kernel", "latent_blend_kernel"):
         assert any(must in n for n in names), must
     bad = []
     for n, r in ks:

@@ -511,3 +511,100 @@ def test_product_prepare_latents_for_strength_matches_the_reference_draw_order()
     assert torch.equal(pb._initial_latents((1, 4, 16, 16), 0.6, ts, given, img, g, "cpu", torch.float32), given)
     with pytest.raises(ValueError):
         pb._initial_latents((1, 4, 16, 16), 0.6, ts, None, None, g, "cpu", torch.float32)
+
+
+def _four_channel_fixture():
+    import make_ref_pipeline_call as M
+    return M, torch.load(os.path.join(HERE, "golden", "ref_pipeline_call_4ch.pt"), weights_only=False)
+
+
+def test_oracle_loop_reproduces_the_reference_call_with_a_4_channel_unet():
+    """The `num_channels_unet == 4` branch (pipeline_PowerPaint.py:927-928,1025-1036; ControlNet pipeline :1612-1613,
+    1725-1736): the oracle loop's restatement against the reference's own `__call__`s, per step and final.  Draw order
+    from the one generator: init-image posterior sample, noise, masked-image posterior sample."""
+    from oracle import loops as OL, schedulers as OS
+    M, gold = _four_channel_fixture()
+    tok, enc, unet, vae = M.components_4ch()
+    img, mask, _ = M.inputs()
+    emb = _emb(tok, enc)
+    m = torch.nn.functional.interpolate(mask, size=(16, 16))
+    with torch.no_grad():
+        c = M.CALL_4CH
+        pos = emb(c["promptA"]) * c["tradoff"] + (1 - c["tradoff"]) * emb(c["promptB"])
+        neg = emb(c["negative_promptA"]) * c["tradoff_nag"] + (1 - c["tradoff_nag"]) * emb(c["negative_promptB"])
+        g = torch.Generator().manual_seed(5)
+        il = vae.encode(img).latent_dist.sample(g) * vae.config.scaling_factor
+        noise = torch.randn(1, 4, 16, 16, generator=g)
+        rec = []
+        out = OL.loop_v1(unet, OS.DDIMScheduler(), noise, torch.cat([m] * 2), None, torch.cat([neg, pos]),
+                         c["num_inference_steps"], c["guidance_scale"], image_latents=il, noise=noise,
+                         eps_hook=lambda i, t, l, e: rec.append((i, int(t), l.clone())))
+        assert [r[:2] for r in rec] == [s[:2] for s in gold["steps"]] == [(0, 751), (1, 501), (2, 251), (3, 1)]
+        for (i, t, l_in), (_, _, l_prev) in zip(rec[1:], gold["steps"][:-1]):
+            assert torch.allclose(l_in, l_prev, atol=1e-4, rtol=1e-4), i
+        assert torch.allclose(out, gold["latents"], atol=1e-4, rtol=1e-4)
+        # the last step puts the CLEAN init latents back outside the mask
+        keep = (m[0, 0] == 0)
+        assert torch.equal(out[0][:, keep], il[0][:, keep])
+        # ControlNet pipeline, DPM-Solver++, strength 0.8: schedule entered at entry 1 of 4
+        c = M.CALL_4CH_CN
+        _, _, _, cn, _ = M.components_cn()
+        pos = emb(c["promptA"]) * c["tradoff"] + (1 - c["tradoff"]) * emb(c["promptB"])
+        neg = emb(c["negative_promptA"]) * c["tradoff_nag"] + (1 - c["tradoff_nag"]) * emb(c["negative_promptB"])
+        sch = OS.DPMSolverMultistepScheduler(**M.DPM_SD15)
+        sch.set_timesteps(c["num_inference_steps"])
+        t_start = c["num_inference_steps"] - int(c["num_inference_steps"] * c["strength"])
+        assert sch.timesteps[t_start:].tolist() == [s[1] for s in gold["steps_cn"]] == [601, 401, 201]
+        g = torch.Generator().manual_seed(6)
+        il = vae.encode(img).latent_dist.sample(g) * vae.config.scaling_factor
+        noise = torch.randn(1, 4, 16, 16, generator=g)
+        lat = sch.add_noise(il, noise, sch.timesteps[t_start:t_start + 1])
+        out = OL.loop_v1(unet, sch, lat, torch.cat([m] * 2), None, torch.cat([neg, pos]), c["num_inference_steps"],
+                         c["guidance_scale"], controlnet=cn, control_image=torch.cat([M.control_image()] * 2),
+                         controlnet_conditioning_scale=c["controlnet_conditioning_scale"], t_start=t_start,
+                         image_latents=il, noise=noise)
+        assert torch.allclose(out, gold["latents_cn"], atol=1e-4, rtol=1e-4)
+
+
+@pytest.mark.gpu
+def test_hip_pipelines_reproduce_the_reference_call_with_a_4_channel_unet():
+    """VERDICT round 2, missing #5: the product's v1 and ControlNet pipelines with a plain 4-channel UNet (known region
+    re-noised and blended back after every step: pp_latent_blend inside the captured step; a duck-typed scheduler takes
+    the torch path with its own add_noise) against the reference's own `__call__`s."""
+    from powerpaint_amd import models as PM, pipelines as PP, schedulers as PS
+    from oracle import schedulers as OS
+    M, gold = _four_channel_fixture()
+    tok, enc, unet, vae = M.components_4ch()
+    img, mask, _ = M.inputs()
+    hu = PM.UNet2DConditionModel(in_channels=4, device="cuda", **M.TINY).load_state_dict(unet.state_dict())
+    hv = PM.AutoencoderKL(device="cuda", **M.VAE_CFG).load_state_dict(vae.state_dict())
+    he = PM.CLIPTextModel(device="cuda", vocab_size=enc.config.vocab_size, num_hidden_layers=1,
+                          eos_token_id=enc.config.eos_token_id)
+    he.load_state_dict(enc.state_dict())
+    outs = []
+    for sch in (PS.DDIMScheduler(), OS.DDIMScheduler()):
+        pipe = PP.StableDiffusionInpaintPipeline(vae=hv, text_encoder=he, tokenizer=tok, unet=hu, scheduler=sch)
+        for use_graph in (True, False):
+            pipe.use_graph = use_graph
+            seen = []
+            out = pipe(image=img, mask=mask, generator=torch.Generator().manual_seed(5), output_type="latent",
+                       return_dict=False, callback=lambda i, t, l: seen.append((int(t), l.clone())), **M.CALL_4CH)[0]
+            assert [s[0] for s in seen] == [751, 501, 251, 1]
+            what = f"v1 pipeline, 4-channel UNet, {type(sch).__module__.split('.')[0]} scheduler, graph={use_graph}"
+            _close_latents(seen[0][1], gold["steps"][0][2], what + " (after step 0)")
+            _close_latents(out, gold["latents"], what)
+            outs.append(out)
+    # latent-space inputs cannot feed this branch (there is no init image to put back)
+    with pytest.raises(ValueError, match="4-channel UNet needs the init image"):
+        pipe(promptA="a", promptB="b", mask_latents=torch.zeros(1, 1, 16, 16), masked_image_latents=torch.zeros(1, 4, 16, 16),
+             height=128, width=128, num_inference_steps=2, output_type="latent")
+    _, _, _, cn, _ = M.components_cn()
+    no_up = {k: v for k, v in M.TINY.items() if k != "up_block_types"}
+    hc = PM.ControlNetModel(in_channels=4, device="cuda", **no_up).load_state_dict(cn.state_dict())
+    pipe = PP.StableDiffusionControlNetInpaintPipeline(vae=hv, text_encoder=he, tokenizer=tok, unet=hu, controlnet=hc,
+                                                       scheduler=PS.DPMSolverMultistepScheduler(**M.DPM_SD15))
+    seen = []
+    out = pipe(image=img, mask=mask, control_image=M.control_image(), generator=torch.Generator().manual_seed(6),
+               output_type="latent", return_dict=False, callback=lambda i, t, l: seen.append(int(t)), **M.CALL_4CH_CN)[0]
+    assert seen == [601, 401, 201]
+    _close_latents(out, gold["latents_cn"], "controlnet pipeline, 4-channel UNet, strength 0.8")

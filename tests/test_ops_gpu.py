@@ -611,3 +611,25 @@ def test_geglu_wave_specialised_kernel(M, C, fold, dtype):
     y = (y + b).reshape(len(rows), N // 4, 4)
     ref = torch.stack([y[..., 0] * F.gelu(y[..., 2]), y[..., 1] * F.gelu(y[..., 3])], -1).reshape(len(rows), N // 2)
     check(new[rows], ref, 3e-2, 1e-2, "wave-specialised GEGLU vs fp32")
+
+
+def test_latent_blend_kernel():
+    """pp_latent_blend = the 4-channel-UNet branch of the v1 loop body (pipeline_PowerPaint.py:1025-1036): row `step` of
+    the re-noise table, first image / first mask broadcast over the batch, clean latents on the (1, 0) row."""
+    B, Cc, h, w = 3, 4, 16, 24
+    lat, nz = rnd(B, Cc, h, w, seed=1), rnd(B, Cc, h, w, seed=2)
+    x0 = rnd(1, Cc, h, w, seed=3)
+    mk = (rnd(1, 1, h, w, seed=4) > 0).float()
+    tab = torch.tensor([[0.3, 0.95], [0.8, 0.6], [1.0, 0.0]], device=DEV)
+    lib = L.lib()
+    for r in range(3):
+        step = torch.tensor([r], dtype=torch.int32, device=DEV)
+        out = lat.clone()
+        rc = lib.pp_latent_blend(out.data_ptr(), x0.data_ptr(), mk.data_ptr(), nz.data_ptr(), tab.data_ptr(), step.data_ptr(),
+                                 B, Cc, h * w, torch.cuda.current_stream().cuda_stream)
+        assert rc == 0
+        proper = x0 if r == 2 else tab[r, 0] * x0 + tab[r, 1] * nz
+        ref = (1 - mk) * proper + mk * lat
+        check(out, ref, 1e-6, 1e-6, f"latent blend row {r}")
+        if r == 2:
+            assert torch.equal(out[:, :, mk[0, 0] == 0], x0.expand(B, -1, -1, -1)[:, :, mk[0, 0] == 0])

@@ -138,3 +138,26 @@ def test_unipc_from_config_refuses_what_it_cannot_compute():
     assert ok.config.solver_type == "bh2"
     assert PS.UniPCMultistepScheduler(solver_type="bh1").config.solver_type == "bh1"
     assert PS.UniPCMultistepScheduler.from_config({**base, "solver_type": "bh1", "solver_order": 3}).config.solver_order == 3
+
+
+@pytest.mark.parametrize("name,kw", [("DDIMScheduler", {}), ("DPMSolverMultistepScheduler", {}), ("PNDMScheduler", {}),
+                                     ("UniPCMultistepScheduler", {})])
+def test_renoise_table_is_add_noise_of_the_next_timestep(name, kw):
+    """`renoise_table()[i]` = what `scheduler.add_noise(x0, noise, timesteps[i + 1])` multiplies x0 and the noise by
+    (pipeline_PowerPaint.py:1029-1033), (1, 0) after the last step; rows follow the step counter (full schedule)."""
+    from oracle import schedulers as OS
+    from powerpaint_amd import schedulers as PS
+    o, h = getattr(OS, name)(**kw), getattr(PS, name)(**kw)
+    o.set_timesteps(7)
+    h.set_timesteps(7)
+    tab = h.renoise_table()
+    ts = [int(t) for t in o.timesteps]
+    assert tab.shape == (len(ts), 2)
+    x0, nz = torch.full((1, 1), 1.0), torch.zeros(1, 1)
+    for i in range(len(ts) - 1):
+        a = float(o.add_noise(x0, nz, torch.tensor([ts[i + 1]])))
+        b = float(o.add_noise(nz, x0, torch.tensor([ts[i + 1]])))
+        assert abs(float(tab[i, 0]) - a) < 1e-6 and abs(float(tab[i, 1]) - b) < 1e-6, (i, tab[i], a, b)
+    assert tab[-1].tolist() == [1.0, 0.0]
+    h.set_timesteps(7)
+    assert h.renoise_table().data_ptr() == tab.data_ptr()             # stable address for the captured step
