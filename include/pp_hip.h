@@ -29,7 +29,7 @@ extern "C" {
 #define PP_ERR_LAUNCH (-3)       /* hipLaunchKernel / hipFuncSetAttribute failed                  */
 #define PP_ERR_WORKSPACE (-4)    /* workspace pointer null or too small                           */
 
-#define PP_ABI_VERSION 9
+#define PP_ABI_VERSION 10
 /* 16-bit storage format of activations and matrix weights ("dtype" arguments; the same codes pp_nchw_to_nhwc uses for
  * its source): bf16 or fp16 -- the reference's default is fp16 (/root/reference/app.py:548,559).  MFMA accumulation,
  * norm statistics, softmax, biases and latents are fp32 with either. */
@@ -275,6 +275,33 @@ int pp_cfg_sched_step(const float* eps2, int cfg, float guidance, float* latents
  * sqrt(1-a_prev-std_dev_t^2)) and `noise` fp32 [n] drawn by the host from the caller's generator, once per step. */
 int pp_ddim_variance_noise(float* latents, const float* noise, int n, const float* coef_table, const int32_t* step_dev,
                            void* stream);
+
+/* Fused cross-attention sub-block of BasicTransformerBlock (norm2 -> attn2 -> residual) for C = 320, 8 heads, <= 80
+ * context tokens -- the three launches `to_q` (pp_gemm_bf16, LayerNorm folded) -> pp_attention_fwd -> `to_out`
+ * (pp_gemm_bf16 + residual + row moments) of the 64x64 level as ONE (ctor site /root/reference/powerpaint/models/
+ * unet_2d_blocks.py:1289-1300; diffusers 0.27 `BasicTransformerBlock.forward`: `attn2(norm2(h), encoder_hidden_states) + h`).
+ * The encoder hidden states do not change during a call, so pp_xattn_fold contracts K into the query projection and V
+ * into the output projection once per prompt:
+ *     gt   [batch][heads*80][c]   G^T[b][h*80+key][:] = scale*log2(e) * sum_d K[b][key][h*d'+d] * wq[h*d'+d][:]   (16-bit)
+ *     gcs, gbias [batch][heads*80] fp32: the same contraction of q_colsum / q_bias (the folded-LayerNorm terms of
+ *          to_q; NULL = 0); gbias = -inf on the padded keys (key >= nctx), which masks them
+ *     ht   [batch][c][heads*80]   H^T[b][n][h*80+key] = sum_d wo[n][h*d'+d] * V^T[b][h*d'+d][key], the contraction
+ *          index permuted inside every group of 32 (position 8*kg + j holds index 16*(j>>2) + 4*kg + (j&3)) so that the
+ *          accumulator registers of the logits are the B fragments of the second GEMM without any data movement
+ * with k [batch*nctx][ldk] and vt [batch][c][ldvt] as pp_attention_fwd takes them, wq / wo [c][c] row-major
+ * ([out][in]).  pp_xattn_block then computes, per 128-row tile (rows_per_batch % 128 == 0),
+ *     p   = softmax_per_head( rstd*(x gt^T - mean*gcs) + gbias )          (exp2 domain; mean / rstd from ln_stats as in
+ *                                                                           PPGemmArgs, NULL = no LayerNorm folded)
+ *     out = p ht^T + bias_o + res ,   row_stats_out[m][c/160][2] = (sum, sum of squares) of the stored values.
+ * pp_xattn_block_supported() = 1 when the shape is one this kernel takes (the caller keeps the three-launch chain
+ * otherwise); both entry points return PP_ERR_UNSUPPORTED for other shapes. */
+int pp_xattn_block_supported(int M, int c, int rows_per_batch, int nctx, int heads);
+int pp_xattn_fold(const void* k, int ldk, const void* vt, int ldvt, int batch, int nctx, int heads, int c, const void* wq,
+                  const float* q_colsum, const float* q_bias, const void* wo, float scale, void* gt, float* gcs,
+                  float* gbias, void* ht, int dtype, void* stream);
+int pp_xattn_block(const void* x, int ldx, const void* res, int ldres, const float* ln_stats, int ln_tiles, float ln_eps,
+                   const void* gt, const float* gcs, const float* gbias, const void* ht, const float* bias_o, void* out,
+                   int ldo, float* row_stats_out, int M, int c, int rows_per_batch, int dtype, void* stream);
 
 /* ppt-v1 with a 4-channel (non-inpainting) UNet -- the `num_channels_unet == 4` branch of the loop body,
  * pipeline_PowerPaint.py:1025-1039: after pp_cfg_sched_step of the same step

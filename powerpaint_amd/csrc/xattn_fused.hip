@@ -1,0 +1,384 @@
+// Fused cross-attention sub-block of BasicTransformerBlock at C = 320 (the 64x64 level of SD-1.5; 128x128 on config 5):
+//
+//     h_out = h + to_out( softmax( to_q(LN2(h)) K^T / sqrt(d) ) V )                 one launch instead of three
+//
+// (reference ctor site /root/reference/powerpaint/models/unet_2d_blocks.py:1289-1300 -> diffusers 0.27
+// BasicTransformerBlock.attn2 + norm2; the unfused plan is engine.py `_transformer`: `linear` (to_q, LayerNorm folded)
+// -> `attention` (77 keys) -> `linear` (to_out + residual + row moments), 20 + 22 + 20 us and 4 x 21 MB of q / o
+// round trips per block at 64x64).
+//
+// The encoder hidden states are step-invariant, so K and V can be folded into the two projections ONCE per prompt
+// (pp_xattn_fold, part of the setup plan):
+//     logits_h = LN2(h) . G_h ,   G_h = scale * Wq_h^T K_h^T      [C][80 keys]  per (batch item, head)
+//     out      = sum_h P_h . H_h ,  H_h = V_h Wo_h^T               [80 keys][C]
+// which turns the sub-block into two chained GEMMs with a per-head softmax in between -- N = 8 heads x 80 keys = 640
+// logit columns, K = C; then K = 640, N = C -- whose intermediate (the probabilities) never leaves the registers:
+// the MFMA accumulator layout of the first GEMM (lane = row, four consecutive columns per register quad) IS the
+// B-operand layout of the second one, up to a fixed permutation of the contraction index that is applied to H when it is
+// packed.  Twice the FLOPs of the unfused chain (13.4 + 13.4 instead of 6.7 + 3.3 + 3.3 + 6.7 GFLOP at 64x64 x 8),
+// none of its HBM round trips.
+//
+// One workgroup = 128 rows of one batch item, eight waves of 16 rows each; a wave owns ALL columns of its rows (softmax
+// and the second contraction need no exchange).  The wave's 16 x 320 input rows are MFMA B fragments loaded straight
+// from global memory; the only thing that streams through LDS is "weights": twenty 40 KB slabs (320 rows x 64 k) --
+// G^T heads 0-3 (5 slabs), G^T heads 4-7 (5), H^T (10) -- through a three-stage LDS-DMA ring with counted vmcnt waits.
+#include <type_traits>
+#include <utility>
+
+#include "pp_common.h"
+
+namespace {
+
+constexpr int XA_C = 320, XA_HEADS = 8, XA_KP = 80, XA_S = XA_HEADS * XA_KP;   // 640 logit columns
+constexpr int XA_BM = 128;
+constexpr int XA_SLAB = 320 * 128, XA_NS = 3, XA_NSLAB = 20;
+constexpr int XA_TAB = XA_NS * XA_SLAB;                   // (logit colsum | logit bias) of the batch item, fp32 [2][640]
+constexpr int XA_LDS = XA_TAB + 2 * XA_S * 4;
+
+typedef __attribute__((address_space(3))) void* xa_lds_ptr_t;
+
+struct XAArgs {
+  const uint16_t* x; int ldx;
+  const uint16_t* res; int ldres;
+  const float* ln_stats; int ln_tiles; float ln_eps;
+  const uint16_t* gt; const float* gcs; const float* gbias; const uint16_t* ht;
+  const float* bias_o;
+  uint16_t* out; int ldo;
+  float* row_stats_out;
+  int M, rows_per_batch;
+};
+
+template <int... I, class F>
+PP_DEVINL void xa_static_for_impl(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+PP_DEVINL void xa_static_for(F&& f) { xa_static_for_impl(std::make_integer_sequence<int, N>{}, f); }
+
+// ---- once per prompt: G^T [B][640][C] (16-bit), logit colsum / bias [B][640] (fp32), H^T [B][C][640] (16-bit, k-permuted)
+template <int EDT>
+__global__ void __launch_bounds__(256) xattn_fold_kernel(const uint16_t* __restrict__ k, int ldk,
+                                                        const uint16_t* __restrict__ vt, int ldvt, int batch, int nctx,
+                                                        const uint16_t* __restrict__ wq, const float* __restrict__ qcs,
+                                                        const float* __restrict__ qb, const uint16_t* __restrict__ wo,
+                                                        float qscale, uint32_t* __restrict__ gt, float* __restrict__ gcs,
+                                                        float* __restrict__ gb, uint32_t* __restrict__ ht) {
+  using E = E16<EDT>;
+  constexpr int C = XA_C, D = XA_C / XA_HEADS;
+  const long long n_g = (long long)batch * XA_S * (C / 2), n_h = (long long)batch * C * (XA_S / 2),
+                  n_v = (long long)batch * XA_S;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n_g + n_h + n_v; i += (long long)gridDim.x * 256) {
+    if (i < n_g) {                                        // G^T[b][n = h * 80 + key][c], two c per thread
+      const int c2 = (int)(i % (C / 2)), n = (int)((i / (C / 2)) % XA_S), b = (int)(i / ((long long)(C / 2) * XA_S));
+      const int h = n / XA_KP, key = n % XA_KP;
+      float s0 = 0.f, s1 = 0.f;
+      if (key < nctx) {
+        const uint16_t* kr = k + ((size_t)b * nctx + key) * ldk + h * D;
+        const uint16_t* wr = wq + (size_t)(h * D) * C + 2 * c2;
+        for (int j = 0; j < D; ++j) {
+          const float kv = E::to_f(kr[j]);
+          const uint32_t w2 = *reinterpret_cast<const uint32_t*>(wr + (size_t)j * C);
+          s0 = fmaf(kv, E::lo(w2), s0);
+          s1 = fmaf(kv, E::hi(w2), s1);
+        }
+      }
+      gt[i] = E::pack2(s0 * qscale, s1 * qscale);
+    } else if (i < n_g + n_h) {                           // H^T[b][n][storage position kp], two kp per thread
+      const long long r = i - n_g;
+      const int p2 = (int)(r % (XA_S / 2)), n = (int)((r / (XA_S / 2)) % C), b = (int)(r / ((long long)(XA_S / 2) * C));
+      float v[2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        // storage position kp of a 32-group holds contraction index 32 s + 16 (j >> 2) + 4 kg + (j & 3), kp = 32 s + 8 kg + j:
+        // a lane's 16-byte A fragment (k-group kg) then lines up with accumulator quads of logit blocks 2s and 2s + 1
+        const int kp = 2 * p2 + e, s32 = kp >> 5, kg = (kp >> 3) & 3, j = kp & 7;
+        const int kk = 32 * s32 + 16 * (j >> 2) + 4 * kg + (j & 3);
+        const int h = kk / XA_KP, key = kk % XA_KP;
+        float s = 0.f;
+        if (key < nctx) {
+          const uint16_t* wr = wo + (size_t)n * C + h * D;
+          const uint16_t* vr = vt + ((size_t)b * C + h * D) * ldvt + key;
+          for (int jj = 0; jj < D; ++jj) s = fmaf(E::to_f(wr[jj]), E::to_f(vr[(size_t)jj * ldvt]), s);
+        }
+        v[e] = s;
+      }
+      ht[r] = E::pack2(v[0], v[1]);
+    } else {                                              // folded-LayerNorm terms of the logits; -inf masks the padded keys
+      const long long r = i - n_g - n_h;
+      const int n = (int)(r % XA_S), b = (int)(r / XA_S);
+      const int h = n / XA_KP, key = n % XA_KP;
+      float s0 = 0.f, s1 = 0.f;
+      if (key < nctx) {
+        const uint16_t* kr = k + ((size_t)b * nctx + key) * ldk + h * D;
+        for (int j = 0; j < D; ++j) {
+          const float kv = E::to_f(kr[j]);
+          if (qcs) s0 = fmaf(kv, qcs[h * D + j], s0);
+          if (qb) s1 = fmaf(kv, qb[h * D + j], s1);
+        }
+      }
+      gcs[r] = s0 * qscale;
+      gb[r] = key < nctx ? s1 * qscale : -INFINITY;
+    }
+  }
+}
+
+// DBG (lab build only): 1 no slab DMA, 2 no MFMAs, 4 no fragment reads, 8 no softmax, 16 no epilogue, 32 no barriers
+template <int EDT, int DBG = 0>
+__global__ void __launch_bounds__(512, 2) xattn_block_kernel(const XAArgs a) {
+  using E = E16<EDT>;
+  typedef typename E::v8 v8_t;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* tabs = reinterpret_cast<float*>(smem + XA_TAB);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r16 = lane & 15, g = lane >> 4;
+  // XCD-aware bijective remap (block b runs on XCD b % 8): consecutive tiles -- the rows of one batch item, which share
+  // G and H -- land on one XCD's L2
+  int lid;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int m_blk = lid * XA_BM;
+  const int b = m_blk / a.rows_per_batch;
+  const int m = m_blk + wave * 16 + r16;                 // this lane's row: MFMA B column / accumulator column
+
+  // ---- the wave's 16 input rows as B fragments (k-group g: eight consecutive channels), straight from global memory
+  v8_t xf[10];
+  {
+    const uint16_t* xr = a.x + (size_t)m * a.ldx + g * 8;
+#pragma unroll
+    for (int s = 0; s < 10; ++s) xf[s] = *reinterpret_cast<const v8_t*>(xr + 32 * s);
+  }
+  for (int i = tid; i < 2 * XA_S; i += 512)
+    tabs[i] = i < XA_S ? a.gcs[(size_t)b * XA_S + i] : a.gbias[(size_t)b * XA_S + i - XA_S];
+  float mean = 0.f, rstd = 1.f;
+  if (a.ln_stats) {
+    const f32x2_t* pm = reinterpret_cast<const f32x2_t*>(a.ln_stats) + (size_t)m * a.ln_tiles;
+    float sm = 0.f, sq = 0.f;
+    for (int t = 0; t < a.ln_tiles; ++t) { const f32x2_t v = pm[t]; sm += v[0]; sq += v[1]; }
+    mean = sm * (1.0f / XA_C);
+    rstd = rsqrtf(fmaxf(sq * (1.0f / XA_C) - mean * mean, 0.f) + a.ln_eps);
+  }
+
+  // ---- slab loader: 40 strips of 8 rows x 128 B per slab, five per wave; lane -> (row of the strip, k-slot it FETCHES so
+  // that its lane-linear LDS slot is swizzled by the row)
+  const int lrow = lane >> 3, kslot = (lane & 7) ^ lrow;
+  int vg[5], vh[5];
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    const int row = 8 * (wave + 8 * j) + lrow;
+    vg[j] = (row * XA_C + kslot * 8) * 2;
+    vh[j] = (row * XA_S + kslot * 8) * 2;
+  }
+  const __amdgpu_buffer_rsrc_t rs_g = make_rsrc(a.gt + (size_t)b * XA_S * XA_C, XA_S * XA_C * 2);
+  const __amdgpu_buffer_rsrc_t rs_h = make_rsrc(a.ht + (size_t)b * XA_C * XA_S, XA_C * XA_S * 2);
+  auto issue = [&](auto T) __attribute__((always_inline)) {
+    constexpr int t = decltype(T)::value;
+    if constexpr (DBG & 1) return;
+    char* st = smem + (t % XA_NS) * XA_SLAB + wave * 1024;
+    if constexpr (t < 10) {                               // G^T rows (t / 5) * 320 .., channels (t % 5) * 64 ..
+      constexpr int so = ((t / 5) * 320 * XA_C + (t % 5) * 64) * 2;
+#pragma unroll
+      for (int j = 0; j < 5; ++j)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_g, (xa_lds_ptr_t)(st + j * 8192), 16, vg[j], so, 0, 0);
+    } else {                                              // H^T rows 0 .. 319, logit columns (t - 10) * 64 ..
+      constexpr int so = (t - 10) * 64 * 2;
+#pragma unroll
+      for (int j = 0; j < 5; ++j)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_h, (xa_lds_ptr_t)(st + j * 8192), 16, vh[j], so, 0, 0);
+    }
+  };
+
+  f32x4_t acc[20];
+  uint32_t pf[20][4];                                     // probabilities as B fragments of the second GEMM
+#pragma unroll
+  for (int nb = 0; nb < 20; ++nb) acc[nb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  // softmax of the four heads whose logits the accumulators hold (half hf of the 640 columns): head hh = blocks 5 hh ..
+  // 5 hh + 4, a row's 80 keys spread over 20 registers x the four lanes that share r16
+  auto softmax_half = [&](auto HF) __attribute__((always_inline)) {
+    constexpr int hf = decltype(HF)::value;
+#pragma unroll
+    for (int hh = 0; hh < 4; ++hh) {
+      float s[20];
+      float mx = -INFINITY;
+#pragma unroll
+      for (int q = 0; q < 5; ++q) {
+        const int n0 = hf * 320 + (5 * hh + q) * 16 + 4 * g;
+        const f32x4_t cs = *reinterpret_cast<const f32x4_t*>(tabs + n0);
+        const f32x4_t gb = *reinterpret_cast<const f32x4_t*>(tabs + XA_S + n0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          s[q * 4 + i] = rstd * (acc[5 * hh + q][i] - mean * cs[i]) + gb[i];
+          mx = fmaxf(mx, s[q * 4 + i]);
+        }
+        acc[5 * hh + q] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      float sum = 0.f;
+#pragma unroll
+      for (int i = 0; i < 20; ++i) {
+        s[i] = __builtin_amdgcn_exp2f(s[i] - mx);
+        sum += s[i];
+      }
+      sum += __shfl_xor(sum, 16, 64);
+      sum += __shfl_xor(sum, 32, 64);
+      const float inv = __builtin_amdgcn_rcpf(sum);
+#pragma unroll
+      for (int q = 0; q < 5; ++q) {
+        const int gbk = hf * 20 + 5 * hh + q;              // logit block 0 .. 39 -> fragment gbk / 2, register pair gbk & 1
+        pf[gbk >> 1][(gbk & 1) * 2 + 0] = E::pack2(s[q * 4 + 0] * inv, s[q * 4 + 1] * inv);
+        pf[gbk >> 1][(gbk & 1) * 2 + 1] = E::pack2(s[q * 4 + 2] * inv, s[q * 4 + 3] * inv);
+      }
+    }
+  };
+
+  // residual and output bias of the epilogue: fetched under the last slab's MFMAs (after stores nothing could be hoisted)
+  const uint16_t* rr = a.res ? a.res + (size_t)m * a.ldres : nullptr;
+  u32x2_t rv[20];
+  f32x4_t bo[20];
+  __syncthreads();                                        // the tables are in LDS
+  issue(std::integral_constant<int, 0>{});
+  issue(std::integral_constant<int, 1>{});
+  xa_static_for<XA_NSLAB>([&](auto T) __attribute__((always_inline)) {
+    constexpr int t = decltype(T)::value;
+    // this wave's five pieces of slab t have landed (slab t + 1's five may still be in flight), then everybody's
+    if constexpr (t + 1 < XA_NSLAB) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (!(DBG & 32)) asm volatile("s_barrier" ::: "memory");
+    if constexpr (t + 2 < XA_NSLAB) issue(std::integral_constant<int, t + 2>{});   // (its stage was read at step t - 1)
+    if constexpr (t + 1 == XA_NSLAB) {
+#pragma unroll
+      for (int nb = 0; nb < 20; ++nb) {
+        const int n = nb * 16 + 4 * g;
+        rv[nb] = rr ? *reinterpret_cast<const u32x2_t*>(rr + n) : u32x2_t{0u, 0u};
+        bo[nb] = a.bias_o ? *reinterpret_cast<const f32x4_t*>(a.bias_o + n) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    const char* st = smem + (t % XA_NS) * XA_SLAB;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int so = ((ks * 4 + g) ^ (r16 & 7)) << 4;
+      v8_t bf;
+      if constexpr (t < 10) bf = xf[(t % 5) * 2 + ks];
+      else {
+        constexpr int f = (t - 10) * 2;
+        bf = __builtin_bit_cast(v8_t, u32x4_t{pf[f + ks][0], pf[f + ks][1], pf[f + ks][2], pf[f + ks][3]});
+      }
+#pragma unroll
+      for (int nb = 0; nb < 20; ++nb) {
+        v8_t af;
+        if constexpr (DBG & 4) af = bf;
+        else af = *reinterpret_cast<const v8_t*>(st + (nb * 16 + r16) * 128 + so);
+        if constexpr (DBG & 2) acc[nb] += __builtin_bit_cast(f32x4_t, af);
+        else acc[nb] = E::mfma16(af, bf, acc[nb]);
+      }
+    }
+    if constexpr (!(DBG & 8)) {
+      if constexpr (t == 4) softmax_half(std::integral_constant<int, 0>{});
+      if constexpr (t == 9) softmax_half(std::integral_constant<int, 1>{});
+    }
+  });
+
+  // ---- epilogue: + bias + residual, 16-bit stores, row moments of the stored values per 160-column tile
+  if constexpr (DBG & 16) {
+    if (acc[0][0] == 12345.f) a.out[m] = 1;
+    return;
+  }
+  uint16_t* orow = a.out + (size_t)m * a.ldo;
+  float sm[2] = {0.f, 0.f}, sq[2] = {0.f, 0.f};
+#pragma unroll
+  for (int nb = 0; nb < 20; ++nb) {
+    const int n = nb * 16 + 4 * g;
+    const f32x4_t v = acc[nb] + bo[nb] + f32x4_t{E::lo(rv[nb][0]), E::hi(rv[nb][0]), E::lo(rv[nb][1]), E::hi(rv[nb][1])};
+    const uint32_t o0 = E::pack2(v[0], v[1]), o1 = E::pack2(v[2], v[3]);
+    *reinterpret_cast<u32x2_t*>(orow + n) = u32x2_t{o0, o1};
+    const float r0 = E::lo(o0), r1 = E::hi(o0), r2 = E::lo(o1), r3 = E::hi(o1);
+    sm[nb / 10] += (r0 + r1) + (r2 + r3);
+    sq[nb / 10] += (r0 * r0 + r1 * r1) + (r2 * r2 + r3 * r3);
+  }
+  if (a.row_stats_out) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      float s0 = sm[t], s1 = sq[t];
+      s0 += __shfl_xor(s0, 16, 64); s1 += __shfl_xor(s1, 16, 64);
+      s0 += __shfl_xor(s0, 32, 64); s1 += __shfl_xor(s1, 32, 64);
+      if (g == 0) *reinterpret_cast<f32x2_t*>(a.row_stats_out + ((size_t)m * 2 + t) * 2) = f32x2_t{s0, s1};
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int pp_xattn_block_supported(int M, int c, int rows_per_batch, int nctx, int heads) {
+  return (c == XA_C && heads == XA_HEADS && nctx > 0 && nctx <= XA_KP && M > 0 && M % XA_BM == 0 && rows_per_batch > 0 &&
+          rows_per_batch % XA_BM == 0 && M % rows_per_batch == 0) ? 1 : 0;
+}
+
+extern "C" int pp_xattn_fold(const void* k, int ldk, const void* vt, int ldvt, int batch, int nctx, int heads, int c,
+                             const void* wq, const float* q_colsum, const float* q_bias, const void* wo, float scale,
+                             void* gt, float* gcs, float* gbias, void* ht, int dtype, void* stream) {
+  if (!k || !vt || !wq || !wo || !gt || !gcs || !gbias || !ht || batch <= 0 || !pp_dt_ok(dtype)) return PP_ERR_BAD_ARG;
+  if (!pp_xattn_block_supported(XA_BM, c, XA_BM, nctx, heads)) return PP_ERR_UNSUPPORTED;
+  if (ldk < c || ldvt < nctx || (c & 1)) return PP_ERR_BAD_ARG;
+  const long long total = (long long)batch * XA_S * (XA_C / 2) * 2 + (long long)batch * XA_S;
+  const unsigned grid = (unsigned)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+  const float qscale = scale * 1.44269504088896340736f;   // the softmax runs in the exp2 domain
+  PP_DT_SWITCH(dtype, hipLaunchKernelGGL((xattn_fold_kernel<EDT>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                                         (const uint16_t*)k, ldk, (const uint16_t*)vt, ldvt, batch, nctx,
+                                         (const uint16_t*)wq, q_colsum, q_bias, (const uint16_t*)wo, qscale, (uint32_t*)gt,
+                                         gcs, gbias, (uint32_t*)ht));
+  PP_CHECK_LAUNCH("xattn_fold_kernel");
+  return PP_OK;
+}
+
+extern "C" int pp_xattn_block(const void* x, int ldx, const void* res, int ldres, const float* ln_stats, int ln_tiles,
+                              float ln_eps, const void* gt, const float* gcs, const float* gbias, const void* ht,
+                              const float* bias_o, void* out, int ldo, float* row_stats_out, int M, int c,
+                              int rows_per_batch, int dtype, void* stream) {
+  if (!x || !gt || !gcs || !gbias || !ht || !out || !pp_dt_ok(dtype)) return PP_ERR_BAD_ARG;
+  if (!pp_xattn_block_supported(M, c, rows_per_batch, XA_KP, XA_HEADS)) return PP_ERR_UNSUPPORTED;
+  if (ldx < c || (ldx & 7) || ldo < c || (ldo & 3) || (res && (ldres < c || (ldres & 3)))) return PP_ERR_BAD_ARG;
+  if (ln_stats && ln_tiles <= 0) return PP_ERR_BAD_ARG;
+  XAArgs a;
+  a.x = (const uint16_t*)x; a.ldx = ldx;
+  a.res = (const uint16_t*)res; a.ldres = ldres;
+  a.ln_stats = ln_stats; a.ln_tiles = ln_tiles; a.ln_eps = ln_eps;
+  a.gt = (const uint16_t*)gt; a.gcs = gcs; a.gbias = gbias; a.ht = (const uint16_t*)ht;
+  a.bias_o = bias_o;
+  a.out = (uint16_t*)out; a.ldo = ldo;
+  a.row_stats_out = row_stats_out;
+  a.M = M; a.rows_per_batch = rows_per_batch;
+  static bool attr_set[3] = {false, false, false};
+  auto go = [&](auto kern, int slot) -> int {
+    if (!attr_set[slot] || slot == 0) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, XA_LDS) !=
+          hipSuccess) {
+        pp_set_last_error("hipFuncSetAttribute(xattn block)", hipGetLastError());
+        return PP_ERR_LAUNCH;
+      }
+      attr_set[slot] = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(M / XA_BM), dim3(512), XA_LDS, (hipStream_t)stream, a);
+    PP_CHECK_LAUNCH("xattn_block_kernel");
+    return PP_OK;
+  };
+#ifdef PP_LAB
+  if (dtype == PP_DT_BF16) switch (pp_lab_env("PP_XA_DBG", 0)) {
+      case 1: return go(xattn_block_kernel<PP_DT_BF16, 1>, 0);
+      case 2: return go(xattn_block_kernel<PP_DT_BF16, 2>, 0);
+      case 4: return go(xattn_block_kernel<PP_DT_BF16, 4>, 0);
+      case 6: return go(xattn_block_kernel<PP_DT_BF16, 6>, 0);
+      case 7: return go(xattn_block_kernel<PP_DT_BF16, 7>, 0);
+      case 8: return go(xattn_block_kernel<PP_DT_BF16, 8>, 0);
+      case 16: return go(xattn_block_kernel<PP_DT_BF16, 16>, 0);
+      case 33: return go(xattn_block_kernel<PP_DT_BF16, 33>, 0);
+      case 39: return go(xattn_block_kernel<PP_DT_BF16, 39>, 0);
+      default: break;
+    }
+#endif
+  if (dtype == PP_DT_F16) return go(xattn_block_kernel<PP_DT_F16>, PP_DT_F16);
+  return go(xattn_block_kernel<PP_DT_BF16>, PP_DT_BF16);
+}

@@ -431,6 +431,10 @@ class SDNet:
     fold_ln = _lab_switch("PP_FOLD_LN")
     # FeedForward.net[2] and Transformer2DModel.proj_out composed into one GEMM ((lab) PP_MERGE_FF2=0: two launches)
     merge_ff2_proj_out = _lab_switch("PP_MERGE_FF2")
+    # (lab, OPT-IN: PP_LAB=1 PP_XATTN_FUSED=1) the C = 320 cross-attention sub-blocks as one pp_xattn_block launch each.
+    # Parity-green, but LDS-bandwidth-bound and no faster than the three launches it replaces
+    # (profiles/r03_xattn_fused_ab.txt), so the product keeps the chain.
+    fuse_xattn = os.environ.get("PP_LAB") == "1" and os.environ.get("PP_XATTN_FUSED", "0") == "1"
     # ResnetBlock2D.conv_shortcut merged into conv2 as a 1x1 K tail (needs 64-channel multiples; (lab) PP_MERGE_SHORTCUT=0 off)
     _merge_shortcut_env = _lab_switch("PP_MERGE_SHORTCUT")
 
@@ -796,11 +800,22 @@ class SDNet:
                        row_stats_out=st, name="linear")
         # cross-attention (K / V^T hoisted out of the step: encoder_hidden_states are step-invariant)
         ln, kw = normed(hs, st, "norm2", "attn2.to_q")
-        q = pb.linear(ln, rows, Cc, P[f"{tb}.attn2.to_q.weight"], Cc, name="linear", **kw)
-        a = pb.attention(q, Cc, kv[0], kv[1], kv[2], kv[3], x.B, self.heads, hw, self._nctx, d)
-        st = producer()
-        hs = pb.linear(a, rows, Cc, P[f"{tb}.attn2.to_out.weight"], Cc, P[f"{tb}.attn2.to_out.bias"], res1=hs,
-                       row_stats_out=st, name="linear")
+        xa = getattr(self, "xa", {}).get(pre)
+        if xa is not None and pb.lib.pp_xattn_block_supported(rows, Cc, hw, self._nctx, self.heads):
+            st2 = producer()
+            o = pb.alloc(rows * Cc * 2)
+            pb.plan.add("xattn_block", pb.lib.pp_xattn_block, ln, Cc, hs, Cc, kw.get("ln_stats"), tiles if fold else 0,
+                        1e-5, xa[0], xa[1], xa[2], xa[3], P[f"{tb}.attn2.to_out.bias"], o, Cc, st2 or None, rows, Cc, hw,
+                        pb.dt)
+            # (the FLOPs of the chain it stands for: the folded form multiplies twice as much)
+            pb.plan.count("xattn_block", 4.0 * rows * Cc * Cc + 4.0 * rows * self._nctx * Cc)
+            hs, st = o, st2
+        else:
+            q = pb.linear(ln, rows, Cc, P[f"{tb}.attn2.to_q.weight"], Cc, name="linear", **kw)
+            a = pb.attention(q, Cc, kv[0], kv[1], kv[2], kv[3], x.B, self.heads, hw, self._nctx, d)
+            st = producer()
+            hs = pb.linear(a, rows, Cc, P[f"{tb}.attn2.to_out.weight"], Cc, P[f"{tb}.attn2.to_out.bias"], res1=hs,
+                           row_stats_out=st, name="linear")
         # feed-forward: GEGLU fused into the first GEMM's epilogue
         ln, kw = normed(hs, st, "norm3", "ff1")
         g = pb.linear(ln, rows, Cc, P[f"{tb}.ff1.weight"], 8 * Cc, act=L.PP_ACT_GEGLU, name="linear_geglu", **kw)
@@ -823,12 +838,24 @@ class SDNet:
         self._nctx = nctx
         ldvt = _align(nctx, 8)
         self.kv: Dict[str, Tuple[int, int, int, int]] = {}
+        self.xa: Dict[str, Tuple[int, int, int, int]] = {}       # folded cross-attention operands (pp_xattn_fold)
         for pre, c in self._attn_specs():
             tb = f"{pre}.transformer_blocks.0"
             vt = pb.alloc(B * c * ldvt * 2)
             k = pb.linear(ehs, B * nctx, self.ctx_dim, self.P[f"{tb}.attn2.kv.weight"], 2 * c, out_vt=vt,
                           vt_col0=c, vt_ld=ldvt, rows_per_batch=nctx, name="linear")
             self.kv[pre] = (k, c, vt, ldvt)
+            tbq = f"{tb}.attn2.to_q"
+            if self.fuse_xattn and pb.lib.pp_xattn_block_supported(128, c, 128, nctx, self.heads):
+                S = self.heads * 80
+                gt, ht = pb.alloc(B * S * c * 2), pb.alloc(B * c * S * 2)
+                gcs, gb = pb.alloc(B * S * 4), pb.alloc(B * S * 4)
+                fold = self.fold_ln
+                pb.plan.add("xattn_fold", pb.lib.pp_xattn_fold, k, c, vt, ldvt, B, nctx, self.heads, c,
+                            self.P[f"{tbq}.weight"], self.P[f"{tbq}.colsum"] if fold else None,
+                            self.P[f"{tbq}.bias"] if fold else None, self.P[f"{tb}.attn2.to_out.weight"],
+                            float(c // self.heads) ** -0.5, gt, gcs, gb, ht, pb.dt)
+                self.xa[pre] = (gt, gcs, gb, ht)
         self.cond_emb = None
         if self.kind == "controlnet":
             assert cond is not None

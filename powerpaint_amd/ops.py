@@ -186,6 +186,36 @@ def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, batch: int, he
     return o
 
 
+def xattn_fold(k: torch.Tensor, vt: torch.Tensor, batch: int, nctx: int, heads: int, wq: torch.Tensor, wo: torch.Tensor,
+               q_colsum=None, q_bias=None, scale: Optional[float] = None):
+    """Once per prompt (pp_xattn_fold): k [batch*nctx, >=c], vt [batch, c, ldvt], wq / wo [c, c] ([out][in]) ->
+    (gt [batch, heads*80, c], gcs [batch, heads*80] fp32, gbias [batch, heads*80] fp32, ht [batch, c, heads*80])."""
+    c = wq.shape[0]
+    dev, dt = k.device, k.dtype
+    gt = torch.empty(batch, heads * 80, c, dtype=dt, device=dev)
+    ht = torch.empty(batch, c, heads * 80, dtype=dt, device=dev)
+    gcs = torch.empty(batch, heads * 80, dtype=torch.float32, device=dev)
+    gb = torch.empty(batch, heads * 80, dtype=torch.float32, device=dev)
+    L.check(L.lib().pp_xattn_fold(_p(k), k.stride(0), _p(vt), vt.stride(1), batch, nctx, heads, c, _p(wq), _p(q_colsum),
+                                  _p(q_bias), _p(wo), scale if scale is not None else (c // heads) ** -0.5, _p(gt),
+                                  _p(gcs), _p(gb), _p(ht), L.dtype_code(dt), _s()), "pp_xattn_fold")
+    return gt, gcs, gb, ht
+
+
+def xattn_block(x: torch.Tensor, folded, bias_o=None, res=None, ln_stats=None, ln_eps: float = 1e-5,
+                rows_per_batch: int = 0, row_stats: bool = False):
+    """out = softmax_per_head(LNfold(x) gt^T) ht^T + bias_o + res  (pp_xattn_block); x [M, c], folded = xattn_fold(...)."""
+    gt, gcs, gb, ht = folded
+    M, c = x.shape
+    out = torch.empty(M, c, dtype=x.dtype, device=x.device)
+    st = torch.zeros(M, c // 160, 2, dtype=torch.float32, device=x.device) if row_stats else None
+    L.check(L.lib().pp_xattn_block(_p(x), x.stride(0), _p(res), res.stride(0) if res is not None else 0, _p(ln_stats),
+                                   ln_stats.shape[1] if ln_stats is not None else 0, ln_eps, _p(gt), _p(gcs), _p(gb), _p(ht),
+                                   _p(bias_o), _p(out), c, _p(st), M, c, rows_per_batch or M, L.dtype_code(x.dtype), _s()),
+            "pp_xattn_block")
+    return (out, st) if row_stats else out
+
+
 def conv3x3_direct(x, w, bias, stride: int = 1, silu: bool = False, add=None):
     """x NHWC bf16 [B,H,W,Cin]; w bf16 [3,3,Cin,Cout]."""
     B, H, W, Cin = x.shape

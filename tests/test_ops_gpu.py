@@ -633,3 +633,75 @@ def test_latent_blend_kernel():
         check(out, ref, 1e-6, 1e-6, f"latent blend row {r}")
         if r == 2:
             assert torch.equal(out[:, :, mk[0, 0] == 0], x0.expand(B, -1, -1, -1)[:, :, mk[0, 0] == 0])
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("fold", [True, False])
+@pytest.mark.parametrize("B,hw,nctx", [(2, 1024, 77), (3, 256, 77), (1, 128, 80), (2, 128, 5)])
+def test_fused_cross_attention_block(B, hw, nctx, fold, dtype):
+    """pp_xattn_fold + pp_xattn_block (norm2 -> attn2 -> + residual of BasicTransformerBlock at C = 320 in one launch)
+    against (a) fp32 torch of the same sub-block and (b) the three-launch chain it replaces (to_q GEMM with the folded
+    LayerNorm, pp_attention_fwd over the 77 keys, to_out GEMM + residual + row moments)."""
+    C, heads = 320, 8
+    d = C // heads
+    M = B * hw
+    tol = 4.0 if dtype == torch.bfloat16 else 1.0                       # (fp16: 8x finer mantissa; gates 4x tighter)
+    h = (rnd(M, C, seed=1, scale=1.5) + 0.4).to(dtype)
+    ctx = rnd(B * nctx, 768, seed=2).to(dtype)
+    g2, b2 = rnd(C, seed=3) * 0.3 + 1.0, rnd(C, seed=4) * 0.2
+    wq, wk, wv = (rnd(C, C, seed=5, scale=C ** -0.5), rnd(C, 768, seed=6, scale=768 ** -0.5),
+                  rnd(C, 768, seed=7, scale=768 ** -0.5))
+    wo, bo = rnd(C, C, seed=8, scale=C ** -0.5), rnd(C, seed=9) * 0.1
+    # step-invariant K and V^T exactly as the setup plan makes them (one GEMM, V transposed by the epilogue)
+    ldvt = (nctx + 7) // 8 * 8
+    wkv = torch.cat([wk, wv]).to(dtype).contiguous()
+    k, vt = ops.gemm(ctx, wkv, vt_col0=C, rows_per_batch=nctx)
+    assert vt.shape == (B, C, nctx)
+    vtp = torch.zeros(B, C, ldvt, dtype=dtype, device=DEV)
+    vtp[:, :, :nctx] = vt
+    hf = h.float()
+    if fold:
+        tiles = C // 160
+        st = torch.stack([hf.reshape(M, tiles, 160).sum(-1), (hf * hf).reshape(M, tiles, 160).sum(-1)], -1).contiguous()
+        wqf = (wq * g2[None, :]).to(dtype).contiguous()
+        cs, tq = wqf.float().sum(1).contiguous(), (wq @ b2).contiguous()
+        x_in, kw_q, kw_f, ln = h, dict(ln_stats=st, ln_colsum=cs, ln_dim=C, bias=tq), dict(q_colsum=cs, q_bias=tq), st
+        mean = hf.mean(-1, keepdim=True)
+        rstd = torch.rsqrt((hf * hf).mean(-1, keepdim=True) - mean * mean + 1e-5)
+        q_ref = rstd * (hf @ wqf.float().t() - mean * cs) + tq
+    else:
+        x_in = F.layer_norm(hf, (C,), g2, b2, 1e-5).to(dtype)
+        wqf = wq.to(dtype).contiguous()
+        kw_q, kw_f, ln = {}, {}, None
+        q_ref = x_in.float() @ wqf.float().t()
+    wod = wo.to(dtype).contiguous()
+    folded = ops.xattn_fold(k, vtp, B, nctx, heads, wqf, wod, **kw_f)
+    out, rs = ops.xattn_block(x_in, folded, bias_o=bo, res=h, ln_stats=ln, rows_per_batch=hw, row_stats=True)
+    # (a) fp32 reference from the same 16-bit operands
+    kf, vf = k.float().reshape(B, nctx, heads, d), vt.float().reshape(B, heads, d, nctx)
+    qh = q_ref.reshape(B, hw, heads, d)
+    p = torch.softmax(torch.einsum("bqhd,bkhd->bhqk", qh, kf) * d ** -0.5, -1)
+    o = torch.einsum("bhqk,bhdk->bqhd", p, vf).reshape(M, C)
+    ref = o @ wod.float().t() + bo + hf
+    check(out, ref, 1.0e-2 * tol, 4e-3 * tol, "fused cross-attention block vs fp32")
+    # (b) the chain it replaces
+    q = ops.gemm(x_in, wqf, **kw_q)
+    ao = ops.attention(q, k, vtp, B, heads, hw, nctx, d)
+    old, rs_old = ops.gemm(ao, wod, bias=bo, res1=h, row_stats=True)
+    check(out, old, 1.2e-2 * tol, 4e-3 * tol, "fused cross-attention block vs the three-launch chain")
+    ofl = out.float()
+    rs_ref = torch.stack([ofl.reshape(M, 2, 160).sum(-1), (ofl * ofl).reshape(M, 2, 160).sum(-1)], -1)
+    check(rs, rs_ref, 2e-3, 1e-5, "row moments of the stored values")
+    # the folded matrices themselves
+    gt, gcs, gb, ht = folded
+    G = torch.einsum("bkhd,hdc->bhkc", kf, wqf.float().reshape(heads, d, C)) * (d ** -0.5 * 1.4426950408889634)
+    check(gt.reshape(B, heads, 80, C)[:, :, :nctx], G, 2e-3 * tol, 4e-3 * tol, "G^T")
+    assert torch.all(gt.reshape(B, heads, 80, C)[:, :, nctx:] == 0)
+    assert torch.all(torch.isinf(gb.reshape(B, heads, 80)[:, :, nctx:])) and torch.isfinite(gb.reshape(B, heads, 80)[:, :, :nctx]).all()
+    H = torch.einsum("nhd,bhdk->bnhk", wod.float().reshape(C, heads, d), vf)                 # [B, C, heads, nctx]
+    kp = torch.arange(640)
+    s32, kg, j = kp // 32, (kp // 8) % 4, kp % 8
+    kk = 32 * s32 + 16 * (j // 4) + 4 * kg + (j % 4)                    # contraction index stored at position kp
+    Hfull = torch.zeros(B, C, heads, 80, device=DEV)
+    Hfull[..., :nctx] = H
+    check(ht, Hfull.reshape(B, C, 640)[:, :, kk.to(DEV)], 2e-3 * tol, 4e-3 * tol, "H^T (k-permuted)")
