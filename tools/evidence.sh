@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-3 evidence run on the GPU box: GPU test suite (arg "tests": + the slow config-parity file), smoke, rocprofv3
+# Evidence run on the GPU box (one gpurun call:  gpurun --timeout 2400 -- bash tools/evidence.sh [tests]): GPU test suite (arg "tests": + the slow config-parity file), smoke, rocprofv3
 # kernel trace + HBM-traffic counters of the headline command, headline bench with cpu_baseline + live roofline,
 # configs 3 / 4 / 5 and fp16.  -> gpurun_out/r03/ ; the profiles the judge reads are copied to profiles/ by hand.
 set -u
