@@ -29,7 +29,7 @@ extern "C" {
 #define PP_ERR_LAUNCH (-3)       /* hipLaunchKernel / hipFuncSetAttribute failed                  */
 #define PP_ERR_WORKSPACE (-4)    /* workspace pointer null or too small                           */
 
-#define PP_ABI_VERSION 10
+#define PP_ABI_VERSION 11
 /* 16-bit storage format of activations and matrix weights ("dtype" arguments; the same codes pp_nchw_to_nhwc uses for
  * its source): bf16 or fp16 -- the reference's default is fp16 (/root/reference/app.py:548,559).  MFMA accumulation,
  * norm statistics, softmax, biases and latents are fp32 with either. */
@@ -230,6 +230,14 @@ int pp_conv3x3_direct(const void* x, int batch, int hin, int win, int cin, const
                       int cout, int stride, int silu_out, const void* add, void* out, int dtype, void* stream);
 int pp_conv3x3_smallcout(const void* x, int batch, int h, int w_, int cin, const void* w, const float* bias, int cout,
                          float* out_nchw, int dtype, void* stream);
+/* conv_norm_out + SiLU + conv_out in one launch (unet_2d_condition.py:1351-1354): GroupNorm statistics from the
+ * producers' accumulators (`acc`, as pp_groupnorm_apply_acc), the normalised activation rounded to the 16-bit format
+ * where the two-launch path stores it, 3x3 / pad 1 conv to `cout` = 4 channels, fp32 NCHW out.  x NHWC [batch][h][w][cin];
+ * w [4][9][cin] (pp_conv3x3_smallcout's layout).  pp_gn_conv3x3_smallcout_supported(): cout == 4, cin % 32 == 0, cin <= 384. */
+int pp_gn_conv3x3_smallcout_supported(int cin, int cout, int groups);
+int pp_gn_conv3x3_smallcout(const void* x, int batch, int h, int w, int cin, int groups, float eps, const float* gamma,
+                            const float* beta, const int64_t* acc, const void* wgt, const float* bias, int cout,
+                            float* out_nchw, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Layout / assembly kernels at the module boundary (NCHW torch tensors <-> internal NHWC bf16).

@@ -242,6 +242,112 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const uint16_t* __restric
   }
 }
 
+// conv_norm_out + SiLU + conv_out (C -> 4 channels) in ONE launch -- the tail of UNet2DConditionModel.forward
+// (/root/reference/powerpaint/models/unet_2d_condition.py:1351-1354).  The unfused pair writes the normalised 64x64x320
+// activation (21 MB) and re-reads it nine times through L1 / L2 (gn_apply 12 us + conv3x3_cout4_mfma 40 us per step).
+// Here a workgroup owns an 8 x 8 output patch: it normalises the 10 x 10 input patch on the fly (statistics from the
+// producers' accumulators, as gn_apply_kernel<.., ACC>; rounded to the 16-bit format exactly where the unfused path
+// stores it) and runs it ONCE through the matrix cores against all 36 (channel, tap) weight rows,
+//     z[pixel][co * 9 + tap] = sum_c W[co][tap][c] * act[pixel][c]          (7 groups of 16 pixels x 3 row blocks),
+// then gathers  out[co][y][x] = bias[co] + sum_tap z[(y + ky, x + kx)][co * 9 + tap]  from LDS.  Input bytes per patch:
+// 100 / 64 of the activation instead of 9x.
+constexpr int GC_ZLD = 37;                               // z row stride (floats): 36 + 1 against bank conflicts
+template <int EDT>
+__global__ void __launch_bounds__(256) gn_conv3x3_cout4_kernel(const uint16_t* __restrict__ x, int h, int w_, int C,
+                                                              const long long* __restrict__ acc, int groups, float eps,
+                                                              const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta,
+                                                              const uint16_t* __restrict__ w,
+                                                              const float* __restrict__ bias, float* __restrict__ out) {
+  using E = E16<EDT>;
+  typedef typename E::v8 v8_t;
+  extern __shared__ __attribute__((aligned(16))) float tab[];   // scale[C] | shift[C] | 2 x 64 group stats | W36 | z
+  const int WLD = 2 * C + 16;                            // weight row stride in bytes (+16: sixteen rows, sixteen bank slots)
+  float* sc = tab;
+  float* sh = tab + C;
+  char* wl = reinterpret_cast<char*>(tab + 2 * C + 128);
+  float* z = reinterpret_cast<float*>(wl + 48 * WLD);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r16 = lane & 15, kg = lane >> 4;
+  const int tiles_x = (w_ + 7) >> 3;
+  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+  const int b = blockIdx.y;
+  const int steps = C >> 5;                              // 32-channel MFMA steps (host: C % 32 == 0, C <= 384: LDS < 64 KB)
+
+  // the 36 weight rows ([co][tap][C] is already row = co * 9 + tap), rows 36 .. 47 zero
+  const int pcs = C >> 3;
+  for (int i = tid; i < 48 * pcs; i += 256) {
+    const int row = i / pcs, pc = i - row * pcs;
+    u32x4_t v = {0u, 0u, 0u, 0u};
+    if (row < 36) v = *reinterpret_cast<const u32x4_t*>(w + (size_t)row * C + pc * 8);
+    *reinterpret_cast<u32x4_t*>(wl + row * WLD + pc * 16) = v;
+  }
+  gn_fold_acc(acc, groups, C, h * w_, eps, gamma, beta, b, tab + 2 * C, tab + 2 * C + 64, sc, sh);   // (syncs inside)
+  __syncthreads();
+
+  for (int pg = wave; pg < 7; pg += 4) {
+    const int q = pg * 16 + r16;                         // pixel of the 10 x 10 patch (>= 100: padding of the last group)
+    const int py = q / 10, px = q - py * 10;
+    const int iy = ty * 8 + py - 1, ix = tx * 8 + px - 1;
+    const bool ok = q < 100 && (unsigned)iy < (unsigned)h && (unsigned)ix < (unsigned)w_;
+    const uint16_t* xp = x + (((size_t)b * h + (ok ? iy : 0)) * w_ + (ok ? ix : 0)) * C + kg * 8;
+    f32x4_t a3[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    constexpr int PF = 6;                                // loads in flight per lane
+    u32x4_t xv[PF];
+#pragma unroll
+    for (int s = 0; s < PF; ++s) xv[s] = (s < steps) ? *reinterpret_cast<const u32x4_t*>(xp + s * 32) : u32x4_t{0u, 0u, 0u, 0u};
+    for (int s0 = 0; s0 < steps; s0 += PF) {
+#pragma unroll
+      for (int u = 0; u < PF; ++u) {
+        const int s = s0 + u;
+        if (s >= steps) break;
+        const u32x4_t v = xv[u];
+        if (s + PF < steps) xv[u] = *reinterpret_cast<const u32x4_t*>(xp + (s + PF) * 32);
+        const int c = s * 32 + kg * 8;
+        const f32x4_t s0v = *reinterpret_cast<const f32x4_t*>(sc + c), s1v = *reinterpret_cast<const f32x4_t*>(sc + c + 4);
+        const f32x4_t h0v = *reinterpret_cast<const f32x4_t*>(sh + c), h1v = *reinterpret_cast<const f32x4_t*>(sh + c + 4);
+        float r[8];
+        r[0] = E::lo(v[0]) * s0v[0] + h0v[0]; r[1] = E::hi(v[0]) * s0v[1] + h0v[1];
+        r[2] = E::lo(v[1]) * s0v[2] + h0v[2]; r[3] = E::hi(v[1]) * s0v[3] + h0v[3];
+        r[4] = E::lo(v[2]) * s1v[0] + h1v[0]; r[5] = E::hi(v[2]) * s1v[1] + h1v[1];
+        r[6] = E::lo(v[3]) * s1v[2] + h1v[2]; r[7] = E::hi(v[3]) * s1v[3] + h1v[3];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = silu_f(r[j]);
+        u32x4_t o;
+        o[0] = E::pack2(r[0], r[1]); o[1] = E::pack2(r[2], r[3]);
+        o[2] = E::pack2(r[4], r[5]); o[3] = E::pack2(r[6], r[7]);
+        if (!ok) o = u32x4_t{0u, 0u, 0u, 0u};            // zero padding applies to the NORMALISED activation
+        const v8_t bfr = __builtin_bit_cast(v8_t, o);
+#pragma unroll
+        for (int rb = 0; rb < 3; ++rb) {
+          const v8_t af = *reinterpret_cast<const v8_t*>(wl + (rb * 16 + r16) * WLD + s * 64 + kg * 16);
+          a3[rb] = E::mfma16(af, bfr, a3[rb]);
+        }
+      }
+    }
+    // D[weight row 16 rb + 4 kg + i][pixel r16]
+#pragma unroll
+    for (int rb = 0; rb < 3; ++rb)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = rb * 16 + kg * 4 + i;
+        if (row < 36) z[q * GC_ZLD + row] = a3[rb][i];
+      }
+  }
+  __syncthreads();
+  {
+    const int co = tid >> 6, p = tid & 63, oy = p >> 3, ox = p & 7;
+    const int gy = ty * 8 + oy, gx = tx * 8 + ox;
+    float sum = bias ? bias[co] : 0.f;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int ky = tap / 3, kx = tap - ky * 3;
+      sum += z[((oy + ky) * 10 + ox + kx) * GC_ZLD + co * 9 + tap];
+    }
+    if (gy < h && gx < w_) out[(((size_t)b * 4 + co) * h + gy) * w_ + gx] = sum;
+  }
+}
+
 // LayerNorm: one wave per row, <= 4 16-B pieces per lane (C <= 2048), two-pass statistics in registers.
 template <int NP, int EDT>
 __global__ void __launch_bounds__(256) layernorm_kernel(const uint16_t* __restrict__ x, int rows, int C,
@@ -387,6 +493,25 @@ extern "C" int pp_groupnorm_apply_acc(const void* x1, int c1, const void* x2, in
                                            (const uint16_t*)x1, c1, (const uint16_t*)x2, c2, hw, accf, 0, groups, eps,
                                            gamma, beta, (uint16_t*)y));
   PP_CHECK_LAUNCH("gn_apply_kernel(acc)");
+  return PP_OK;
+}
+
+extern "C" int pp_gn_conv3x3_smallcout_supported(int cin, int cout, int groups) {
+  return (cout == 4 && cin > 0 && cin % 32 == 0 && cin <= 384 && groups > 0 && groups <= 32 && cin % groups == 0) ? 1 : 0;
+}
+
+extern "C" int pp_gn_conv3x3_smallcout(const void* x, int batch, int h, int w_, int cin, int groups, float eps,
+                                       const float* gamma, const float* beta, const int64_t* acc, const void* w,
+                                       const float* bias, int cout, float* out_nchw, int dtype, void* stream) {
+  if (!x || !gamma || !beta || !acc || !w || !out_nchw || batch <= 0 || h <= 0 || w_ <= 0 || !pp_dt_ok(dtype))
+    return PP_ERR_BAD_ARG;
+  if (!pp_gn_conv3x3_smallcout_supported(cin, cout, groups)) return PP_ERR_UNSUPPORTED;
+  const size_t lds = (size_t)(2 * cin + 128) * sizeof(float) + 48 * (size_t)(2 * cin + 16) + 112 * GC_ZLD * sizeof(float);
+  const dim3 grid(((w_ + 7) / 8) * ((h + 7) / 8), batch);
+  PP_DT_SWITCH(dtype, hipLaunchKernelGGL((gn_conv3x3_cout4_kernel<EDT>), grid, dim3(256), lds, (hipStream_t)stream,
+                                         (const uint16_t*)x, h, w_, cin, reinterpret_cast<const long long*>(acc), groups,
+                                         eps, gamma, beta, (const uint16_t*)w, bias, out_nchw));
+  PP_CHECK_LAUNCH("gn_conv3x3_cout4_kernel");
   return PP_OK;
 }
 

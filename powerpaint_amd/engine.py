@@ -431,6 +431,7 @@ class SDNet:
     fold_ln = _lab_switch("PP_FOLD_LN")
     # FeedForward.net[2] and Transformer2DModel.proj_out composed into one GEMM ((lab) PP_MERGE_FF2=0: two launches)
     merge_ff2_proj_out = _lab_switch("PP_MERGE_FF2")
+    fuse_conv_out = _lab_switch("PP_FUSE_CONV_OUT")      # (lab) =0: conv_norm_out apply and conv_out as two launches
     # (lab, OPT-IN: PP_LAB=1 PP_XATTN_FUSED=1) the C = 320 cross-attention sub-blocks as one pp_xattn_block launch each.
     # Parity-green, but LDS-bandwidth-bound and no faster than the three launches it replaces
     # (profiles/r03_xattn_fused_ab.txt), so the product keeps the chain.
@@ -1007,10 +1008,19 @@ class SDNet:
             nd = len(brush_down)
             return {"down": outs[:nd], "mid": outs[nd], "up": outs[nd + 1:]}
 
-        # 6. out
-        h = pb.groupnorm(s, P["conv_norm_out.weight"], P["conv_norm_out.bias"], self.eps, True, groups=self.groups)
+        # 6. out: conv_norm_out + SiLU + conv_out -- one launch when the GroupNorm statistics arrive from the producer's
+        # epilogue (the normalised 64x64x320 activation is then never written), else norm launch(es) + conv
         eps = pb.alloc(B * self.out_channels * H * W * 4)
-        pb.plan.add("conv_out", lib.pp_conv3x3_smallcout, h.ptr, B, H, W, boc[0], P["conv_out.weight"],
-                    P["conv_out.bias"], self.out_channels, eps, pb.dt)
+        acc = 0
+        if self.fuse_conv_out and lib.pp_gn_conv3x3_smallcout_supported(boc[0], self.out_channels, self.groups):
+            acc = pb._subscribe_gn_stats(s, None, self.groups)
+        if acc:
+            pb.plan.add("conv_out", lib.pp_gn_conv3x3_smallcout, s.ptr, B, H, W, boc[0], self.groups, self.eps,
+                        P["conv_norm_out.weight"], P["conv_norm_out.bias"], acc, P["conv_out.weight"],
+                        P["conv_out.bias"], self.out_channels, eps, pb.dt)
+        else:
+            h = pb.groupnorm(s, P["conv_norm_out.weight"], P["conv_norm_out.bias"], self.eps, True, groups=self.groups)
+            pb.plan.add("conv_out", lib.pp_conv3x3_smallcout, h.ptr, B, H, W, boc[0], P["conv_out.weight"],
+                        P["conv_out.bias"], self.out_channels, eps, pb.dt)
         pb.plan.count("conv_out", 2.0 * B * H * W * self.out_channels * 9 * boc[0])
         return {"eps": eps}

@@ -216,6 +216,16 @@ def xattn_block(x: torch.Tensor, folded, bias_o=None, res=None, ln_stats=None, l
     return (out, st) if row_stats else out
 
 
+def gn_conv3x3_smallcout(x, acc, gamma, beta, eps: float, w, bias, groups: int = 32):
+    """conv_norm_out + SiLU + conv_out in one launch: x NHWC 16-bit [B,H,W,Cin], acc int64 [B,groups,2] (the producers'
+    GroupNorm accumulators), w [4, 9*Cin] -> fp32 NCHW [B,4,H,W]."""
+    B, H, W, Cin = x.shape
+    out = torch.empty(B, w.shape[0], H, W, dtype=torch.float32, device=x.device)
+    L.check(L.lib().pp_gn_conv3x3_smallcout(_p(x), B, H, W, Cin, groups, eps, _p(gamma), _p(beta), _p(acc), _p(w), _p(bias),
+                                            w.shape[0], _p(out), L.dtype_code(x.dtype), _s()), "pp_gn_conv3x3_smallcout")
+    return out
+
+
 def conv3x3_direct(x, w, bias, stride: int = 1, silu: bool = False, add=None):
     """x NHWC bf16 [B,H,W,Cin]; w bf16 [3,3,Cin,Cout]."""
     B, H, W, Cin = x.shape

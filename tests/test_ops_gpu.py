@@ -705,3 +705,28 @@ def test_fused_cross_attention_block(B, hw, nctx, fold, dtype):
     Hfull = torch.zeros(B, C, heads, 80, device=DEV)
     Hfull[..., :nctx] = H
     check(ht, Hfull.reshape(B, C, 640)[:, :, kk.to(DEV)], 2e-3 * tol, 4e-3 * tol, "H^T (k-permuted)")
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,H,W,C", [(2, 64, 64, 320), (1, 24, 40, 320), (2, 13, 9, 128), (1, 8, 8, 64)])
+def test_fused_groupnorm_silu_conv_out(B, H, W, C, dtype):
+    """pp_gn_conv3x3_smallcout (conv_norm_out + SiLU + conv_out in one launch) against the two launches it replaces
+    (pp_groupnorm_apply_acc -> pp_conv3x3_smallcout: same rounding point of the normalised activation, so only the fp32
+    summation order differs) and against fp32 torch; ragged sizes exercise the patch borders."""
+    groups = 32
+    cg = C // groups
+    x = (rnd(B, H, W, C, seed=1, scale=2.0) + 0.5).to(dtype)
+    xf = x.float().reshape(B, H * W, groups, cg)
+    acc = torch.stack([(xf.sum((1, 3)).double() * 2 ** 24).round().long(),
+                       ((xf * xf).sum((1, 3)).double() * 2 ** 20).round().long()], -1).contiguous()
+    g, b = rnd(C, seed=2) * 0.3 + 1.0, rnd(C, seed=3) * 0.2
+    w = rnd(4, 9 * C, seed=4, scale=(9 * C) ** -0.5).to(dtype).contiguous()
+    bias = rnd(4, seed=5)
+    out = ops.gn_conv3x3_smallcout(x, acc, g, b, 1e-5, w, bias)
+    y = ops.groupnorm_apply_acc(x, acc, g, b, 1e-5, True)
+    old = ops.conv3x3_smallcout(y, w, bias)
+    tol = 1.0 if dtype == torch.bfloat16 else 0.25
+    check(out, old, 2e-4, 1e-4, "fused conv_out vs groupnorm_apply_acc + conv3x3_smallcout")
+    yn = F.silu(F.group_norm(x.float().permute(0, 3, 1, 2), groups, g, b, 1e-5))
+    ref = F.conv2d(yn, w.float().reshape(4, 3, 3, C).permute(0, 3, 1, 2), bias, padding=1)
+    check(out, ref, 3e-2 * tol, 1e-2 * tol, "fused conv_out vs fp32")
