@@ -479,6 +479,10 @@ pp_gemm_kernel_v2(const PPGemmArgs a, const GemmDerived d) {   // 2nd bound = wa
                            : (XMODE == PP_X_PLAIN ? (uint32_t)a.M * (uint32_t)a.ldx2 * 2u
                                                   : (uint32_t)a.batch * (uint32_t)a.hin * (uint32_t)a.win * (uint32_t)a.c2 * 2u);
   const uint32_t wbytes = (uint32_t)a.N * (uint32_t)a.K * 2u;
+  // per-batch-item weights (w_batch_stride > 0: GroupNorm folded into the 1x1 proj_in, pp_gn_fold_weights): the tile's
+  // rows belong to ONE batch item (host-checked: rows_per_batch % BM == 0)
+  const void* const w_base = a.w_batch_stride > 0
+      ? (const void*)((const uint16_t*)a.w + (size_t)(m_blk / a.rows_per_batch) * (size_t)a.w_batch_stride) : a.w;
 
   // ---- per-lane offsets.  PLAIN: vx1/vx2 = byte offset of (row m, k-slot) in source 1 / 2 (OOB if m >= M), fixed.
   //      CONV : pixel coordinates kept in (xa, xb, xc); vx1 recomputed when the (tap, source) pair changes.
@@ -590,7 +594,7 @@ pp_gemm_kernel_v2(const PPGemmArgs a, const GemmDerived d) {   // 2nd bound = wa
         if (!tail && cc == ctot) { cc = 0; ++tap; retap = true; }
       }
     }
-    is_rsw = make_rsrc(a.w, live ? wbytes : 0u);
+    is_rsw = make_rsrc(w_base, live ? wbytes : 0u);
     is_sow = k0 * 2;
   };
   auto issue_piece = [&](int i) __attribute__((always_inline)) {      // i is a compile-time constant at every call site
@@ -665,7 +669,7 @@ pp_gemm_kernel_v2(const PPGemmArgs a, const GemmDerived d) {   // 2nd bound = wa
     bool second = false;
     int sox = 0, sow = kt_begin * 128;
     const void* const qx1 = reinterpret_cast<const void*>(px1);
-    const void* const qw = a.w;
+    const void* const qw = w_base;
     const int up_ = a.up, win_ = a.win;
     __amdgpu_buffer_rsrc_t rsx = make_rsrc(qx1, 0u), rsw = make_rsrc(qw, wbytes);
     int vx[XP];
@@ -1839,6 +1843,14 @@ int validate(const PPGemmArgs& a) {
   if (a.ln_stats && (!a.ln_colsum || a.ln_tiles <= 0 || a.ln_dim <= 0)) return PP_ERR_BAD_ARG;
   if (a.row_stats_out && (a.out_f32 || a.out_vt || a.act == PP_ACT_GEGLU || !v2_ok(a))) return PP_ERR_UNSUPPORTED;
   if ((a.gn_acc[0] || a.gn_acc[1]) && !gn_stats_supported(a)) return PP_ERR_UNSUPPORTED;
+  if (a.w_batch_stride < 0) return PP_ERR_BAD_ARG;
+  if (a.w_batch_stride > 0) {      // one weight matrix per batch item: every tile (<= 256 rows) inside one item
+    if (a.x_mode != PP_X_PLAIN || a.rows_per_batch <= 0 || a.rows_per_batch % 256 || a.M % a.rows_per_batch ||
+        a.w_batch_stride < a.N * a.K || a.w_batch_stride % 8)
+      return PP_ERR_BAD_ARG;
+    if (!v2_ok(a) || a.act == PP_ACT_GEGLU || a.out_vt) return PP_ERR_UNSUPPORTED;
+    if ((uint64_t)(a.M / a.rows_per_batch) * (uint64_t)a.w_batch_stride * 2u >= 0x80000000ull) return PP_ERR_UNSUPPORTED;
+  }
   return PP_OK;
 }
 
@@ -1911,7 +1923,8 @@ extern "C" int pp_gemm_bf16(const PPGemmArgs* args, void* stream) {
   const Choice c = choose(a);
   if (c.splitk > 1 && !a.workspace) return PP_ERR_WORKSPACE;
   if (c.tile > 10 && !v2_ok(a)) return PP_ERR_BAD_ARG;
-  if ((a.row_stats_out || a.gn_acc[0] || a.gn_acc[1] || (a.x_mode == PP_X_CONV3X3 && a.c3 > 0)) && c.tile < 10)
+  if ((a.row_stats_out || a.gn_acc[0] || a.gn_acc[1] || (a.x_mode == PP_X_CONV3X3 && a.c3 > 0) || a.w_batch_stride > 0) &&
+      c.tile < 10)
     return PP_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   if (a.dtype == PP_DT_F16) return dispatch<PP_DT_F16>(a, c, st);

@@ -730,3 +730,39 @@ def test_fused_groupnorm_silu_conv_out(B, H, W, C, dtype):
     yn = F.silu(F.group_norm(x.float().permute(0, 3, 1, 2), groups, g, b, 1e-5))
     ref = F.conv2d(yn, w.float().reshape(4, 3, 3, C).permute(0, 3, 1, 2), bias, padding=1)
     check(out, ref, 3e-2 * tol, 1e-2 * tol, "fused conv_out vs fp32")
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,hw,C", [(2, 4096, 320), (3, 1024, 640), (1, 256, 320)])
+def test_groupnorm_folded_into_proj_in_weights(B, hw, C, dtype):
+    """Transformer2DModel.norm -> proj_in without the normalised activation: pp_gn_fold_weights builds one weight matrix
+    and one bias row per batch item from the GroupNorm accumulators, pp_gemm_bf16 (w_batch_stride, per-batch rowvec, row
+    moments for the next folded LayerNorm) applies them -- against the two-launch path (groupnorm_apply_acc -> GEMM) and
+    fp32 torch.  Inputs with a large mean exercise the cancellation of the mean term."""
+    groups, cg = 32, C // 32
+    M = B * hw
+    x = (rnd(B, hw, C, seed=1, scale=1.5) + rnd(B, 1, C, seed=2) * 2.0 + 1.0).to(dtype)
+    xf = x.float().reshape(B, hw, groups, cg)
+    acc = torch.stack([(xf.sum((1, 3)).double() * 2 ** 24).round().long(),
+                       ((xf * xf).sum((1, 3)).double() * 2 ** 20).round().long()], -1).contiguous()
+    g, b = rnd(C, seed=3) * 0.3 + 1.0, rnd(C, seed=4) * 0.2
+    w = rnd(C, C, seed=5, scale=C ** -0.5).to(dtype).contiguous()
+    bias = rnd(C, seed=6)
+    wb, rv = ops.gn_fold_weights(acc, hw, g, b, 1e-6, w, bias)
+    out, st = ops.gemm(x.reshape(M, C), wb, rowvec=rv, rows_per_batch=hw, row_stats=True, w_batch_stride=C * C)
+    y = ops.groupnorm_apply_acc(x.reshape(B, hw, 1, C), acc, g, b, 1e-6, False)
+    old, st_old = ops.gemm(y.reshape(M, C), w, bias=bias, row_stats=True)
+    tol = 1.0 if dtype == torch.bfloat16 else 0.25
+    ref = F.group_norm(x.float().permute(0, 2, 1), groups, g, b, 1e-6).permute(0, 2, 1).reshape(M, C) @ w.float().t() + bias
+    check(out, ref, 4e-2 * tol, 1e-2 * tol, "GN folded into proj_in vs fp32")
+    check(out, old, 5e-2 * tol, 1e-2 * tol, "GN folded into proj_in vs apply + GEMM")
+    of = out.float()
+    st_ref = torch.stack([of.reshape(M, C // 160, 160).sum(-1), (of * of).reshape(M, C // 160, 160).sum(-1)], -1)
+    check(st, st_ref, 2e-3 * max(1.0, float(st_ref.abs().max()) / 100), 1e-5, "row moments")
+    # the folded operands themselves
+    mean = xf.mean((1, 3))
+    rstd = torch.rsqrt(xf.var((1, 3), unbiased=False) + 1e-6)
+    sc = (g.reshape(groups, cg)[None] * rstd[:, :, None]).reshape(B, 1, C)
+    check(wb, w.float()[None] * sc, 1e-3, 8e-3 * tol, "per-batch weights")
+    rv_ref = bias[None] + (w.float() @ b)[None] - (wb.float() * mean.repeat_interleave(cg, 1)[:, None, :]).sum(-1)
+    check(rv, rv_ref, 2e-3, 1e-4, "per-batch bias row")
