@@ -1,5 +1,5 @@
 #!/bin/bash
-# Evidence run on the GPU box (one gpurun call:  gpurun --timeout 2400 -- bash tools/evidence.sh [tests]): GPU test suite (arg "tests": + the slow config-parity file), smoke, rocprofv3
+# Evidence run on the GPU box (one gpurun call:  gpurun --timeout 2400 -- bash tools/evidence.sh [tests|profiles]): GPU test suite (arg "tests": + the slow config-parity file), smoke, rocprofv3
 # kernel trace + HBM-traffic counters of the headline command, headline bench with cpu_baseline + live roofline,
 # configs 3 / 4 / 5 and fp16.  -> gpurun_out/r03/ ; the profiles the judge reads are copied to profiles/ by hand.
 set -u
@@ -8,12 +8,14 @@ O=gpurun_out/r03
 mkdir -p $O
 export TMPDIR=/tmp
 rm -f gpurun_out/parity_achieved.txt
-if [ "${1:-}" = "tests" ]; then
+if [ "${1:-}" = "profiles" ]; then
+  echo "(profiles only: test suite and smoke skipped)"
+elif [ "${1:-}" = "tests" ]; then
   timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider --timeout=900 > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -3 $O/pytest_gpu.log
 else
   timeout 1200 python -m pytest tests -m gpu -q -p no:cacheprovider --timeout=900 --ignore=tests/test_config_parity_gpu.py > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -3 $O/pytest_gpu.log
 fi
-timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?"; tail -2 $O/smoke.log
+[ "${1:-}" = "profiles" ] || { timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?"; tail -2 $O/smoke.log; }
 (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d /root/repo/$O/prof -o r -- python /root/repo/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline > /root/repo/$O/prof.log 2>&1; echo "prof rc=$?")
 python tools/prof_summary.py $(find $O/prof -name "*.db" | head -1) $O/kernel_stats.txt "bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline" > /dev/null 2>&1; rm -rf $O/prof; head -14 $O/kernel_stats.txt
 bash tools/hbm_traffic.sh > $O/hbm.log 2>&1; cp gpurun_out/hbm_traffic.json $O/hbm_traffic.json
