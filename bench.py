@@ -150,12 +150,12 @@ KERNEL_STATS_PROFILE = "profiles/r03_kernel_stats.txt"     # rocprofv3 --kernel-
 
 
 def lib_sha16() -> str:
-    """sha256 prefix of the libpp_hip.so this process runs: a committed profile names the build it was taken from."""
-    import hashlib
+    """Identity of the libpp_hip.so this process runs (pp_build_id: a digest of the sources, headers and flags it was built
+    from -- stable across rebuilds, unlike a hash of the binary): a committed profile names the build it was taken from."""
     from powerpaint_amd import _lib as L
     try:
-        return hashlib.sha256(open(L.LIB_PATH, "rb").read()).hexdigest()[:16]
-    except OSError:
+        return L.build_id()
+    except Exception:
         return ""
 
 

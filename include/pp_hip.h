@@ -29,7 +29,7 @@ extern "C" {
 #define PP_ERR_LAUNCH (-3)       /* hipLaunchKernel / hipFuncSetAttribute failed                  */
 #define PP_ERR_WORKSPACE (-4)    /* workspace pointer null or too small                           */
 
-#define PP_ABI_VERSION 12
+#define PP_ABI_VERSION 13
 /* 16-bit storage format of activations and matrix weights ("dtype" arguments; the same codes pp_nchw_to_nhwc uses for
  * its source): bf16 or fp16 -- the reference's default is fp16 (/root/reference/app.py:548,559).  MFMA accumulation,
  * norm statistics, softmax, biases and latents are fp32 with either. */
@@ -37,6 +37,9 @@ extern "C" {
 #define PP_DT_BF16 1
 #define PP_DT_F16 2
 int pp_abi_version(void);
+/* Digest (hex) of the sources, headers and extra flags this library was built from -- what a committed profile or bench
+ * record names as "the build it was taken from" (stable across rebuilds and checkout paths). */
+const char* pp_build_id(void);
 /* hipGetLastError() text of the last PP_ERR_LAUNCH on this thread (host pointer, static storage). */
 const char* pp_last_error(void);
 

@@ -16,7 +16,7 @@ PP_ACT_NONE, PP_ACT_GEGLU, PP_ACT_SILU = 0, 1, 2
 PP_TILE_AUTO, PP_TILE_128x160, PP_TILE_64x160, PP_TILE_256x160 = 0, 1, 2, 3
 PP_DT_F32, PP_DT_BF16, PP_DT_F16 = 0, 1, 2      # dtype codes of the C ABI (include/pp_hip.h)
 PP_ATTN_AUTO, PP_ATTN_PHASED, PP_ATTN_PIPE_Q32, PP_ATTN_PIPE_Q64 = 0, 1, 2, 3   # pp_attention_fwd_variant
-ABI_VERSION = 12                                  # PP_ABI_VERSION of include/pp_hip.h this binding was written against
+ABI_VERSION = 13                                  # PP_ABI_VERSION of include/pp_hip.h this binding was written against
 PP_ERR = {0: "PP_OK", -1: "PP_ERR_BAD_ARG", -2: "PP_ERR_UNSUPPORTED", -3: "PP_ERR_LAUNCH", -4: "PP_ERR_WORKSPACE"}
 
 vp, i32, f32, sz = C.c_void_p, C.c_int32, C.c_float, C.c_size_t
@@ -49,6 +49,7 @@ class PPGemmArgs(C.Structure):
 SIGNATURES = {
     "pp_abi_version": (C.c_int, []),
     "pp_last_error": (C.c_char_p, []),
+    "pp_build_id": (C.c_char_p, []),
     "pp_gemm_bf16": (C.c_int, [C.POINTER(PPGemmArgs), vp]),
     "pp_gemm_workspace_bytes": (sz, [C.POINTER(PPGemmArgs)]),
     "pp_linear_skinny": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
@@ -129,6 +130,11 @@ def dtype_code(dtype) -> int:
     if dtype == torch.float16:
         return PP_DT_F16
     raise PPError(f"the HIP path computes in bf16 or fp16 (fp32 accumulate), not {dtype}")
+
+
+def build_id() -> str:
+    """What the loaded library was built from (pp_build_id: digest of sources + headers + extra flags)."""
+    return lib().pp_build_id().decode()
 
 
 def check(rc: int, what: str = ""):

@@ -60,3 +60,22 @@ def test_bad_args_are_rejected_without_a_gpu():
     b.M = b.N = b.K = 64
     b.dtype = 7                                                      # not bf16 / fp16
     assert lib.pp_gemm_bf16(ctypes.byref(b), None) == -1
+
+
+def test_build_id_names_the_sources_the_library_was_built_from():
+    """pp_build_id() = the digest the Makefile computes over the sources, pp_common.h and include/pp_hip.h: stable across
+    rebuilds and checkout paths (bench.py and the committed rocprof summaries name builds by it) -- and a library that
+    is STALE against the tree (sources edited, `make` not run) fails here instead of being measured."""
+    import hashlib
+    import re
+    from powerpaint_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "powerpaint_amd", "csrc")
+    mk = open(os.path.join(csrc, "Makefile")).read()
+    srcs = re.search(r"^SRCS := (.*)$", mk, re.M).group(1).split()
+    h = hashlib.sha256()
+    for f in [os.path.join(csrc, s) for s in srcs] + [os.path.join(csrc, "pp_common.h"), os.path.join(root, "include", "pp_hip.h")]:
+        h.update(open(f, "rb").read())
+    bid = _lib.build_id()
+    assert re.fullmatch(r"[0-9a-f]{12}", bid), bid
+    assert bid == h.hexdigest()[:12], "libpp_hip.so is stale against powerpaint_amd/csrc: run `make -C powerpaint_amd/csrc`"

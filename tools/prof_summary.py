@@ -1,11 +1,18 @@
 #!/usr/bin/env python
 """Turn a rocprofv3 (--kernel-trace --stats) rocpd SQLite database into a text kernel summary for profiles/."""
-import hashlib
+import ctypes
 import os
 import sqlite3
 import sys
 
 LIB = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "powerpaint_amd", "libpp_hip.so")
+
+
+def build_id():
+    """pp_build_id() of the in-tree library (digest of the sources it was built from), without importing torch."""
+    lib = ctypes.CDLL(LIB)
+    lib.pp_build_id.restype = ctypes.c_char_p
+    return lib.pp_build_id().decode()
 
 
 def main(db, out, title=""):
@@ -14,8 +21,8 @@ def main(db, out, title=""):
     with open(out, "w") as f:
         f.write(f"# rocprofv3 --kernel-trace --stats summary  {title}\n# source: {db}\n")
         try:       # the build this trace was taken from (bench.py compares it with the library it runs)
-            f.write(f"# lib_sha16: {hashlib.sha256(open(LIB, 'rb').read()).hexdigest()[:16]}\n")
-        except OSError:
+            f.write(f"# lib_sha16: {build_id()}\n")
+        except (OSError, AttributeError):
             pass
         f.write(f"# {'calls':>7} {'total_ms':>11} {'avg_us':>10} {'pct':>6}  kernel\n")
         for name, calls, tot, avg, pct in rows:
