@@ -5,7 +5,7 @@
 // (reference ctor site /root/reference/powerpaint/models/unet_2d_blocks.py:1289-1300 -> diffusers 0.27
 // BasicTransformerBlock.attn2 + norm2; the unfused plan is engine.py `_transformer`: `linear` (to_q, LayerNorm folded)
 // -> `attention` (77 keys) -> `linear` (to_out + residual + row moments), 20 + 22 + 20 us and 4 x 21 MB of q / o
-// round trips per block at 64x64).
+// round trips per block at 64x64; this kernel: 55 us, profiles/r03_xattn_fused_ab.txt).
 //
 // The encoder hidden states are step-invariant, so K and V can be folded into the two projections ONCE per prompt
 // (pp_xattn_fold, part of the setup plan):
@@ -34,6 +34,7 @@ constexpr int XA_BM = 128;
 constexpr int XA_SLAB = 320 * 128, XA_NS = 3, XA_NSLAB = 20;
 constexpr int XA_TAB = XA_NS * XA_SLAB;                   // (logit colsum | logit bias) of the batch item, fp32 [2][640]
 constexpr int XA_LDS = XA_TAB + 2 * XA_S * 4;
+constexpr int XA_QD = 8;                                  // fragment reads kept in flight ahead of their MFMA
 
 typedef __attribute__((address_space(3))) void* xa_lds_ptr_t;
 
@@ -121,7 +122,7 @@ __global__ void __launch_bounds__(256) xattn_fold_kernel(const uint16_t* __restr
 }
 
 // DBG (lab build only): 1 no slab DMA, 2 no MFMAs, 4 no fragment reads, 8 no softmax, 16 no epilogue, 32 no barriers
-template <int EDT, int DBG = 0>
+template <int EDT, int DBG = 0, int QD = XA_QD>
 __global__ void __launch_bounds__(512, 2) xattn_block_kernel(const XAArgs a) {
   using E = E16<EDT>;
   typedef typename E::v8 v8_t;
@@ -235,7 +236,7 @@ __global__ void __launch_bounds__(512, 2) xattn_block_kernel(const XAArgs a) {
     }
   };
 
-  // residual and output bias of the epilogue: fetched under the last slab's MFMAs (after stores nothing could be hoisted)
+  // residual of the epilogue: fetched under the last slab's MFMAs (after stores nothing could be hoisted)
   const uint16_t* rr = a.res ? a.res + (size_t)m * a.ldres : nullptr;
   u32x2_t rv[20];
   f32x4_t bo[20];
@@ -254,27 +255,40 @@ __global__ void __launch_bounds__(512, 2) xattn_block_kernel(const XAArgs a) {
       for (int nb = 0; nb < 20; ++nb) {
         const int n = nb * 16 + 4 * g;
         rv[nb] = rr ? *reinterpret_cast<const u32x2_t*>(rr + n) : u32x2_t{0u, 0u};
-        bo[nb] = a.bias_o ? *reinterpret_cast<const f32x4_t*>(a.bias_o + n) : f32x4_t{0.f, 0.f, 0.f, 0.f};
       }
     }
     const char* st = smem + (t % XA_NS) * XA_SLAB;
+    // the slab's 40 weight fragments (ks 0 / 1 x 20 blocks) as a hand-made software pipeline: eight ds_read_b128 stay in
+    // flight ahead of the MFMA that consumes the oldest (left to itself the compiler keeps ~5 reads ahead of an MFMA that
+    // depends on each of them, with nothing else to issue); nine rotating fragment registers
+    v8_t q[QD + 1];
+    const int so0 = ((0 * 4 + g) ^ (r16 & 7)) << 4, so1 = ((1 * 4 + g) ^ (r16 & 7)) << 4;
+    auto load_frag = [&](int i) __attribute__((always_inline)) -> v8_t {
+      return *reinterpret_cast<const v8_t*>(st + ((i % 20) * 16 + r16) * 128 + (i < 20 ? so0 : so1));
+    };
+    v8_t bfr[2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      const int so = ((ks * 4 + g) ^ (r16 & 7)) << 4;
-      v8_t bf;
-      if constexpr (t < 10) bf = xf[(t % 5) * 2 + ks];
+      if constexpr (t < 10) bfr[ks] = xf[(t % 5) * 2 + ks];
       else {
         constexpr int f = (t - 10) * 2;
-        bf = __builtin_bit_cast(v8_t, u32x4_t{pf[f + ks][0], pf[f + ks][1], pf[f + ks][2], pf[f + ks][3]});
+        bfr[ks] = __builtin_bit_cast(v8_t, u32x4_t{pf[f + ks][0], pf[f + ks][1], pf[f + ks][2], pf[f + ks][3]});
       }
+    }
+    if constexpr (!(DBG & 4)) {
 #pragma unroll
-      for (int nb = 0; nb < 20; ++nb) {
-        v8_t af;
-        if constexpr (DBG & 4) af = bf;
-        else af = *reinterpret_cast<const v8_t*>(st + (nb * 16 + r16) * 128 + so);
-        if constexpr (DBG & 2) acc[nb] += __builtin_bit_cast(f32x4_t, af);
-        else acc[nb] = E::mfma16(af, bf, acc[nb]);
+      for (int i = 0; i < QD; ++i) q[i] = load_frag(i);
+    }
+#pragma unroll
+    for (int i = 0; i < 40; ++i) {
+      if constexpr (!(DBG & 4)) {
+        if (i + QD < 40) q[(i + QD) % (QD + 1)] = load_frag(i + QD);
+        __builtin_amdgcn_sched_barrier(0);
       }
+      const v8_t af = (DBG & 4) ? bfr[i / 20] : q[i % (QD + 1)];
+      if constexpr (DBG & 2) acc[i % 20] += __builtin_bit_cast(f32x4_t, af);
+      else acc[i % 20] = E::mfma16(af, bfr[i / 20], acc[i % 20]);
+      if constexpr (!(DBG & 4)) __builtin_amdgcn_sched_barrier(0);
     }
     if constexpr (!(DBG & 8)) {
       if constexpr (t == 4) softmax_half(std::integral_constant<int, 0>{});
@@ -288,6 +302,9 @@ __global__ void __launch_bounds__(512, 2) xattn_block_kernel(const XAArgs a) {
     return;
   }
   uint16_t* orow = a.out + (size_t)m * a.ldo;
+#pragma unroll
+  for (int nb = 0; nb < 20; ++nb)                        // (L2-resident 1.25 KB; all twenty loads before the first store)
+    bo[nb] = a.bias_o ? *reinterpret_cast<const f32x4_t*>(a.bias_o + nb * 16 + 4 * g) : f32x4_t{0.f, 0.f, 0.f, 0.f};
   float sm[2] = {0.f, 0.f}, sq[2] = {0.f, 0.f};
 #pragma unroll
   for (int nb = 0; nb < 20; ++nb) {
@@ -376,6 +393,13 @@ extern "C" int pp_xattn_block(const void* x, int ldx, const void* res, int ldres
       case 16: return go(xattn_block_kernel<PP_DT_BF16, 16>, 0);
       case 33: return go(xattn_block_kernel<PP_DT_BF16, 33>, 0);
       case 39: return go(xattn_block_kernel<PP_DT_BF16, 39>, 0);
+      default: break;
+    }
+  if (dtype == PP_DT_BF16) switch (pp_lab_env("PP_XA_QD", XA_QD)) {
+      case 4: return go(xattn_block_kernel<PP_DT_BF16, 0, 4>, 0);
+      case 6: return go(xattn_block_kernel<PP_DT_BF16, 0, 6>, 0);
+      case 10: return go(xattn_block_kernel<PP_DT_BF16, 0, 10>, 0);
+      case 12: return go(xattn_block_kernel<PP_DT_BF16, 0, 12>, 0);
       default: break;
     }
 #endif

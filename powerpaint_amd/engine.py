@@ -437,10 +437,10 @@ class SDNet:
     # (pp_gn_fold_weights + PPGemmArgs.w_batch_stride): parity-green, +0.5 % on the step (profiles/r03_gn_proj_in_fold_ab.txt)
     fold_gn_proj_in = os.environ.get("PP_LAB") == "1" and os.environ.get("PP_FOLD_GN_PROJ_IN", "0") == "1"
     fuse_conv_out = _lab_switch("PP_FUSE_CONV_OUT")      # (lab) =0: conv_norm_out apply and conv_out as two launches
-    # (lab, OPT-IN: PP_LAB=1 PP_XATTN_FUSED=1) the C = 320 cross-attention sub-blocks as one pp_xattn_block launch each.
-    # Parity-green, but bound by its LDS-read -> MFMA dependency chain and no faster than the three launches it replaces
-    # (profiles/r03_xattn_fused_ab.txt), so the product keeps the chain.
-    fuse_xattn = os.environ.get("PP_LAB") == "1" and os.environ.get("PP_XATTN_FUSED", "0") == "1"
+    # the C = 320 cross-attention sub-blocks (norm2 -> to_q -> 77-key attention -> to_out + residual) as ONE pp_xattn_block
+    # launch each, K / V folded into the projections once per prompt (pp_xattn_fold in the setup plan): 55 against 66 us
+    # per block at 64x64, step -0.55 % (profiles/r03_xattn_fused_ab.txt).  (lab) PP_XATTN_FUSED=0: the three-launch chain
+    fuse_xattn = _lab_switch("PP_XATTN_FUSED")
     # ResnetBlock2D.conv_shortcut merged into conv2 as a 1x1 K tail (needs 64-channel multiples; (lab) PP_MERGE_SHORTCUT=0 off)
     _merge_shortcut_env = _lab_switch("PP_MERGE_SHORTCUT")
 

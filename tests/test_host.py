@@ -66,7 +66,12 @@ def test_full_size_plans_and_flop_accounting():
             assert n_stats == 0 and names.count("zero_u64") == 1 and "conv3x3_direct" not in names
         else:
             assert n_stats == n_gn
-        assert len(names) == exp[kind][1] - (n_gn - n_stats) + names.count("zero_u64") - fused_out
+        # ... and the C = 320 cross-attention sub-blocks (to_q -> attention -> to_out) are one pp_xattn_block launch each,
+        # their K / V folded into the projections by pp_xattn_fold in the setup plan
+        n_x = names.count("xattn_block")
+        assert n_x == ({"unet": 5, "brushnet": 5, "controlnet": 2}[kind] if SDNet.fuse_xattn else 0)
+        assert [c[2] for c in rt.setup_plan.calls].count("xattn_fold") == n_x
+        assert len(names) == exp[kind][1] - (n_gn - n_stats) + names.count("zero_u64") - fused_out - 2 * n_x
         assert len(rt.setup_plan.calls) >= 15
 
 
