@@ -266,7 +266,12 @@ def test_pipeline_v1_duck_typed_scheduler(kind):
         unet=h, scheduler={"ddim": OS.DDIMScheduler, "pndm": OS.PNDMScheduler}[kind]())
     duck = pipe(callback=lambda i, t, l: seen.append(int(t)), **kw)[0]
     assert seen == [int(t) for t in pipe.scheduler.timesteps]
-    close(duck, fused, f"duck-typed {kind} scheduler vs fused step", cos_min=0.9999, rel=2e-3)
+    # The two paths feed the SAME network program; their scheduler arithmetic (fp32 kernel vs the object's torch code)
+    # agrees to ~1e-6.  Usually that is also the final difference (2e-6) -- unless one latent value sits within 1e-6 of a
+    # 16-bit rounding boundary of the network input: then two inputs differ by one ulp and guidance 7.5 amplifies that
+    # to ~0.4 % of max|latent| (measured: PNDM, step 2 -> 0.083 of 21; profiles/r03_duck_typed_rounding_flip.txt).  The
+    # gate allows for one such flip; a wrong timestep or a stale table would be off by tens of percent.
+    close(duck, fused, f"duck-typed {kind} scheduler vs fused step", cos_min=0.9999, rel=1e-2)
     pipe.use_graph = False
     close(pipe(**kw)[0], duck, "duck-typed eager vs graph", cos_min=0.99999, rel=1e-4)
 
