@@ -575,17 +575,21 @@ def test_unipc_step_kernel_vs_oracle(K, N, spacing, off):
         check(xh.cpu(), xo, 1e-4 * max(1.0, float(xo.abs().max())), 1e-4, f"unipc step {k}")
 
 
-@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("fold", [False, True])
-@pytest.mark.parametrize("M,C", [(32768, 320), (8192, 640), (2048, 1280), (65536, 320)])
-def test_geglu_wave_specialised_kernel(M, C, fold, dtype):
-    """LAB BUILD ONLY (PP_LAB=1 PP_LIB=.../libpp_hip_lab.so PP_GEGLU_WS=1; skipped on the shipping library, which does
+def test_geglu_wave_specialised_kernel():
+    """LAB BUILD ONLY (PP_LAB=1 PP_LIB=.../libpp_hip_lab.so PP_GEGLU_WS=1; ONE skip on the shipping library, which does
     not contain the kernel): pp_geglu_ws_kernel (geglu_ws.hip) against the tiled EPI = 2 kernel (an explicit tile id
     keeps the launch on pp_gemm_kernel_v2): same MFMA operand order and fp32 epilogue arithmetic -> bit-identical; and
-    against fp32 torch on a row sample."""
+    against fp32 torch on a row sample.  16 cases: four FeedForward shapes x LayerNorm folded or not x bf16 / fp16."""
+    import itertools
     import os
     if not (os.environ.get("PP_LAB") == "1" and os.environ.get("PP_GEGLU_WS") == "1"):
         pytest.skip("lab experiment: the shipping library has no wave-specialised GEGLU kernel")
+    for (M, C), fold, dtype in itertools.product([(32768, 320), (8192, 640), (2048, 1280), (65536, 320)], [False, True],
+                                                 [torch.bfloat16, torch.float16]):
+        _geglu_ws_case(M, C, fold, dtype)
+
+
+def _geglu_ws_case(M, C, fold, dtype):
     from powerpaint_amd.engine import _geglu_interleave
     N = 8 * C
     x = (rnd(M, C, seed=1, scale=2.0) + 0.3).to(dtype).cuda()
