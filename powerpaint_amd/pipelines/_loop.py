@@ -2,7 +2,12 @@
 
 Per step (reference: /root/reference/powerpaint/pipelines/pipeline_PowerPaint.py:988-1041,
 pipeline_PowerPaint_Brushnet_CA.py:1384-1466, pipeline_PowerPaint_ControlNet.py:1663-1741):
-    t            <- timesteps[step]                                   (device table, pp_step_select_t)
+    temb_all     <- temb_table[step]                                  (one row copy, pp_embed_splice indexed by the device
+                                                                       step counter: the sinusoid -> time_embedding MLP ->
+                                                                       every resnet's time_emb_proj chain depends on t
+                                                                       alone, unet_2d_condition.py:1155-1156, so it is run
+                                                                       once per schedule row when the timesteps change,
+                                                                       not four launches per network and step)
     x_in[:, 0:4] <- cat([latents] * 2)                                (pp_nchw_to_nhwc with batch wrap, no copy of the cat)
     [BrushNet | ControlNet forward]                                   (own launch plan, residuals stay in HBM as NHWC)
     eps          <- UNet(x_in, t, ctx, residuals)
@@ -23,6 +28,12 @@ import torch
 from .. import _lib as L
 from ..engine import Plan
 from ..schedulers import _SchedulerBase, variance_noise
+
+
+def _temb_table_enabled() -> bool:
+    """(lab) PP_LAB=1 PP_TEMB_TABLE=0: every step runs the time-embedding chain again."""
+    import os
+    return not (os.environ.get("PP_LAB") == "1" and os.environ.get("PP_TEMB_TABLE", "1") == "0")
 
 
 class DenoiseLoop:
@@ -135,6 +146,7 @@ class DenoiseLoop:
         key = (tuple(latents_shape), bool(do_cfg), bool(guess_mode), self._eta > 0, float(guidance_scale), id(rt.step_plan),
                id(side_rt.step_plan) if side_rt is not None else None, kind, ts.data_ptr(), step.data_ptr(),
                0 if self.foreign else sch.coef_table().data_ptr(), mp.data_ptr() if mp is not None else 0, src.data_ptr(),
+               _temb_table_enabled(),
                tuple(b.data_ptr() for b in self._blend) if self._blend is not None else None,
                sch.renoise_table().data_ptr() if (self._blend is not None and not self.foreign) else 0)
         if key == self._key and self.program is not None:
@@ -146,17 +158,23 @@ class DenoiseLoop:
         self._key = key
         hw = h * w
         mod = B if do_cfg else 0
+        self._temb = {}
         for r in ([side_rt] if side_rt is not None else []) + [rt]:
-            prog.add("step_select_t", lib.pp_step_select_t, ts.data_ptr(), step.data_ptr(), r.lay["t_dev"])
+            info = self._temb_split(r, ts) if _temb_table_enabled() else None
+            if info is not None:
+                self._temb[id(r)] = info
+                prog.add("temb_row", lib.pp_embed_splice, info["table"].data_ptr(), None, step.data_ptr(), info["out"], 1,
+                         info["total"] * 4)
+            else:
+                prog.add("step_select_t", lib.pp_step_select_t, ts.data_ptr(), step.data_ptr(), r.lay["t_dev"])
             x = r.lay["x_in"]
             nb_r = Bs if r is side_rt else Be                    # (guess mode: the side network takes `latents` as is)
             prog.add("nchw_to_nhwc", lib.pp_nchw_to_nhwc, src.data_ptr(), 0, nb_r, Cl, hw, mod if nb_r != B else 0,
                      x.ptr, x.C, 0, L.dtype_code(r.net.dtype))
-        if side_rt is not None:
-            prog.calls += side_rt.step_plan.calls
-            prog.flops += side_rt.step_plan.flops
-        prog.calls += rt.step_plan.calls
-        prog.flops += rt.step_plan.flops
+        for r in ([side_rt] if side_rt is not None else []) + [rt]:
+            skip = set(self._temb[id(r)]["idx"]) if id(r) in self._temb else ()
+            prog.calls += [c for i, c in enumerate(r.step_plan.calls) if i not in skip]
+            prog.flops += r.step_plan.flops
         if not self.foreign:
             prog.add("cfg_sched_step", lib.pp_cfg_sched_step, rt.outputs["eps"], int(do_cfg), float(guidance_scale),
                      lat.data_ptr(), mp.data_ptr() if mp is not None else None, lat.numel(), sch.kind,
@@ -176,6 +194,48 @@ class DenoiseLoop:
         self.graph = None
         self._keep = (ts, step, mp, lat)
         return self
+
+    # ---- time-embedding table
+    def _temb_split(self, r, ts):
+        """The four leading time-embedding launches of a network's step plan (`timestep_embedding` + three
+        `linear_skinny`: sinusoid, time_embedding.linear_1/2, all time_emb_proj rows at once) and where their result
+        lands; plus a [rows of the schedule][temb_total] fp32 table at a stable address.  None = unexpected layout."""
+        calls = r.step_plan.calls
+        idx = [i for i, c in enumerate(calls) if c[2] in ("timestep_embedding", "linear_skinny")]
+        if len(idx) != 4 or idx != list(range(idx[0], idx[0] + 4)) or calls[idx[0]][2] != "timestep_embedding":
+            return None
+        a = calls[idx[-1]][1]
+        out, total = int(a[6]), int(a[5])
+        tabs = self.__dict__.setdefault("_temb_tables", {})
+        k = (id(r), int(ts.numel()), total)
+        if k not in tabs:
+            tabs[k] = dict(table=torch.zeros(int(ts.numel()), total, dtype=torch.float32, device=ts.device), ts=None,
+                           plan=None)
+        ent = tabs[k]
+        if ent["plan"] is not r.step_plan:           # new weights / new plan: the rows are stale
+            ent["plan"], ent["ts"] = r.step_plan, None
+        return dict(idx=idx, out=out, total=total, table=ent["table"], ent=ent, rt=r)
+
+    def _fill_temb_tables(self):
+        """(Re)compute the table rows when the timestep table changed since they were made: per row the network's own
+        four launches, eagerly, with the step counter pointing at that row."""
+        ts, step = self._keep[0], self._keep[1]
+        for info in getattr(self, "_temb", {}).values():
+            ent, r = info["ent"], info["rt"]
+            if ent["ts"] is not None and ent["ts"].shape == ts.shape and torch.equal(ent["ts"], ts):
+                continue
+            stream = torch.cuda.current_stream().cuda_stream
+            saved = step.clone()
+            view = r.arena.view(info["out"], (info["total"],), torch.float32)
+            calls = [r.step_plan.calls[i] for i in info["idx"]]
+            for i in range(int(ts.numel())):
+                step.fill_(i)
+                L.check(self.lib.pp_step_select_t(ts.data_ptr(), step.data_ptr(), r.lay["t_dev"], stream), "pp_step_select_t")
+                for fn, args, name in calls:
+                    L.check(fn(*args, stream), name)
+                info["table"][i].copy_(view)
+            step.copy_(saved)
+            ent["ts"] = ts.clone()
 
     def _side_scale(self, v):
         """One entry of `run`'s scale schedule as the side runtime stores it (guess mode: the per-residual ramp)."""
@@ -220,6 +280,7 @@ class DenoiseLoop:
         self.scheduler.reset()
         if self.scheduler.kind >= 1:
             self._keep[2].zero_()
+        self._fill_temb_tables()
         self.latents.copy_(latents.to(self.latents.device, torch.float32))
         varying = scale_schedule is not None and len(set(scale_schedule)) > 1
         if not varying and scale_schedule and self.side_rt is not None and \
@@ -258,6 +319,7 @@ class DenoiseLoop:
         if num_steps > tsv.numel():
             raise L.PPError(f"{num_steps} steps requested, {tsv.numel()} timesteps given")
         self._f_ts[:tsv.numel()].copy_(tsv)
+        self._fill_temb_tables()
         self._f_step.zero_()
         lat = latents.to(self.latents.device, torch.float32).clone()
         varying = scale_schedule is not None and len(set(scale_schedule)) > 1
