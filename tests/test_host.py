@@ -489,3 +489,23 @@ def test_runtime_scale_schedule_representation_is_stable():
     rt.ensure(2, 8, 8, 77, 9, scale=0.5)
     rt.ensure(2, 8, 8, 77, 9, scale=0.5)
     assert len(calls) == 2
+
+
+def test_time_embedding_chain_is_where_the_loop_expects_it():
+    """DenoiseLoop replaces the four t-only launches of a network's step plan (sinusoid, time_embedding.linear_1/2, all
+    time_emb_proj rows) by one table-row copy: the plan compiler must keep emitting them as four consecutive calls whose
+    last one writes `temb_total` floats (else the loop silently falls back to running the chain every step)."""
+    import types
+    from powerpaint_amd.pipelines._loop import DenoiseLoop
+    for kind, cin, nk in (("unet", 9, {}), ("brushnet", 4, dict(conditioning_channels=5)),
+                          ("controlnet", 4, dict(conditioning_channels=3))):
+        net = SDNet(kind, cin, **TINY, **nk)
+        net.load_state_dict(net.synthetic_state_dict(meta=True), "cpu", materialize=False)
+        rt = NetRuntime(net, "cpu")
+        rt.ensure(2, 16, 16, 77, 9 if kind != "controlnet" else 4, ("plain",), cond_hw=(128, 128))
+        info = DenoiseLoop._temb_split(types.SimpleNamespace(), rt, torch.zeros(7))
+        assert info is not None, kind
+        names = [rt.step_plan.calls[i][2] for i in info["idx"]]
+        assert names == ["timestep_embedding", "linear_skinny", "linear_skinny", "linear_skinny"], (kind, names)
+        assert info["total"] == net.temb_total and tuple(info["table"].shape) == (7, net.temb_total)
+        assert sum(c[2] in ("timestep_embedding", "linear_skinny") for c in rt.step_plan.calls) == 4
