@@ -29,7 +29,7 @@ extern "C" {
 #define PP_ERR_LAUNCH (-3)       /* hipLaunchKernel / hipFuncSetAttribute failed                  */
 #define PP_ERR_WORKSPACE (-4)    /* workspace pointer null or too small                           */
 
-#define PP_ABI_VERSION 13
+#define PP_ABI_VERSION 14
 /* 16-bit storage format of activations and matrix weights ("dtype" arguments; the same codes pp_nchw_to_nhwc uses for
  * its source): bf16 or fp16 -- the reference's default is fp16 (/root/reference/app.py:548,559).  MFMA accumulation,
  * norm statistics, softmax, biases and latents are fp32 with either. */
@@ -139,6 +139,22 @@ typedef struct PPGemmArgs {
   const void* x4;
   int32_t c3;
   int32_t c4;
+  /* PP_X_CONV3X3, stride 1, no upsample (ABI v14): `GroupNorm(gn_in_groups) -> SiLU` of the conv INPUT concat(x1, x2)
+   * applied by the loader, i.e. ResnetBlock2D's `norm1 -> nonlinearity -> conv1` / `norm2 -> nonlinearity -> dropout
+   * -> conv2` (diffusers 0.27 ResnetBlock2D.forward; ctor sites /root/reference/powerpaint/models/unet_2d_blocks.py:
+   * 1274-1285) as ONE launch: the normalised activation is never written to memory.  x1 / x2 then hold the RAW
+   * (un-normalised) tensors; gn_in_acc -> int64 [batch][gn_in_groups][2] = the (sum, sum of squares) accumulators of
+   * concat(x1, x2) in the fixed-point format of gn_acc above, COMPLETE before this launch (written by the producers'
+   * epilogues); gn_in_gb -> fp32 [c1 + c2][2] = (gamma, beta) interleaved per channel.  The optional 1x1 tail (x3, x4)
+   * is NOT normalised.  Zero padding applies to the normalised tensor, as in the reference.  Supported shapes:
+   * pp_conv_gn_supported(); the arithmetic of the normalisation is that of pp_groupnorm_apply_acc (values rounded to
+   * the 16-bit format before the convolution, exactly as the two-launch path stores them). */
+  const int64_t* gn_in_acc;
+  const float* gn_in_gb;
+  int32_t gn_in_groups;
+  int32_t gn_in_silu;   /* must be 1 (every GroupNorm in front of a 3x3 conv of the path is followed by SiLU) */
+  float gn_in_eps;
+  int32_t reserved3;
 } PPGemmArgs;
 #define PP_GN_SUM_SCALE 16777216.0f /* 2^24 */
 #define PP_GN_SQ_SCALE 1048576.0f   /* 2^20 */
@@ -152,6 +168,9 @@ int pp_gemm_bf16(const PPGemmArgs* args, void* stream);   /* (historic name: bf1
 size_t pp_gemm_workspace_bytes(const PPGemmArgs* args);
 /* 1 if this launch (as pp_gemm_bf16 would configure it) can accumulate GroupNorm statistics (gn_acc), else 0 */
 int pp_gemm_gn_stats_ok(const PPGemmArgs* args);
+/* 1 if pp_gemm_bf16 runs this PP_X_CONV3X3 request with the GroupNorm + SiLU of its input fused into the loader
+ * (gn_in_acc / gn_in_gb set), else 0 -- the caller then keeps pp_groupnorm_apply_acc + a plain conv. */
+int pp_conv_gn_supported(const PPGemmArgs* args);
 
 /* Small-M ("skinny") linear in fp32 accumulate: out[b][n] = act_in(x[b][:]) . W[n][:] + bias[n], b < rows <= 16.
  * Replaces TimestepEmbedding.linear_1/linear_2 and the 22 ResnetBlock2D.time_emb_proj (batched into one call by

@@ -1,0 +1,656 @@
+// ResnetBlock2D's `GroupNorm -> SiLU -> Conv2d(3x3)` as ONE launch for gfx950 (MI355X): a halo-tile implicit GEMM whose
+// loader applies the normalisation.
+//
+// Reference: diffusers 0.27 ResnetBlock2D.forward (norm1 -> nonlinearity -> conv1, norm2 -> nonlinearity -> dropout ->
+// conv2; ctor sites /root/reference/powerpaint/models/unet_2d_blocks.py:1274-1285, 1457-1500, 2696-2770).  The two-launch
+// form of this repository is pp_groupnorm_apply_acc (norm.hip) + pp_gemm_bf16(PP_X_CONV3X3) (gemm.hip): the apply launch
+// reads and rewrites the whole activation (~10 us of launch floor 44 times per UNet step), and the tap-major implicit
+// GEMM then pulls every activation row through the CU's 64 B/clk global->LDS path nine times (52 KB per K step for a
+// 256 x 160 tile: 0.65 of the MFMA time on the address unit, 4.2x the algorithmic fabric traffic).
+//
+// Here the K walk is CHANNEL-CHUNK major: for each 64-channel chunk the workgroup brings the tile's rows PLUS one image
+// row above and below (the "halo tile", (BM / W + 2) x W pixels x 64 channels, <= 48 KB) into LDS ONCE, normalises it in
+// place (x * scale[c] + shift[c], SiLU, rounded to the 16-bit format exactly as the two-launch path stores it) and then
+// runs the nine taps against it: a tap is a constant pixel offset (ky * W + kx - 1) on the fragment-read address.  The
+// horizontal halo needs no storage: tiles span full image rows, so the out-of-row lanes of the kx = 0 / 2 taps are
+// redirected to a 128-byte block of zeros.  Per K step only the 20 KB weight tile moves (LDS-DMA, 3-stage ring); the
+// halo tile of the NEXT chunk is DMA'd raw into the second halo buffer during taps 0 .. 2 and normalised by the lanes
+// that fetched it, one 8-pixel strip per tap, in the READ phase of the ping-pong loop -- VALU + LDS work that runs
+// beside the partner wave's MFMA phase on the same SIMD (MI355X_MICROARCH.md "Two waves per SIMD": the complementary
+// pairing).  The optional 1x1 tail over (x3, x4) (ResnetBlock2D.conv_shortcut merged into conv2) follows as a plain
+// 3-stage GEMM phase on the same accumulators.  Epilogue = the staged 64-row passes of gemm.hip (bias, time-embedding
+// row vector, residuals, GroupNorm statistics of the OUTPUT for the next norm, split-K slabs).
+#include <type_traits>
+#include <utility>
+
+#include "pp_common.h"
+#include "gemm_gn.h"
+
+namespace {
+
+typedef __attribute__((address_space(3))) void* cg_lds_t;
+
+constexpr int CG_T = 512, CG_BN = 160, CG_NI = 5;
+constexpr int CG_WP = 3;                        // weight-tile DMA pieces per wave and K step (20 strips of 8 rows, 8 waves)
+constexpr int CG_HPW = 6;                       // halo DMA pieces per wave and chunk (48 strips of 8 pixels)
+constexpr int CG_HALO_PX = 384;
+constexpr int CG_HALO = CG_HALO_PX * 128;       // one halo buffer
+constexpr int CG_WST = CG_BN * 128;             // one weight stage
+constexpr int CG_WOFF = 2 * CG_HALO;
+constexpr int CG_TAB = CG_WOFF + 3 * CG_WST;
+constexpr int CG_T_STATS = CG_TAB;              // (mean, rstd) of the batch item's groups (<= 32)
+constexpr int CG_T_ZERO = CG_TAB + 256;         // 128 bytes of zeros: where the out-of-row lanes of the kx = 0 / 2 taps read
+constexpr int CG_T_GB = CG_TAB + 1024;          // 2 x 1 KB: (gamma, beta) of a chunk's 64 channels
+constexpr int CG_LDS = CG_TAB + 3072;           // 162,816 B of the CU's 163,840
+static_assert(CG_LDS <= 160 * 1024, "LDS budget");
+
+struct CGDerived {
+  int tiles_m, tiles_n, n_major;
+  int nch1, nch;        // 64-channel chunks of x1, of concat(x1, x2)
+  int ntail3, ntail;    // 64-deep K tiles of x3, of concat(x3, x4) (the 1x1 tail)
+  int hp;               // pixels of the halo tile = BM + 2 W
+  int cg;               // channels per group of the input norm
+  float inv_cg;
+};
+
+template <int... I, class F>
+PP_DEVINL void cg_static_for_impl(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+PP_DEVINL void cg_static_for(F&& f) { cg_static_for_impl(std::make_integer_sequence<int, N>{}, f); }
+
+// PP: ping-pong main loop (waves 0-3 / 4-7 half a K step apart, two barriers per K step); else lock-step (one barrier).
+template <int BM, bool PP, int EDT>
+__global__ void __launch_bounds__(CG_T, 2) pp_conv_gn_kernel(const PPGemmArgs a, const CGDerived d) {
+  using E = E16<EDT>;
+  typedef typename E::v8 v8_t;
+  constexpr int T = CG_T, WN = 2, MI = BM / 64, NI = CG_NI, BN = CG_BN;
+  constexpr int XP2 = BM / 64;                    // phase-2 (tail) X-tile pieces per wave and K step
+  constexpr int P2 = XP2 + CG_WP;
+  constexpr int ST2 = BM * 128;                   // phase-2 X stage (three of them over the two halo buffers)
+  constexpr int EPI_ROWS = 64, EPI_LD = BN * 4 + 16;
+  constexpr int RS_OFF = EPI_ROWS * EPI_LD + BM * 8;
+  static_assert(3 * ST2 <= 2 * CG_HALO, "tail stages live in the halo buffers");
+  static_assert(MI * 16 <= EPI_ROWS && EPI_ROWS % (MI * 16) == 0, "wave rows vs epilogue pass");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int grp = wave >> 2;
+
+  int lid;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  int tile_m, tile_n;
+  if (d.n_major) {
+    tile_n = lid / d.tiles_m;
+    tile_m = lid - tile_n * d.tiles_m;
+  } else {
+    tile_m = lid / d.tiles_n;
+    tile_n = lid - tile_m * d.tiles_n;
+  }
+  const int m_blk = tile_m * BM, n_blk = tile_n * BN;
+  const int split = blockIdx.y, splits = gridDim.y;
+  // every split takes an equal share of the chunks AND of the tail tiles
+  const int ch_b = split * d.nch / splits, ch_e = (split + 1) * d.nch / splits;
+  const int tk_b = split * d.ntail / splits, tk_e = (split + 1) * d.ntail / splits;
+
+  const int Wd = a.win, Hd = a.hin, HW = Hd * Wd;
+  const int bimg = m_blk / HW;                        // the tile lies inside ONE image (host-checked: HW % BM == 0)
+  const int y0 = (m_blk - bimg * HW) / Wd;            // its first image row (BM % W == 0)
+  const int ctot = a.c1 + a.c2;
+  const uint32_t wbytes = (uint32_t)a.N * (uint32_t)a.K * 2u;
+
+  // lane -> (row of an 8-row strip, the k-slot it FETCHES so that its lane-linear LDS slot is swizzled by the row)
+  const int lrow = lane >> 3;
+  const int kslot = (lane & 7) ^ lrow;
+
+  // ---- weight tile: strips of 8 rows, three per wave (a wave whose third strip falls beyond 160 re-issues its second)
+  int vw[CG_WP], wlds[CG_WP];
+#pragma unroll
+  for (int i = 0; i < CG_WP; ++i) {
+    const int strip = (wave * 8 + i * 64 < BN) ? i : i - 1;
+    const int n = n_blk + wave * 8 + lrow + strip * 64;
+    vw[i] = (n < a.N) ? (n * a.K + kslot * 8) * 2 : (int)PP_OOB;
+    wlds[i] = (wave * 8 + strip * 64) * 128;
+  }
+  // ---- halo tile: strip s = wave + 8 j covers halo pixels 8 s .. 8 s + 7; halo pixel hp = (row hp / W, column hp % W), halo
+  //      row 0 = the image row above the tile.  hpix = linear pixel index in the source tensors, -1 outside the image
+  int hpix[CG_HPW];
+#pragma unroll
+  for (int j = 0; j < CG_HPW; ++j) {
+    const int hp = (wave + 8 * j) * 8 + lrow;
+    const int hr = hp / Wd, hx = hp - hr * Wd;
+    const int iy = y0 + hr - 1;
+    hpix[j] = (hp < d.hp && iy >= 0 && iy < Hd) ? bimg * HW + iy * Wd + hx : -1;
+  }
+  // ---- fragments: lane (r16, g) reads row (.. + r16), k-slot (ks * 4 + g) of a 16 x 32 fragment
+  const int r16 = lane & 15, g = lane >> 4;
+  const int fsw = r16 & 7;
+  const int wrow0 = wn * (NI * 16) + r16;
+  const int rt0 = wm * (MI * 16) + r16;             // tile row of fragment 0 (fragment mi: + 16 mi); halo pixel of tap
+                                                    // (ky, kx) = tile row + ky W + kx - 1
+  unsigned edge = 0u;                               // bit mi: first pixel of an image row, bit 8 + mi: last one
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    const int lx = (rt0 + mi * 16) % Wd;
+    if (lx == 0) edge |= 1u << mi;
+    if (lx == Wd - 1) edge |= 1u << (8 + mi);
+  }
+
+  f32x4_t acc[NI][MI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  auto mfma_all = [&](const v8_t (&wf)[2][NI], const v8_t (&xf)[2][MI]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = E::mfma16(wf[ks][ni], xf[ks][mi], acc[ni][mi]);
+  };
+
+  // =====================================================================================================================
+  // phase 1: the nine taps over the normalised halo tiles of chunks ch_b .. ch_e - 1
+  // =====================================================================================================================
+  if (ch_b < ch_e) {
+    float sc[8], sh[8];                              // scale / shift of this lane's eight channels (k-slot) of a chunk
+
+    // (gamma, beta) of chunk c -> table buffer gbuf (every wave issues the same 1 KB piece: identical bytes)
+    auto issue_gb = [&](int c, int gbuf, bool live) __attribute__((always_inline)) {
+      const __amdgpu_buffer_rsrc_t rs = make_rsrc(a.gn_in_gb, live ? (uint32_t)ctot * 8u : 0u);
+      const int vo = lane < 32 ? lane * 16 : (int)PP_OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (cg_lds_t)(smem + CG_T_GB + gbuf * 1024), 16, vo, c * 512, 0, 0);
+    };
+    // scale / shift of chunk c from the table buffer (landed: the caller's vmcnt) and the groups' (mean, rstd)
+    auto compute_scsh = [&](int c, int gbuf) __attribute__((always_inline)) {
+      const char* gp = smem + CG_T_GB + gbuf * 1024 + kslot * 64;
+      const f32x2_t* st = reinterpret_cast<const f32x2_t*>(smem + CG_T_STATS);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4_t gbv = *reinterpret_cast<const f32x4_t*>(gp + q * 16);    // (gamma, beta) of channels 2 q, 2 q + 1
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int e = 2 * q + h;
+          const int ch = c * 64 + kslot * 8 + e;                                // channel of the (concatenated) norm input
+          const int gi = (int)(((float)ch + 0.5f) * d.inv_cg);
+          const f32x2_t mr = st[gi];
+          const float s = mr[1] * gbv[2 * h];
+          sc[e] = s;
+          sh[e] = gbv[2 * h + 1] - mr[0] * s;
+        }
+      }
+    };
+    // in-place normalisation of this lane's 16 bytes of halo strip (wave + 8 j) in buffer hbuf: what the lane's own DMA
+    // wrote (ordered by the wave's vmcnt), rounded exactly as pp_groupnorm_apply_acc stores it; pixels outside the image
+    // stay zero (the convolution pads the NORMALISED tensor)
+    auto norm_piece = [&](int hbuf, int j) __attribute__((always_inline)) {
+      char* p = smem + hbuf * CG_HALO + (wave + 8 * j) * 1024 + lane * 16;
+      if (hpix[j] >= 0) {
+        const u32x4_t v = *reinterpret_cast<const u32x4_t*>(p);
+        float r[8];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          r[2 * q] = E::lo(v[q]) * sc[2 * q] + sh[2 * q];
+          r[2 * q + 1] = E::hi(v[q]) * sc[2 * q + 1] + sh[2 * q + 1];
+        }
+        // SiLU with the hardware reciprocal (1 ulp) instead of silu_f's IEEE division (~10 instructions per element in a
+        // phase that must not outlast the partner's 40 MFMAs); the 16-bit rounding that follows hides the difference
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          r[e] = r[e] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(r[e] * -1.44269504088896340736f));
+        u32x4_t o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o[q] = E::pack2(r[2 * q], r[2 * q + 1]);
+        *reinterpret_cast<u32x4_t*>(p) = o;
+      }
+    };
+
+    // next chunk's halo source (refreshed per chunk): descriptor, per-lane offsets, channel offset inside the source
+    __amdgpu_buffer_rsrc_t rs_h = make_rsrc(a.x1, 0u);
+    int hsoff = 0, hcsrc = 0;
+    auto halo_source = [&](int c, bool live) __attribute__((always_inline)) {
+      const bool first = c < d.nch1;
+      int csrc;
+      if (first) {
+        csrc = a.c1;
+        rs_h = make_rsrc(a.x1, live ? (uint32_t)a.batch * (uint32_t)HW * (uint32_t)a.c1 * 2u : 0u);
+        hsoff = c * 128;
+      } else {
+        csrc = a.c2;
+        rs_h = make_rsrc(a.x2 ? a.x2 : a.x1, (live && a.x2) ? (uint32_t)a.batch * (uint32_t)HW * (uint32_t)a.c2 * 2u : 0u);
+        hsoff = (c - d.nch1) * 128;
+      }
+      hcsrc = csrc;
+    };
+    auto issue_halo_piece = [&](int hbuf, int j) __attribute__((always_inline)) {
+      const int vo = hpix[j] >= 0 ? (hpix[j] * hcsrc + kslot * 8) * 2 : (int)PP_OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_h, (cg_lds_t)(smem + hbuf * CG_HALO + (wave + 8 * j) * 1024), 16, vo,
+                                               hsoff, 0, 0);
+    };
+    auto issue_w_piece = [&](const __amdgpu_buffer_rsrc_t rs, int stage, int i, int sow) __attribute__((always_inline)) {
+      const int vo = vw[i], lo = wlds[i];
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (cg_lds_t)(smem + CG_WOFF + stage * CG_WST + lo), 16, vo, sow, 0, 0);
+    };
+
+    // ---- prologue: weight tiles of K steps 0 and 1, the first halo tile and its table; the groups' (mean, rstd)
+    {
+      const __amdgpu_buffer_rsrc_t rsw = make_rsrc(a.w, wbytes);
+#pragma unroll
+      for (int i = 0; i < CG_WP; ++i) issue_w_piece(rsw, 0, i, (0 * ctot + ch_b * 64) * 2);
+#pragma unroll
+      for (int i = 0; i < CG_WP; ++i) issue_w_piece(rsw, 1, i, (1 * ctot + ch_b * 64) * 2);
+      halo_source(ch_b, true);
+#pragma unroll
+      for (int j = 0; j < CG_HPW; ++j) issue_halo_piece(0, j);
+      issue_gb(ch_b, 0, true);
+    }
+    if (tid < a.gn_in_groups) {     // (the arithmetic of gn_fold_acc, norm.hip)
+      const long long* ap = reinterpret_cast<const long long*>(a.gn_in_acc) + ((size_t)bimg * a.gn_in_groups + tid) * 2;
+      const double s = (double)ap[0] * (1.0 / (double)PP_GN_SUM_SCALE);
+      const double q = (double)ap[1] * (1.0 / (double)PP_GN_SQ_SCALE);
+      const double n = (double)HW * (double)d.cg;
+      const double mean = s / n;
+      double var = q / n - mean * mean;
+      if (var < 0.0) var = 0.0;
+      reinterpret_cast<f32x2_t*>(smem + CG_T_STATS)[tid] = f32x2_t{(float)mean, (float)(1.0 / sqrt(var + (double)a.gn_in_eps))};
+    }
+    if (tid < 32) reinterpret_cast<float*>(smem + CG_T_ZERO)[tid] = 0.f;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    compute_scsh(ch_b, 0);
+#pragma unroll
+    for (int j = 0; j < CG_HPW; ++j) norm_piece(0, j);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (PP && grp == 1) asm volatile("s_barrier" ::: "memory");      // group 1 runs one phase behind group 0
+
+    int hb = 0;
+#pragma unroll 1
+    for (int c = ch_b; c < ch_e; ++c) {
+      const bool nxt = c + 1 < ch_e;
+      halo_source(c + 1, nxt);
+      const __amdgpu_buffer_rsrc_t rsw_same = make_rsrc(a.w, wbytes);
+      const __amdgpu_buffer_rsrc_t rsw_next = make_rsrc(a.w, nxt ? wbytes : 0u);
+      const int hoff = hb * CG_HALO;
+      const int hbn = hb ^ 1;
+      int Wl = Wd;                                  // (opaque per iteration: keeps the nine taps' fragment addresses -- 2 x 9
+      asm volatile("" : "+s"(Wl));                  //  registers, hoisted out of the chunk loop otherwise -- inside it)
+
+      cg_static_for<9>([&](auto TT) __attribute__((always_inline)) {
+        constexpr int t = decltype(TT)::value;
+        constexpr int st_r = t % 3, st_w = (t + 2) % 3;             // (9 % 3 == 0: the stage of tap t is t % 3 in every chunk)
+        constexpr int NX = t == 0 ? CG_HPW + 1 : 0;                 // extra DMA pieces of this tap: next halo + its table
+        // weight tile of K step + 2
+        const __amdgpu_buffer_rsrc_t rsw = t + 2 <= 8 ? rsw_same : rsw_next;
+        const int sow = t + 2 <= 8 ? ((t + 2) * ctot + c * 64) * 2 : ((t + 2 - 9) * ctot + (c + 1) * 64) * 2;
+
+        if constexpr (PP) {
+          asm volatile("s_barrier" ::: "memory");   // X: everyone's weight tile of this step is in LDS; the partner left its read phase
+        } else {
+          // this wave's weight pieces of this K step have landed (the pieces issued after them may still be in flight)
+          constexpr int V = (t == 1 || t == 2) ? CG_WP + CG_HPW + 1 : CG_WP;
+          asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(V) : "memory");
+        }
+        // ---- the next chunk's halo tile: landed at the end of tap 2 (its pieces are older than tap 2's weight pieces, which
+        //      the wait of tap 2 [PP] / the head of tap 3 [lock-step] leaves in flight); one strip per tap from tap 3 on,
+        //      BEFORE the fragment reads (whose 72 registers are then not live beside the normalisation's)
+        if constexpr (t >= 3) {
+          if (nxt) {
+            if constexpr (t == 3) compute_scsh(c + 1, hbn);
+            norm_piece(hbn, t - 3);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- read phase: fragment reads of this K step, the DMA pieces spread between them
+        const char* ws = smem + CG_WOFF + st_r * CG_WST;
+        const int hp0 = rt0 + (t / 3) * Wl + (t % 3) - 1;
+        const int xbase = hoff + (hp0 << 7) + ((g ^ (hp0 & 7)) << 4);
+        v8_t wf[2][NI], xf[2][MI];
+        constexpr int NR = NI + MI, NPC = CG_WP + NX;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+          if (r < NI) {
+            const int ni = r < NI ? r : 0;
+            const char* pw = ws + (wrow0 + ni * 16) * 128;
+            wf[0][ni] = *reinterpret_cast<const v8_t*>(pw + ((g ^ fsw) << 4));
+            wf[1][ni] = *reinterpret_cast<const v8_t*>(pw + (((4 + g) ^ fsw) << 4));
+          } else {
+            const int mi = r >= NI ? r - NI : 0;
+            // k-slot g of halo pixel hp0 + 16 mi (same swizzle for every mi: 16 = 0 mod 8; ks = 1: slot g + 4 = ^ 64 B)
+            int o0 = xbase + mi * 2048;
+            if constexpr (t % 3 == 0) o0 = (edge >> mi) & 1u ? CG_T_ZERO : o0;
+            if constexpr (t % 3 == 2) o0 = (edge >> (8 + mi)) & 1u ? CG_T_ZERO : o0;
+            xf[0][mi] = *reinterpret_cast<const v8_t*>(smem + o0);
+            xf[1][mi] = *reinterpret_cast<const v8_t*>(smem + (o0 ^ 64));
+          }
+          // piece k goes after read number ceil((k + 1) * NR / (NPC + 1))
+#pragma unroll
+          for (int k = 0; k < NPC; ++k)
+            if (((k + 1) * NR + NPC) / (NPC + 1) == r + 1) {
+              __builtin_amdgcn_sched_barrier(0);
+              if (k < CG_WP) issue_w_piece(rsw, st_w, k < CG_WP ? k : 0, sow);
+              else if (k < CG_WP + CG_HPW) issue_halo_piece(hbn, k - CG_WP < CG_HPW ? k - CG_WP : 0);
+              else issue_gb(c + 1, hbn, nxt);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if constexpr (PP) {
+          // Y: this wave's weight pieces of the NEXT K step have landed, its fragments of this one are in registers
+          constexpr int V = t == 0 ? CG_WP + NX : (t == 1 ? CG_HPW + 1 + CG_WP : CG_WP);
+          asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(V) : "memory");
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+        mfma_all(wf, xf);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      hb ^= 1;
+    }
+    if (PP && grp == 0) asm volatile("s_barrier" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+
+  // =====================================================================================================================
+  // phase 2: the 1x1 tail over concat(x3, x4) at the output pixel -- a plain 3-stage LDS-DMA GEMM on the same accumulators
+  // =====================================================================================================================
+  if (tk_b < tk_e) {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // everyone left phase 1's LDS
+    const int mrow = m_blk + wave * 8 + lrow;        // this lane's row of X strip 0 (strip i: + 64 i)
+    const uint32_t xb3 = (uint32_t)a.M * (uint32_t)a.c3 * 2u, xb4 = a.x4 ? (uint32_t)a.M * (uint32_t)a.c4 * 2u : 0u;
+    auto issue2 = [&](int kt, int stage) __attribute__((always_inline)) {
+      const bool live = kt < tk_e;
+      const bool first = kt < d.ntail3;
+      const __amdgpu_buffer_rsrc_t rsx = first ? make_rsrc(a.x3, live ? xb3 : 0u) : make_rsrc(a.x4 ? a.x4 : a.x3, live ? xb4 : 0u);
+      const int sox = (first ? kt : kt - d.ntail3) * 128;
+      const int csrc = first ? a.c3 : a.c4;          // (per-lane offsets from the scalar: a select between two per-lane
+                                                     //  arrays becomes a private-memory table)
+      const __amdgpu_buffer_rsrc_t rsw = make_rsrc(a.w, live ? wbytes : 0u);
+      const int sow = (9 * ctot + kt * 64) * 2;
+#pragma unroll
+      for (int i = 0; i < XP2; ++i) {
+        const int m = mrow + i * 64;
+        const int vo = m < a.M ? (m * csrc + kslot * 8) * 2 : (int)PP_OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (cg_lds_t)(smem + stage * ST2 + (wave * 8 + i * 64) * 128), 16, vo, sox,
+                                                 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < CG_WP; ++i) {
+        const int vo = vw[i], lo = wlds[i];
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (cg_lds_t)(smem + CG_WOFF + stage * CG_WST + lo), 16, vo, sow, 0, 0);
+      }
+    };
+    issue2(tk_b, 0);
+    issue2(tk_b + 1, 1);
+    const int xrow0 = wm * (MI * 16) + r16;
+    int stage = 0;
+#pragma unroll 1
+    for (int kt = tk_b; kt < tk_e; ++kt) {
+      asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(P2) : "memory");
+      int nstage = stage + 2;
+      if (nstage >= 3) nstage -= 3;
+      issue2(kt + 2, nstage);
+      const char* xs = smem + stage * ST2;
+      const char* ws = smem + CG_WOFF + stage * CG_WST;
+      v8_t wf[2][NI], xf[2][MI];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int so = ((ks * 4 + g) ^ fsw) << 4;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) wf[ks][ni] = *reinterpret_cast<const v8_t*>(ws + (wrow0 + ni * 16) * 128 + so);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) xf[ks][mi] = *reinterpret_cast<const v8_t*>(xs + (xrow0 + mi * 16) * 128 + so);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+      mfma_all(wf, xf);
+      __builtin_amdgcn_s_setprio(0);
+      stage = stage + 1 == 3 ? 0 : stage + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+
+  // =====================================================================================================================
+  // epilogue: 64-row passes through LDS (the staged form of gemm.hip): lane holds columns n = .. + 4 (lane >> 4) + {0..3}
+  // of row m = .. + (lane & 15); thread = fixed 8-column strip on the read-back side
+  // =====================================================================================================================
+  const bool splitk = splits > 1;
+  const bool gns = !splitk && (a.gn_acc[0] || a.gn_acc[1]);
+  const int my_pass = (wm * (MI * 16)) / EPI_ROWS;
+  const int my_row0 = (wm * (MI * 16)) % EPI_ROWS;
+  float gcs[8], gcq[8];
+#pragma unroll
+  for (int jj = 0; jj < 8; ++jj) { gcs[jj] = 0.f; gcq[jj] = 0.f; }
+  constexpr int EC = BN / 8, ER = T / EC, EP = (EPI_ROWS + ER - 1) / ER;
+  const int c8 = tid % EC, r0 = tid / EC;
+  const int n = n_blk + c8 * 8;
+#pragma unroll 1
+  for (int pass = 0; pass < BM / EPI_ROWS; ++pass) {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // LDS free: main loop (pass 0) / previous read-out finished
+    if (my_pass == pass) {
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+          *reinterpret_cast<f32x4_t*>(smem + (my_row0 + mi * 16 + r16) * EPI_LD + (wn * (NI * 16) + ni * 16 + 4 * g) * 4) =
+              acc[ni][mi];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    const int m0 = m_blk + pass * EPI_ROWS;
+    if (r0 < ER && n < a.N) {
+      if (splitk) {
+#pragma unroll
+        for (int j = 0; j < EP; ++j) {
+          const int row = r0 + j * ER, m = m0 + row;
+          if (row < EPI_ROWS && m < a.M) {
+            float* wsp = a.workspace + ((size_t)split * a.M + m) * a.N + n;
+            *reinterpret_cast<f32x4_t*>(wsp) = *reinterpret_cast<const f32x4_t*>(smem + row * EPI_LD + c8 * 32);
+            *reinterpret_cast<f32x4_t*>(wsp + 4) = *reinterpret_cast<const f32x4_t*>(smem + row * EPI_LD + c8 * 32 + 16);
+          }
+        }
+      } else {
+        // all residual loads of the pass are issued BEFORE the math so that their latencies overlap
+        u32x4_t r1[EP], r2[EP];
+#pragma unroll
+        for (int j = 0; j < EP; ++j) {
+          const int row = r0 + j * ER, m = m0 + row;
+          const bool ok = row < EPI_ROWS && m < a.M;
+          r1[j] = (ok && a.res1) ? *reinterpret_cast<const u32x4_t*>((const uint16_t*)a.res1 + (size_t)m * a.ldres1 + n)
+                                 : u32x4_t{0u, 0u, 0u, 0u};
+          r2[j] = (ok && a.res2) ? *reinterpret_cast<const u32x4_t*>((const uint16_t*)a.res2 + (size_t)m * a.ldres2 + n)
+                                 : u32x4_t{0u, 0u, 0u, 0u};
+        }
+        f32x4_t bs0 = {0.f, 0.f, 0.f, 0.f}, bs1 = {0.f, 0.f, 0.f, 0.f};
+        if (a.bias) {
+          bs0 = *reinterpret_cast<const f32x4_t*>(a.bias + n);
+          bs1 = *reinterpret_cast<const f32x4_t*>(a.bias + n + 4);
+        }
+        if (a.rowvec) {                                 // (one batch item per tile)
+          const float* rv = a.rowvec + (size_t)(m_blk / a.rows_per_batch) * a.ld_rowvec + n;
+          bs0 += *reinterpret_cast<const f32x4_t*>(rv);
+          bs1 += *reinterpret_cast<const f32x4_t*>(rv + 4);
+        }
+#pragma unroll
+        for (int j = 0; j < EP; ++j) {
+          const int row = r0 + j * ER, m = m0 + row;
+          if (row < EPI_ROWS && m < a.M) {
+            f32x4_t v0 = *reinterpret_cast<const f32x4_t*>(smem + row * EPI_LD + c8 * 32);
+            f32x4_t v1 = *reinterpret_cast<const f32x4_t*>(smem + row * EPI_LD + c8 * 32 + 16);
+            v0 += bs0;
+            v1 += bs1;
+            v0 *= a.scale;
+            v1 *= a.scale;
+            v0[0] += E::lo(r1[j][0]) + E::lo(r2[j][0]); v0[1] += E::hi(r1[j][0]) + E::hi(r2[j][0]);
+            v0[2] += E::lo(r1[j][1]) + E::lo(r2[j][1]); v0[3] += E::hi(r1[j][1]) + E::hi(r2[j][1]);
+            v1[0] += E::lo(r1[j][2]) + E::lo(r2[j][2]); v1[1] += E::hi(r1[j][2]) + E::hi(r2[j][2]);
+            v1[2] += E::lo(r1[j][3]) + E::lo(r2[j][3]); v1[3] += E::hi(r1[j][3]) + E::hi(r2[j][3]);
+            u32x4_t o;
+            o[0] = E::pack2(v0[0], v0[1]); o[1] = E::pack2(v0[2], v0[3]);
+            o[2] = E::pack2(v1[0], v1[1]); o[3] = E::pack2(v1[2], v1[3]);
+            *reinterpret_cast<u32x4_t*>((uint16_t*)a.out + (size_t)m * a.ldo + n) = o;
+            if (gns) {   // per-column moments of the values as stored, over this thread's rows of the tile
+#pragma unroll
+              for (int jj = 0; jj < 4; ++jj) {
+                const float lo = E::lo(o[jj]), hi = E::hi(o[jj]);
+                gcs[2 * jj] += lo; gcq[2 * jj] += lo * lo;
+                gcs[2 * jj + 1] += hi; gcq[2 * jj + 1] += hi * hi;
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+  if (gns) {
+    // per-thread column moments -> LDS [row-thread][column] -> the 160 column threads fold the ER row-threads in fixed order
+    // and add into the groups' integer slots -> one 64-bit atomic per (consumer, group) to the global accumulators
+    unsigned long long* slots = reinterpret_cast<unsigned long long*>(smem + RS_OFF);
+    if (tid < 2 * GN_SLOTS * 2) slots[tid] = 0ull;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (r0 < ER && n < a.N) {
+      float* dstp = reinterpret_cast<float*>(smem) + ((size_t)r0 * BN + c8 * 8) * 2;
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj)
+        *reinterpret_cast<f32x4_t*>(dstp + 4 * jj) = f32x4_t{gcs[2 * jj], gcq[2 * jj], gcs[2 * jj + 1], gcq[2 * jj + 1]};
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    const int ncols = min(BN, a.N - n_blk);
+    if (tid < ncols) {
+      float sm = 0.f, sq = 0.f;
+#pragma unroll 5
+      for (int r = 0; r < ER; ++r) {
+        const f32x2_t v = *reinterpret_cast<const f32x2_t*>(smem + ((size_t)r * BN + tid) * 8);
+        sm += v[0];
+        sq += v[1];
+      }
+      gn_column(a, slots, n_blk, tid, sm, sq);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    gn_flush(a, slots, m_blk, n_blk, ncols, tid);
+  }
+}
+
+// ---- host side ----------------------------------------------------------------------------------------------------------
+struct CGChoice {
+  int bm, splitk;
+};
+
+// the loader's geometry: stride 1, no upsample, tiles of whole image rows inside one image, halo tile <= 384 pixels
+bool cg_shape_ok(const PPGemmArgs& a, int bm) {
+  const int hw = a.hin * a.win;
+  return bm % a.win == 0 && hw % bm == 0 && bm + 2 * a.win <= CG_HALO_PX;
+}
+
+bool cg_supported(const PPGemmArgs& a) {
+  if (a.x_mode != PP_X_CONV3X3 || !a.gn_in_acc || !a.gn_in_gb || !pp_dt_ok(a.dtype)) return false;
+  if (a.stride != 1 || a.up || a.hin != a.hout || a.win != a.wout || a.win < 8 || (a.win & 7)) return false;
+  if (a.gn_in_silu != 1 || a.gn_in_groups <= 0 || a.gn_in_groups > 32) return false;
+  const int ctot = a.c1 + a.c2;
+  if (a.c1 <= 0 || a.c1 % 64 || a.c2 % 64 || (a.c2 > 0 && !a.x2) || ctot % a.gn_in_groups) return false;
+  if (a.c3 < 0 || a.c4 < 0 || a.c3 % 64 || a.c4 % 64 || (a.c3 > 0 && !a.x3) || (a.c4 > 0 && (!a.x4 || a.c3 == 0))) return false;
+  if (a.K != 9 * ctot + a.c3 + a.c4 || a.M != a.batch * a.hout * a.wout || a.M <= 0 || a.N <= 0) return false;
+  if (a.N % 8 || a.ldo % 8 || a.out_f32 || a.out_vt || a.act != PP_ACT_NONE || a.ln_stats || a.row_stats_out ||
+      a.w_batch_stride)
+    return false;
+  if ((a.res1 && a.ldres1 % 8) || (a.res2 && a.ldres2 % 8)) return false;
+  if (a.rows_per_batch != a.hout * a.wout) return false;
+  if ((uint64_t)a.batch * a.hin * a.win * (uint64_t)(a.c1 > a.c2 ? a.c1 : a.c2) * 2u >= 0x80000000ull) return false;
+  if ((uint64_t)a.N * (uint64_t)a.K * 2u >= 0x80000000ull) return false;
+  if ((uint64_t)a.M * (uint64_t)(a.c3 > a.c4 ? a.c3 : a.c4) * 2u >= 0x80000000ull) return false;
+  for (int k = 0; k < 2; ++k)
+    if (a.gn_acc[k] && (a.gn_cg[k] < 8 || a.gn_groups[k] <= 0 || a.gn_c0[k] < 0)) return false;
+  return cg_shape_ok(a, 256) || cg_shape_ok(a, 128) || cg_shape_ok(a, 64);
+}
+
+CGChoice cg_choose(const PPGemmArgs& a) {
+  const int tn = (a.N + 159) / 160;
+  auto tiles = [&](int bm) { return (a.M / bm) * tn; };
+  CGChoice c{0, 1};
+  // explicit tile request (PP_TILE_256x160 / 128x160 / 64x160), else: the largest tile that still fills the chip;
+  // failing that the largest tile, split over the channel chunks
+  const int want = a.tile == PP_TILE_256x160 ? 256 : a.tile == PP_TILE_128x160 ? 128 : a.tile == PP_TILE_64x160 ? 64 : 0;
+  if (want && cg_shape_ok(a, want)) c.bm = want;
+  else if (cg_shape_ok(a, 256) && tiles(256) >= 224) c.bm = 256;
+  else if (cg_shape_ok(a, 128) && tiles(128) >= 224) c.bm = 128;
+  else if (cg_shape_ok(a, 256)) c.bm = 256;
+  else if (cg_shape_ok(a, 128)) c.bm = 128;
+  else c.bm = 64;
+  const int nch = (a.c1 + a.c2) / 64;
+  int sk = 1;
+  while (tiles(c.bm) * sk * 2 <= 256 && nch / (sk * 2) >= 2 && sk < 8) sk *= 2;
+  c.splitk = a.splitk > 0 ? a.splitk : sk;
+  if (c.splitk > 8) c.splitk = 8;
+  if (c.splitk > nch) c.splitk = nch;
+  return c;
+}
+
+template <int BM, bool PP, int EDT>
+int cg_launch(const PPGemmArgs& a, int splitk, hipStream_t st) {
+  static bool attr_set = false;
+  auto kern = pp_conv_gn_kernel<BM, PP, EDT>;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, CG_LDS) !=
+        hipSuccess) {
+      pp_set_last_error("hipFuncSetAttribute(conv_gn)", hipGetLastError());
+      return PP_ERR_LAUNCH;
+    }
+    attr_set = true;
+  }
+  CGDerived d;
+  d.tiles_m = a.M / BM;
+  d.tiles_n = (a.N + CG_BN - 1) / CG_BN;
+  d.n_major = (d.tiles_m < d.tiles_n && d.tiles_m <= 8) ? 1 : 0;
+  d.nch1 = a.c1 / 64;
+  d.nch = (a.c1 + a.c2) / 64;
+  d.ntail3 = a.c3 / 64;
+  d.ntail = (a.c3 + a.c4) / 64;
+  d.hp = BM + 2 * a.win;
+  d.cg = (a.c1 + a.c2) / a.gn_in_groups;
+  d.inv_cg = 1.0f / (float)d.cg;
+  hipLaunchKernelGGL(kern, dim3(d.tiles_m * d.tiles_n, splitk, 1), dim3(CG_T), CG_LDS, st, a, d);
+  PP_CHECK_LAUNCH("pp_conv_gn_kernel");
+  return PP_OK;
+}
+
+// (lab build) PP_CONV_GN_PP=0: the lock-step main loop instead of the ping-pong one
+bool cg_pingpong() {
+  static const int v = pp_lab_env("PP_CONV_GN_PP", 1);
+  return v != 0;
+}
+
+template <int EDT>
+int cg_dispatch(const PPGemmArgs& a, const CGChoice& c, hipStream_t st) {
+#ifdef PP_LAB
+  if (!cg_pingpong()) switch (c.bm) {
+      case 256: return cg_launch<256, false, EDT>(a, c.splitk, st);
+      case 128: return cg_launch<128, false, EDT>(a, c.splitk, st);
+      default: return cg_launch<64, false, EDT>(a, c.splitk, st);
+    }
+#endif
+  switch (c.bm) {
+    case 256: return cg_launch<256, true, EDT>(a, c.splitk, st);
+    case 128: return cg_launch<128, true, EDT>(a, c.splitk, st);
+    default: return cg_launch<64, true, EDT>(a, c.splitk, st);
+  }
+}
+
+}  // namespace
+
+// entry points used by gemm.hip's pp_gemm_bf16 / pp_gemm_workspace_bytes (one C-ABI call per conv, whichever kernel runs)
+bool pp_conv_gn_wanted(const PPGemmArgs& a) { return a.x_mode == PP_X_CONV3X3 && a.gn_in_acc != nullptr; }
+int pp_conv_gn_splitk(const PPGemmArgs& a) { return cg_supported(a) ? cg_choose(a).splitk : 0; }
+int pp_conv_gn_run(const PPGemmArgs& a, hipStream_t st) {
+  if (!cg_supported(a)) return PP_ERR_UNSUPPORTED;
+  const CGChoice c = cg_choose(a);
+  if (c.splitk > 1 && !a.workspace) return PP_ERR_WORKSPACE;
+  return a.dtype == PP_DT_F16 ? cg_dispatch<PP_DT_F16>(a, c, st) : cg_dispatch<PP_DT_BF16>(a, c, st);
+}
+
+extern "C" int pp_conv_gn_supported(const PPGemmArgs* args) { return (args && cg_supported(*args)) ? 1 : 0; }

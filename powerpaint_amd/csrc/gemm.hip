@@ -19,6 +19,7 @@
 //   * workgroup id -> tile mapping is XCD-aware (8 XCDs, private 4 MiB L2 each): the blocks resident on one XCD walk
 //     consecutive N tiles of the same M panel, so the activation panel is fetched from HBM once per XCD.
 #include "pp_common.h"
+#include "gemm_gn.h"
 
 // The LDS-staged epilogue (64-row passes, full-row 16-byte stores) is the shipping form.  -DPP_EPI_DIRECT (lab builds)
 // selects the register-direct epilogue instead: parity-green on every suite, but measured SLOWER on MI355X
@@ -37,42 +38,6 @@ struct GemmDerived {
   int tiles_m, tiles_n, kt_total, kt_per_split, ctiles;
   int n_major;   // 1: consecutive tile ids walk the M tiles of one N tile (the blocks of an XCD share the W strip)
 };
-
-// GroupNorm statistics from an epilogue.  A pass / tile = up to 64 output rows of ONE batch item x the <= 160 columns
-// [n_blk, n_blk + ncols).  Stage 1 (gn_column): the thread that owns column `col` adds its column's (sum, sumsq), in
-// fixed point, to the LDS slot of the group the column belongs to (64-bit integer LDS atomics: order-independent).
-// Stage 2 (gn_flush, after a barrier): one thread per (subscription, group) moves the slot to the global accumulator
-// with a 64-bit integer atomic and clears it.  Integer arithmetic end to end => bit-reproducible.
-constexpr int GN_SLOTS = 24;   // >= groups one 160-column tile can touch (160 / 10 + 2)
-PP_DEVINL void gn_column(const PPGemmArgs& a, unsigned long long* slots, int n_blk, int col, float sm, float sq) {
-  const unsigned long long fs = (unsigned long long)(long long)__float2ll_rn(sm * PP_GN_SUM_SCALE);
-  const unsigned long long fq = (unsigned long long)(long long)__float2ll_rn(sq * PP_GN_SQ_SCALE);
-#pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    if (!a.gn_acc[k]) continue;
-    const int cg = a.gn_cg[k], cbase = a.gn_c0[k] + n_blk;
-    const int gl = (cbase + col) / cg - cbase / cg;          // group index relative to the first group of the tile
-    __hip_atomic_fetch_add(slots + (k * GN_SLOTS + gl) * 2, fs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    __hip_atomic_fetch_add(slots + (k * GN_SLOTS + gl) * 2 + 1, fq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  }
-}
-PP_DEVINL void gn_flush(const PPGemmArgs& a, unsigned long long* slots, int m0, int n_blk, int ncols, int tid) {
-  const int k = tid / GN_SLOTS, gl = tid - k * GN_SLOTS;
-  if (k < 2 && a.gn_acc[k]) {
-    const int cg = a.gn_cg[k], cbase = a.gn_c0[k] + n_blk;
-    const int g_first = cbase / cg, g_last = (cbase + ncols - 1) / cg;
-    if (g_first + gl <= g_last) {
-      const int b = m0 / a.rows_per_batch;
-      unsigned long long* dst =
-          reinterpret_cast<unsigned long long*>(a.gn_acc[k]) + ((size_t)b * a.gn_groups[k] + g_first + gl) * 2;
-      unsigned long long* sl = slots + (k * GN_SLOTS + gl) * 2;
-      __hip_atomic_fetch_add(dst, sl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_fetch_add(dst + 1, sl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      sl[0] = 0ull;
-      sl[1] = 0ull;
-    }
-  }
-}
 
 // Folded LayerNorm: per-row (mean, rstd) from the producer's per-N-tile (sum, sum of squares) partials.
 PP_DEVINL void ln_row_moments(const PPGemmArgs& a, int m, float& mean, float& rstd) {
@@ -1683,6 +1648,22 @@ Choice choose(const PPGemmArgs& a) {
   return c;
 }
 
+// the deterministic split-K combine (+ the GroupNorm statistics of the output, if subscribed) behind a GEMM / conv launch
+// that wrote `splitk` fp32 slabs to a.workspace
+template <int EDT>
+int launch_combine(const PPGemmArgs& a, int splitk, hipStream_t st) {
+  const long long total = (long long)a.M * (a.N / 8);
+  int nb = (int)((total + 255) / 256);
+  if (nb > 4096) nb = 4096;
+  if (a.gn_acc[0] || a.gn_acc[1]) {
+    const int tn = (a.N + 159) / 160;
+    hipLaunchKernelGGL(pp_splitk_reduce_gn_kernel<EDT>, dim3(((a.M + 15) / 16) * tn), dim3(320), 0, st, a, splitk, tn);
+  } else if (reduce_lean_ok(a)) hipLaunchKernelGGL((pp_splitk_reduce_kernel<true, EDT>), dim3(nb), dim3(256), 0, st, a, splitk);
+  else hipLaunchKernelGGL((pp_splitk_reduce_kernel<false, EDT>), dim3(nb), dim3(256), 0, st, a, splitk);
+  PP_CHECK_LAUNCH("pp_splitk_reduce_kernel");
+  return PP_OK;
+}
+
 template <int BM, int BN, int WM, int WN, int XMODE, int EDT>
 int launch(const PPGemmArgs& a, int splitk, hipStream_t st) {
   constexpr int T = WM * WN * 64;
@@ -1707,17 +1688,7 @@ int launch(const PPGemmArgs& a, int splitk, hipStream_t st) {
   dim3 grid(d.tiles_m * d.tiles_n, splitk, 1);
   hipLaunchKernelGGL(kern, grid, dim3(T), LDS, st, a, d);
   PP_CHECK_LAUNCH("pp_gemm_kernel");
-  if (splitk > 1) {
-    const long long total = (long long)a.M * (a.N / 8);
-    int nb = (int)((total + 255) / 256);
-    if (nb > 4096) nb = 4096;
-    if (a.gn_acc[0] || a.gn_acc[1]) {
-      const int tn = (a.N + 159) / 160;
-      hipLaunchKernelGGL(pp_splitk_reduce_gn_kernel<EDT>, dim3(((a.M + 15) / 16) * tn), dim3(320), 0, st, a, splitk, tn);
-    } else if (reduce_lean_ok(a)) hipLaunchKernelGGL((pp_splitk_reduce_kernel<true, EDT>), dim3(nb), dim3(256), 0, st, a, splitk);
-    else hipLaunchKernelGGL((pp_splitk_reduce_kernel<false, EDT>), dim3(nb), dim3(256), 0, st, a, splitk);
-    PP_CHECK_LAUNCH("pp_splitk_reduce_kernel");
-  }
+  if (splitk > 1) return launch_combine<EDT>(a, splitk, st);
   return PP_OK;
 }
 
@@ -1785,17 +1756,7 @@ int launch2(const PPGemmArgs& a, int splitk, hipStream_t st) {
   dim3 grid(d.tiles_m * d.tiles_n, splitk, 1);
   hipLaunchKernelGGL(kern, grid, dim3(T), LDS, st, a, d);
   PP_CHECK_LAUNCH("pp_gemm_kernel_v2");
-  if (splitk > 1) {
-    const long long total = (long long)a.M * (a.N / 8);
-    int nb = (int)((total + 255) / 256);
-    if (nb > 4096) nb = 4096;
-    if (a.gn_acc[0] || a.gn_acc[1]) {
-      const int tn = (a.N + 159) / 160;
-      hipLaunchKernelGGL(pp_splitk_reduce_gn_kernel<EDT>, dim3(((a.M + 15) / 16) * tn), dim3(320), 0, st, a, splitk, tn);
-    } else if (reduce_lean_ok(a)) hipLaunchKernelGGL((pp_splitk_reduce_kernel<true, EDT>), dim3(nb), dim3(256), 0, st, a, splitk);
-    else hipLaunchKernelGGL((pp_splitk_reduce_kernel<false, EDT>), dim3(nb), dim3(256), 0, st, a, splitk);
-    PP_CHECK_LAUNCH("pp_splitk_reduce_kernel");
-  }
+  if (splitk > 1) return launch_combine<EDT>(a, splitk, st);
   return PP_OK;
   }
 }
@@ -1887,17 +1848,27 @@ int dispatch(const PPGemmArgs& a, const Choice& c, hipStream_t st) {
 
 }  // namespace
 
+// conv_gn.hip: GroupNorm + SiLU of the conv input fused into the loader (PPGemmArgs.gn_in_acc)
+bool pp_conv_gn_wanted(const PPGemmArgs& a);
+int pp_conv_gn_splitk(const PPGemmArgs& a);       // 0 = shape not supported by the fused kernel
+int pp_conv_gn_run(const PPGemmArgs& a, hipStream_t st);
+
 extern "C" int pp_gemm_gn_stats_ok(const PPGemmArgs* args) {
   if (!args) return 0;
   PPGemmArgs a = *args;
   a.gn_acc[0] = a.gn_acc[1] = nullptr;
   if (validate(a) != PP_OK || !gn_stats_supported(a)) return 0;
+  if (pp_conv_gn_wanted(a)) return pp_conv_gn_splitk(a) > 0 ? 1 : 0;
   const Choice c = choose(a);
   return c.tile > 10 ? 1 : 0;
 }
 
 extern "C" size_t pp_gemm_workspace_bytes(const PPGemmArgs* args) {
   if (!args || validate(*args) != PP_OK) return 0;
+  if (pp_conv_gn_wanted(*args)) {
+    const int sk = pp_conv_gn_splitk(*args);
+    return sk > 1 ? (size_t)sk * args->M * args->N * sizeof(float) : 0;
+  }
   const Choice c = choose(*args);
   return c.splitk > 1 ? (size_t)c.splitk * args->M * args->N * sizeof(float) : 0;
 }
@@ -1920,6 +1891,15 @@ extern "C" int pp_gemm_bf16(const PPGemmArgs* args, void* stream) {
     if (rc != PP_ERR_UNSUPPORTED) return rc;
   }
 #endif
+  if (pp_conv_gn_wanted(a)) {      // norm -> SiLU -> conv3x3 as one launch (no silent fallback: pp_conv_gn_supported() tells)
+    const int sk = pp_conv_gn_splitk(a);
+    if (sk <= 0) return PP_ERR_UNSUPPORTED;
+    if ((a.gn_acc[0] || a.gn_acc[1]) && !gn_stats_supported(a)) return PP_ERR_UNSUPPORTED;
+    const int rc = pp_conv_gn_run(a, (hipStream_t)stream);
+    if (rc != PP_OK || sk == 1) return rc;
+    return a.dtype == PP_DT_F16 ? launch_combine<PP_DT_F16>(a, sk, (hipStream_t)stream)
+                                : launch_combine<PP_DT_BF16>(a, sk, (hipStream_t)stream);
+  }
   const Choice c = choose(a);
   if (c.splitk > 1 && !a.workspace) return PP_ERR_WORKSPACE;
   if (c.tile > 10 && !v2_ok(a)) return PP_ERR_BAD_ARG;

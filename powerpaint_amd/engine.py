@@ -36,6 +36,8 @@ def _lab_switch(name: str) -> bool:
 
 # (lab) PP_GN_EPILOGUE=0: every GroupNorm keeps its own statistics launch
 GN_STATS_IN_EPILOGUE = _lab_switch("PP_GN_EPILOGUE")
+# ResnetBlock2D's norm -> SiLU -> conv3x3 as ONE launch (csrc/conv_gn.hip).  (lab) PP_FUSE_GN_CONV=0: apply launch + conv
+FUSE_GN_CONV = _lab_switch("PP_FUSE_GN_CONV")
 
 
 class Arena:
@@ -283,7 +285,20 @@ class Builder:
     def conv3x3(self, x: Act, w: int, cout: int, bias: int = 0, stride: int = 1, up: bool = False,
                 x2: Optional[Act] = None, rowvec: int = 0, res1: int = 0, res2: int = 0, scale: float = 1.0,
                 out: Optional[Act] = None, x3: Optional[Act] = None, x4: Optional[Act] = None,
-                name: str = "conv3x3") -> Act:
+                name: str = "conv3x3", gn_in: Optional[Tuple[int, int, int, float, int]] = None) -> Act:
+        """gn_in = (gamma, beta, gamma_beta_interleaved, eps, groups): the conv input is SiLU(GroupNorm(concat(x, x2))).
+        Where the statistics arrive from the producers' epilogues and the shape suits csrc/conv_gn.hip the norm runs in
+        the conv's loader (ONE launch, the normalised activation is never written); else pp_groupnorm_apply(_acc) + conv."""
+        if gn_in is not None:
+            gamma, beta, gb, eps, groups = gn_in
+            acc = self._subscribe_gn_stats(x, x2, groups) if FUSE_GN_CONV else 0
+            fused = None
+            if acc:
+                fused = (acc, gb, groups, eps)
+            else:
+                x, x2 = self.groupnorm(x, gamma, beta, eps, True, x2=x2, groups=groups), None
+        else:
+            fused = None
         hv, wv = (x.H * 2, x.W * 2) if up else (x.H, x.W)
         ho, wo = (hv + 2 - 3) // stride + 1, (wv + 2 - 3) // stride + 1
         if out is None:
@@ -305,6 +320,19 @@ class Builder:
         a.res1, a.ldres1, a.res2, a.ldres2 = res1 or None, cout, res2 or None, cout
         a.scale, a.act = scale, 0
         a.out, a.ldo, a.out_f32 = out.ptr, cout, 0
+        if fused is not None:
+            a.gn_in_acc, a.gn_in_gb, a.gn_in_groups, a.gn_in_eps, a.gn_in_silu = fused[0], fused[1], fused[2], fused[3], 1
+            a.dtype = self.dt
+            if not self.lib.pp_conv_gn_supported(C.byref(a)):
+                # (the statistics subscription stays: the apply launch reads the same accumulators)
+                a.gn_in_acc, a.gn_in_gb, a.gn_in_groups, a.gn_in_silu = None, None, 0, 0
+                gamma, beta, gb, eps, groups = gn_in
+                self.release(m)
+                xn = self.new_act(x.B, x.H, x.W, x.C + c2)
+                self.plan.add("groupnorm_apply", self.lib.pp_groupnorm_apply_acc, x.ptr, x.C, x2.ptr if x2 is not None else None,
+                              c2, x.B, x.H * x.W, groups, eps, gamma, beta, fused[0], 1, xn.ptr, self.dt)
+                m = self.mark()
+                a.x1, a.x2, a.c1, a.c2 = xn.ptr, None, x.C + c2, 0
         self._gemm(a, name)
         out.producer = a
         self.release(m)
@@ -633,6 +661,8 @@ class SDNet:
             for nrm in ("norm1", "norm2"):
                 pk.add(f"{pre}.{nrm}.weight", W(f"{pre}.{nrm}.weight"), f32)
                 pk.add(f"{pre}.{nrm}.bias", W(f"{pre}.{nrm}.bias"), f32)
+                # (gamma, beta) interleaved per channel: what the fused norm -> SiLU -> conv loader DMAs per 64-channel chunk
+                pk.add(f"{pre}.{nrm}.gb", torch.stack([W(f"{pre}.{nrm}.weight"), W(f"{pre}.{nrm}.bias")], 1), f32)
             pk.add(f"{pre}.conv1.weight", _conv_igemm(W(f"{pre}.conv1.weight")), bf)
             pk.add(f"{pre}.conv1.bias", W(f"{pre}.conv1.bias"), f32)
             if cin != cout and self.merge_shortcut:
@@ -741,13 +771,14 @@ class SDNet:
         cin = x.C + (x2.C if x2 is not None else 0)
         out = pb.new_act(x.B, x.H, x.W, cout)
         m = pb.mark()
-        h = pb.groupnorm(x, P[f"{pre}.norm1.weight"], P[f"{pre}.norm1.bias"], self.eps, True, x2=x2, groups=self.groups)
-        h = pb.conv3x3(h, P[f"{pre}.conv1.weight"], cout, P[f"{pre}.conv1.bias"],
-                       rowvec=temb_all + 4 * self.temb_off[pre], name="conv3x3")
-        h = pb.groupnorm(h, P[f"{pre}.norm2.weight"], P[f"{pre}.norm2.bias"], self.eps, True, groups=self.groups)
+        def gn(nrm):
+            return (P[f"{pre}.{nrm}.weight"], P[f"{pre}.{nrm}.bias"], P[f"{pre}.{nrm}.gb"], self.eps, self.groups)
+
+        h = pb.conv3x3(x, P[f"{pre}.conv1.weight"], cout, P[f"{pre}.conv1.bias"], x2=x2,
+                       rowvec=temb_all + 4 * self.temb_off[pre], name="conv3x3", gn_in=gn("norm1"))
         if cin != cout and self.merge_shortcut:
             pb.conv3x3(h, P[f"{pre}.conv2.weight"], cout, P[f"{pre}.conv2.bias"], res2=res2, out=out, x3=x, x4=x2,
-                       name="conv3x3")
+                       name="conv3x3", gn_in=gn("norm2"))
             pb.release(m)
             return out
         if cin != cout:
@@ -757,7 +788,7 @@ class SDNet:
             assert x2 is None
             sc = x.ptr
         pb.conv3x3(h, P[f"{pre}.conv2.weight"], cout, P[f"{pre}.conv2.bias"], res1=sc, res2=res2, out=out,
-                   name="conv3x3")
+                   name="conv3x3", gn_in=gn("norm2"))
         pb.release(m)
         return out
 

@@ -90,9 +90,42 @@ def gemm(x: torch.Tensor, w: torch.Tensor, bias=None, x2=None, res1=None, res2=N
     return (out, vt) if vt_col0 else out
 
 
+def gn_gamma_beta(gamma: torch.Tensor, beta: torch.Tensor) -> torch.Tensor:
+    """(gamma, beta) interleaved per channel, fp32 [C][2]: PPGemmArgs.gn_in_gb."""
+    return torch.stack([gamma.float(), beta.float()], 1).contiguous()
+
+
+def conv_gn_supported(x: torch.Tensor, cout: int, x2=None, x3=None, x4=None, groups: int = 32) -> bool:
+    """Would conv3x3(..., gn_in=...) run as the fused GroupNorm + SiLU + conv launch for these shapes?"""
+    a, _ = _conv_args(x, cout, 1, False, x2, x3, x4)
+    a.gn_in_acc, a.gn_in_gb, a.gn_in_groups, a.gn_in_silu, a.gn_in_eps = 1, 1, groups, 1, 1e-5   # (non-null placeholders)
+    return bool(L.lib().pp_conv_gn_supported(C.byref(a)))
+
+
+def _conv_args(x, cout, stride, up, x2, x3, x4):
+    B, H, W, C1 = x.shape
+    C2 = x2.shape[3] if x2 is not None else 0
+    hv, wv = (2 * H, 2 * W) if up else (H, W)
+    ho, wo = (hv - 1) // stride + 1, (wv - 1) // stride + 1
+    a = L.PPGemmArgs()
+    a.dtype = L.dtype_code(x.dtype)
+    C3 = x3.shape[3] if x3 is not None else 0
+    C4 = x4.shape[3] if x4 is not None else 0
+    a.M, a.N, a.K, a.x_mode = B * ho * wo, cout, 9 * (C1 + C2) + C3 + C4, L.PP_X_CONV3X3
+    a.x1, a.x2, a.c1, a.c2 = _p(x), _p(x2), C1, C2
+    a.x3, a.x4, a.c3, a.c4 = _p(x3), _p(x4), C3, C4     # 1x1 tail over concat(x3, x4) at the output pixel
+    a.batch, a.hin, a.win, a.hout, a.wout, a.stride, a.up = B, H, W, ho, wo, stride, int(up)
+    a.rows_per_batch, a.ldres1, a.ldres2, a.ldo, a.scale = ho * wo, cout, cout, cout, 1.0
+    return a, (B, ho, wo)
+
+
 def conv3x3(x: torch.Tensor, w: torch.Tensor, bias=None, stride: int = 1, up: bool = False, x2=None, rowvec=None,
-            res1=None, res2=None, scale: float = 1.0, tile: int = 0, splitk: int = 0, gn=None, x3=None, x4=None):
-    """x NHWC bf16 [B,H,W,C1] (+x2 [B,H,W,C2]); w bf16 [Cout, 9*(C1+C2)] (k = (ky*3+kx)*C + c) -> NHWC bf16."""
+            res1=None, res2=None, scale: float = 1.0, tile: int = 0, splitk: int = 0, gn=None, x3=None, x4=None,
+            gn_in=None):
+    """x NHWC bf16 [B,H,W,C1] (+x2 [B,H,W,C2]); w bf16 [Cout, 9*(C1+C2)] (k = (ky*3+kx)*C + c) -> NHWC bf16.
+    gn_in = (acc int64 [B][groups][2], gamma_beta fp32 [C1+C2][2], groups, eps): GroupNorm + SiLU of concat(x, x2) fused
+    into the loader (x, x2 are then the RAW tensors); raises PPError(PP_ERR_UNSUPPORTED) where conv_gn_supported() is
+    False."""
     lib = L.lib()
     B, H, W, C1 = x.shape
     C2 = x2.shape[3] if x2 is not None else 0
@@ -115,6 +148,10 @@ def conv3x3(x: torch.Tensor, w: torch.Tensor, bias=None, stride: int = 1, up: bo
     a.scale, a.act, a.out, a.ldo = scale, 0, _p(out), cout
     a.tile, a.splitk = tile, splitk
     _set_gn(a, gn, ho * wo)
+    if gn_in is not None:
+        acc, gb, groups, eps = gn_in
+        assert gb.dtype == torch.float32 and gb.shape == (C1 + C2, 2) and gb.is_contiguous()
+        a.gn_in_acc, a.gn_in_gb, a.gn_in_groups, a.gn_in_silu, a.gn_in_eps = _p(acc), _p(gb), groups, 1, eps
     ws = lib.pp_gemm_workspace_bytes(C.byref(a))
     wsb = torch.empty(max(ws, 4) // 4, dtype=torch.float32, device=x.device) if ws else None
     a.workspace = _p(wsb)

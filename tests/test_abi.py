@@ -74,7 +74,9 @@ def test_build_id_names_the_sources_the_library_was_built_from():
     mk = open(os.path.join(csrc, "Makefile")).read()
     srcs = re.search(r"^SRCS := (.*)$", mk, re.M).group(1).split()
     h = hashlib.sha256()
-    for f in [os.path.join(csrc, s) for s in srcs] + [os.path.join(csrc, "pp_common.h"), os.path.join(root, "include", "pp_hip.h")]:
+    hdrs = re.search(r"^SRC_ID := \$\(shell cat \$\(SRCS\) (.*?) \$\(ROOT\)/include/pp_hip.h", mk, re.M).group(1).split()
+    assert "pp_common.h" in hdrs
+    for f in [os.path.join(csrc, s) for s in srcs + hdrs] + [os.path.join(root, "include", "pp_hip.h")]:
         h.update(open(f, "rb").read())
     bid = _lib.build_id()
     assert re.fullmatch(r"[0-9a-f]{12}", bid), bid

@@ -1,0 +1,173 @@
+"""-m gpu: `GroupNorm -> SiLU -> conv3x3` as ONE launch (csrc/conv_gn.hip, PPGemmArgs.gn_in_*) through the C ABI.
+
+Two checkers per case: (1) the two launches it replaces -- pp_groupnorm_apply_acc -> pp_gemm_bf16(PP_X_CONV3X3) -- whose
+normalised activation is rounded to 16 bits at the same point, so only the fp32 summation order (chunk-major instead of
+tap-major) and the reciprocal of the SiLU differ: at most one 16-bit ulp on a small fraction of the outputs; (2) plain
+fp32 torch (F.group_norm / F.silu / F.conv2d) on the same 16-bit inputs.  gamma / beta are random (the synthetic network
+weights use (1, 0), which would hide a channel-indexing bug).
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from powerpaint_amd import _lib as L  # noqa: E402
+from powerpaint_amd import ops  # noqa: E402
+
+DEV = "cuda"
+T256, T128, T64 = L.PP_TILE_256x160, L.PP_TILE_128x160, L.PP_TILE_64x160
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator("cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(DEV)
+
+
+def gn_acc(x, groups=32):
+    """int64 [B][groups][2] fixed-point (sum, sum of squares) of x [B,H,W,C], as the producers' epilogues leave them."""
+    B, H, W, C = x.shape
+    xf = x.double().reshape(B, H * W, groups, C // groups)
+    return torch.stack([(xf.sum((1, 3)) * 2 ** 24).round().long(), ((xf * xf).sum((1, 3)) * 2 ** 20).round().long()],
+                       -1).contiguous()
+
+
+def close(out, ref, atol, rtol, what):
+    out, ref = out.float(), ref.float()
+    assert torch.isfinite(out).all(), f"{what}: non-finite output"
+    err = (out - ref).abs()
+    bad = err > atol + rtol * ref.abs()
+    assert not bad.any(), (f"{what}: {int(bad.sum())}/{bad.numel()} off; max abs err {float(err.max()):.4g} "
+                           f"(ref max {float(ref.abs().max()):.4g})")
+
+
+def run_case(B, H, W, C1, C2, Cout, dtype=torch.bfloat16, tile=0, splitk=0, tail=(0, 0), epi=False, gn_out=False, seed=0):
+    groups, eps = 32, 1e-5
+    x1 = (rnd(B, H, W, C1, seed=seed + 1, scale=1.5) + 0.3).to(dtype)
+    x2 = (rnd(B, H, W, C2, seed=seed + 2, scale=0.7) - 0.2).to(dtype) if C2 else None
+    xc = torch.cat([x1, x2], -1) if C2 else x1
+    Ct = C1 + C2
+    acc = gn_acc(xc, groups)
+    g, b = rnd(Ct, seed=seed + 3) * 0.3 + 1.0, rnd(Ct, seed=seed + 4) * 0.3
+    C3, C4 = tail
+    x3 = rnd(B, H, W, C3, seed=seed + 5).to(dtype) if C3 else None
+    x4 = rnd(B, H, W, C4, seed=seed + 6).to(dtype) if C4 else None
+    K = 9 * Ct + C3 + C4
+    w = rnd(Cout, K, seed=seed + 7, scale=K ** -0.5).to(dtype).contiguous()
+    kw = {}
+    if epi:
+        kw = dict(rowvec=rnd(B, Cout, seed=seed + 9), res1=rnd(B, H, W, Cout, seed=seed + 10).to(dtype),
+                  res2=rnd(B, H, W, Cout, seed=seed + 11).to(dtype))
+    bias = rnd(Cout, seed=seed + 8)
+    assert ops.conv_gn_supported(x1, Cout, x2=x2, x3=x3, x4=x4)
+    acc_new = acc_old = None
+    if gn_out:      # the statistics of the OUTPUT for two downstream norms (plain, and as channels 64.. of a wider concat)
+        acc_new = [torch.zeros(B, 32, 2, dtype=torch.int64, device=DEV) for _ in range(2)]
+        acc_old = [torch.zeros(B, 32, 2, dtype=torch.int64, device=DEV) for _ in range(2)]
+        sub = lambda A: [(A[0], Cout // 32, 0, 32), (A[1], (Cout + 64) // 32, 64, 32)]   # noqa: E731
+    out = ops.conv3x3(x1, w, bias, x2=x2, x3=x3, x4=x4, tile=tile, splitk=splitk, gn_in=(acc, ops.gn_gamma_beta(g, b), groups, eps),
+                      gn=sub(acc_new) if gn_out else None, **kw)
+    out2 = ops.conv3x3(x1, w, bias, x2=x2, x3=x3, x4=x4, tile=tile, splitk=splitk, gn_in=(acc, ops.gn_gamma_beta(g, b), groups, eps),
+                       gn=sub([torch.zeros_like(a) for a in acc_new]) if gn_out else None, **kw)
+    assert torch.equal(out, out2), "fused conv: not deterministic"
+    # (1) the two launches it replaces
+    y = ops.groupnorm_apply_acc(x1, acc, g, b, eps, True, x2=x2)
+    old = ops.conv3x3(y, w, bias, x3=x3, x4=x4, gn=sub(acc_old) if gn_out else None, **kw)
+    ulp = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    close(out, old, 2 * ulp, 1.5 * ulp, "fused vs groupnorm_apply_acc + conv3x3")
+    frac = (out != old).float().mean().item()
+    assert frac < 0.08, f"fused vs two-launch: {frac:.3f} of the outputs differ (expected rare one-ulp flips)"
+    # (2) fp32 torch
+    yn = F.silu(F.group_norm(xc.float().permute(0, 3, 1, 2), groups, g, b, eps))
+    ref = F.conv2d(yn, w[:, :9 * Ct].float().reshape(Cout, 3, 3, Ct).permute(0, 3, 1, 2), bias, padding=1).permute(0, 2, 3, 1)
+    if C3:
+        xt = torch.cat([x3, x4], -1) if C4 else x3
+        ref = ref + xt.float() @ w[:, 9 * Ct:].float().t()
+    if epi:
+        ref = ref + kw["rowvec"].view(B, 1, 1, Cout) + kw["res1"].float() + kw["res2"].float()
+    tol = 1.0 if dtype == torch.bfloat16 else 0.25
+    close(out, ref, 3e-2 * tol, 1e-2 * tol, "fused vs fp32 torch")
+    if gn_out:
+        for k in range(2):
+            a, o = acc_new[k].double(), acc_old[k].double()
+            rel = ((a - o).abs() / (o.abs() + 2.0 ** 20)).max().item()
+            assert rel < 2e-3, f"output GroupNorm statistics (consumer {k}) differ from the two-launch path: {rel:.3g}"
+    return out
+
+
+# the shapes of the SD-1.5 levels (reduced batch), every tile size the chooser can pick, with and without split-K
+@pytest.mark.parametrize("B,H,W,C,Cout,tile,splitk", [
+    (2, 64, 64, 320, 320, 0, 0),          # 64x64 level: 256-row tiles = 4 image rows
+    (1, 64, 64, 64, 320, T256, 1),        # a single chunk (no next halo tile at all)
+    (1, 64, 64, 128, 160, T256, 2),       # one chunk per split
+    (2, 32, 32, 640, 640, 0, 0),          # 32x32: 128-row tiles
+    (2, 32, 32, 640, 640, T256, 2),       # ... or 256-row tiles (8 image rows) split over the chunks
+    (2, 16, 16, 1280, 1280, 0, 0),        # 16x16: one image per tile, split-K 4
+    (2, 16, 16, 320, 320, T128, 1),
+    (2, 8, 8, 1280, 1280, 0, 0),          # 8x8: 64-row tiles, two image rows per 16-row fragment
+    (3, 8, 8, 256, 160, T64, 1),
+    (1, 48, 32, 192, 320, 0, 0),          # non-square, 6 tiles per image
+    (1, 96, 64, 128, 320, T256, 1),
+    (1, 16, 128, 64, 160, T128, 1),       # W = 128 (config 5): one image row per tile
+])
+def test_conv_gn_levels(B, H, W, C, Cout, tile, splitk):
+    run_case(B, H, W, C, 0, Cout, tile=tile, splitk=splitk)
+
+
+@pytest.mark.parametrize("C1,C2", [(320, 320), (1280, 640), (640, 320), (64, 64)])
+def test_conv_gn_concat_sources(C1, C2):
+    """conv1 of the up blocks: GroupNorm over concat(hidden, skip) -- group boundaries that straddle the two tensors
+    ((1280 + 640) / 32 = 60 channels per group), chunks from either source."""
+    run_case(2, 16, 16, C1, C2, 320, seed=10)
+    run_case(1, 32, 32, C1, C2, 160, tile=T128, splitk=1, seed=20)
+
+
+@pytest.mark.parametrize("tile,splitk", [(0, 0), (T256, 1), (T256, 3), (T128, 1), (T128, 2), (T64, 1)])
+@pytest.mark.parametrize("tail", [(640, 0), (640, 320), (64, 0)])
+def test_conv_gn_with_1x1_tail(tile, splitk, tail):
+    """conv2 with ResnetBlock2D.conv_shortcut merged in: the (un-normalised) block input rides as a 1x1 K tail."""
+    run_case(2, 16, 16, 320, 0, 320, tile=tile, splitk=splitk, tail=tail, seed=30)
+
+
+@pytest.mark.parametrize("tile,splitk", [(0, 0), (T256, 1), (T128, 1), (T256, 4), (T64, 2)])
+def test_conv_gn_epilogue_and_output_statistics(tile, splitk):
+    """bias + time-embedding row vector + two residuals, and the GroupNorm statistics of the output for two consumers
+    (from the epilogue, or from the split-K combine)."""
+    run_case(2, 16, 16, 320, 0, 320, tile=tile, splitk=splitk, epi=True, gn_out=True, seed=40)
+    run_case(2, 32, 32, 128, 64, 640, tile=tile, splitk=min(splitk, 3), epi=True, gn_out=True, tail=(128, 0), seed=50)
+
+
+@pytest.mark.parametrize("B,H,W,C,Cout", [(2, 32, 32, 320, 320), (1, 64, 64, 128, 160), (2, 8, 8, 640, 320)])
+def test_conv_gn_fp16(B, H, W, C, Cout):
+    run_case(B, H, W, C, 0, Cout, dtype=torch.float16, epi=True, seed=60)
+
+
+def test_conv_gn_padding_is_of_the_normalised_tensor():
+    """gamma = 0, beta with silu(beta) = 1: the normalised activation is exactly 1 inside the image, so with all-ones
+    weights every output equals (valid taps) * C -- the zero padding must apply AFTER the normalisation, on every border,
+    for every tile size (catches halo-row, out-of-row-lane and tap-offset errors exactly)."""
+    beta0 = 1.2784645427610738      # silu(beta0) = 1
+    for (H, W, tile) in [(64, 64, T256), (32, 32, T128), (16, 16, T256), (8, 8, T64), (16, 16, T64), (32, 32, T256)]:
+        B, C, Cout = 2, 128, 160
+        x = rnd(B, H, W, C, seed=3).to(torch.bfloat16)
+        g, b = torch.zeros(C, device=DEV), torch.full((C,), beta0, device=DEV)
+        w = torch.full((Cout, 9 * C), 1.0 / 128, dtype=torch.bfloat16, device=DEV)
+        out = ops.conv3x3(x, w, None, tile=tile, splitk=1, gn_in=(gn_acc(x), ops.gn_gamma_beta(g, b), 32, 1e-5)).float()
+        cnt = F.conv2d(torch.ones(1, 1, H, W, device=DEV), torch.ones(1, 1, 3, 3, device=DEV), padding=1)[0, 0]
+        for bi in range(B):
+            for ch in (0, Cout - 1):
+                assert torch.equal(out[bi, :, :, ch], cnt), (H, W, tile, bi, ch, (out[bi, :, :, ch] - cnt).abs().max())
+
+
+def test_conv_gn_unsupported_shapes_are_refused():
+    x = rnd(1, 24, 40, 64).to(torch.bfloat16)          # W = 40: no tile of whole image rows divides 24 x 40
+    assert not ops.conv_gn_supported(x, 320)
+    w = rnd(320, 9 * 64).to(torch.bfloat16)
+    with pytest.raises(L.PPError):
+        ops.conv3x3(x, w, None, gn_in=(gn_acc(x), ops.gn_gamma_beta(torch.ones(64, device=DEV), torch.zeros(64, device=DEV)), 32, 1e-5))
+
+
+def test_conv_gn_benchmark_shape_full_batch():
+    """The launch configuration of the headline benchmark: batch 8 at 64x64, C = 320 (256 workgroups, one per CU)."""
+    run_case(8, 64, 64, 320, 0, 320, epi=True, gn_out=True, seed=70)
+    run_case(8, 64, 64, 640, 320, 320, seed=80)
