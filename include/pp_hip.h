@@ -29,7 +29,7 @@ extern "C" {
 #define PP_ERR_LAUNCH (-3)       /* hipLaunchKernel / hipFuncSetAttribute failed                  */
 #define PP_ERR_WORKSPACE (-4)    /* workspace pointer null or too small                           */
 
-#define PP_ABI_VERSION 14
+#define PP_ABI_VERSION 15
 /* 16-bit storage format of activations and matrix weights ("dtype" arguments; the same codes pp_nchw_to_nhwc uses for
  * its source): bf16 or fp16 -- the reference's default is fp16 (/root/reference/app.py:548,559).  MFMA accumulation,
  * norm statistics, softmax, biases and latents are fp32 with either. */
@@ -100,7 +100,8 @@ typedef struct PPGemmArgs {
   int32_t splitk;     /* 0 = auto */
   int32_t tile;       /* 0 = auto; else PP_TILE_* */
   float* workspace;   /* split-K partials, pp_gemm_workspace_bytes() */
-  int32_t dbg;        /* timing-experiment switches (tools/gemm_ablate.py); 0 in production */
+  int32_t dbg;        /* 0.  (Phase-ablation switches of the measurement scripts under tools/: honoured by -DPP_LAB builds
+                       * only, libpp_hip.so ignores the field.) */
   int32_t dtype;      /* PP_DT_BF16 | PP_DT_F16: format of x*, w, res*, out (unless out_f32), out_vt */
   int32_t reserved[2];
   /* LayerNorm folded into the GEMM (BasicTransformerBlock.norm1/2/3 -> the Linear that follows):
@@ -116,10 +117,7 @@ typedef struct PPGemmArgs {
   int32_t ln_tiles;
   int32_t ln_dim;
   float ln_eps;
-  /* > 0: `w` holds one [N][K] matrix PER BATCH ITEM, w_batch_stride elements apart (GroupNorm folded into the 1x1
-   * proj_in of a transformer, pp_gn_fold_weights); rows m of batch item m / rows_per_batch multiply matrix number
-   * m / rows_per_batch.  PLAIN mode, rows_per_batch % 256 == 0, no split-K restrictions beyond the usual ones. */
-  int32_t w_batch_stride;
+  int32_t reserved_w;   /* 0 (was w_batch_stride, ABI v12-v14: a rejected experiment) */
   /* GroupNorm statistics of the OUTPUT, accumulated by the epilogue (the stats launch of the consuming GroupNorm
    * disappears).  Up to two consumers per tensor (a UNet skip tensor feeds the next layer's norm and, concatenated,
    * an up-block norm):  gn_acc[k] -> int64 [batch][gn_groups[k]][2] = (sum, sum of squares) of the stored bf16 values
@@ -204,18 +202,6 @@ int pp_groupnorm_apply(const void* x1, int c1, const void* x2, int c2, int batch
 int pp_groupnorm_apply_acc(const void* x1, int c1, const void* x2, int c2, int batch, int hw, int groups, float eps,
                            const float* gamma, const float* beta, const int64_t* acc, int silu, void* y, int dtype,
                            void* stream);
-/* GroupNorm (affine only, no activation) followed by a 1x1 convolution / Linear -- `Transformer2DModel.norm` ->
- * `proj_in` (diffusers 0.27 transformer_2d.py; ctor site unet_2d_blocks.py:1289-1300) -- folded into per-batch-item
- * weights, so the normalised activation is never materialised:
- *     GN(x)[m][c] = (x[m][c] - mean[b][g(c)]) * rstd[b][g(c)] * gamma[c] + beta[c]
- *     w_out[b][n][c] = round16( w[n][c] * gamma[c] * rstd[b][g(c)] )
- *     rowvec_out[b][n] = bias[n] + sum_c w[n][c] * beta[c] - sum_c w_out[b][n][c] * mean[b][g(c)]
- * => proj_in(GN(x)) = x w_out[b]^T + rowvec_out[b]  (pp_gemm_bf16 with w_batch_stride = n * c, rowvec = rowvec_out,
- * ld_rowvec = n).  Statistics from the producers' accumulators `acc` (as pp_groupnorm_apply_acc).  w [n][c] 16-bit,
- * bias [n] fp32 or NULL. */
-int pp_gn_fold_weights(const int64_t* acc, int batch, int hw, int groups, float eps, const float* gamma, const float* beta,
-                       const void* w, const float* bias, int n, int c, void* w_out, float* rowvec_out, int dtype,
-                       void* stream);
 /* dst[0..n) = 0 (64-bit words): one launch zeroes the statistics accumulators of a whole forward pass */
 int pp_zero_u64(void* dst, long long n, void* stream);
 

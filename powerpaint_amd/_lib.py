@@ -16,7 +16,7 @@ PP_ACT_NONE, PP_ACT_GEGLU, PP_ACT_SILU = 0, 1, 2
 PP_TILE_AUTO, PP_TILE_128x160, PP_TILE_64x160, PP_TILE_256x160 = 0, 1, 2, 3
 PP_DT_F32, PP_DT_BF16, PP_DT_F16 = 0, 1, 2      # dtype codes of the C ABI (include/pp_hip.h)
 PP_ATTN_AUTO, PP_ATTN_PHASED, PP_ATTN_PIPE_Q32, PP_ATTN_PIPE_Q64 = 0, 1, 2, 3   # pp_attention_fwd_variant
-ABI_VERSION = 14                                  # PP_ABI_VERSION of include/pp_hip.h this binding was written against
+ABI_VERSION = 15                                  # PP_ABI_VERSION of include/pp_hip.h this binding was written against
 PP_ERR = {0: "PP_OK", -1: "PP_ERR_BAD_ARG", -2: "PP_ERR_UNSUPPORTED", -3: "PP_ERR_LAUNCH", -4: "PP_ERR_WORKSPACE"}
 
 vp, i32, f32, sz = C.c_void_p, C.c_int32, C.c_float, C.c_size_t
@@ -39,7 +39,7 @@ class PPGemmArgs(C.Structure):
         ("workspace", vp),
         ("dbg", i32), ("dtype", i32), ("reserved", i32 * 2),
         ("row_stats_out", vp), ("ln_stats", vp), ("ln_colsum", vp),
-        ("ln_tiles", i32), ("ln_dim", i32), ("ln_eps", f32), ("w_batch_stride", i32),
+        ("ln_tiles", i32), ("ln_dim", i32), ("ln_eps", f32), ("reserved_w", i32),
         ("gn_acc", vp * 2), ("gn_cg", i32 * 2), ("gn_c0", i32 * 2), ("gn_groups", i32 * 2),
         ("x3", vp), ("x4", vp), ("c3", i32), ("c4", i32),
         ("gn_in_acc", vp), ("gn_in_gb", vp), ("gn_in_groups", i32), ("gn_in_silu", i32), ("gn_in_eps", f32),
@@ -85,8 +85,6 @@ SIGNATURES = {
     "pp_step_select_t": (C.c_int, [vp, vp, vp, vp]),
     "pp_ddim_variance_noise": (C.c_int, [vp, vp, C.c_int, vp, vp, vp]),
     "pp_latent_blend": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
-    "pp_gn_fold_weights": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_float, vp, vp, vp, vp, C.c_int, C.c_int, vp, vp,
-                                     C.c_int, vp]),
     "pp_gn_conv3x3_smallcout_supported": (C.c_int, [C.c_int] * 3),
     "pp_gn_conv3x3_smallcout": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, vp, vp, vp, vp, vp,
                                           C.c_int, vp, C.c_int, vp]),

@@ -41,7 +41,8 @@ constexpr int CG_TAB = CG_WOFF + 3 * CG_WST;
 constexpr int CG_T_STATS = CG_TAB;              // (mean, rstd) of the batch item's groups (<= 32)
 constexpr int CG_T_ZERO = CG_TAB + 256;         // 128 bytes of zeros: where the out-of-row lanes of the kx = 0 / 2 taps read
 constexpr int CG_T_GB = CG_TAB + 1024;          // 2 x 1 KB: (gamma, beta) of a chunk's 64 channels
-constexpr int CG_LDS = CG_TAB + 3072;           // 162,816 B of the CU's 163,840
+constexpr int CG_T_SCSH = CG_TAB + 3072;        // 512 B: (scale, shift) of the chunk being normalised, [k-slot][8 channels][2]
+constexpr int CG_LDS = CG_TAB + 3584;           // 163,328 B of the CU's 163,840
 static_assert(CG_LDS <= 160 * 1024, "LDS budget");
 
 struct CGDerived {
@@ -59,7 +60,8 @@ template <int N, class F>
 PP_DEVINL void cg_static_for(F&& f) { cg_static_for_impl(std::make_integer_sequence<int, N>{}, f); }
 
 // PP: ping-pong main loop (waves 0-3 / 4-7 half a K step apart, two barriers per K step); else lock-step (one barrier).
-template <int BM, bool PP, int EDT>
+// NMODE: where the normalisation of the next halo tile runs -- 1 inside the MFMA burst, 0 in the read phase (lab A/B).
+template <int BM, bool PP, int NMODE, int EDT>
 __global__ void __launch_bounds__(CG_T, 2) pp_conv_gn_kernel(const PPGemmArgs a, const CGDerived d) {
   using E = E16<EDT>;
   typedef typename E::v8 v8_t;
@@ -162,31 +164,33 @@ __global__ void __launch_bounds__(CG_T, 2) pp_conv_gn_kernel(const PPGemmArgs a,
   // phase 1: the nine taps over the normalised halo tiles of chunks ch_b .. ch_e - 1
   // =====================================================================================================================
   if (ch_b < ch_e) {
-    float sc[8], sh[8];                              // scale / shift of this lane's eight channels (k-slot) of a chunk
-
     // (gamma, beta) of chunk c -> table buffer gbuf (every wave issues the same 1 KB piece: identical bytes)
     auto issue_gb = [&](int c, int gbuf, bool live) __attribute__((always_inline)) {
       const __amdgpu_buffer_rsrc_t rs = make_rsrc(a.gn_in_gb, live ? (uint32_t)ctot * 8u : 0u);
       const int vo = lane < 32 ? lane * 16 : (int)PP_OOB;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (cg_lds_t)(smem + CG_T_GB + gbuf * 1024), 16, vo, c * 512, 0, 0);
     };
-    // scale / shift of chunk c from the table buffer (landed: the caller's vmcnt) and the groups' (mean, rstd)
+    // (scale, shift) of chunk c -> LDS table [k-slot][8][2], from the (gamma, beta) buffer (landed: the caller's vmcnt) and
+    // the groups' (mean, rstd).  Every wave holds all eight k-slots and writes the whole table (identical bytes), then
+    // reads only behind its own writes: no cross-wave ordering needed.  (In LDS, not in 16 registers per lane: the
+    // 256 x 160 tile has 152 accumulator + fragment registers live in the MFMA phase that applies them.)
     auto compute_scsh = [&](int c, int gbuf) __attribute__((always_inline)) {
       const char* gp = smem + CG_T_GB + gbuf * 1024 + kslot * 64;
       const f32x2_t* st = reinterpret_cast<const f32x2_t*>(smem + CG_T_STATS);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const f32x4_t gbv = *reinterpret_cast<const f32x4_t*>(gp + q * 16);    // (gamma, beta) of channels 2 q, 2 q + 1
+        f32x4_t o;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          const int e = 2 * q + h;
-          const int ch = c * 64 + kslot * 8 + e;                                // channel of the (concatenated) norm input
-          const int gi = (int)(((float)ch + 0.5f) * d.inv_cg);
+          const int ch = c * 64 + kslot * 8 + 2 * q + h;                        // channel of the (concatenated) norm input
+          const int gi = min((int)(((float)ch + 0.5f) * d.inv_cg), 31);      // (clamp: the dead chunk behind the last one)
           const f32x2_t mr = st[gi];
-          const float s = mr[1] * gbv[2 * h];
-          sc[e] = s;
-          sh[e] = gbv[2 * h + 1] - mr[0] * s;
+          const float sv = mr[1] * gbv[2 * h];
+          o[2 * h] = sv;
+          o[2 * h + 1] = gbv[2 * h + 1] - mr[0] * sv;
         }
+        *reinterpret_cast<f32x4_t*>(smem + CG_T_SCSH + kslot * 64 + q * 16) = o;
       }
     };
     // in-place normalisation of this lane's 16 bytes of halo strip (wave + 8 j) in buffer hbuf: what the lane's own DMA
@@ -199,8 +203,9 @@ __global__ void __launch_bounds__(CG_T, 2) pp_conv_gn_kernel(const PPGemmArgs a,
         float r[8];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          r[2 * q] = E::lo(v[q]) * sc[2 * q] + sh[2 * q];
-          r[2 * q + 1] = E::hi(v[q]) * sc[2 * q + 1] + sh[2 * q + 1];
+          const f32x4_t ss = *reinterpret_cast<const f32x4_t*>(smem + CG_T_SCSH + kslot * 64 + q * 16);
+          r[2 * q] = E::lo(v[q]) * ss[0] + ss[1];
+          r[2 * q + 1] = E::hi(v[q]) * ss[2] + ss[3];
         }
         // SiLU with the hardware reciprocal (1 ulp) instead of silu_f's IEEE division (~10 instructions per element in a
         // phase that must not outlast the partner's 40 MFMAs); the 16-bit rounding that follows hides the difference
@@ -212,6 +217,24 @@ __global__ void __launch_bounds__(CG_T, 2) pp_conv_gn_kernel(const PPGemmArgs a,
         for (int q = 0; q < 4; ++q) o[q] = E::pack2(r[2 * q], r[2 * q + 1]);
         *reinterpret_cast<u32x4_t*>(p) = o;
       }
+    };
+
+    // the same arithmetic as a pure register function (for the MFMA-burst placement): every lane computes, the lanes whose
+    // pixel lies outside the image (vmask = 0) return zeros
+    auto norm_math = [&](const u32x4_t v, uint32_t vmask) __attribute__((always_inline)) -> u32x4_t {
+      u32x4_t o;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {      // pair by pair: beside the MFMAs the matrix instruction in between hides the chain
+        const f32x4_t ss = *reinterpret_cast<const f32x4_t*>(smem + CG_T_SCSH + kslot * 64 + q * 16);
+        float r0 = E::lo(v[q]) * ss[0] + ss[1];
+        float r1 = E::hi(v[q]) * ss[2] + ss[3];
+        const float e0 = __builtin_amdgcn_exp2f(r0 * -1.44269504088896340736f);
+        const float e1 = __builtin_amdgcn_exp2f(r1 * -1.44269504088896340736f);
+        r0 *= __builtin_amdgcn_rcpf(1.0f + e0);
+        r1 *= __builtin_amdgcn_rcpf(1.0f + e1);
+        o[q] = E::pack2(r0, r1) & vmask;        // (a mask, not a select: hipcc turns the select into a branch around the math)
+      }
+      return o;
     };
 
     // next chunk's halo source (refreshed per chunk): descriptor, per-lane offsets, channel offset inside the source
@@ -286,7 +309,10 @@ __global__ void __launch_bounds__(CG_T, 2) pp_conv_gn_kernel(const PPGemmArgs a,
       cg_static_for<9>([&](auto TT) __attribute__((always_inline)) {
         constexpr int t = decltype(TT)::value;
         constexpr int st_r = t % 3, st_w = (t + 2) % 3;             // (9 % 3 == 0: the stage of tap t is t % 3 in every chunk)
-        constexpr int NX = t == 0 ? CG_HPW + 1 : 0;                 // extra DMA pieces of this tap: next halo + its table
+        // extra DMA pieces of a tap, after its three weight pieces: the next chunk's halo strips two per tap over taps
+        // 0 .. 2 (strip j is needed from tap 3 + j on) and, in tap 0, the chunk's (gamma, beta) table
+        constexpr auto NXT = [](int tt) constexpr { return tt == 0 ? 3 : (tt == 1 || tt == 2) ? 2 : 0; };
+        constexpr int NX = NXT(t);
         // weight tile of K step + 2
         const __amdgpu_buffer_rsrc_t rsw = t + 2 <= 8 ? rsw_same : rsw_next;
         const int sow = t + 2 <= 8 ? ((t + 2) * ctot + c * 64) * 2 : ((t + 2 - 9) * ctot + (c + 1) * 64) * 2;
@@ -294,19 +320,25 @@ __global__ void __launch_bounds__(CG_T, 2) pp_conv_gn_kernel(const PPGemmArgs a,
         if constexpr (PP) {
           asm volatile("s_barrier" ::: "memory");   // X: everyone's weight tile of this step is in LDS; the partner left its read phase
         } else {
-          // this wave's weight pieces of this K step have landed (the pieces issued after them may still be in flight)
-          constexpr int V = (t == 1 || t == 2) ? CG_WP + CG_HPW + 1 : CG_WP;
+          // this wave's weight pieces of this K step (issued two taps ago) have landed; younger pieces may be in flight
+          constexpr int V = NXT((t + 7) % 9) + CG_WP + NXT((t + 8) % 9);
           asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(V) : "memory");
         }
-        // ---- the next chunk's halo tile: landed at the end of tap 2 (its pieces are older than tap 2's weight pieces, which
-        //      the wait of tap 2 [PP] / the head of tap 3 [lock-step] leaves in flight); one strip per tap from tap 3 on,
-        //      BEFORE the fragment reads (whose 72 registers are then not live beside the normalisation's)
-        if constexpr (t >= 3) {
-          if (nxt) {
-            if constexpr (t == 3) compute_scsh(c + 1, hbn);
-            norm_piece(hbn, t - 3);
-          }
-          __builtin_amdgcn_sched_barrier(0);
+        // ---- the next chunk's halo tile.  Strip j of this wave (DMA'd in tap j / 2) has landed when tap 3 + j begins: the
+        //      counted waits of taps 2 .. 4 leave only younger pieces in flight.  Its normalisation -- ~70 VALU instructions --
+        //      rides INSIDE this wave's MFMA burst (NMODE 1: two per MFMA, in the issue slots the 16-cycle matrix
+        //      instruction leaves free) or sits in the read phase (NMODE 0, where the partner wave's s_setprio 1 starves
+        //      its transcendentals: MI355X_MICROARCH.md "Two waves per SIMD", item 2).
+        constexpr bool NT = t >= 3;                                  // a tap that carries one strip
+        char* const np = smem + hbn * CG_HALO + (wave + 8 * (NT ? t - 3 : 0)) * 1024 + lane * 16;
+        u32x4_t nv = {0u, 0u, 0u, 0u};
+        if constexpr (NT) {
+          // (unconditional: behind the last chunk this works on the zeros of the dead DMAs in the unused buffer -- a branch
+          //  around the MFMA burst would put the 80 accumulator registers through a phi and double them)
+          if constexpr (t == 3) compute_scsh(c + 1, hbn);
+          if constexpr (NMODE == 0) norm_piece(hbn, t - 3);
+          else nv = *reinterpret_cast<const u32x4_t*>(np);
+          if constexpr (NMODE == 0) __builtin_amdgcn_sched_barrier(0);
         }
         // ---- read phase: fragment reads of this K step, the DMA pieces spread between them
         const char* ws = smem + CG_WOFF + st_r * CG_WST;
@@ -336,19 +368,33 @@ __global__ void __launch_bounds__(CG_T, 2) pp_conv_gn_kernel(const PPGemmArgs a,
             if (((k + 1) * NR + NPC) / (NPC + 1) == r + 1) {
               __builtin_amdgcn_sched_barrier(0);
               if (k < CG_WP) issue_w_piece(rsw, st_w, k < CG_WP ? k : 0, sow);
-              else if (k < CG_WP + CG_HPW) issue_halo_piece(hbn, k - CG_WP < CG_HPW ? k - CG_WP : 0);
-              else issue_gb(c + 1, hbn, nxt);
+              else if (t == 0 && k == CG_WP + 2) issue_gb(c + 1, hbn, nxt);
+              else issue_halo_piece(hbn, 2 * t + (k - CG_WP < 2 ? k - CG_WP : 0));
               __builtin_amdgcn_sched_barrier(0);
             }
         }
         if constexpr (PP) {
-          // Y: this wave's weight pieces of the NEXT K step have landed, its fragments of this one are in registers
-          constexpr int V = t == 0 ? CG_WP + NX : (t == 1 ? CG_HPW + 1 + CG_WP : CG_WP);
+          // Y: this wave's weight pieces of the NEXT K step (issued in the previous tap) have landed, its fragments of this
+          // one are in registers
+          constexpr int V = NXT((t + 8) % 9) + CG_WP + NX;
           asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(V) : "memory");
         }
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
-        mfma_all(wf, xf);
+        if constexpr (NT && NMODE == 1) {
+          mfma_all(wf, xf);
+          const u32x4_t o = norm_math(nv, ~(uint32_t)(hpix[NT ? t - 3 : 0] >> 31));   // all ones inside the image, else 0
+          *reinterpret_cast<u32x4_t*>(np) = o;
+          // one matrix instruction, then two of the normalisation's VALU instructions, ...; the LDS store last
+#pragma unroll
+          for (int i = 0; i < 2 * MI * NI; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, (70 + 2 * MI * NI - 1) / (2 * MI * NI), 0);
+          }
+          __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        } else {
+          mfma_all(wf, xf);
+        }
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
       });
@@ -556,9 +602,7 @@ bool cg_supported(const PPGemmArgs& a) {
   if (a.c1 <= 0 || a.c1 % 64 || a.c2 % 64 || (a.c2 > 0 && !a.x2) || ctot % a.gn_in_groups) return false;
   if (a.c3 < 0 || a.c4 < 0 || a.c3 % 64 || a.c4 % 64 || (a.c3 > 0 && !a.x3) || (a.c4 > 0 && (!a.x4 || a.c3 == 0))) return false;
   if (a.K != 9 * ctot + a.c3 + a.c4 || a.M != a.batch * a.hout * a.wout || a.M <= 0 || a.N <= 0) return false;
-  if (a.N % 8 || a.ldo % 8 || a.out_f32 || a.out_vt || a.act != PP_ACT_NONE || a.ln_stats || a.row_stats_out ||
-      a.w_batch_stride)
-    return false;
+  if (a.N % 8 || a.ldo % 8 || a.out_f32 || a.out_vt || a.act != PP_ACT_NONE || a.ln_stats || a.row_stats_out) return false;
   if ((a.res1 && a.ldres1 % 8) || (a.res2 && a.ldres2 % 8)) return false;
   if (a.rows_per_batch != a.hout * a.wout) return false;
   if ((uint64_t)a.batch * a.hin * a.win * (uint64_t)(a.c1 > a.c2 ? a.c1 : a.c2) * 2u >= 0x80000000ull) return false;
@@ -591,10 +635,10 @@ CGChoice cg_choose(const PPGemmArgs& a) {
   return c;
 }
 
-template <int BM, bool PP, int EDT>
+template <int BM, bool PP, int NMODE, int EDT>
 int cg_launch(const PPGemmArgs& a, int splitk, hipStream_t st) {
   static bool attr_set = false;
-  auto kern = pp_conv_gn_kernel<BM, PP, EDT>;
+  auto kern = pp_conv_gn_kernel<BM, PP, NMODE, EDT>;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, CG_LDS) !=
         hipSuccess) {
@@ -619,25 +663,30 @@ int cg_launch(const PPGemmArgs& a, int splitk, hipStream_t st) {
   return PP_OK;
 }
 
-// (lab build) PP_CONV_GN_PP=0: the lock-step main loop instead of the ping-pong one
-bool cg_pingpong() {
-  static const int v = pp_lab_env("PP_CONV_GN_PP", 1);
-  return v != 0;
-}
-
+// (lab build) PP_CONV_GN_PP=0: the lock-step main loop instead of the ping-pong one; PP_CONV_GN_NMODE=0: the halo
+// normalisation in the read phase instead of inside the MFMA burst
 template <int EDT>
 int cg_dispatch(const PPGemmArgs& a, const CGChoice& c, hipStream_t st) {
 #ifdef PP_LAB
-  if (!cg_pingpong()) switch (c.bm) {
-      case 256: return cg_launch<256, false, EDT>(a, c.splitk, st);
-      case 128: return cg_launch<128, false, EDT>(a, c.splitk, st);
-      default: return cg_launch<64, false, EDT>(a, c.splitk, st);
+  static const int pp = pp_lab_env("PP_CONV_GN_PP", 1), nm = pp_lab_env("PP_CONV_GN_NMODE", 1);
+  if (!pp || !nm) {
+#define CG_CASE(BM_)                                                          \
+    case BM_:                                                                 \
+      if (pp) return cg_launch<BM_, true, 0, EDT>(a, c.splitk, st);           \
+      return nm ? cg_launch<BM_, false, 1, EDT>(a, c.splitk, st) : cg_launch<BM_, false, 0, EDT>(a, c.splitk, st);
+    switch (c.bm) {
+      CG_CASE(256)
+      CG_CASE(128)
+      default:
+      CG_CASE(64)
     }
+#undef CG_CASE
+  }
 #endif
   switch (c.bm) {
-    case 256: return cg_launch<256, true, EDT>(a, c.splitk, st);
-    case 128: return cg_launch<128, true, EDT>(a, c.splitk, st);
-    default: return cg_launch<64, true, EDT>(a, c.splitk, st);
+    case 256: return cg_launch<256, true, 1, EDT>(a, c.splitk, st);
+    case 128: return cg_launch<128, true, 1, EDT>(a, c.splitk, st);
+    default: return cg_launch<64, true, 1, EDT>(a, c.splitk, st);
   }
 }
 

@@ -21,17 +21,9 @@
 #include "pp_common.h"
 #include "gemm_gn.h"
 
-// The LDS-staged epilogue (64-row passes, full-row 16-byte stores) is the shipping form.  -DPP_EPI_DIRECT (lab builds)
-// selects the register-direct epilogue instead: parity-green on every suite, but measured SLOWER on MI355X
-// (profiles/r03_epilogue_ab.txt: UNet step 9.85 -> 10.00 ms, the 64x64-level convs +1.6 .. +6.6 us per launch) -- what the
-// "no epilogue" switch attributes to the staged epilogue (6.7 us of the 256x160 tile) is mostly the drain of the
-// output tensor itself, and 64-byte half-line pieces scattered over 16 rows drain worse than whole rows.
-#ifdef PP_EPI_DIRECT
-#define PP_DIRECT_EPILOGUE true
-#else
-#define PP_DIRECT_EPILOGUE false
-#endif
-
+// Epilogue: accumulators staged through LDS in 64-row passes, full-row 16-byte stores.  (A register-direct epilogue was
+// built and measured in round 3 -- parity-green, +1 % on the UNet step: profiles/r03_epilogue_ab.txt, DESIGN.md section 8;
+// the code left the tree in round 4, `git log -S PP_EPI_DIRECT` finds it.)
 namespace {
 
 struct GemmDerived {
@@ -384,12 +376,6 @@ pp_gemm_kernel_v2(const PPGemmArgs a, const GemmDerived d) {   // 2nd bound = wa
   // the pipeline stages at kernel start, so the short-K epilogue never waits on a global load.
   constexpr int LN_TMAX = 4;                      // row-moment partials per row kept in LDS (C <= 640); more -> global
   constexpr int PRE_B = NS * STAGE, PRE_C = PRE_B + 1024, PRE_M = PRE_C + 1024;
-  // GNS (direct epilogue): the groups' integer LDS slots live BEHIND the pipeline stages -- one set per 64-row strip of
-  // the tile (strips of one tile may belong to different batch items at the 8x8 level) -- zeroed at kernel start, so
-  // the epilogue needs a single barrier (before the flush to the global accumulators)
-  constexpr int GN_STRIPS = (BM + 63) / 64;
-  constexpr int GN_OFF = NS * STAGE;
-  constexpr int GN_BYTES = GN_STRIPS * 2 * GN_SLOTS * 2 * 8;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -444,10 +430,7 @@ pp_gemm_kernel_v2(const PPGemmArgs a, const GemmDerived d) {   // 2nd bound = wa
                            : (XMODE == PP_X_PLAIN ? (uint32_t)a.M * (uint32_t)a.ldx2 * 2u
                                                   : (uint32_t)a.batch * (uint32_t)a.hin * (uint32_t)a.win * (uint32_t)a.c2 * 2u);
   const uint32_t wbytes = (uint32_t)a.N * (uint32_t)a.K * 2u;
-  // per-batch-item weights (w_batch_stride > 0: GroupNorm folded into the 1x1 proj_in, pp_gn_fold_weights): the tile's
-  // rows belong to ONE batch item (host-checked: rows_per_batch % BM == 0)
-  const void* const w_base = a.w_batch_stride > 0
-      ? (const void*)((const uint16_t*)a.w + (size_t)(m_blk / a.rows_per_batch) * (size_t)a.w_batch_stride) : a.w;
+  const void* const w_base = a.w;
 
   // ---- per-lane offsets.  PLAIN: vx1/vx2 = byte offset of (row m, k-slot) in source 1 / 2 (OOB if m >= M), fixed.
   //      CONV : pixel coordinates kept in (xa, xb, xc); vx1 recomputed when the (tap, source) pair changes.
@@ -595,10 +578,6 @@ pp_gemm_kernel_v2(const PPGemmArgs a, const GemmDerived d) {   // 2nd bound = wa
 
   const bool ln = LNF && a.ln_stats != nullptr;
   const bool ln_lds = ln && a.ln_tiles <= LN_TMAX;
-  if constexpr (GNS && PP_DIRECT_EPILOGUE) {      // (ordered before the epilogue's LDS atomics by the main loop's barriers)
-    for (int i = tid; i < GN_BYTES / 8; i += T) reinterpret_cast<unsigned long long*>(smem + GN_OFF)[i] = 0ull;
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  }
   if (LNF) {   // older than every tile load -> covered by the counted vmcnt waits below
     if (wave == 0) {
       const __amdgpu_buffer_rsrc_t rb = make_rsrc(a.bias ? (const void*)a.bias : (const void*)a.w, a.bias ? (uint32_t)a.N * 4u : 0u);
@@ -903,281 +882,6 @@ pp_gemm_kernel_v2(const PPGemmArgs a, const GemmDerived d) {   // 2nd bound = wa
     }
     ln_mr = f32x2_t{mean, rstd};
   }
-  if constexpr (PP_DIRECT_EPILOGUE && EPI != 2) {
-    if (!vt_blk) {
-      // ================= epilogue, register-direct =================
-      // Every wave finishes its own (MI*16) x (NI*16) tile from the accumulator registers: no LDS round trip, no
-      // barrier between waves (the staged form below -- 64-row passes through LDS, two barriers each, most waves idle
-      // while two write -- cost 6.7 us of the 256x160 tile's 17.5 us of K-independent time).
-      //   * lane (r16 = lane & 15, g = lane >> 4) holds, per 16 x 16 block (mi, ni), columns 4g .. 4g+3 of row r16;
-      //   * two neighbouring blocks (a, b) are re-paired with v_permlane16_swap so that a lane owns 8 CONSECUTIVE
-      //     columns (g even: block a, g odd: block b; half g >> 1) -> 16-byte stores and residual loads (the store tail
-      //     of an MFMA epilogue is issue-bound: half the instructions, half the time); the odd fifth block keeps 8 bytes;
-      //   * all residual loads of the wave are issued before any arithmetic;
-      //   * GroupNorm statistics: column moments reduced over the 16 rows of a block with DPP rotations inside the
-      //     16-lane row, then one 64-bit integer LDS atomic per (column, consumer) -- order-independent, bit-reproducible;
-      //   * LayerNorm row moments: reduced over a lane's columns, the four lane groups (two ds_bpermute steps) and the
-      //     two waves of a row strip (LDS).
-      constexpr int NP = NI / 2;                        // re-paired block pairs; block NI-1 stays single if NI is odd
-      constexpr bool ODD = (NI & 1) != 0;
-      const int r16 = lane & 15, g = lane >> 4;
-      const int mrow0 = m_blk + wm * (MI * 16) + r16;   // + mi * 16
-      const int nwave = n_blk + wn * (NI * 16);
-      if (splitk) {                                     // fp32 partial slab of this K slice (combined by the reduce kernel)
-        float* wsp = a.workspace + (size_t)split * a.M * a.N;
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-          const int m = mrow0 + mi * 16;
-#pragma unroll
-          for (int ni = 0; ni < NI; ++ni) {
-            const int n = nwave + ni * 16 + 4 * g;
-            if (m < a.M && n < a.N) *reinterpret_cast<f32x4_t*>(wsp + (size_t)m * a.N + n) = acc[ni][mi];
-          }
-        }
-        return;
-      }
-      const bool rs_out = LNF && a.row_stats_out != nullptr;
-      // ---- residual loads: everything this wave will need, in flight at once
-      //      paired blocks: 16 bytes at the lane's 8 consecutive columns; single block: 8 bytes at its 4 columns
-      const int pcol = nwave + ((g & 1) ? 16 : 0) + ((g >> 1) << 3);   // + 32 * pair: first of the lane's 8 columns
-      const int scol = nwave + (NI - 1) * 16 + 4 * g;                  // single (odd) block
-      // (TIGHT: the 8-wave 128x160x2 tile lives on 128 VGPRs -- its second residual, rare on that tile, is loaded at
-      //  the point of use instead of being held)
-      constexpr bool TIGHT = !PP && WM * WN == 8 && MI * NI <= 10;
-      u32x4_t r1p[MI][NP > 0 ? NP : 1], r2p[TIGHT ? 1 : MI][NP > 0 ? NP : 1];
-      u32x2_t r1s[MI], r2s[TIGHT ? 1 : MI];
-      auto ld16 = [&](const void* base, int ld, int m, int n, bool ok) __attribute__((always_inline)) {
-        return (ok && base) ? *reinterpret_cast<const u32x4_t*>((const uint16_t*)base + (size_t)m * ld + n) : u32x4_t{0u, 0u, 0u, 0u};
-      };
-      auto ld8 = [&](const void* base, int ld, int m, int n, bool ok) __attribute__((always_inline)) {
-        return (ok && base) ? *reinterpret_cast<const u32x2_t*>((const uint16_t*)base + (size_t)m * ld + n) : u32x2_t{0u, 0u};
-      };
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi) {
-        const int m = mrow0 + mi * 16;
-        const bool mok = m < a.M;
-#pragma unroll
-        for (int pp = 0; pp < NP; ++pp) {
-          const int n = pcol + 32 * pp;
-          r1p[mi][pp] = ld16(a.res1, a.ldres1, m, n, mok && n < a.N);
-          if (!TIGHT) r2p[mi][pp] = ld16(a.res2, a.ldres2, m, n, mok && n < a.N);
-        }
-        if (ODD) {
-          r1s[mi] = ld8(a.res1, a.ldres1, m, scol, mok && scol < a.N);
-          if (!TIGHT) r2s[mi] = ld8(a.res2, a.ldres2, m, scol, mok && scol < a.N);
-        }
-      }
-      // ---- folded LayerNorm: (mean, rstd) of this block's rows -> LDS table (the pipeline stages are free now)
-      if (ln) {
-        asm volatile("s_barrier" ::: "memory");
-        if (tid < BM) *reinterpret_cast<f32x2_t*>(smem + LN_OFF + tid * 8) = ln_mr;
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      } else if (rs_out) {
-        asm volatile("s_barrier" ::: "memory");          // RS_OFF lies inside the stages: everyone must have left the loop
-      }
-      f32x2_t mr[MI];
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi)
-        mr[mi] = ln ? *reinterpret_cast<const f32x2_t*>(smem + LN_OFF + (wm * (MI * 16) + mi * 16 + r16) * 8) : f32x2_t{0.f, 1.f};
-      // per-batch row vector (time embedding): wave-uniform batch item when a batch item holds whole wave strips
-      const bool rv_uni = a.rowvec && (a.rows_per_batch % (MI * 16)) == 0;
-      const float* rvw = rv_uni ? a.rowvec + (size_t)((m_blk + wm * (MI * 16)) / a.rows_per_batch) * a.ld_rowvec : nullptr;
-      float rsum[MI], rsq[MI];
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi) { rsum[mi] = 0.f; rsq[mi] = 0.f; }
-      const int strip = (wm * (MI * 16)) >> 6;           // 64-row strip of the tile this wave's rows belong to (GNS)
-      unsigned long long* gslots = reinterpret_cast<unsigned long long*>(smem + GN_OFF) + strip * (2 * GN_SLOTS * 2);
-
-      // one 16 x 16 block column set `ni`: epilogue arithmetic on acc[ni][*] in place (bias, LN, row vector, scale);
-      // returns nothing -- residuals / activation / packing happen on the paired data below
-      auto colmath = [&](int ni) __attribute__((always_inline)) {
-        const int nl = wn * (NI * 16) + ni * 16 + 4 * g;           // column inside the block tile
-        const int n = n_blk + nl;
-        const bool nok = n < a.N;
-        f32x4_t bs = {0.f, 0.f, 0.f, 0.f}, cs = {0.f, 0.f, 0.f, 0.f}, rv = {0.f, 0.f, 0.f, 0.f};
-        if (LNF) {
-          bs = *reinterpret_cast<const f32x4_t*>(smem + PRE_B + nl * 4);
-          cs = *reinterpret_cast<const f32x4_t*>(smem + PRE_C + nl * 4);
-        } else if (a.bias && nok) {
-          bs = *reinterpret_cast<const f32x4_t*>(a.bias + n);
-        }
-        if (rv_uni && nok) rv = *reinterpret_cast<const f32x4_t*>(rvw + n);
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-          f32x4_t v = acc[ni][mi];
-          if (ln) v = (v - cs * mr[mi][0]) * mr[mi][1];
-          v += bs;
-          if (a.rowvec) {
-            if (rv_uni) v += rv;
-            else {
-              const int m = mrow0 + mi * 16;
-              if (m < a.M && nok) v += *reinterpret_cast<const f32x4_t*>(a.rowvec + (size_t)(m / a.rows_per_batch) * a.ld_rowvec + n);
-            }
-          }
-          acc[ni][mi] = v * a.scale;
-        }
-      };
-      // GroupNorm: moments of 4 lane-local columns over the wave's rows -> DPP rotate-reduce over the 16 lanes of the
-      // row -> lane r16 == j adds column j's pair to the groups' LDS slots
-      auto gn_cols = [&](const float (&cs4)[4], const float (&cq4)[4], int col0) __attribute__((always_inline)) {
-        float s4[4], q4[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          float sv = cs4[j], qv = cq4[j];
-          // row_ror:8, 4, 2, 1 inside each 16-lane row: afterwards every lane holds the row's total
-#define PP_ROR_ADD(X, N) X += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, X), 0x120 + N, 0xf, 0xf, false))
-          PP_ROR_ADD(sv, 8); PP_ROR_ADD(qv, 8);
-          PP_ROR_ADD(sv, 4); PP_ROR_ADD(qv, 4);
-          PP_ROR_ADD(sv, 2); PP_ROR_ADD(qv, 2);
-          PP_ROR_ADD(sv, 1); PP_ROR_ADD(qv, 1);
-#undef PP_ROR_ADD
-          s4[j] = sv;
-          q4[j] = qv;
-        }
-        if (r16 < 4) {
-          const float sm = r16 == 0 ? s4[0] : r16 == 1 ? s4[1] : r16 == 2 ? s4[2] : s4[3];
-          const float sq = r16 == 0 ? q4[0] : r16 == 1 ? q4[1] : r16 == 2 ? q4[2] : q4[3];
-          const int col = col0 + r16;                   // column inside the block tile
-          if (n_blk + col < a.N) gn_column(a, gslots, n_blk, col, sm, sq);
-        }
-      };
-      // finish 4 values of one row: + residuals, activation, pack; moments of the values AS STORED
-      auto fin4 = [&](f32x4_t v, uint32_t ra0, uint32_t ra1, uint32_t rb0, uint32_t rb1, uint32_t& o0, uint32_t& o1)
-          __attribute__((always_inline)) {
-        v[0] += E16<EDT>::lo(ra0) + E16<EDT>::lo(rb0); v[1] += E16<EDT>::hi(ra0) + E16<EDT>::hi(rb0);
-        v[2] += E16<EDT>::lo(ra1) + E16<EDT>::lo(rb1); v[3] += E16<EDT>::hi(ra1) + E16<EDT>::hi(rb1);
-        if (a.act == PP_ACT_SILU) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] = silu_f(v[j]);
-        }
-        o0 = E16<EDT>::pack2(v[0], v[1]);
-        o1 = E16<EDT>::pack2(v[2], v[3]);
-        return v;
-      };
-#pragma unroll
-      for (int pp = 0; pp < NP; ++pp) {
-        colmath(2 * pp);
-        colmath(2 * pp + 1);
-        float csA[4] = {0.f, 0.f, 0.f, 0.f}, cqA[4] = {0.f, 0.f, 0.f, 0.f};
-        float csB[4] = {0.f, 0.f, 0.f, 0.f}, cqB[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-          const int m = mrow0 + mi * 16;
-          // residuals arrive in the paired layout: un-pair them (the swap is an involution) to the MFMA layout
-          u32x4_t q1 = r1p[mi][pp];
-          u32x4_t q2 = TIGHT ? ld16(a.res2, a.ldres2, m, pcol + 32 * pp, m < a.M && pcol + 32 * pp < a.N) : r2p[TIGHT ? 0 : mi][pp];
-          if (a.res1) {
-            const auto s0 = __builtin_amdgcn_permlane16_swap(q1[0], q1[2], false, false);
-            const auto s1 = __builtin_amdgcn_permlane16_swap(q1[1], q1[3], false, false);
-            q1 = u32x4_t{s0[0], s1[0], s0[1], s1[1]};    // (block a dwords 0,1 | block b dwords 0,1)
-          }
-          if (a.res2) {
-            const auto s0 = __builtin_amdgcn_permlane16_swap(q2[0], q2[2], false, false);
-            const auto s1 = __builtin_amdgcn_permlane16_swap(q2[1], q2[3], false, false);
-            q2 = u32x4_t{s0[0], s1[0], s0[1], s1[1]};
-          }
-          uint32_t a0, a1, b0, b1;
-          const f32x4_t va = fin4(acc[2 * pp][mi], q1[0], q1[1], q2[0], q2[1], a0, a1);
-          const f32x4_t vb = fin4(acc[2 * pp + 1][mi], q1[2], q1[3], q2[2], q2[3], b0, b1);
-          if (a.out_f32) {
-            if (m < a.M) {
-              float* op = (float*)a.out + (size_t)m * a.ldo + nwave + 4 * g;
-              if (nwave + 32 * pp + 4 * g < a.N) *reinterpret_cast<f32x4_t*>(op + 32 * pp) = va;
-              if (nwave + 32 * pp + 16 + 4 * g < a.N) *reinterpret_cast<f32x4_t*>(op + 32 * pp + 16) = vb;
-            }
-          } else {
-            if (GNS || rs_out) {                         // moments of the stored (rounded) values, in the MFMA layout
-              const float x0 = E16<EDT>::lo(a0), x1 = E16<EDT>::hi(a0), x2 = E16<EDT>::lo(a1), x3 = E16<EDT>::hi(a1);
-              const float y0 = E16<EDT>::lo(b0), y1 = E16<EDT>::hi(b0), y2 = E16<EDT>::lo(b1), y3 = E16<EDT>::hi(b1);
-              const bool okm = m < a.M;
-              if (GNS && okm) {
-                csA[0] += x0; cqA[0] += x0 * x0; csA[1] += x1; cqA[1] += x1 * x1;
-                csA[2] += x2; cqA[2] += x2 * x2; csA[3] += x3; cqA[3] += x3 * x3;
-                csB[0] += y0; cqB[0] += y0 * y0; csB[1] += y1; cqB[1] += y1 * y1;
-                csB[2] += y2; cqB[2] += y2 * y2; csB[3] += y3; cqB[3] += y3 * y3;
-              }
-              if (rs_out) {
-                const bool oka = nwave + 32 * pp + 4 * g < a.N, okb = nwave + 32 * pp + 16 + 4 * g < a.N;
-                if (oka) { rsum[mi] += (x0 + x1) + (x2 + x3); rsq[mi] += (x0 * x0 + x1 * x1) + (x2 * x2 + x3 * x3); }
-                if (okb) { rsum[mi] += (y0 + y1) + (y2 + y3); rsq[mi] += (y0 * y0 + y1 * y1) + (y2 * y2 + y3 * y3); }
-              }
-            }
-            // pair the two blocks: afterwards this lane owns 8 consecutive columns (16 bytes)
-            const auto s0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
-            const auto s1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
-            const u32x4_t o = {s0[0], s1[0], s0[1], s1[1]};
-            const int n = pcol + 32 * pp;
-            if (m < a.M && n < a.N) *reinterpret_cast<u32x4_t*>((uint16_t*)a.out + (size_t)m * a.ldo + n) = o;
-          }
-        }
-        if (GNS) {
-          gn_cols(csA, cqA, wn * (NI * 16) + (2 * pp) * 16 + 4 * g);
-          gn_cols(csB, cqB, wn * (NI * 16) + (2 * pp + 1) * 16 + 4 * g);
-        }
-      }
-      if (ODD) {
-        colmath(NI - 1);
-        float csA[4] = {0.f, 0.f, 0.f, 0.f}, cqA[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-          const int m = mrow0 + mi * 16;
-          uint32_t a0, a1;
-          const u32x2_t q2s = TIGHT ? ld8(a.res2, a.ldres2, m, scol, m < a.M && scol < a.N) : r2s[TIGHT ? 0 : mi];
-          const f32x4_t va = fin4(acc[NI - 1][mi], r1s[mi][0], r1s[mi][1], q2s[0], q2s[1], a0, a1);
-          const bool ok = m < a.M && scol < a.N;
-          if (a.out_f32) {
-            if (ok) *reinterpret_cast<f32x4_t*>((float*)a.out + (size_t)m * a.ldo + scol) = va;
-          } else {
-            if (GNS || rs_out) {
-              const float x0 = E16<EDT>::lo(a0), x1 = E16<EDT>::hi(a0), x2 = E16<EDT>::lo(a1), x3 = E16<EDT>::hi(a1);
-              if (GNS && m < a.M) {
-                csA[0] += x0; cqA[0] += x0 * x0; csA[1] += x1; cqA[1] += x1 * x1;
-                csA[2] += x2; cqA[2] += x2 * x2; csA[3] += x3; cqA[3] += x3 * x3;
-              }
-              if (rs_out && scol < a.N) { rsum[mi] += (x0 + x1) + (x2 + x3); rsq[mi] += (x0 * x0 + x1 * x1) + (x2 * x2 + x3 * x3); }
-            }
-            if (ok) *reinterpret_cast<u32x2_t*>((uint16_t*)a.out + (size_t)m * a.ldo + scol) = u32x2_t{a0, a1};
-          }
-        }
-        if (GNS) gn_cols(csA, cqA, wn * (NI * 16) + (NI - 1) * 16 + 4 * g);
-      }
-      if (GNS) {
-        // flush: one thread per (strip, consumer, group slot); strips of one tile may belong to different batch items
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        const int ncols = min(BN, a.N - n_blk);
-        for (int i = tid; i < GN_STRIPS * 2 * GN_SLOTS; i += T) {
-          const int st = i / (2 * GN_SLOTS), rem = i - st * (2 * GN_SLOTS);
-          const int m_first = m_blk + st * 64;
-          if (m_first < a.M)
-            gn_flush(a, reinterpret_cast<unsigned long long*>(smem + GN_OFF) + st * (2 * GN_SLOTS * 2), m_first, n_blk, ncols, rem);
-        }
-      }
-      if (rs_out) {
-        // row moments: over the four lane groups of a row (lanes r16, +16, +32, +48), then over the WN waves of the strip
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-          rsum[mi] += __shfl_xor(rsum[mi], 16, 64); rsq[mi] += __shfl_xor(rsq[mi], 16, 64);
-          rsum[mi] += __shfl_xor(rsum[mi], 32, 64); rsq[mi] += __shfl_xor(rsq[mi], 32, 64);
-          if (g == 0)
-            *reinterpret_cast<f32x2_t*>(smem + RS_OFF + ((wm * (MI * 16) + mi * 16 + r16) * WN + wn) * 8) = f32x2_t{rsum[mi], rsq[mi]};
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        if (tid < BM && m_blk + tid < a.M) {
-          float sm = 0.f, sq = 0.f;
-#pragma unroll
-          for (int w = 0; w < WN; ++w) {
-            const f32x2_t v = *reinterpret_cast<const f32x2_t*>(smem + RS_OFF + (tid * WN + w) * 8);
-            sm += v[0];
-            sq += v[1];
-          }
-          const int tiles_n = (a.N + BN - 1) / BN;
-          *reinterpret_cast<f32x2_t*>(a.row_stats_out + ((size_t)(m_blk + tid) * tiles_n + n_blk / BN) * 2) = f32x2_t{sm, sq};
-        }
-      }
-      return;
-    }
-  }
-
   // ================= epilogue: 64-row passes through LDS (V^T blocks; every block in a -DPP_EPI_STAGED lab build) ====
   const int my_pass = (wm * (MI * 16)) / EPI_ROWS;
   const int my_row0 = (wm * (MI * 16)) % EPI_ROWS;
@@ -1721,9 +1425,8 @@ int launch2(const PPGemmArgs& a, int splitk, hipStream_t st) {
   }
   constexpr bool LNF = EPI == 1 || EPI == 2;
   constexpr int T = WM * WN * 64;
-  // + epilogue-operand prefetch (LNF) / the GroupNorm group slots of the direct epilogue (EPI 4: one set per 64-row strip)
-  constexpr int LDS = NS * (BM + BN) * 128 + (LNF ? 2048 + BM * 32 : 0) +
-                      ((EPI == 4 && PP_DIRECT_EPILOGUE) ? ((BM + 63) / 64) * 2 * GN_SLOTS * 2 * 8 : 0);
+  // + epilogue-operand prefetch (LNF)
+  constexpr int LDS = NS * (BM + BN) * 128 + (LNF ? 2048 + BM * 32 : 0);
   static_assert(LDS <= 160 * 1024 || (LNF && NS > 2), "LDS budget");
   if constexpr (LDS > 160 * 1024) {   // 256x160 x 3 stages has no room for the prefetch: drop to 2 stages (lock-step)
     return launch2<BM, BN, WM, WN, XMODE, 2, EPI, false, EDT>(a, splitk, st);
@@ -1804,14 +1507,6 @@ int validate(const PPGemmArgs& a) {
   if (a.ln_stats && (!a.ln_colsum || a.ln_tiles <= 0 || a.ln_dim <= 0)) return PP_ERR_BAD_ARG;
   if (a.row_stats_out && (a.out_f32 || a.out_vt || a.act == PP_ACT_GEGLU || !v2_ok(a))) return PP_ERR_UNSUPPORTED;
   if ((a.gn_acc[0] || a.gn_acc[1]) && !gn_stats_supported(a)) return PP_ERR_UNSUPPORTED;
-  if (a.w_batch_stride < 0) return PP_ERR_BAD_ARG;
-  if (a.w_batch_stride > 0) {      // one weight matrix per batch item: every tile (<= 256 rows) inside one item
-    if (a.x_mode != PP_X_PLAIN || a.rows_per_batch <= 0 || a.rows_per_batch % 256 || a.M % a.rows_per_batch ||
-        a.w_batch_stride < a.N * a.K || a.w_batch_stride % 8)
-      return PP_ERR_BAD_ARG;
-    if (!v2_ok(a) || a.act == PP_ACT_GEGLU || a.out_vt) return PP_ERR_UNSUPPORTED;
-    if ((uint64_t)(a.M / a.rows_per_batch) * (uint64_t)a.w_batch_stride * 2u >= 0x80000000ull) return PP_ERR_UNSUPPORTED;
-  }
   return PP_OK;
 }
 
@@ -1873,24 +1568,12 @@ extern "C" size_t pp_gemm_workspace_bytes(const PPGemmArgs* args) {
   return c.splitk > 1 ? (size_t)c.splitk * args->M * args->N * sizeof(float) : 0;
 }
 
-#ifdef PP_LAB
-// geglu_ws.hip (lab build only): wave-specialised GEGLU GEMM, main loop of one tile beside the GELU epilogue of the
-// previous one.  Bit-identical to EPI = 2 but 15-50 % slower (profiles/r03_geglu_ws_ab.txt) -> PP_GEGLU_WS=1 opts in.
-bool pp_geglu_ws_ok(const PPGemmArgs& a);
-int pp_geglu_ws_launch(const PPGemmArgs& a, hipStream_t st);
-#endif
 
 extern "C" int pp_gemm_bf16(const PPGemmArgs* args, void* stream) {
   if (!args) return PP_ERR_BAD_ARG;
   const PPGemmArgs& a = *args;
   const int v = validate(a);
   if (v != PP_OK) return v;
-#ifdef PP_LAB
-  if (pp_lab_env("PP_GEGLU_WS", 0) && pp_geglu_ws_ok(a)) {
-    const int rc = pp_geglu_ws_launch(a, (hipStream_t)stream);
-    if (rc != PP_ERR_UNSUPPORTED) return rc;
-  }
-#endif
   if (pp_conv_gn_wanted(a)) {      // norm -> SiLU -> conv3x3 as one launch (no silent fallback: pp_conv_gn_supported() tells)
     const int sk = pp_conv_gn_splitk(a);
     if (sk <= 0) return PP_ERR_UNSUPPORTED;
@@ -1903,7 +1586,7 @@ extern "C" int pp_gemm_bf16(const PPGemmArgs* args, void* stream) {
   const Choice c = choose(a);
   if (c.splitk > 1 && !a.workspace) return PP_ERR_WORKSPACE;
   if (c.tile > 10 && !v2_ok(a)) return PP_ERR_BAD_ARG;
-  if ((a.row_stats_out || a.gn_acc[0] || a.gn_acc[1] || (a.x_mode == PP_X_CONV3X3 && a.c3 > 0) || a.w_batch_stride > 0) &&
+  if ((a.row_stats_out || a.gn_acc[0] || a.gn_acc[1] || (a.x_mode == PP_X_CONV3X3 && a.c3 > 0)) &&
       c.tile < 10)
     return PP_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;

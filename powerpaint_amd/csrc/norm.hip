@@ -242,58 +242,6 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const uint16_t* __restric
   }
 }
 
-// GroupNorm (affine only) folded into the weights of the 1x1 conv that follows it (Transformer2DModel.norm -> proj_in):
-// block (n-tile of 8 output rows, batch item); thread = channel (C <= 2048: up to eight channels per thread).
-template <int EDT>
-__global__ void __launch_bounds__(256) gn_fold_weights_kernel(const long long* __restrict__ acc, int hw, int groups,
-                                                             float eps, const float* __restrict__ gamma,
-                                                             const float* __restrict__ beta,
-                                                             const uint16_t* __restrict__ w,
-                                                             const float* __restrict__ bias, int N, int C,
-                                                             uint16_t* __restrict__ w_out, float* __restrict__ rv_out) {
-  using E = E16<EDT>;
-  __shared__ float mean_s[64], rstd_s[64];
-  __shared__ float red[8][4];
-  const int tid = threadIdx.x, b = blockIdx.y, n0 = blockIdx.x * 8;
-  if (tid < groups) {
-    const double s = (double)acc[((size_t)b * groups + tid) * 2] * (1.0 / (double)PP_GN_SUM_SCALE);
-    const double q = (double)acc[((size_t)b * groups + tid) * 2 + 1] * (1.0 / (double)PP_GN_SQ_SCALE);
-    const double n = (double)hw * (double)(C / groups);
-    const double mean = s / n;
-    double var = q / n - mean * mean;
-    if (var < 0.0) var = 0.0;
-    mean_s[tid] = (float)mean;
-    rstd_s[tid] = (float)(1.0 / sqrt(var + (double)eps));
-  }
-  __syncthreads();
-  const int cg = C / groups;
-  float part[8];
-#pragma unroll
-  for (int r = 0; r < 8; ++r) part[r] = 0.f;
-  for (int c = tid; c < C; c += 256) {
-    const int g = c / cg;
-    const float sc = gamma[c] * rstd_s[g], mu = mean_s[g], bt = beta[c];
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      const int n = n0 + r;
-      if (n < N) {
-        const float wv = E::to_f(w[(size_t)n * C + c]);
-        const uint16_t wr = E::from_f(wv * sc);
-        w_out[((size_t)b * N + n) * C + c] = wr;
-        part[r] += wv * bt - E::to_f(wr) * mu;          // (the ROUNDED weight: the mean term cancels exactly in the GEMM)
-      }
-    }
-  }
-#pragma unroll
-  for (int r = 0; r < 8; ++r) {
-    const float v = wave_sum(part[r]);
-    if ((tid & 63) == 0) red[r][tid >> 6] = v;
-  }
-  __syncthreads();
-  if (tid < 8 && n0 + tid < N)
-    rv_out[(size_t)b * N + n0 + tid] = (bias ? bias[n0 + tid] : 0.f) + ((red[tid][0] + red[tid][1]) + (red[tid][2] + red[tid][3]));
-}
-
 // conv_norm_out + SiLU + conv_out (C -> 4 channels) in ONE launch -- the tail of UNet2DConditionModel.forward
 // (/root/reference/powerpaint/models/unet_2d_condition.py:1351-1354).  The unfused pair writes the normalised 64x64x320
 // activation (21 MB) and re-reads it nine times through L1 / L2 (gn_apply 12 us + conv3x3_cout4_mfma 40 us per step).
@@ -545,19 +493,6 @@ extern "C" int pp_groupnorm_apply_acc(const void* x1, int c1, const void* x2, in
                                            (const uint16_t*)x1, c1, (const uint16_t*)x2, c2, hw, accf, 0, groups, eps,
                                            gamma, beta, (uint16_t*)y));
   PP_CHECK_LAUNCH("gn_apply_kernel(acc)");
-  return PP_OK;
-}
-
-extern "C" int pp_gn_fold_weights(const int64_t* acc, int batch, int hw, int groups, float eps, const float* gamma,
-                                  const float* beta, const void* w, const float* bias, int n, int c, void* w_out,
-                                  float* rowvec_out, int dtype, void* stream) {
-  if (!acc || !gamma || !beta || !w || !w_out || !rowvec_out || batch <= 0 || hw <= 0 || n <= 0 || c <= 0 || !pp_dt_ok(dtype))
-    return PP_ERR_BAD_ARG;
-  if (groups <= 0 || groups > 64 || c % groups) return PP_ERR_BAD_ARG;
-  PP_DT_SWITCH(dtype, hipLaunchKernelGGL((gn_fold_weights_kernel<EDT>), dim3((n + 7) / 8, batch), dim3(256), 0,
-                                         (hipStream_t)stream, reinterpret_cast<const long long*>(acc), hw, groups, eps, gamma,
-                                         beta, (const uint16_t*)w, bias, n, c, (uint16_t*)w_out, rowvec_out));
-  PP_CHECK_LAUNCH("gn_fold_weights_kernel");
   return PP_OK;
 }
 

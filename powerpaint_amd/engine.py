@@ -253,8 +253,7 @@ class Builder:
                ldres2: int = 0, scale: float = 1.0, act: int = 0, out: int = 0, ldo: Optional[int] = None,
                rowvec: int = 0, ld_rowvec: int = 0, rows_per_batch: int = 0, out_vt: int = 0, vt_col0: int = 0,
                vt_ld: int = 0, out_f32: bool = False, row_stats_out: int = 0, ln_stats: int = 0, ln_colsum: int = 0,
-               ln_tiles: int = 0, ln_dim: int = 0, ln_eps: float = 1e-5, w_batch_stride: int = 0,
-               name: str = "gemm") -> int:
+               ln_tiles: int = 0, ln_dim: int = 0, ln_eps: float = 1e-5, name: str = "gemm") -> int:
         """out[rows][N] = epilogue(X[rows][K(+K2)] @ W[N][K+K2]^T).  Returns the output pointer.
         row_stats_out / ln_*: LayerNorm folded across two GEMMs (see include/pp_hip.h)."""
         n_out = N // 2 if act == L.PP_ACT_GEGLU else (vt_col0 if out_vt else N)
@@ -275,7 +274,6 @@ class Builder:
         a.out, a.ldo, a.out_f32 = out, ldo, int(out_f32)
         a.out_vt, a.vt_col0, a.vt_ld = out_vt or None, vt_col0, vt_ld
         a.row_stats_out = row_stats_out or None
-        a.w_batch_stride = w_batch_stride
         if ln_stats:
             a.ln_stats, a.ln_colsum, a.ln_tiles, a.ln_dim, a.ln_eps = ln_stats, ln_colsum, ln_tiles, ln_dim, ln_eps
         self._gemm(a, name)
@@ -461,9 +459,6 @@ class SDNet:
     fold_ln = _lab_switch("PP_FOLD_LN")
     # FeedForward.net[2] and Transformer2DModel.proj_out composed into one GEMM ((lab) PP_MERGE_FF2=0: two launches)
     merge_ff2_proj_out = _lab_switch("PP_MERGE_FF2")
-    # (lab, OPT-IN: PP_LAB=1 PP_FOLD_GN_PROJ_IN=1) Transformer2DModel.norm folded into per-batch proj_in weights
-    # (pp_gn_fold_weights + PPGemmArgs.w_batch_stride): parity-green, +0.5 % on the step (profiles/r03_gn_proj_in_fold_ab.txt)
-    fold_gn_proj_in = os.environ.get("PP_LAB") == "1" and os.environ.get("PP_FOLD_GN_PROJ_IN", "0") == "1"
     fuse_conv_out = _lab_switch("PP_FUSE_CONV_OUT")      # (lab) =0: conv_norm_out apply and conv_out as two launches
     # the C = 320 cross-attention sub-blocks (norm2 -> to_q -> 77-key attention -> to_out + residual) as ONE pp_xattn_block
     # launch each, K / V folded into the projections once per prompt (pp_xattn_fold in the setup plan): 55 against 66 us
@@ -815,24 +810,9 @@ class SDNet:
             return xn, (dict(bias=P[f"{tb}.{lin}.bias"]) if lin == "ff1" else {})
 
         st = producer()
-        # Transformer2DModel.norm (GroupNorm, affine only) -> proj_in (1x1): where the activation is much larger than B
-        # weight matrices (hw >= 8 C) and the statistics arrive from the producer's epilogue, the norm is folded into
-        # per-batch-item weights + a per-batch bias row by one small launch and the 21 MB normalised activation of the
-        # 64x64 level is never written
-        acc = 0
-        if self.fold_gn_proj_in and hw % 256 == 0 and hw >= 8 * Cc:      # (SD-1.5: the 64x64 and 128x128 levels, C = 320)
-            acc = pb._subscribe_gn_stats(x, None, self.groups)
-        if acc:
-            wb, rv = pb.alloc(x.B * Cc * Cc * 2), pb.alloc(x.B * Cc * 4)
-            pb.plan.add("gn_fold_weights", pb.lib.pp_gn_fold_weights, acc, x.B, hw, self.groups, 1e-6,
-                        P[f"{pre}.norm.weight"], P[f"{pre}.norm.bias"], P[f"{pre}.proj_in.weight"],
-                        P[f"{pre}.proj_in.bias"], Cc, Cc, wb, rv, pb.dt)
-            hs = pb.linear(x.ptr, rows, Cc, wb, Cc, rowvec=rv, ld_rowvec=Cc, rows_per_batch=hw, w_batch_stride=Cc * Cc,
-                           row_stats_out=st, name="conv1x1")
-        else:
-            n = pb.groupnorm(x, P[f"{pre}.norm.weight"], P[f"{pre}.norm.bias"], 1e-6, False, groups=self.groups)
-            hs = pb.linear(n.ptr, rows, Cc, P[f"{pre}.proj_in.weight"], Cc, P[f"{pre}.proj_in.bias"], row_stats_out=st,
-                           name="conv1x1")
+        n = pb.groupnorm(x, P[f"{pre}.norm.weight"], P[f"{pre}.norm.bias"], 1e-6, False, groups=self.groups)
+        hs = pb.linear(n.ptr, rows, Cc, P[f"{pre}.proj_in.weight"], Cc, P[f"{pre}.proj_in.bias"], row_stats_out=st,
+                       name="conv1x1")
         # self-attention: fused QKV GEMM, V written transposed by the epilogue
         ln, kw = normed(hs, st, "norm1", "attn1.qkv")
         if hw % 8 == 0:

@@ -45,16 +45,15 @@ def groupnorm_apply_acc(x: torch.Tensor, acc: torch.Tensor, gamma, beta, eps: fl
 def gemm(x: torch.Tensor, w: torch.Tensor, bias=None, x2=None, res1=None, res2=None, scale: float = 1.0, act: int = 0,
          rowvec=None, rows_per_batch: int = 0, out_f32: bool = False, vt_col0: int = 0, tile: int = 0,
          splitk: int = 0, row_stats: bool = False, ln_stats=None, ln_colsum=None, ln_dim: int = 0,
-         ln_eps: float = 1e-5, gn=None, w_batch_stride: int = 0):
+         ln_eps: float = 1e-5, gn=None):
     """x [M,K1] (+ x2 [M,K2]) bf16, w [N,K1+K2] bf16 -> out [M,N] (or [M,N/2] for GEGLU; (out, vt) when vt_col0).
     row_stats=True additionally returns the per-row (sum, sumsq) partials [M, ceil(N/160), 2] fp32;
     ln_stats (that layout) + ln_colsum [N] fp32 apply the folded-LayerNorm correction (see include/pp_hip.h)."""
     lib = L.lib()
     M, K1 = x.shape
     K2 = x2.shape[1] if x2 is not None else 0
-    N = w.shape[-2]                   # (w [N, K], or [batch, N, K] with w_batch_stride = N * K: one matrix per batch item)
+    N = w.shape[0]
     a = L.PPGemmArgs()
-    a.w_batch_stride = w_batch_stride
     a.M, a.N, a.K, a.x_mode = M, N, K1 + K2, L.PP_X_PLAIN
     a.x1, a.x2, a.c1, a.c2, a.ldx1, a.ldx2 = _p(x), _p(x2), K1, K2, x.stride(0), (x2.stride(0) if x2 is not None else 0)
     a.w, a.bias = _p(w), _p(bias)
@@ -252,18 +251,6 @@ def xattn_block(x: torch.Tensor, folded, bias_o=None, res=None, ln_stats=None, l
                                    _p(bias_o), _p(out), c, _p(st), M, c, rows_per_batch or M, L.dtype_code(x.dtype), _s()),
             "pp_xattn_block")
     return (out, st) if row_stats else out
-
-
-def gn_fold_weights(acc, hw: int, gamma, beta, eps: float, w, bias=None, groups: int = 32):
-    """GroupNorm (affine only) folded into the 1x1 conv / Linear that follows (pp_gn_fold_weights): acc int64
-    [B, groups, 2], w [N, C] -> (w_b [B, N, C] 16-bit, rowvec [B, N] fp32) with conv(GN(x)) = x w_b[b]^T + rowvec[b]."""
-    B = acc.shape[0]
-    N, Cc = w.shape
-    wb = torch.empty(B, N, Cc, dtype=w.dtype, device=w.device)
-    rv = torch.empty(B, N, dtype=torch.float32, device=w.device)
-    L.check(L.lib().pp_gn_fold_weights(_p(acc), B, hw, groups, eps, _p(gamma), _p(beta), _p(w), _p(bias), N, Cc, _p(wb),
-                                       _p(rv), L.dtype_code(w.dtype), _s()), "pp_gn_fold_weights")
-    return wb, rv
 
 
 def gn_conv3x3_smallcout(x, acc, gamma, beta, eps: float, w, bias, groups: int = 32):

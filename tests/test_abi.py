@@ -30,6 +30,20 @@ def test_python_binding_covers_header():
     assert _lib.lib().pp_abi_version() == _lib.ABI_VERSION
 
 
+def test_every_exported_symbol_is_called_by_the_product():
+    """The public header describes the PRODUCT: every entry point it declares is called from powerpaint_amd/ (the launch-plan
+    compiler, the pipelines, the tensor-level wrappers) -- rejected experiments and measurement hooks do not live in it
+    (VERDICT round 3, item 6)."""
+    import glob
+    src = ""
+    for f in glob.glob(os.path.join(ROOT, "powerpaint_amd", "**", "*.py"), recursive=True):
+        if os.path.basename(f) != "_lib.py":
+            src += open(f).read()
+    plumbing = {"pp_abi_version", "pp_last_error", "pp_build_id"}          # used by _lib.py itself
+    unused = [s for s in header_symbols() if s not in plumbing and not re.search(r"\b%s\b" % s, src)]
+    assert not unused, f"declared in include/pp_hip.h but never called by powerpaint_amd/: {unused}"
+
+
 def test_gemm_args_struct_layout_matches_header():
     """sizeof(PPGemmArgs) from the C compiler == ctypes.sizeof (guards against silent ABI drift)."""
     import subprocess

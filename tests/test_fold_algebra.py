@@ -4,7 +4,6 @@ unfused computation they replace (the GPU tests check the kernels against the sa
 * pp_xattn_fold / pp_xattn_block (include/pp_hip.h): norm2 -> to_q -> softmax(q K^T / sqrt d) V -> to_out + residual with
   K and V contracted into the projections, the folded-LayerNorm terms carried as a logit column sum / bias, padded keys
   masked by a -inf logit bias, and H stored with the contraction index permuted inside every group of 32.
-* pp_gn_fold_weights: GroupNorm (affine only) followed by a Linear as per-batch weights plus a per-batch bias row.
 """
 import math
 
@@ -57,19 +56,3 @@ def test_cross_attention_fold_is_the_attention_block():
     # the kernel's second GEMM contracts P (in accumulator-register order = the same permutation) with H as stored
     out = p[:, :, kk] @ Ht_stored.transpose(1, 2) + bo + h
     assert torch.allclose(out, ref, atol=1e-10, rtol=1e-10), (out - ref).abs().max()
-
-
-def test_groupnorm_fold_into_linear_weights():
-    B, hw, C, N, groups = 3, 50, 64, 48, 32
-    cg = C // groups
-    x = gen(B, hw, C, seed=1) * 2 + gen(B, 1, C, seed=2) * 3
-    gamma, beta = gen(C, seed=3) * 0.3 + 1, gen(C, seed=4) * 0.2
-    w, bias = gen(N, C, seed=5) / math.sqrt(C), gen(N, seed=6)
-    ref = F.group_norm(x.transpose(1, 2), groups, gamma, beta, 1e-6).transpose(1, 2) @ w.t() + bias
-    xg = x.reshape(B, hw, groups, cg)
-    mean = xg.mean((1, 3)).repeat_interleave(cg, 1)                            # [B, C]
-    rstd = torch.rsqrt(xg.var((1, 3), unbiased=False) + 1e-6).repeat_interleave(cg, 1)
-    wb = w[None] * (gamma[None] * rstd)[:, None, :]                            # [B, N, C]
-    rv = bias[None] + (w @ beta)[None] - (wb * mean[:, None, :]).sum(-1)       # [B, N]
-    out = torch.einsum("bmc,bnc->bmn", x, wb) + rv[:, None, :]
-    assert torch.allclose(out, ref, atol=1e-9, rtol=1e-9), (out - ref).abs().max()

@@ -52,16 +52,12 @@ def test_full_size_plans_and_flop_accounting():
         # producer's epilogue: one GroupNorm launch less in the UNet, and one launch less overall
         from powerpaint_amd.engine import GN_STATS_IN_EPILOGUE
         fused_out = 1 if (kind == "unet" and SDNet.fuse_conv_out and GN_STATS_IN_EPILOGUE) else 0
-        # ... (lab opt-in) Transformer2DModel.norm of the 64x64 level (hw >= 8 C) folded into per-batch proj_in weights by
-        # a small launch of its own (same launch count, no normalised activation)
-        n_fold = names.count("gn_fold_weights")
-        assert n_fold == ({"unet": 5, "brushnet": 5, "controlnet": 2}[kind] if (SDNet.fold_gn_proj_in and GN_STATS_IN_EPILOGUE) else 0)
         # ... and the two norms of every ResnetBlock2D (22 / 22 / 10 blocks) run in the loader of the conv that consumes them
         # (csrc/conv_gn.hip, PPGemmArgs.gn_in_*): at 64x64 latents every level has a tile of whole image rows
         from powerpaint_amd.engine import FUSE_GN_CONV
         n_cg = {"unet": 44, "brushnet": 44, "controlnet": 20}[kind] if (FUSE_GN_CONV and GN_STATS_IN_EPILOGUE) else 0
         assert sum(1 for a in rt.step_plan.keep if getattr(a, "gn_in_acc", None)) == n_cg
-        assert names.count("groupnorm_apply") == n_gn - fused_out - n_fold - n_cg
+        assert names.count("groupnorm_apply") == n_gn - fused_out - n_cg
         if fused_out:
             assert names.count("conv_out") == 1
         # GroupNorm statistics come out of the producing GEMMs' epilogues -- every producer is a GEMM-family launch

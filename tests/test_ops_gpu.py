@@ -575,48 +575,6 @@ def test_unipc_step_kernel_vs_oracle(K, N, spacing, off):
         check(xh.cpu(), xo, 1e-4 * max(1.0, float(xo.abs().max())), 1e-4, f"unipc step {k}")
 
 
-def test_geglu_wave_specialised_kernel():
-    """LAB BUILD ONLY (PP_LAB=1 PP_LIB=.../libpp_hip_lab.so PP_GEGLU_WS=1; ONE skip on the shipping library, which does
-    not contain the kernel): pp_geglu_ws_kernel (geglu_ws.hip) against the tiled EPI = 2 kernel (an explicit tile id
-    keeps the launch on pp_gemm_kernel_v2): same MFMA operand order and fp32 epilogue arithmetic -> bit-identical; and
-    against fp32 torch on a row sample.  16 cases: four FeedForward shapes x LayerNorm folded or not x bf16 / fp16."""
-    import itertools
-    import os
-    if not (os.environ.get("PP_LAB") == "1" and os.environ.get("PP_GEGLU_WS") == "1"):
-        pytest.skip("lab experiment: the shipping library has no wave-specialised GEGLU kernel")
-    for (M, C), fold, dtype in itertools.product([(32768, 320), (8192, 640), (2048, 1280), (65536, 320)], [False, True],
-                                                 [torch.bfloat16, torch.float16]):
-        _geglu_ws_case(M, C, fold, dtype)
-
-
-def _geglu_ws_case(M, C, fold, dtype):
-    from powerpaint_amd.engine import _geglu_interleave
-    N = 8 * C
-    x = (rnd(M, C, seed=1, scale=2.0) + 0.3).to(dtype).cuda()
-    w = _geglu_interleave(rnd(N, C, seed=2, scale=C ** -0.5)).to(dtype).contiguous().cuda()
-    b = _geglu_interleave(rnd(N, seed=3)).contiguous().cuda()
-    kw = {}
-    if fold:
-        xf = x.float()
-        tiles = C // 160
-        st = torch.stack([xf.reshape(M, tiles, 160).sum(-1), (xf * xf).reshape(M, tiles, 160).sum(-1)], -1).contiguous()
-        kw = dict(ln_stats=st, ln_colsum=w.float().sum(1).contiguous(), ln_dim=C)
-    new = ops.gemm(x, w, bias=b, act=L.PP_ACT_GEGLU, **kw)
-    old = ops.gemm(x, w, bias=b, act=L.PP_ACT_GEGLU, tile=24, **kw)
-    torch.cuda.synchronize()
-    assert torch.equal(new, old), f"max diff {(new.float() - old.float()).abs().max().item():.3g}"
-    rows = torch.arange(0, M, 97, device="cuda")
-    xr = x[rows].float()
-    y = xr @ w.float().t()
-    if fold:
-        mean = xr.mean(-1, keepdim=True)
-        rstd = torch.rsqrt((xr * xr).mean(-1, keepdim=True) - mean * mean + 1e-5)
-        y = rstd * (y - mean * kw["ln_colsum"])
-    y = (y + b).reshape(len(rows), N // 4, 4)
-    ref = torch.stack([y[..., 0] * F.gelu(y[..., 2]), y[..., 1] * F.gelu(y[..., 3])], -1).reshape(len(rows), N // 2)
-    check(new[rows], ref, 3e-2, 1e-2, "wave-specialised GEGLU vs fp32")
-
-
 def test_latent_blend_kernel():
     """pp_latent_blend = the 4-channel-UNet branch of the v1 loop body (pipeline_PowerPaint.py:1025-1036): row `step` of
     the re-noise table, first image / first mask broadcast over the batch, clean latents on the (1, 0) row."""
@@ -736,37 +694,3 @@ def test_fused_groupnorm_silu_conv_out(B, H, W, C, dtype):
     check(out, ref, 3e-2 * tol, 1e-2 * tol, "fused conv_out vs fp32")
 
 
-@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("B,hw,C", [(2, 4096, 320), (3, 1024, 640), (1, 256, 320)])
-def test_groupnorm_folded_into_proj_in_weights(B, hw, C, dtype):
-    """Transformer2DModel.norm -> proj_in without the normalised activation: pp_gn_fold_weights builds one weight matrix
-    and one bias row per batch item from the GroupNorm accumulators, pp_gemm_bf16 (w_batch_stride, per-batch rowvec, row
-    moments for the next folded LayerNorm) applies them -- against the two-launch path (groupnorm_apply_acc -> GEMM) and
-    fp32 torch.  Inputs with a large mean exercise the cancellation of the mean term."""
-    groups, cg = 32, C // 32
-    M = B * hw
-    x = (rnd(B, hw, C, seed=1, scale=1.5) + rnd(B, 1, C, seed=2) * 2.0 + 1.0).to(dtype)
-    xf = x.float().reshape(B, hw, groups, cg)
-    acc = torch.stack([(xf.sum((1, 3)).double() * 2 ** 24).round().long(),
-                       ((xf * xf).sum((1, 3)).double() * 2 ** 20).round().long()], -1).contiguous()
-    g, b = rnd(C, seed=3) * 0.3 + 1.0, rnd(C, seed=4) * 0.2
-    w = rnd(C, C, seed=5, scale=C ** -0.5).to(dtype).contiguous()
-    bias = rnd(C, seed=6)
-    wb, rv = ops.gn_fold_weights(acc, hw, g, b, 1e-6, w, bias)
-    out, st = ops.gemm(x.reshape(M, C), wb, rowvec=rv, rows_per_batch=hw, row_stats=True, w_batch_stride=C * C)
-    y = ops.groupnorm_apply_acc(x.reshape(B, hw, 1, C), acc, g, b, 1e-6, False)
-    old, st_old = ops.gemm(y.reshape(M, C), w, bias=bias, row_stats=True)
-    tol = 1.0 if dtype == torch.bfloat16 else 0.25
-    ref = F.group_norm(x.float().permute(0, 2, 1), groups, g, b, 1e-6).permute(0, 2, 1).reshape(M, C) @ w.float().t() + bias
-    check(out, ref, 4e-2 * tol, 1e-2 * tol, "GN folded into proj_in vs fp32")
-    check(out, old, 5e-2 * tol, 1e-2 * tol, "GN folded into proj_in vs apply + GEMM")
-    of = out.float()
-    st_ref = torch.stack([of.reshape(M, C // 160, 160).sum(-1), (of * of).reshape(M, C // 160, 160).sum(-1)], -1)
-    check(st, st_ref, 2e-3 * max(1.0, float(st_ref.abs().max()) / 100), 1e-5, "row moments")
-    # the folded operands themselves
-    mean = xf.mean((1, 3))
-    rstd = torch.rsqrt(xf.var((1, 3), unbiased=False) + 1e-6)
-    sc = (g.reshape(groups, cg)[None] * rstd[:, :, None]).reshape(B, 1, C)
-    check(wb, w.float()[None] * sc, 1e-3, 8e-3 * tol, "per-batch weights")
-    rv_ref = bias[None] + (w.float() @ b)[None] - (wb.float() * mean.repeat_interleave(cg, 1)[:, None, :]).sum(-1)
-    check(rv, rv_ref, 2e-3, 1e-4, "per-batch bias row")
