@@ -35,7 +35,7 @@ GFLOP_PER_SAMPLE_BY_LATENT = {32: {"unet9": 180.1, "unet4": 180.1, "brushnet": 1
                               128: {"unet9": 4674.5, "unet4": 4674.0, "brushnet": 4765.5, "controlnet": 1717.1}}
 
 
-def build_pipeline(cfg, device, rank, world, net_kw=None, dtype=torch.bfloat16, scheduler=None):
+def build_pipeline(cfg, device, rank, world, net_kw=None, dtype=torch.bfloat16, scheduler=None, bcast_timeout=0.0):
     """Networks + pipeline of one rank.  Rank 0 creates the (random-init) weights; every other rank only lays out its
     packed parameter buffer (`meta=True` state dict, `materialize=False`) and receives the bytes in the one start-up
     broadcast.  `net_kw` overrides the architecture (tests run this function with a reduced network)."""
@@ -62,9 +62,14 @@ def build_pipeline(cfg, device, rank, world, net_kw=None, dtype=torch.bfloat16, 
     if on_gpu:
         torch.cuda.synchronize()
     t0 = time.perf_counter()
-    ppdist.broadcast_params([m.param_buffer() for m in nets], src=0)     # the ONE collective (RCCL over xGMI)
-    if on_gpu:
-        torch.cuda.synchronize()
+    # (the watchdog covers the collective only: a slow but healthy local build -- random init, packing -- must not be
+    #  killed and blamed on the broadcast)
+    with ppdist.Watchdog(bcast_timeout if world > 1 else 0.0, "weight broadcast"):
+        ppdist.broadcast_params([m.param_buffer() for m in nets], src=0)     # the ONE collective (RCCL over xGMI)
+        if on_gpu:
+            torch.cuda.synchronize()
+    for m in nets:
+        m.params_changed()
     bcast_s = time.perf_counter() - t0
     sched = {"ddim": PS.DDIMScheduler, "dpm": PS.DPMSolverMultistepScheduler, "pndm": PS.PNDMScheduler,
              "unipc": PS.UniPCMultistepScheduler}[scheduler or ("dpm" if cfg == "v2" else "ddim")]()
@@ -420,8 +425,8 @@ def main():
     device = torch.device("cuda", local)
 
     dtype = torch.float16 if args.dtype == "fp16" else torch.bfloat16
-    with ppdist.Watchdog(args.dist_timeout if world > 1 else 0.0, "weight broadcast (build_pipeline)"):
-        pipe, nets, bcast_s = build_pipeline(args.config, device, rank, world, dtype=dtype, scheduler=args.scheduler)
+    pipe, nets, bcast_s = build_pipeline(args.config, device, rank, world, dtype=dtype, scheduler=args.scheduler,
+                                         bcast_timeout=args.dist_timeout)
     rank_log = ppdist.gather_strings(f"rank {rank}: {ppdist.device_identity(local)}; weight_broadcast_s {bcast_s:.3f}")
     if rank == 0 and world > 1:
         for line in rank_log:

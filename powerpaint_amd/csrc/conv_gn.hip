@@ -32,7 +32,7 @@ typedef __attribute__((address_space(3))) void* cg_lds_t;
 
 constexpr int CG_T = 512, CG_BN = 160, CG_NI = 5;
 constexpr int CG_WP = 3;                        // weight-tile DMA pieces per wave and K step (20 strips of 8 rows, 8 waves)
-constexpr int CG_HPW = 6;                       // halo DMA pieces per wave and chunk (48 strips of 8 pixels)
+constexpr int CG_HPW_MAX = 6;                   // halo DMA pieces per wave and chunk at most (48 strips of 8 pixels)
 constexpr int CG_HALO_PX = 384;
 constexpr int CG_HALO = CG_HALO_PX * 128;       // one halo buffer
 constexpr int CG_WST = CG_BN * 128;             // one weight stage
@@ -60,12 +60,18 @@ template <int N, class F>
 PP_DEVINL void cg_static_for(F&& f) { cg_static_for_impl(std::make_integer_sequence<int, N>{}, f); }
 
 // PP: ping-pong main loop (waves 0-3 / 4-7 half a K step apart, two barriers per K step); else lock-step (one barrier).
-// NMODE: where the normalisation of the next halo tile runs -- 1 inside the MFMA burst, 0 in the read phase (lab A/B).
-template <int BM, bool PP, int NMODE, int EDT>
+// HPW: halo strips per wave = ceil((BM + 2 W) / 64): a wave DMAs and normalises strips wave + 8 j, j < HPW, of the next chunk.
+// NMODE: where the normalisation of the next halo tile runs -- 1 inside the MFMA burst, 0 in the read phase; lab timing
+// probes: 2 = no normalisation at all (the loop skeleton on raw data), 3 = read phase and no s_setprio around the burst.
+template <int BM, int HPW, bool PP, int NMODE, int EDT>
 __global__ void __launch_bounds__(CG_T, 2) pp_conv_gn_kernel(const PPGemmArgs a, const CGDerived d) {
   using E = E16<EDT>;
   typedef typename E::v8 v8_t;
   constexpr int T = CG_T, WN = 2, MI = BM / 64, NI = CG_NI, BN = CG_BN;
+  constexpr int CG_HPW = HPW;
+  constexpr bool NORM = NMODE != 2;
+  constexpr bool NREAD = NMODE == 0 || NMODE == 3;      // normalisation in the read phase
+  static_assert(HPW >= 2 && HPW <= CG_HPW_MAX, "halo strips per wave");
   constexpr int XP2 = BM / 64;                    // phase-2 (tail) X-tile pieces per wave and K step
   constexpr int P2 = XP2 + CG_WP;
   constexpr int ST2 = BM * 128;                   // phase-2 X stage (three of them over the two halo buffers)
@@ -288,9 +294,11 @@ __global__ void __launch_bounds__(CG_T, 2) pp_conv_gn_kernel(const PPGemmArgs a,
     }
     if (tid < 32) reinterpret_cast<float*>(smem + CG_T_ZERO)[tid] = 0.f;
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    compute_scsh(ch_b, 0);
+    if constexpr (NORM) {
+      compute_scsh(ch_b, 0);
 #pragma unroll
-    for (int j = 0; j < CG_HPW; ++j) norm_piece(0, j);
+      for (int j = 0; j < CG_HPW; ++j) norm_piece(0, j);
+    }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     if (PP && grp == 1) asm volatile("s_barrier" ::: "memory");      // group 1 runs one phase behind group 0
 
@@ -311,7 +319,10 @@ __global__ void __launch_bounds__(CG_T, 2) pp_conv_gn_kernel(const PPGemmArgs a,
         constexpr int st_r = t % 3, st_w = (t + 2) % 3;             // (9 % 3 == 0: the stage of tap t is t % 3 in every chunk)
         // extra DMA pieces of a tap, after its three weight pieces: the next chunk's halo strips two per tap over taps
         // 0 .. 2 (strip j is needed from tap 3 + j on) and, in tap 0, the chunk's (gamma, beta) table
-        constexpr auto NXT = [](int tt) constexpr { return tt == 0 ? 3 : (tt == 1 || tt == 2) ? 2 : 0; };
+        constexpr auto NXT = [](int tt) constexpr {
+          const int nh = tt > 2 ? 0 : (2 * tt + 2 <= CG_HPW ? 2 : 2 * tt + 1 <= CG_HPW ? 1 : 0);   // strips 2 tt, 2 tt + 1
+          return nh + (tt == 0 ? 1 : 0);
+        };
         constexpr int NX = NXT(t);
         // weight tile of K step + 2
         const __amdgpu_buffer_rsrc_t rsw = t + 2 <= 8 ? rsw_same : rsw_next;
@@ -329,16 +340,16 @@ __global__ void __launch_bounds__(CG_T, 2) pp_conv_gn_kernel(const PPGemmArgs a,
         //      rides INSIDE this wave's MFMA burst (NMODE 1: two per MFMA, in the issue slots the 16-cycle matrix
         //      instruction leaves free) or sits in the read phase (NMODE 0, where the partner wave's s_setprio 1 starves
         //      its transcendentals: MI355X_MICROARCH.md "Two waves per SIMD", item 2).
-        constexpr bool NT = t >= 3;                                  // a tap that carries one strip
+        constexpr bool NT = NORM && t >= 3 && t - 3 < CG_HPW;        // a tap that carries one strip
         char* const np = smem + hbn * CG_HALO + (wave + 8 * (NT ? t - 3 : 0)) * 1024 + lane * 16;
         u32x4_t nv = {0u, 0u, 0u, 0u};
         if constexpr (NT) {
           // (unconditional: behind the last chunk this works on the zeros of the dead DMAs in the unused buffer -- a branch
           //  around the MFMA burst would put the 80 accumulator registers through a phi and double them)
           if constexpr (t == 3) compute_scsh(c + 1, hbn);
-          if constexpr (NMODE == 0) norm_piece(hbn, t - 3);
+          if constexpr (NREAD) norm_piece(hbn, t - 3);
           else nv = *reinterpret_cast<const u32x4_t*>(np);
-          if constexpr (NMODE == 0) __builtin_amdgcn_sched_barrier(0);
+          if constexpr (NREAD) __builtin_amdgcn_sched_barrier(0);
         }
         // ---- read phase: fragment reads of this K step, the DMA pieces spread between them
         const char* ws = smem + CG_WOFF + st_r * CG_WST;
@@ -368,7 +379,7 @@ __global__ void __launch_bounds__(CG_T, 2) pp_conv_gn_kernel(const PPGemmArgs a,
             if (((k + 1) * NR + NPC) / (NPC + 1) == r + 1) {
               __builtin_amdgcn_sched_barrier(0);
               if (k < CG_WP) issue_w_piece(rsw, st_w, k < CG_WP ? k : 0, sow);
-              else if (t == 0 && k == CG_WP + 2) issue_gb(c + 1, hbn, nxt);
+              else if (t == 0 && k == NPC - 1) issue_gb(c + 1, hbn, nxt);
               else issue_halo_piece(hbn, 2 * t + (k - CG_WP < 2 ? k - CG_WP : 0));
               __builtin_amdgcn_sched_barrier(0);
             }
@@ -380,7 +391,7 @@ __global__ void __launch_bounds__(CG_T, 2) pp_conv_gn_kernel(const PPGemmArgs a,
           asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(V) : "memory");
         }
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
+        if constexpr (NMODE != 3) __builtin_amdgcn_s_setprio(1);
         if constexpr (NT && NMODE == 1) {
           mfma_all(wf, xf);
           const u32x4_t o = norm_math(nv, ~(uint32_t)(hpix[NT ? t - 3 : 0] >> 31));   // all ones inside the image, else 0
@@ -395,7 +406,7 @@ __global__ void __launch_bounds__(CG_T, 2) pp_conv_gn_kernel(const PPGemmArgs a,
         } else {
           mfma_all(wf, xf);
         }
-        __builtin_amdgcn_s_setprio(0);
+        if constexpr (NMODE != 3) __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
       });
       hb ^= 1;
@@ -635,10 +646,10 @@ CGChoice cg_choose(const PPGemmArgs& a) {
   return c;
 }
 
-template <int BM, bool PP, int NMODE, int EDT>
+template <int BM, int HPW, bool PP, int NMODE, int EDT>
 int cg_launch(const PPGemmArgs& a, int splitk, hipStream_t st) {
   static bool attr_set = false;
-  auto kern = pp_conv_gn_kernel<BM, PP, NMODE, EDT>;
+  auto kern = pp_conv_gn_kernel<BM, HPW, PP, NMODE, EDT>;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, CG_LDS) !=
         hipSuccess) {
@@ -663,17 +674,37 @@ int cg_launch(const PPGemmArgs& a, int splitk, hipStream_t st) {
   return PP_OK;
 }
 
+// halo strips per wave for a tile: ceil((BM + 2 W) / 64), rounded up to an instantiated count
+//   BM = 256: W = 64 -> 6, W = 32 / 16 -> 5;  BM = 128: W = 128 -> 6, 64 -> 4, <= 32 -> 3;  BM = 64: W = 64 -> 3, <= 32 -> 2
+template <int BM, bool PP, int NMODE, int EDT>
+int cg_launch_hpw(const PPGemmArgs& a, int splitk, hipStream_t st) {
+  const int need = (BM + 2 * a.win + 63) / 64;
+  if constexpr (BM == 256) {
+    if (need <= 5) return cg_launch<256, 5, PP, NMODE, EDT>(a, splitk, st);
+    return cg_launch<256, 6, PP, NMODE, EDT>(a, splitk, st);
+  } else if constexpr (BM == 128) {
+    if (need <= 3) return cg_launch<128, 3, PP, NMODE, EDT>(a, splitk, st);
+    if (need <= 4) return cg_launch<128, 4, PP, NMODE, EDT>(a, splitk, st);
+    return cg_launch<128, 6, PP, NMODE, EDT>(a, splitk, st);
+  } else {
+    if (need <= 2) return cg_launch<64, 2, PP, NMODE, EDT>(a, splitk, st);
+    return cg_launch<64, 3, PP, NMODE, EDT>(a, splitk, st);
+  }
+}
+
 // (lab build) PP_CONV_GN_PP=0: the lock-step main loop instead of the ping-pong one; PP_CONV_GN_NMODE=0: the halo
-// normalisation in the read phase instead of inside the MFMA burst
+// normalisation in the read phase instead of inside the MFMA burst; 2 / 3: timing probes (see the kernel)
 template <int EDT>
 int cg_dispatch(const PPGemmArgs& a, const CGChoice& c, hipStream_t st) {
 #ifdef PP_LAB
   static const int pp = pp_lab_env("PP_CONV_GN_PP", 1), nm = pp_lab_env("PP_CONV_GN_NMODE", 1);
-  if (!pp || !nm) {
-#define CG_CASE(BM_)                                                          \
-    case BM_:                                                                 \
-      if (pp) return cg_launch<BM_, true, 0, EDT>(a, c.splitk, st);           \
-      return nm ? cg_launch<BM_, false, 1, EDT>(a, c.splitk, st) : cg_launch<BM_, false, 0, EDT>(a, c.splitk, st);
+  if (!pp || nm != 1) {
+#define CG_CASE(BM_)                                                                        \
+    case BM_:                                                                               \
+      if (!pp) return cg_launch_hpw<BM_, false, 1, EDT>(a, c.splitk, st);                   \
+      if (nm == 0) return cg_launch_hpw<BM_, true, 0, EDT>(a, c.splitk, st);                \
+      if (nm == 2) return cg_launch_hpw<BM_, true, 2, EDT>(a, c.splitk, st);                \
+      return cg_launch_hpw<BM_, true, 3, EDT>(a, c.splitk, st);
     switch (c.bm) {
       CG_CASE(256)
       CG_CASE(128)
@@ -684,9 +715,9 @@ int cg_dispatch(const PPGemmArgs& a, const CGChoice& c, hipStream_t st) {
   }
 #endif
   switch (c.bm) {
-    case 256: return cg_launch<256, true, 1, EDT>(a, c.splitk, st);
-    case 128: return cg_launch<128, true, 1, EDT>(a, c.splitk, st);
-    default: return cg_launch<64, true, 1, EDT>(a, c.splitk, st);
+    case 256: return cg_launch_hpw<256, true, 1, EDT>(a, c.splitk, st);
+    case 128: return cg_launch_hpw<128, true, 1, EDT>(a, c.splitk, st);
+    default: return cg_launch_hpw<64, true, 1, EDT>(a, c.splitk, st);
   }
 }
 

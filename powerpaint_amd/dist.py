@@ -31,6 +31,9 @@ class Watchdog:
                          f"MASTER_PORT={os.environ.get('MASTER_PORT')}, "
                          f"HSA_ENABLE_IPC_MODE_LEGACY={os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')})\n")
         sys.stderr.flush()
+        sys.stdout.flush()
+        # hard exit with the documented code 3 (both streams flushed above): a rank wedged inside a collective in native
+        # code acts on neither an exception raised in this timer thread nor, reliably, on SIGTERM
         os._exit(3)
 
     def __enter__(self):
@@ -129,6 +132,8 @@ def broadcast_models(models, src: int = 0):
     for m in models:
         if hasattr(m, "param_buffer"):
             dist.broadcast(m.param_buffer(), src=src)
+            if hasattr(m, "params_changed"):
+                m.params_changed()      # (stale time-embedding rows / folded cross-attention operands otherwise)
             continue
         if not isinstance(m, torch.nn.Module):
             raise TypeError(f"cannot broadcast {type(m).__name__}: neither param_buffer() nor an nn.Module")

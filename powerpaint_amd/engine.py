@@ -95,6 +95,11 @@ class ParamPack:
         self.total = 0
         self.buf = None
         self.ptr: Dict[str, int] = {}
+        self.version = 0      # bumped whenever the VALUES in `buf` change in place (re-broadcast, param_buffer() writes):
+        #                       caches derived from the weights (time-embedding table, folded cross-attention operands) key on it
+
+    def touch(self):
+        self.version += 1
 
     def add(self, name: str, t: torch.Tensor, dtype: torch.dtype):
         assert name not in self.offsets, name

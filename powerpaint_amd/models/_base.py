@@ -115,8 +115,16 @@ class _HipModel(PretrainedMixin):
         return self
 
     def param_buffer(self) -> torch.Tensor:
-        """The single contiguous device buffer holding every parameter (unit of the RCCL weight broadcast)."""
+        """The single contiguous device buffer holding every parameter (unit of the RCCL weight broadcast).  Whoever
+        writes into it in place calls `params_changed()` afterwards (dist.broadcast_models does)."""
         return self.net.params.buf
+
+    def params_changed(self):
+        """The parameter values were rewritten in place: everything derived from them at run time (hoisted cross-attention
+        K / V^T and the folded Wq / Wo, the per-schedule time-embedding table) is recomputed on the next call."""
+        self.net.params.touch()
+        self.rt._ctx_id = None
+        return self
 
     def _nctx(self, ehs: torch.Tensor) -> int:
         if ehs is None or ehs.dim() != 3 or ehs.shape[-1] != self.net.ctx_dim:

@@ -109,6 +109,19 @@ class PipelineBase(PipelinePretrainedMixin):
         return self.unet.device
 
     def to(self, *a, **k):
+        """Forwards the request to every component that has a `.to` (int arguments = cuda indices): the packed HIP
+        networks are no-ops for their own device / dtype and REFUSE a different one (models/_base.py), so
+        `pipe.to(torch.float16)` on a bf16 pipeline raises instead of being silently ignored."""
+        a = tuple(torch.device("cuda", v) if isinstance(v, int) and not isinstance(v, bool) else v for v in a)
+        if isinstance(k.get("device"), int):
+            k = dict(k, device=torch.device("cuda", k["device"]))
+        for name, m in getattr(self, "_modules", {}).items():
+            if m is None or not hasattr(m, "to") or name == "scheduler":
+                continue
+            r = m.to(*a, **k)
+            if isinstance(m, torch.nn.Module) and r is not None:
+                setattr(self, name, r)
+                self._modules[name] = r
         return self
 
     def progress_bar(self, iterable=None, total=None):

@@ -146,7 +146,7 @@ class DenoiseLoop:
         key = (tuple(latents_shape), bool(do_cfg), bool(guess_mode), self._eta > 0, float(guidance_scale), id(rt.step_plan),
                id(side_rt.step_plan) if side_rt is not None else None, kind, ts.data_ptr(), step.data_ptr(),
                0 if self.foreign else sch.coef_table().data_ptr(), mp.data_ptr() if mp is not None else 0, src.data_ptr(),
-               _temb_table_enabled(),
+               _temb_table_enabled(), int(ts.numel()), tuple(getattr(r.net.params, "version", 0) for r in (rt, side_rt) if r is not None),
                tuple(b.data_ptr() for b in self._blend) if self._blend is not None else None,
                sch.renoise_table().data_ptr() if (self._blend is not None and not self.foreign) else 0)
         if key == self._key and self.program is not None:
@@ -212,8 +212,9 @@ class DenoiseLoop:
             tabs[k] = dict(table=torch.zeros(int(ts.numel()), total, dtype=torch.float32, device=ts.device), ts=None,
                            plan=None)
         ent = tabs[k]
-        if ent["plan"] is not r.step_plan:           # new weights / new plan: the rows are stale
-            ent["plan"], ent["ts"] = r.step_plan, None
+        pver = getattr(r.net.params, "version", 0)
+        if ent["plan"] is not r.step_plan or ent.get("pver") != pver:     # new plan / weights rewritten in place: stale rows
+            ent["plan"], ent["ts"], ent["pver"] = r.step_plan, None, pver
         return dict(idx=idx, out=out, total=total, table=ent["table"], ent=ent, rt=r)
 
     def _fill_temb_tables(self):

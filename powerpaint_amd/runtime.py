@@ -162,7 +162,7 @@ class NetRuntime:
 
     def set_context(self, ehs: torch.Tensor, force: bool = False):
         """encoder_hidden_states [B, nctx, ctx_dim]; recomputes the hoisted cross-attention K/V^T only on change."""
-        ident = (ehs.data_ptr(), ehs._version, tuple(ehs.shape))
+        ident = (ehs.data_ptr(), ehs._version, tuple(ehs.shape), getattr(self.net.params, "version", 0))
         if not force and ident == self._ctx_id:
             return
         dst = self.arena.view(self.lay["ehs"], (self.B, self.nctx, self.net.ctx_dim), self.net.dtype)
