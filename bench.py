@@ -478,6 +478,8 @@ def main():
                        "weight_broadcast_s": round(bcast_s, 4), "ranks": rank_log},
             "ms_per_denoise_step": ms_denoise_step,
             "unet_step_mfma_util": tflop_step / (ms_denoise_step * 1e-3) / MFMA_PEAK_TFLOPS,
+            "launches_per_denoise_step": len(pipe._loop.program.calls) if getattr(pipe, "_loop", None) is not None
+            and getattr(pipe._loop, "program", None) is not None else None,
         }
         if not args.no_roofline:
             try:

@@ -29,7 +29,7 @@ extern "C" {
 #define PP_ERR_LAUNCH (-3)       /* hipLaunchKernel / hipFuncSetAttribute failed                  */
 #define PP_ERR_WORKSPACE (-4)    /* workspace pointer null or too small                           */
 
-#define PP_ABI_VERSION 15
+#define PP_ABI_VERSION 16
 /* 16-bit storage format of activations and matrix weights ("dtype" arguments; the same codes pp_nchw_to_nhwc uses for
  * its source): bf16 or fp16 -- the reference's default is fp16 (/root/reference/app.py:548,559).  MFMA accumulation,
  * norm statistics, softmax, biases and latents are fp32 with either. */
@@ -169,6 +169,11 @@ int pp_gemm_gn_stats_ok(const PPGemmArgs* args);
 /* 1 if pp_gemm_bf16 runs this PP_X_CONV3X3 request with the GroupNorm + SiLU of its input fused into the loader
  * (gn_in_acc / gn_in_gb set), else 0 -- the caller then keeps pp_groupnorm_apply_acc + a plain conv. */
 int pp_conv_gn_supported(const PPGemmArgs* args);
+/* (ABI v16) 1 if the fused launch is supported AND, by the per-shape measurements on MI355X (profiles/
+ * r04_conv_gn_variants.txt), at least as fast as pp_groupnorm_apply_acc + the plain conv it replaces; the engine asks this
+ * one when it lays out a ResnetBlock2D.  The normalisation costs ~600 wave cycles per 8-pixel x 64-channel strip and is
+ * repeated per 160-column tile and per halo row: it pays at the 64 x 64 level (and where K is short), not at 8 x 8. */
+int pp_conv_gn_preferred(const PPGemmArgs* args);
 
 /* Small-M ("skinny") linear in fp32 accumulate: out[b][n] = act_in(x[b][:]) . W[n][:] + bias[n], b < rows <= 16.
  * Replaces TimestepEmbedding.linear_1/linear_2 and the 22 ResnetBlock2D.time_emb_proj (batched into one call by

@@ -343,12 +343,17 @@ __global__ void __launch_bounds__(CG_T, 2) pp_conv_gn_kernel(const PPGemmArgs a,
         constexpr bool NT = NORM && t >= 3 && t - 3 < CG_HPW;        // a tap that carries one strip
         char* const np = smem + hbn * CG_HALO + (wave + 8 * (NT ? t - 3 : 0)) * 1024 + lane * 16;
         u32x4_t nv = {0u, 0u, 0u, 0u};
+        f32x4_t ss0 = {0.f, 0.f, 0.f, 0.f}, ss1 = {0.f, 0.f, 0.f, 0.f};     // first half of this lane's (scale, shift) row
         if constexpr (NT) {
           // (unconditional: behind the last chunk this works on the zeros of the dead DMAs in the unused buffer -- a branch
           //  around the MFMA burst would put the 80 accumulator registers through a phi and double them)
           if constexpr (t == 3) compute_scsh(c + 1, hbn);
           if constexpr (NREAD) norm_piece(hbn, t - 3);
-          else nv = *reinterpret_cast<const u32x4_t*>(np);
+          else {
+            nv = *reinterpret_cast<const u32x4_t*>(np);
+            ss0 = *reinterpret_cast<const f32x4_t*>(smem + CG_T_SCSH + kslot * 64);
+            ss1 = *reinterpret_cast<const f32x4_t*>(smem + CG_T_SCSH + kslot * 64 + 16);
+          }
           if constexpr (NREAD) __builtin_amdgcn_sched_barrier(0);
         }
         // ---- read phase: fragment reads of this K step, the DMA pieces spread between them
@@ -393,16 +398,64 @@ __global__ void __launch_bounds__(CG_T, 2) pp_conv_gn_kernel(const PPGemmArgs a,
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (NMODE != 3) __builtin_amdgcn_s_setprio(1);
         if constexpr (NT && NMODE == 1) {
-          mfma_all(wf, xf);
-          const u32x4_t o = norm_math(nv, ~(uint32_t)(hpix[NT ? t - 3 : 0] >> 31));   // all ones inside the image, else 0
-          *reinterpret_cast<u32x4_t*>(np) = o;
-          // one matrix instruction, then two of the normalisation's VALU instructions, ...; the LDS store last
-#pragma unroll
-          for (int i = 0; i < 2 * MI * NI; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, (70 + 2 * MI * NI - 1) / (2 * MI * NI), 0);
-          }
-          __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+          // One matrix instruction per slot, and behind each a fixed slice of the strip's normalisation, pinned by
+          // sched_barrier(0) -- left to the scheduler (sched_group_barrier) the 64 VALU instructions ended up BEHIND the
+          // burst as one dependent chain of LDS round trips and transcendental latencies (~600 cycles per strip, nothing
+          // hidden; profiles/r04_conv_gn_variants.txt).  The program works on two channel pairs at a time (four
+          // independent chains, a dependent instruction at least two slots = 32 cycles behind its producer, 12 live
+          // registers besides the strip itself), one transcendental per slot at most:
+          //   U unpack, F x * scale + shift, M * -log2(e), X exp2 (one per slot), A 1 +, R rcp (one per slot), S *, C pack
+          // for pairs (0, 1), then (2, 3) with the second half of the (scale, shift) row loaded meanwhile; LDS store last.
+          constexpr int NM = 2 * MI * NI, NG = 41;
+          const uint32_t vmask = ~(uint32_t)(hpix[NT ? t - 3 : 0] >> 31);   // all ones inside the image, else 0
+          const char* const sp = smem + CG_T_SCSH + kslot * 64;
+          float xa[4], ea[4];
+          u32x4_t no;
+          auto micro = [&](auto GG) __attribute__((always_inline)) {
+            constexpr int g = decltype(GG)::value;
+            if constexpr (g == 40) {
+              *reinterpret_cast<u32x4_t*>(np) = no;
+            } else {
+              constexpr int h = g / 20, gg = g % 20, p0 = 2 * h, p1 = 2 * h + 1;
+              if constexpr (gg == 0) { xa[0] = E::lo(nv[p0]); xa[1] = E::hi(nv[p0]); }
+              if constexpr (gg == 1) { xa[2] = E::lo(nv[p1]); xa[3] = E::hi(nv[p1]); }
+              if constexpr (gg == 2) { xa[0] = __builtin_fmaf(xa[0], ss0[0], ss0[1]); xa[1] = __builtin_fmaf(xa[1], ss0[2], ss0[3]); }
+              if constexpr (gg == 3) { xa[2] = __builtin_fmaf(xa[2], ss1[0], ss1[1]); xa[3] = __builtin_fmaf(xa[3], ss1[2], ss1[3]); }
+              if constexpr (gg == 4) { ea[0] = xa[0] * -1.44269504088896340736f; ea[1] = xa[1] * -1.44269504088896340736f; }
+              if constexpr (gg == 5) { ea[2] = xa[2] * -1.44269504088896340736f; ea[3] = xa[3] * -1.44269504088896340736f; }
+              if constexpr (gg == 6) {
+                ea[0] = __builtin_amdgcn_exp2f(ea[0]);
+                if constexpr (h == 0) ss0 = *reinterpret_cast<const f32x4_t*>(sp + 32);
+              }
+              if constexpr (gg == 7) {
+                ea[1] = __builtin_amdgcn_exp2f(ea[1]);
+                if constexpr (h == 0) ss1 = *reinterpret_cast<const f32x4_t*>(sp + 48);
+              }
+              if constexpr (gg == 8) ea[2] = __builtin_amdgcn_exp2f(ea[2]);
+              if constexpr (gg == 9) ea[3] = __builtin_amdgcn_exp2f(ea[3]);
+              if constexpr (gg == 10) { ea[0] += 1.0f; ea[1] += 1.0f; }
+              if constexpr (gg == 11) { ea[2] += 1.0f; ea[3] += 1.0f; }
+              if constexpr (gg == 12) ea[0] = __builtin_amdgcn_rcpf(ea[0]);
+              if constexpr (gg == 13) ea[1] = __builtin_amdgcn_rcpf(ea[1]);
+              if constexpr (gg == 14) ea[2] = __builtin_amdgcn_rcpf(ea[2]);
+              if constexpr (gg == 15) ea[3] = __builtin_amdgcn_rcpf(ea[3]);
+              if constexpr (gg == 16) { xa[0] *= ea[0]; xa[1] *= ea[1]; }
+              if constexpr (gg == 17) { xa[2] *= ea[2]; xa[3] *= ea[3]; }
+              if constexpr (gg == 18) no[p0] = E::pack2(xa[0], xa[1]) & vmask;   // (a mask, not a select: hipcc turns the
+              if constexpr (gg == 19) no[p1] = E::pack2(xa[2], xa[3]) & vmask;   //  select into a branch around the math)
+            }
+          };
+          cg_static_for<NM>([&](auto II) __attribute__((always_inline)) {
+            constexpr int i = decltype(II)::value;
+            constexpr int ks = i / (NI * MI), ni = (i / MI) % NI, mi = i % MI;
+            acc[ni][mi] = E::mfma16(wf[ks][ni], xf[ks][mi], acc[ni][mi]);
+            __builtin_amdgcn_sched_barrier(0);
+            constexpr int G0 = i * NG / NM, G1 = (i + 1) * NG / NM;
+            cg_static_for<G1 - G0>([&](auto JJ) __attribute__((always_inline)) {
+              micro(std::integral_constant<int, G0 + decltype(JJ)::value>{});
+            });
+            __builtin_amdgcn_sched_barrier(0);
+          });
         } else {
           mfma_all(wf, xf);
         }
@@ -734,3 +787,28 @@ int pp_conv_gn_run(const PPGemmArgs& a, hipStream_t st) {
 }
 
 extern "C" int pp_conv_gn_supported(const PPGemmArgs* args) { return (args && cg_supported(*args)) ? 1 : 0; }
+
+// Where the fused launch beats pp_groupnorm_apply_acc + plain conv inside the UNet step (same-box A/Bs of the headline
+// benchmark and per-launch timings, profiles/r04_conv_gn_variants.txt): the normalisation is ~600 wave cycles per strip
+// that no placement hides behind the matrix pipe, repeated per N tile (N / 160) and per halo row ((BM + 2 W) / BM):
+//   class 1  W >= 64 (256-row tiles of 4 image rows, N = 320: 3x redundancy): every shape, -10 .. -15 us per conv
+//   class 2  W = 32, at most five 64-channel chunks, one source: short K, the removed apply launch outweighs it
+//   class 4  W = 16 (N = 1280): draws per launch, wins the launch boundary
+//   class 8  W = 32 otherwise (concatenated inputs / long tails, 128-row tiles): +10 .. +40 us per launch back to back,
+//            a draw inside the step (9.61 against 9.62 ms) -- fused for the nine launches it removes
+//   class 16 W <= 8: 64-row tiles, one workgroup per CU at 10 MFMAs per wave and K step: +10 .. +26 us, NOT fused
+//            (9.76 against 9.61 ms per step with it)
+// same-box step times, masks 0 / 1 / 5 / 7 / 15 / 31: 9.75 / 9.64 / 9.62 / 9.62 / 9.61 / 9.76 ms (251 .. 207 launches)
+// (lab build: PP_CONV_GN_ROUTE = bit mask of the classes to fuse)
+extern "C" int pp_conv_gn_preferred(const PPGemmArgs* args) {
+  if (!args || !cg_supported(*args)) return 0;
+  const PPGemmArgs& a = *args;
+  const int nch = (a.c1 + a.c2) / 64;
+  int cls;
+  if (a.win >= 64) cls = 1;
+  else if (a.win == 32) cls = (nch <= 5 && a.c2 == 0) ? 2 : 8;
+  else if (a.win == 16) cls = 4;
+  else cls = a.win < 16 ? 16 : 8;
+  static const int mask = pp_lab_env("PP_CONV_GN_ROUTE", 1 | 2 | 4 | 8);
+  return (mask & cls) ? 1 : 0;
+}

@@ -326,7 +326,7 @@ class Builder:
         if fused is not None:
             a.gn_in_acc, a.gn_in_gb, a.gn_in_groups, a.gn_in_eps, a.gn_in_silu = fused[0], fused[1], fused[2], fused[3], 1
             a.dtype = self.dt
-            if not self.lib.pp_conv_gn_supported(C.byref(a)):
+            if not self.lib.pp_conv_gn_preferred(C.byref(a)):
                 # (the statistics subscription stays: the apply launch reads the same accumulators)
                 a.gn_in_acc, a.gn_in_gb, a.gn_in_groups, a.gn_in_silu = None, None, 0, 0
                 gamma, beta, gb, eps, groups = gn_in
