@@ -1529,6 +1529,7 @@ int dispatch(const PPGemmArgs& a, const Choice& c, hipStream_t st) {
       PP_V2(22, 64, 2, 2, false)
       PP_V2(32, 64, 2, 3, false)
       PP_V2(42, 64, 2, 4, false)
+      PP_V2(62, 64, 2, 5, false)    // (five stages: 140 KB, one block per CU)
       PP_V2(23, 256, 4, 2, false)
       PP_V2(33, 256, 4, 3, false)
       PP_V2(24, 128, 4, 2, false)   // 8-wave 128x160 (wave tile 32x80): 4 waves / SIMD with two co-resident blocks

@@ -61,9 +61,9 @@ __global__ void __launch_bounds__(256) xattn_fold_kernel(const uint16_t* __restr
                                                         const uint16_t* __restrict__ wq, const float* __restrict__ qcs,
                                                         const float* __restrict__ qb, const uint16_t* __restrict__ wo,
                                                         float qscale, uint32_t* __restrict__ gt, float* __restrict__ gcs,
-                                                        float* __restrict__ gb, uint32_t* __restrict__ ht) {
+                                                        float* __restrict__ gb, uint32_t* __restrict__ ht, int C) {
   using E = E16<EDT>;
-  constexpr int C = XA_C, D = XA_C / XA_HEADS;
+  const int D = C / XA_HEADS;
   const long long n_g = (long long)batch * XA_S * (C / 2), n_h = (long long)batch * C * (XA_S / 2),
                   n_v = (long long)batch * XA_S;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n_g + n_h + n_v; i += (long long)gridDim.x * 256) {
@@ -327,11 +327,237 @@ __global__ void __launch_bounds__(512, 2) xattn_block_kernel(const XAArgs a) {
   }
 }
 
+// ---- C = 640 / 1280 (the 32x32, 16x16 and 8x8 levels): the same two chained GEMMs, re-tiled for few rows -----------------
+// At those levels a 128-row tile per workgroup leaves most of the chip idle (M = 8192 / 2048 / 512 rows), so a workgroup
+// takes 64 rows (four waves of 16) and ONE 320-column group of the output: grid = (M / 64) x (C / 320).  Every column group
+// of a row tile recomputes the logits and the softmax (K = C, twice 320 logit columns) and contracts its own 320 rows of
+// H^T -- redundant MFMA work (x2 at C = 640, x4 at C = 1280) bought back by the two launches (to_q, attention) and the
+// q / o round trips that disappear: the three-launch chain costs 46 us per block at these levels, of which ~7 us are MFMA
+// work (profiles/r04_step_timeline.txt).  The input rows are not register resident (C / 32 fragments would not fit): the two
+// B fragments of a slab are loaded from global memory one slab ahead, in front of the slab DMAs of the step so that one
+// counted vmcnt covers both.  Slab = 320 weight rows x 64 k (40 KB), three-stage LDS-DMA ring, ten pieces per wave.
+template <int C, int EDT>
+__global__ void __launch_bounds__(256, 1) xattn_wide_kernel(const XAArgs a) {
+  using E = E16<EDT>;
+  typedef typename E::v8 v8_t;
+  constexpr int NS1 = C / 64, NSLAB = 2 * NS1 + 10, NSPLIT = C / 320, BM = 64, QD = XA_QD;
+  static_assert(NS1 % 2 == 0, "the first GEMM's slab loop is unrolled by two");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* tabs = reinterpret_cast<float*>(smem + XA_TAB);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r16 = lane & 15, g = lane >> 4;
+  int lid;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tile = lid / NSPLIT, cg = lid - tile * NSPLIT;       // (the column groups of a row tile share G: neighbours)
+  const int m_blk = tile * BM;
+  const int b = m_blk / a.rows_per_batch;
+  const int m = m_blk + wave * 16 + r16;
+
+  for (int i = tid; i < 2 * XA_S; i += 256)
+    tabs[i] = i < XA_S ? a.gcs[(size_t)b * XA_S + i] : a.gbias[(size_t)b * XA_S + i - XA_S];
+  float mean = 0.f, rstd = 1.f;
+  if (a.ln_stats) {
+    const f32x2_t* pm = reinterpret_cast<const f32x2_t*>(a.ln_stats) + (size_t)m * a.ln_tiles;
+    float sm = 0.f, sq = 0.f;
+    for (int t = 0; t < a.ln_tiles; ++t) { const f32x2_t v = pm[t]; sm += v[0]; sq += v[1]; }
+    mean = sm * (1.0f / C);
+    rstd = rsqrtf(fmaxf(sq * (1.0f / C) - mean * mean, 0.f) + a.ln_eps);
+  }
+
+  const int lrow = lane >> 3, kslot = (lane & 7) ^ lrow;
+  // piece j of a wave = strip wave + 4 j (8 rows): row 8 (wave + 4 j) + lrow -- the j part rides in the scalar offset
+  const int vg0 = ((8 * wave + lrow) * C + kslot * 8) * 2, vh0 = ((8 * wave + lrow) * XA_S + kslot * 8) * 2;
+  const __amdgpu_buffer_rsrc_t rs_g = make_rsrc(a.gt + (size_t)b * XA_S * C, (uint32_t)XA_S * C * 2u);
+  const __amdgpu_buffer_rsrc_t rs_h = make_rsrc(a.ht + ((size_t)b * C + (size_t)cg * 320) * XA_S, 320u * XA_S * 2u);
+  // slab t: t < NS1 the logit rows 0 .. 319 (heads 0-3) of G^T, channels 64 t ..; t < 2 NS1 rows 320 .. 639; then the ten
+  // 64-wide logit slices of this column group's 320 rows of H^T
+  // (a wave's ten pieces of a slab are NOT issued as one burst: ten back-to-back LDS-DMA instructions hold an in-order
+  //  wave ~800 cycles in VMEM issue before its first MFMA of the step -- one piece rides behind every fourth MFMA)
+  // SRC (compile time): 0 = G^T slab tn (runtime, < 2 NS1), 1 = H^T slab tn (index among the ten), -1 = nothing.  The
+  // descriptor is never chosen at run time: a run-time select between two descriptors lands in VGPRs and scratch.
+  auto issue_piece = [&](auto SRC, int tn, int stage, auto J) __attribute__((always_inline)) {
+    constexpr int src = decltype(SRC)::value, j = decltype(J)::value;
+    char* st = smem + stage * XA_SLAB + wave * 1024 + j * 4096;
+    if constexpr (src == 0) {
+      const int half = tn >= NS1 ? 1 : 0;
+      const int so = (half * 320 * C + (tn - half * NS1) * 64) * 2 + j * (32 * C * 2);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_g, (xa_lds_ptr_t)st, 16, vg0, so, 0, 0);
+    } else if constexpr (src == 1) {
+      const int so = tn * 64 * 2 + j * (32 * XA_S * 2);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_h, (xa_lds_ptr_t)st, 16, vh0, so, 0, 0);
+    }
+  };
+  const uint16_t* const xr = a.x + (size_t)m * a.ldx + g * 8;
+  auto load_x = [&](int t, v8_t (&dst)[2]) __attribute__((always_inline)) {
+    const int kt = t >= NS1 ? t - NS1 : t;
+    dst[0] = *reinterpret_cast<const v8_t*>(xr + kt * 64);
+    dst[1] = *reinterpret_cast<const v8_t*>(xr + kt * 64 + 32);
+  };
+
+  f32x4_t acc[20];
+  uint32_t pf[20][4];
+#pragma unroll
+  for (int nb = 0; nb < 20; ++nb) acc[nb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  auto softmax_half = [&](auto HF) __attribute__((always_inline)) {
+    constexpr int hf = decltype(HF)::value;
+#pragma unroll
+    for (int hh = 0; hh < 4; ++hh) {
+      float s[20];
+      float mx = -INFINITY;
+#pragma unroll
+      for (int q = 0; q < 5; ++q) {
+        const int n0 = hf * 320 + (5 * hh + q) * 16 + 4 * g;
+        const f32x4_t cs = *reinterpret_cast<const f32x4_t*>(tabs + n0);
+        const f32x4_t gb = *reinterpret_cast<const f32x4_t*>(tabs + XA_S + n0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          s[q * 4 + i] = rstd * (acc[5 * hh + q][i] - mean * cs[i]) + gb[i];
+          mx = fmaxf(mx, s[q * 4 + i]);
+        }
+        acc[5 * hh + q] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      float sum = 0.f;
+#pragma unroll
+      for (int i = 0; i < 20; ++i) {
+        s[i] = __builtin_amdgcn_exp2f(s[i] - mx);
+        sum += s[i];
+      }
+      sum += __shfl_xor(sum, 16, 64);
+      sum += __shfl_xor(sum, 32, 64);
+      const float inv = __builtin_amdgcn_rcpf(sum);
+#pragma unroll
+      for (int q = 0; q < 5; ++q) {
+        const int gbk = hf * 20 + 5 * hh + q;
+        pf[gbk >> 1][(gbk & 1) * 2 + 0] = E::pack2(s[q * 4 + 0] * inv, s[q * 4 + 1] * inv);
+        pf[gbk >> 1][(gbk & 1) * 2 + 1] = E::pack2(s[q * 4 + 2] * inv, s[q * 4 + 3] * inv);
+      }
+    }
+  };
+
+  // one slab against the wave's two B fragments: 40 weight fragments, QD reads in flight ahead of the MFMA that consumes
+  // the oldest (the hand-made pipeline of xattn_block_kernel)
+  const int so0 = ((0 * 4 + g) ^ (r16 & 7)) << 4, so1 = ((1 * 4 + g) ^ (r16 & 7)) << 4;
+  auto slab_mma = [&](const char* st, const v8_t b0, const v8_t b1, auto SRC, int tn, int stage_n) __attribute__((always_inline)) {
+    v8_t q[QD + 1];
+    auto load_frag = [&](int i) __attribute__((always_inline)) -> v8_t {
+      return *reinterpret_cast<const v8_t*>(st + ((i % 20) * 16 + r16) * 128 + (i < 20 ? so0 : so1));
+    };
+#pragma unroll
+    for (int i = 0; i < QD; ++i) q[i] = load_frag(i);
+    xa_static_for<40>([&](auto I) __attribute__((always_inline)) {
+      constexpr int i = decltype(I)::value;
+      if constexpr (i + QD < 40) q[(i + QD) % (QD + 1)] = load_frag(i + QD);
+      __builtin_amdgcn_sched_barrier(0);
+      acc[i % 20] = E::mfma16(q[i % (QD + 1)], i < 20 ? b0 : b1, acc[i % 20]);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (i % 4 == 1 && decltype(SRC)::value >= 0) {      // DMA piece i / 4 of the slab two steps ahead
+        issue_piece(SRC, tn, stage_n, std::integral_constant<int, i / 4>{});
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    });
+  };
+
+  __syncthreads();                                        // the tables are in LDS
+  v8_t xq[2][2];
+  load_x(0, xq[0]);
+  __builtin_amdgcn_sched_barrier(0);
+  xa_static_for<10>([&](auto J) __attribute__((always_inline)) { issue_piece(std::integral_constant<int, 0>{}, 0, 0, J); });
+  xa_static_for<10>([&](auto J) __attribute__((always_inline)) { issue_piece(std::integral_constant<int, 0>{}, 1, 1, J); });
+  // ---- first GEMM: logits, one half (four heads) at a time.  Per step: x fragments of slab t + 1, then (spread over the
+  //      step's MFMAs) the DMAs of slab t + 2; the wait at the top of a step leaves only the previous step's ten DMAs in
+  //      flight.  `stage` = t % 3 is carried, not divided.
+  int stage = 0;
+  auto step1 = [&](int t, auto BUF, auto SRC, int tn) __attribute__((always_inline)) {
+    constexpr int buf = decltype(BUF)::value;
+    asm volatile("s_waitcnt vmcnt(10)\n\ts_barrier" ::: "memory");
+    if (t + 1 < 2 * NS1) load_x(t + 1, xq[buf ^ 1]);
+    __builtin_amdgcn_sched_barrier(0);                    // (x fragments in FRONT of the DMAs: see the vmcnt above)
+    const int stage_n = stage == 0 ? 2 : stage - 1;       // (t + 2) % 3
+    slab_mma(smem + stage * XA_SLAB, xq[buf][0], xq[buf][1], SRC, tn, stage_n);
+    stage = stage == 2 ? 0 : stage + 1;
+  };
+  constexpr std::integral_constant<int, 0> SG{};
+  constexpr std::integral_constant<int, 1> SH{};
+  constexpr std::integral_constant<int, 0> B0{};
+  constexpr std::integral_constant<int, 1> B1{};
+#pragma unroll 1
+  for (int t = 0; t < NS1; t += 2) {
+    step1(t, B0, SG, t + 2);
+    step1(t + 1, B1, SG, t + 3);
+  }
+  softmax_half(std::integral_constant<int, 0>{});
+#pragma unroll 1
+  for (int t = NS1; t < 2 * NS1 - 2; t += 2) {
+    step1(t, B0, SG, t + 2);
+    step1(t + 1, B1, SG, t + 3);
+  }
+  step1(2 * NS1 - 2, B0, SH, 0);                          // (the last two steps already fetch H^T slabs 0 and 1)
+  step1(2 * NS1 - 1, B1, SH, 1);
+  softmax_half(std::integral_constant<int, 1>{});
+
+  // ---- second GEMM: this column group's 320 outputs, K = 640 probabilities out of the registers
+  const int n_out = cg * 320;
+  const uint16_t* rr = a.res ? a.res + (size_t)m * a.ldres + n_out : nullptr;
+  u32x2_t rv[20];
+  f32x4_t bo[20];
+  xa_static_for<10>([&](auto U) __attribute__((always_inline)) {
+    constexpr int u = decltype(U)::value;
+    constexpr int t = 2 * NS1 + u;
+    if constexpr (u + 1 < 10) asm volatile("s_waitcnt vmcnt(10)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    if constexpr (u + 1 == 10) {
+#pragma unroll
+      for (int nb = 0; nb < 20; ++nb)
+        rv[nb] = rr ? *reinterpret_cast<const u32x2_t*>(rr + nb * 16 + 4 * g) : u32x2_t{0u, 0u};
+    }
+    const v8_t b0 = __builtin_bit_cast(v8_t, u32x4_t{pf[2 * u][0], pf[2 * u][1], pf[2 * u][2], pf[2 * u][3]});
+    const v8_t b1 = __builtin_bit_cast(v8_t, u32x4_t{pf[2 * u + 1][0], pf[2 * u + 1][1], pf[2 * u + 1][2], pf[2 * u + 1][3]});
+    slab_mma(smem + (t % XA_NS) * XA_SLAB, b0, b1, std::integral_constant<int, (u + 2 < 10 ? 1 : -1)>{}, u + 2, (t + 2) % XA_NS);
+  });
+
+  // ---- epilogue: + bias + residual, 16-bit stores, row moments of the stored values per 160-column tile
+  uint16_t* orow = a.out + (size_t)m * a.ldo + n_out;
+#pragma unroll
+  for (int nb = 0; nb < 20; ++nb)
+    bo[nb] = a.bias_o ? *reinterpret_cast<const f32x4_t*>(a.bias_o + n_out + nb * 16 + 4 * g) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+  float sm[2] = {0.f, 0.f}, sq[2] = {0.f, 0.f};
+#pragma unroll
+  for (int nb = 0; nb < 20; ++nb) {
+    const int n = nb * 16 + 4 * g;
+    const f32x4_t v = acc[nb] + bo[nb] + f32x4_t{E::lo(rv[nb][0]), E::hi(rv[nb][0]), E::lo(rv[nb][1]), E::hi(rv[nb][1])};
+    const uint32_t o0 = E::pack2(v[0], v[1]), o1 = E::pack2(v[2], v[3]);
+    *reinterpret_cast<u32x2_t*>(orow + n) = u32x2_t{o0, o1};
+    const float r0 = E::lo(o0), r1 = E::hi(o0), r2 = E::lo(o1), r3 = E::hi(o1);
+    sm[nb / 10] += (r0 + r1) + (r2 + r3);
+    sq[nb / 10] += (r0 * r0 + r1 * r1) + (r2 * r2 + r3 * r3);
+  }
+  if (a.row_stats_out) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      float s0 = sm[t], s1 = sq[t];
+      s0 += __shfl_xor(s0, 16, 64); s1 += __shfl_xor(s1, 16, 64);
+      s0 += __shfl_xor(s0, 32, 64); s1 += __shfl_xor(s1, 32, 64);
+      if (g == 0)
+        *reinterpret_cast<f32x2_t*>(a.row_stats_out + ((size_t)m * (C / 160) + 2 * cg + t) * 2) = f32x2_t{s0, s1};
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int pp_xattn_block_supported(int M, int c, int rows_per_batch, int nctx, int heads) {
-  return (c == XA_C && heads == XA_HEADS && nctx > 0 && nctx <= XA_KP && M > 0 && M % XA_BM == 0 && rows_per_batch > 0 &&
-          rows_per_batch % XA_BM == 0 && M % rows_per_batch == 0) ? 1 : 0;
+  if (heads != XA_HEADS || nctx <= 0 || nctx > XA_KP || M <= 0 || rows_per_batch <= 0 || M % rows_per_batch) return 0;
+  const int bm = c == XA_C ? XA_BM : (c == 640 || c == 1280) ? 64 : 0;     // C = 320: 128-row tiles; wider: 64-row tiles
+  return (bm && M % bm == 0 && rows_per_batch % bm == 0) ? 1 : 0;
 }
 
 extern "C" int pp_xattn_fold(const void* k, int ldk, const void* vt, int ldvt, int batch, int nctx, int heads, int c,
@@ -340,13 +566,13 @@ extern "C" int pp_xattn_fold(const void* k, int ldk, const void* vt, int ldvt, i
   if (!k || !vt || !wq || !wo || !gt || !gcs || !gbias || !ht || batch <= 0 || !pp_dt_ok(dtype)) return PP_ERR_BAD_ARG;
   if (!pp_xattn_block_supported(XA_BM, c, XA_BM, nctx, heads)) return PP_ERR_UNSUPPORTED;
   if (ldk < c || ldvt < nctx || (c & 1)) return PP_ERR_BAD_ARG;
-  const long long total = (long long)batch * XA_S * (XA_C / 2) * 2 + (long long)batch * XA_S;
+  const long long total = (long long)batch * XA_S * (c / 2) * 2 + (long long)batch * XA_S;
   const unsigned grid = (unsigned)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
   const float qscale = scale * 1.44269504088896340736f;   // the softmax runs in the exp2 domain
   PP_DT_SWITCH(dtype, hipLaunchKernelGGL((xattn_fold_kernel<EDT>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
                                          (const uint16_t*)k, ldk, (const uint16_t*)vt, ldvt, batch, nctx,
                                          (const uint16_t*)wq, q_colsum, q_bias, (const uint16_t*)wo, qscale, (uint32_t*)gt,
-                                         gcs, gbias, (uint32_t*)ht));
+                                         gcs, gbias, (uint32_t*)ht, c));
   PP_CHECK_LAUNCH("xattn_fold_kernel");
   return PP_OK;
 }
@@ -368,6 +594,27 @@ extern "C" int pp_xattn_block(const void* x, int ldx, const void* res, int ldres
   a.out = (uint16_t*)out; a.ldo = ldo;
   a.row_stats_out = row_stats_out;
   a.M = M; a.rows_per_batch = rows_per_batch;
+  if (c != XA_C) {
+    static bool wattr[2][3] = {{false, false, false}, {false, false, false}};
+    auto gow = [&](auto kern, int ci, int grid) -> int {
+      if (!wattr[ci][dtype]) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, XA_LDS) !=
+            hipSuccess) {
+          pp_set_last_error("hipFuncSetAttribute(xattn wide)", hipGetLastError());
+          return PP_ERR_LAUNCH;
+        }
+        wattr[ci][dtype] = true;
+      }
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(256), XA_LDS, (hipStream_t)stream, a);
+      PP_CHECK_LAUNCH("xattn_wide_kernel");
+      return PP_OK;
+    };
+    if (c == 640)
+      return dtype == PP_DT_F16 ? gow(xattn_wide_kernel<640, PP_DT_F16>, 0, (M / 64) * 2)
+                                : gow(xattn_wide_kernel<640, PP_DT_BF16>, 0, (M / 64) * 2);
+    return dtype == PP_DT_F16 ? gow(xattn_wide_kernel<1280, PP_DT_F16>, 1, (M / 64) * 4)
+                              : gow(xattn_wide_kernel<1280, PP_DT_BF16>, 1, (M / 64) * 4);
+  }
   static bool attr_set[3] = {false, false, false};
   auto go = [&](auto kern, int slot) -> int {
     if (!attr_set[slot] || slot == 0) {

@@ -469,6 +469,13 @@ class SDNet:
     # launch each, K / V folded into the projections once per prompt (pp_xattn_fold in the setup plan): 55 against 66 us
     # per block at 64x64, step -0.55 % (profiles/r03_xattn_fused_ab.txt).  (lab) PP_XATTN_FUSED=0: the three-launch chain
     fuse_xattn = _lab_switch("PP_XATTN_FUSED")
+    # round 4: the same for C = 640 / 1280 (64-row tiles x 320-column groups, xattn_wide_kernel).  (lab) PP_XATTN_WIDE=0
+    # keeps the chain at those levels
+    fuse_xattn_wide = _lab_switch("PP_XATTN_WIDE")
+    # ... up to this width: at C = 1280 the kernel loses (59 against 47 us per block: four column groups recompute the
+    # logits, and a 4-wave workgroup pays ~150 cycles of issue per LDS-DMA piece with no partner wave to hide it);
+    # (lab) PP_XATTN_WIDE_C=1280 runs it there too
+    xattn_wide_max_c = int(os.environ.get("PP_XATTN_WIDE_C", "640")) if os.environ.get("PP_LAB") == "1" else 640
     # ResnetBlock2D.conv_shortcut merged into conv2 as a 1x1 K tail (needs 64-channel multiples; (lab) PP_MERGE_SHORTCUT=0 off)
     _merge_shortcut_env = _lab_switch("PP_MERGE_SHORTCUT")
 
@@ -883,7 +890,8 @@ class SDNet:
                           vt_col0=c, vt_ld=ldvt, rows_per_batch=nctx, name="linear")
             self.kv[pre] = (k, c, vt, ldvt)
             tbq = f"{tb}.attn2.to_q"
-            if self.fuse_xattn and pb.lib.pp_xattn_block_supported(128, c, 128, nctx, self.heads):
+            if self.fuse_xattn and (c == 320 or (self.fuse_xattn_wide and c <= self.xattn_wide_max_c)) and \
+                    pb.lib.pp_xattn_block_supported(128, c, 128, nctx, self.heads):
                 S = self.heads * 80
                 gt, ht = pb.alloc(B * S * c * 2), pb.alloc(B * c * S * 2)
                 gcs, gb = pb.alloc(B * S * 4), pb.alloc(B * S * 4)

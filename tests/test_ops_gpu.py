@@ -599,12 +599,15 @@ def test_latent_blend_kernel():
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("fold", [True, False])
-@pytest.mark.parametrize("B,hw,nctx", [(2, 1024, 77), (3, 256, 77), (1, 128, 80), (2, 128, 5)])
-def test_fused_cross_attention_block(B, hw, nctx, fold, dtype):
-    """pp_xattn_fold + pp_xattn_block (norm2 -> attn2 -> + residual of BasicTransformerBlock at C = 320 in one launch)
-    against (a) fp32 torch of the same sub-block and (b) the three-launch chain it replaces (to_q GEMM with the folded
-    LayerNorm, pp_attention_fwd over the 77 keys, to_out GEMM + residual + row moments)."""
-    C, heads = 320, 8
+@pytest.mark.parametrize("B,hw,nctx,C", [(2, 1024, 77, 320), (3, 256, 77, 320), (1, 128, 80, 320), (2, 128, 5, 320),
+                                         (2, 1024, 77, 640), (3, 64, 77, 640), (1, 128, 5, 640),
+                                         (2, 256, 77, 1280), (3, 64, 80, 1280), (1, 192, 7, 1280)])
+def test_fused_cross_attention_block(B, hw, nctx, C, fold, dtype):
+    """pp_xattn_fold + pp_xattn_block (norm2 -> attn2 -> + residual of BasicTransformerBlock in one launch: 128-row tiles
+    at C = 320, 64-row tiles x 320-column groups at C = 640 / 1280 -- the 32x32, 16x16 and 8x8 levels) against (a) fp32
+    torch of the same sub-block and (b) the three-launch chain it replaces (to_q GEMM with the folded LayerNorm,
+    pp_attention_fwd over the 77 keys, to_out GEMM + residual + row moments)."""
+    heads = 8
     d = C // heads
     M = B * hw
     tol = 4.0 if dtype == torch.bfloat16 else 1.0                       # (fp16: 8x finer mantissa; gates 4x tighter)
@@ -652,7 +655,7 @@ def test_fused_cross_attention_block(B, hw, nctx, fold, dtype):
     old, rs_old = ops.gemm(ao, wod, bias=bo, res1=h, row_stats=True)
     check(out, old, 1.2e-2 * tol, 4e-3 * tol, "fused cross-attention block vs the three-launch chain")
     ofl = out.float()
-    rs_ref = torch.stack([ofl.reshape(M, 2, 160).sum(-1), (ofl * ofl).reshape(M, 2, 160).sum(-1)], -1)
+    rs_ref = torch.stack([ofl.reshape(M, C // 160, 160).sum(-1), (ofl * ofl).reshape(M, C // 160, 160).sum(-1)], -1)
     check(rs, rs_ref, 2e-3, 1e-5, "row moments of the stored values")
     # the folded matrices themselves
     gt, gcs, gb, ht = folded
