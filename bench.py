@@ -150,8 +150,8 @@ def roofline_pass(pipe):
     return per, flops, counts, alg_bytes, hbm_bytes
 
 
-TRAFFIC_PROFILE = "profiles/r03_hbm_traffic.json"         # tools/hbm_traffic.sh (two rocprofv3 --pmc passes of this bench)
-KERNEL_STATS_PROFILE = "profiles/r03_kernel_stats.txt"     # rocprofv3 --kernel-trace --stats of this bench (tools/gpu_round.sh)
+TRAFFIC_PROFILE = "profiles/r04_hbm_traffic.json"         # tools/hbm_traffic.sh (two rocprofv3 --pmc passes of this bench)
+KERNEL_STATS_PROFILE = "profiles/r04_kernel_stats.txt"     # rocprofv3 --kernel-trace --stats of this bench (tools/gpu_round.sh)
 
 
 def lib_sha16() -> str:
@@ -199,7 +199,7 @@ def family_replay_us(pipe, names, reps: int = 20):
 def measured_traffic():
     """HBM bytes per 3x3 implicit-GEMM launch from the committed PMC passes (two rocprofv3 --pmc runs of this benchmark
     cannot happen inside this process).  None if the profile is absent."""
-    for rel in (TRAFFIC_PROFILE, "profiles/r02_hbm_traffic.json"):
+    for rel in (TRAFFIC_PROFILE, "profiles/r03_hbm_traffic.json"):
         try:
             fam = json.load(open(os.path.join(ROOT, rel)))["families"]["conv3x3 implicit GEMM"]
             return fam["bytes_per_launch"], rel
@@ -209,18 +209,19 @@ def measured_traffic():
 
 
 def profiled_conv_launch_us():
-    """Average duration of the implicit-GEMM 3x3 kernels (template argument XMODE = 1 of pp_gemm_kernel_v2, plus the
-    split-K combine launches that finish them) in the committed rocprofv3 --stats summary of this benchmark, and the
+    """Average duration of the 3x3 convolution kernels -- pp_conv_gn_kernel (round 4: halo-tile implicit GEMM with the
+    GroupNorm + SiLU of its input in the loader) and pp_gemm_kernel_v2 with template argument XMODE = 1 (tap-major implicit
+    GEMM: 8x8 level, strided / upsampling convs) -- in the committed rocprofv3 --stats summary of this benchmark, and the
     build that summary was taken from (`# lib_sha16:` header line).  -> (us per conv launch, lib sha) or (None, None)."""
     import re
-    for rel in (KERNEL_STATS_PROFILE, "profiles/r02_kernel_stats.txt"):
+    for rel in (KERNEL_STATS_PROFILE, "profiles/r03_kernel_stats.txt"):
         try:
             calls, total_ms, sha = 0, 0.0, None
             for line in open(os.path.join(ROOT, rel)):
                 m = re.match(r"#\s*lib_sha16:\s*(\w+)", line)
                 if m:
                     sha = m.group(1)
-                m = re.match(r"\s*(\d+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+.*pp_gemm_kernel_v2<\d+, 160, \d, 2, 1,", line)
+                m = re.match(r"\s*(\d+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+.*(pp_gemm_kernel_v2<\d+, 160, \d, 2, 1,|pp_conv_gn_kernel<)", line)
                 if m:
                     calls += int(m.group(1))
                     total_ms += float(m.group(2))
@@ -327,8 +328,9 @@ HBM_PEAK_GBS = 6290.0            # measured float4 copy, /opt/skills/guides/MI35
 
 
 def roofline_report(pipe, dump_launches=None, peak=MFMA_PEAK_TFLOPS, profile_matches=True) -> dict:
-    """`roofline` of the dominant kernel family (the implicit-GEMM 3x3 convolution launches of pp_gemm_kernel_v2 with
-    their split-K combines).  `achieved` / `frac` are a LIVE measurement of this run: the family's launches replayed as
+    """`roofline` of the dominant kernel family (the 3x3 convolution launches: pp_conv_gn_kernel -- halo-tile implicit GEMM
+    with GroupNorm + SiLU in its loader -- and pp_gemm_kernel_v2<XMODE = 1>, with their split-K combines; the FLOPs counted
+    are the convolution's MACs only, the fused normalisation is extra work of the same launches).  `achieved` / `frac` are a LIVE measurement of this run: the family's launches replayed as
     their own hipGraph between one HIP event pair (`family_replay_us`).  Next to it: `frac_event` (an event pair around
     every launch of an eager step: includes the eager launch gap) and `frac_profile` (kernel-only average of the
     committed rocprofv3 --stats summary, valid only for the build named in that file).  `hbm_roofline`: the plain
@@ -343,7 +345,8 @@ def roofline_report(pipe, dump_launches=None, peak=MFMA_PEAK_TFLOPS, profile_mat
     ach_prof = (flops[k] / counts[k]) / (prof_us * 1e-6) / 1e12 if prof_us else None
     traffic, traffic_src = measured_traffic() if profile_matches else (None, None)
     sha = lib_sha16()
-    out = {"roofline": {"bound": "mfma", "kernel": "pp_gemm_kernel_v2<...,XMODE=1,...> (implicit-GEMM 3x3 conv) + split-K combines",
+    out = {"roofline": {"bound": "mfma", "kernel": "pp_conv_gn_kernel<...> (halo-tile implicit-GEMM 3x3 conv, GroupNorm + SiLU in the loader) / "
+                                                            "pp_gemm_kernel_v2<...,XMODE=1,...> (tap-major implicit GEMM) + split-K combines",
                         "achieved": ach_live, "peak": peak, "unit": "TFLOP/s", "frac": ach_live / peak,
                         "time_base": "live: the family's launches replayed as their own hipGraph between one HIP event "
                                      "pair in this run (launch boundaries and split-K combines included)",

@@ -29,7 +29,7 @@ extern "C" {
 #define PP_ERR_LAUNCH (-3)       /* hipLaunchKernel / hipFuncSetAttribute failed                  */
 #define PP_ERR_WORKSPACE (-4)    /* workspace pointer null or too small                           */
 
-#define PP_ABI_VERSION 16
+#define PP_ABI_VERSION 17
 /* 16-bit storage format of activations and matrix weights ("dtype" arguments; the same codes pp_nchw_to_nhwc uses for
  * its source): bf16 or fp16 -- the reference's default is fp16 (/root/reference/app.py:548,559).  MFMA accumulation,
  * norm statistics, softmax, biases and latents are fp32 with either. */
@@ -153,6 +153,22 @@ typedef struct PPGemmArgs {
   int32_t gn_in_silu;   /* must be 1 (every GroupNorm in front of a 3x3 conv of the path is followed by SiLU) */
   float gn_in_eps;
   int32_t reserved3;
+  /* (ABI v17) The GroupNorm (+ SiLU) that CONSUMES this launch's output, applied by the split-K combine itself: where one
+   * workgroup of the combine owns a whole (batch item, 160-column tile) -- rows_per_batch <= 256, i.e. the 16 x 16 and 8 x 8
+   * levels -- and the consumer's groups lie whole inside the tile, the tile's fixed-point (sum, sum of squares) ARE the
+   * groups' statistics, so the combine writes `out` (the raw tensor: residual / skip consumers) AND
+   * gn_next_out = [SiLU](GroupNorm(out)) with the arithmetic of pp_groupnorm_apply_acc (bit-identical), and the separate
+   * apply launch (6.5 .. 12 us each at those levels) disappears.  gn_next_sub = which of gn_acc[0 / 1] carries the
+   * consumer's grouping (its accumulator is still updated).  Honoured only where pp_gemm_gn_next_ok() = 1; ignored
+   * (never silently: the caller asks first) otherwise.  Reference: the norm1 / norm2 / Transformer2DModel.norm modules
+   * behind a ResnetBlock2D conv, /root/reference/powerpaint/models/unet_2d_blocks.py:1274-1300. */
+  void* gn_next_out;
+  const float* gn_next_gamma;
+  const float* gn_next_beta;
+  float gn_next_eps;
+  int32_t gn_next_silu;
+  int32_t gn_next_sub;
+  int32_t reserved4;
 } PPGemmArgs;
 #define PP_GN_SUM_SCALE 16777216.0f /* 2^24 */
 #define PP_GN_SQ_SCALE 1048576.0f   /* 2^20 */
@@ -174,6 +190,9 @@ int pp_conv_gn_supported(const PPGemmArgs* args);
  * one when it lays out a ResnetBlock2D.  The normalisation costs ~600 wave cycles per 8-pixel x 64-channel strip and is
  * repeated per 160-column tile and per halo row: it pays at the 64 x 64 level (and where K is short), not at 8 x 8. */
 int pp_conv_gn_preferred(const PPGemmArgs* args);
+/* (ABI v17) 1 if this launch, as pp_gemm_bf16 would configure it, ends in the split-K combine that can apply the consumer
+ * GroupNorm of subscription `sub` (PPGemmArgs.gn_next_*), else 0. */
+int pp_gemm_gn_next_ok(const PPGemmArgs* args, int sub);
 
 /* Small-M ("skinny") linear in fp32 accumulate: out[b][n] = act_in(x[b][:]) . W[n][:] + bias[n], b < rows <= 16.
  * Replaces TimestepEmbedding.linear_1/linear_2 and the 22 ResnetBlock2D.time_emb_proj (batched into one call by

@@ -467,13 +467,13 @@ attn_pipe_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __rest
 #ifndef PP_ATTN_OPT_DEFAULT
 #define PP_ATTN_OPT_DEFAULT 29
 #endif
-template <int KB, int DBG, int EDT, int NW = 4, int QB = 1, int OPT = (KB == 32 ? PP_ATTN_OPT_DEFAULT : (PP_ATTN_OPT_DEFAULT & ~16))>
+template <int KB, int DBG, int EDT, int NW = 4, int QB = 1, int OPT = (KB == 32 ? PP_ATTN_OPT_DEFAULT : (PP_ATTN_OPT_DEFAULT & ~16)), int D = 40>
 static int launch_pipe(const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt, void* o, int ldo,
                        int batch, int heads, int nq, int nk, float sl2, hipStream_t st) {
-  using C = PCfg<40, KB, NW, (OPT & 16) ? 2 : 1>;
+  using C = PCfg<D, KB, NW, (OPT & 16) ? 2 : 1>;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_pipe_kernel<40, KB, DBG, EDT, NW, QB, OPT>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_pipe_kernel<D, KB, DBG, EDT, NW, QB, OPT>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS) != hipSuccess) {
       pp_set_last_error("hipFuncSetAttribute(attention pipe)", hipGetLastError());
       return PP_ERR_LAUNCH;
@@ -481,7 +481,7 @@ static int launch_pipe(const void* q, int ldq, const void* k, int ldk, const voi
     attr_set = true;
   }
   const dim3 grid((nq + 32 * QB * NW - 1) / (32 * QB * NW), heads, batch), block(64 * NW);
-  hipLaunchKernelGGL((attn_pipe_kernel<40, KB, DBG, EDT, NW, QB, OPT>), grid, block, C::LDS, st, (const uint16_t*)q, ldq,
+  hipLaunchKernelGGL((attn_pipe_kernel<D, KB, DBG, EDT, NW, QB, OPT>), grid, block, C::LDS, st, (const uint16_t*)q, ldq,
                      (const uint16_t*)k, ldk, (const uint16_t*)vt, ldvt, (uint16_t*)o, ldo, heads, nq, nk, sl2);
   PP_CHECK_LAUNCH("attn_pipe_kernel");
   return PP_OK;
@@ -494,7 +494,18 @@ int pp_attention_pipe_launch(const void* q, int ldq, const void* k, int ldk, con
                              hipStream_t st) {
 #define PP_ARGS q, ldq, k, ldk, vt, ldvt, o, ldo, batch, heads, nq, nk, sl2, st
   // both tile sizes need whole tiles and at least four of them (three look-ahead issues + the prologue)
-  if (d != 40 || nk % 64 != 0 || nk < 4 * 64) return PP_ERR_UNSUPPORTED;
+  if (nk % 64 != 0 || nk < 4 * 64) return PP_ERR_UNSUPPORTED;
+#ifdef PP_LAB
+  // d = 80 (the 32x32 level) on the pipelined loop, 32 queries per wave: measured and NOT shipped -- 38.6 against 36.5 us
+  // per launch for the three-phase kernel inside the step (9.515 against 9.481 ms per step; the 96-row V^T tiles leave room
+  // for one 4-wave workgroup per CU only).  PP_ATTN_PIPE80=1 in a lab build runs it.
+  if (d == 80 && pp_lab_env("PP_ATTN_PIPE80", 0)) {
+    constexpr int OPT80 = PP_ATTN_OPT_DEFAULT & ~16;
+    if (dtype == PP_DT_F16) return launch_pipe<64, 0, PP_DT_F16, 4, 1, OPT80, 80>(PP_ARGS);
+    return launch_pipe<64, 0, PP_DT_BF16, 4, 1, OPT80, 80>(PP_ARGS);
+  }
+#endif
+  if (d != 40) return PP_ERR_UNSUPPORTED;
 #ifdef PP_LAB
   // timing experiments (tools/attn_ablate.py, tools/attn_pmc.sh): PP_ATTN_KB=32 32-key tiles at 4 workgroups per CU,
   // PP_ATTN_NW=8 one 8-wave workgroup per CU, PP_ATTN_DBG ablation masks (results are garbage), PP_ATTN_QB=1|2

@@ -196,6 +196,11 @@ __global__ void __launch_bounds__(CG_T, 2) pp_conv_gn_kernel(const PPGemmArgs a,
           o[2 * h] = sv;
           o[2 * h + 1] = gbv[2 * h + 1] - mr[0] * sv;
         }
+        // (every lane stores: the eight lanes that share a k-slot write the same bytes to the same address -- an 8-way
+        //  serialised LDS store, 2.4 M bank-conflict cycles per launch in profiles/r04_gemm_pmc.txt, ~2 % of the kernel.
+        //  Letting ONE lane per k-slot store makes the table a cross-lane hand-off inside the wave: hipcc then sinks the
+        //  whole computation into the storing lanes' branch and runs the other lanes' table reads BEFORE it -- stale
+        //  (scale, shift), caught by the op tests.  A lane reads only what it wrote itself.)
         *reinterpret_cast<f32x4_t*>(smem + CG_T_SCSH + kslot * 64 + q * 16) = o;
       }
     };

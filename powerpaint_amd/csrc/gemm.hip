@@ -1270,6 +1270,126 @@ __global__ void __launch_bounds__(320) pp_splitk_reduce_gn_kernel(const PPGemmAr
   gn_flush(a, slots, m0, n_blk, ncols, tid);
 }
 
+// The lean combine of a launch whose CONSUMER is a GroupNorm (+ SiLU) apply, at the levels where one workgroup can own a
+// whole (batch item, group) population: hw = rows_per_batch <= 256 rows (16 x 16 and 8 x 8 latents), single-tensor norm.
+// Tile = all hw rows of one batch item x 40 columns -- 40 = lcm(8, channels per group) for SD-1.5's 10 / 20 / 40-channel
+// groups, so a tile holds whole groups and B x N / 40 workgroups fill the chip (8 x 32 at the 8x8 level; a 160-column tile
+// version with 64 workgroups looping over the rows was 0.9 % SLOWER on the step than the two launches it replaced).
+// The tile's fixed-point (sum, sum of squares) ARE the groups' statistics -- folded per 16-row block in the order of
+// pp_splitk_reduce_gn_kernel, so the integers the accumulators receive are the same -- and mean / rstd / scale / shift
+// follow gn_fold_acc bit for bit; the workgroup then normalises its own finished values (kept as the 16-bit words it
+// stored to `out`) into gn_next_out.  One launch less per such norm (6.5 .. 12 us each).
+template <int EDT>
+__global__ void __launch_bounds__(640) pp_splitk_reduce_gn_apply_kernel(const PPGemmArgs a, int splits, int tiles_n, int rows_pass) {
+  using E = E16<EDT>;
+  constexpr int BN = 40, EC = BN / 8, RMAX = 128;
+  __shared__ __attribute__((aligned(16))) char vals[256 * BN * 2];       // [hw][BN] 16-bit words of the finished tile
+  __shared__ __attribute__((aligned(16))) float tile[RMAX][BN + 4];
+  __shared__ unsigned long long slots[2 * GN_SLOTS * 2];
+  __shared__ __attribute__((aligned(16))) float sc_s[BN], sh_s[BN];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.x / tiles_n, tile_n = blockIdx.x - b * tiles_n;
+  const int hw = a.rows_per_batch, n_blk = tile_n * BN;
+  const int c8 = tid % EC, row = tid / EC;                 // blockDim.x = rows_pass * EC
+  const int n = n_blk + c8 * 8;
+  for (int i = tid; i < 2 * GN_SLOTS * 2; i += blockDim.x) slots[i] = 0ull;
+  const size_t slab = (size_t)a.M * a.N;
+  for (int r0 = 0; r0 < hw; r0 += rows_pass) {
+    const int m = b * hw + r0 + row;
+    const float* src = a.workspace + (size_t)m * a.N + n;
+    f32x4_t p0[8], p1[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      if (s < splits) {
+        p0[s] = *reinterpret_cast<const f32x4_t*>(src + s * slab);
+        p1[s] = *reinterpret_cast<const f32x4_t*>(src + s * slab + 4);
+      } else {
+        p0[s] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        p1[s] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    u32x4_t r1 = {0u, 0u, 0u, 0u}, r2 = {0u, 0u, 0u, 0u};
+    if (a.res1) r1 = *reinterpret_cast<const u32x4_t*>((const uint16_t*)a.res1 + (size_t)m * a.ldres1 + n);
+    if (a.res2) r2 = *reinterpret_cast<const u32x4_t*>((const uint16_t*)a.res2 + (size_t)m * a.ldres2 + n);
+    f32x4_t v0 = p0[0], v1 = p1[0];
+#pragma unroll
+    for (int s = 1; s < 8; ++s) { v0 += p0[s]; v1 += p1[s]; }
+    if (a.bias) {
+      v0 += *reinterpret_cast<const f32x4_t*>(a.bias + n);
+      v1 += *reinterpret_cast<const f32x4_t*>(a.bias + n + 4);
+    }
+    if (a.rowvec) {
+      const float* rv = a.rowvec + (size_t)b * a.ld_rowvec + n;
+      v0 += *reinterpret_cast<const f32x4_t*>(rv);
+      v1 += *reinterpret_cast<const f32x4_t*>(rv + 4);
+    }
+    v0 *= a.scale;
+    v1 *= a.scale;
+    v0[0] += E::lo(r1[0]) + E::lo(r2[0]); v0[1] += E::hi(r1[0]) + E::hi(r2[0]);
+    v0[2] += E::lo(r1[1]) + E::lo(r2[1]); v0[3] += E::hi(r1[1]) + E::hi(r2[1]);
+    v1[0] += E::lo(r1[2]) + E::lo(r2[2]); v1[1] += E::hi(r1[2]) + E::hi(r2[2]);
+    v1[2] += E::lo(r1[3]) + E::lo(r2[3]); v1[3] += E::hi(r1[3]) + E::hi(r2[3]);
+    u32x4_t o;
+    o[0] = E::pack2(v0[0], v0[1]); o[1] = E::pack2(v0[2], v0[3]);
+    o[2] = E::pack2(v1[0], v1[1]); o[3] = E::pack2(v1[2], v1[3]);
+    *reinterpret_cast<u32x4_t*>((uint16_t*)a.out + (size_t)m * a.ldo + n) = o;
+    *reinterpret_cast<u32x4_t*>(vals + ((size_t)(r0 + row) * BN + c8 * 8) * 2) = o;
+    *reinterpret_cast<f32x4_t*>(&tile[row][c8 * 8]) = f32x4_t{E::lo(o[0]), E::hi(o[0]), E::lo(o[1]), E::hi(o[1])};
+    *reinterpret_cast<f32x4_t*>(&tile[row][c8 * 8 + 4]) = f32x4_t{E::lo(o[2]), E::hi(o[2]), E::lo(o[3]), E::hi(o[3])};
+    __syncthreads();
+    // (16-row block, column) pairs: the partial sums of pp_splitk_reduce_gn_kernel, in its order
+    if (tid < (rows_pass >> 4) * BN) {
+      const int blk = tid / BN, col = tid - blk * BN;
+      float sm = 0.f, sq = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float v = tile[blk * 16 + r][col];
+        sm += v;
+        sq += v * v;
+      }
+      gn_column(a, slots, n_blk, col, sm, sq);
+    }
+    __syncthreads();
+  }
+  // the consumer's (scale, shift) of the tile's 40 columns from its complete slots: the arithmetic of gn_fold_acc
+  if (tid < BN) {
+    const int k = a.gn_next_sub, cg = a.gn_cg[k], cbase = a.gn_c0[k] + n_blk;
+    const int gl = (cbase + tid) / cg - cbase / cg;
+    const double s = (double)(long long)slots[(k * GN_SLOTS + gl) * 2] * (1.0 / (double)PP_GN_SUM_SCALE);
+    const double q = (double)(long long)slots[(k * GN_SLOTS + gl) * 2 + 1] * (1.0 / (double)PP_GN_SQ_SCALE);
+    const double cnt = (double)hw * (double)cg;
+    const double mean = s / cnt;
+    double var = q / cnt - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float meanf = (float)mean, rstdf = (float)(1.0 / sqrt(var + (double)a.gn_next_eps));
+    const float sc = rstdf * a.gn_next_gamma[n_blk + tid];
+    sc_s[tid] = sc;
+    sh_s[tid] = a.gn_next_beta[n_blk + tid] - meanf * sc;
+  }
+  __syncthreads();
+  gn_flush(a, slots, b * hw, n_blk, BN, tid);               // (the global accumulators: any second consumer reads them)
+  const f32x4_t a0 = *reinterpret_cast<const f32x4_t*>(sc_s + c8 * 8), a1 = *reinterpret_cast<const f32x4_t*>(sc_s + c8 * 8 + 4);
+  const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(sh_s + c8 * 8), b1 = *reinterpret_cast<const f32x4_t*>(sh_s + c8 * 8 + 4);
+  const bool silu = a.gn_next_silu != 0;
+  for (int r0 = 0; r0 < hw; r0 += rows_pass) {
+    const int m = b * hw + r0 + row;
+    const u32x4_t v = *reinterpret_cast<const u32x4_t*>(vals + ((size_t)(r0 + row) * BN + c8 * 8) * 2);
+    float r[8];
+    r[0] = E::lo(v[0]) * a0[0] + b0[0]; r[1] = E::hi(v[0]) * a0[1] + b0[1];
+    r[2] = E::lo(v[1]) * a0[2] + b0[2]; r[3] = E::hi(v[1]) * a0[3] + b0[3];
+    r[4] = E::lo(v[2]) * a1[0] + b1[0]; r[5] = E::hi(v[2]) * a1[1] + b1[1];
+    r[6] = E::lo(v[3]) * a1[2] + b1[2]; r[7] = E::hi(v[3]) * a1[3] + b1[3];
+    if (silu) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) r[j] = silu_f(r[j]);
+    }
+    u32x4_t o;
+    o[0] = E::pack2(r[0], r[1]); o[1] = E::pack2(r[2], r[3]);
+    o[2] = E::pack2(r[4], r[5]); o[3] = E::pack2(r[6], r[7]);
+    *reinterpret_cast<u32x4_t*>((uint16_t*)a.gn_next_out + (size_t)m * a.N + n) = o;
+  }
+}
+
 // the LEAN combine handles: no activation, bf16 output, no transposed / GEGLU / folded-LN epilogue, 16-byte aligned rows
 bool reduce_lean_ok(const PPGemmArgs& a) {
   return a.act == PP_ACT_NONE && !a.out_f32 && !a.out_vt && !a.ln_stats && a.ldo % 8 == 0 &&
@@ -1354,11 +1474,31 @@ Choice choose(const PPGemmArgs& a) {
 
 // the deterministic split-K combine (+ the GroupNorm statistics of the output, if subscribed) behind a GEMM / conv launch
 // that wrote `splitk` fp32 slabs to a.workspace
+// PPGemmArgs.gn_next_*: can the combine of this (split-K) launch apply the consumer GroupNorm of subscription `sub`?
+bool gn_next_shape_ok(const PPGemmArgs& a, int sub) {
+  if (sub < 0 || sub > 1 || !a.gn_acc[sub] || a.gn_c0[sub] != 0 || a.gn_cg[sub] < 8 || 40 % a.gn_cg[sub]) return false;
+  if (a.gn_cg[sub] * a.gn_groups[sub] != a.N || a.N % 40 || !reduce_lean_ok(a)) return false;
+  const int o = 1 - sub;      // a second subscription: its groups per 40-column tile must fit the LDS slots as well
+  if (a.gn_acc[o] && (a.gn_cg[o] < 8)) return false;
+  const int hw = a.rows_per_batch;
+  return hw >= 16 && hw <= 256 && hw % 16 == 0 && (hw <= 128 || hw % 128 == 0) && a.M % hw == 0 && a.ldo == a.N;
+}
+
 template <int EDT>
 int launch_combine(const PPGemmArgs& a, int splitk, hipStream_t st) {
   const long long total = (long long)a.M * (a.N / 8);
   int nb = (int)((total + 255) / 256);
   if (nb > 4096) nb = 4096;
+  if (a.gn_next_out && gn_next_shape_ok(a, a.gn_next_sub)) {
+    if (!a.gn_next_gamma || !a.gn_next_beta) return PP_ERR_BAD_ARG;
+    const int tn = a.N / 40;
+    const int rows_pass = a.rows_per_batch < 128 ? a.rows_per_batch : 128;
+    hipLaunchKernelGGL(pp_splitk_reduce_gn_apply_kernel<EDT>, dim3((a.M / a.rows_per_batch) * tn), dim3(rows_pass * 5), 0, st, a,
+                       splitk, tn, rows_pass);
+    PP_CHECK_LAUNCH("pp_splitk_reduce_gn_apply_kernel");
+    return PP_OK;
+  }
+  if (a.gn_next_out) return PP_ERR_UNSUPPORTED;      // (the caller asked pp_gemm_gn_next_ok() first: never a silent skip)
   if (a.gn_acc[0] || a.gn_acc[1]) {
     const int tn = (a.N + 159) / 160;
     hipLaunchKernelGGL(pp_splitk_reduce_gn_kernel<EDT>, dim3(((a.M + 15) / 16) * tn), dim3(320), 0, st, a, splitk, tn);
@@ -1559,6 +1699,18 @@ extern "C" int pp_gemm_gn_stats_ok(const PPGemmArgs* args) {
   return c.tile > 10 ? 1 : 0;
 }
 
+// the split-K factor pp_gemm_bf16 will run this launch with (1 = no combine launch behind it)
+static int planned_splitk(const PPGemmArgs& a) {
+  if (pp_conv_gn_wanted(a)) return pp_conv_gn_splitk(a);
+  const Choice c = choose(a);
+  return c.tile > 10 ? c.splitk : 1;
+}
+
+extern "C" int pp_gemm_gn_next_ok(const PPGemmArgs* args, int sub) {
+  if (!args || validate(*args) != PP_OK) return 0;
+  return (planned_splitk(*args) > 1 && gn_next_shape_ok(*args, sub)) ? 1 : 0;
+}
+
 extern "C" size_t pp_gemm_workspace_bytes(const PPGemmArgs* args) {
   if (!args || validate(*args) != PP_OK) return 0;
   if (pp_conv_gn_wanted(*args)) {
@@ -1575,6 +1727,7 @@ extern "C" int pp_gemm_bf16(const PPGemmArgs* args, void* stream) {
   const PPGemmArgs& a = *args;
   const int v = validate(a);
   if (v != PP_OK) return v;
+  if (a.gn_next_out && !(planned_splitk(a) > 1 && gn_next_shape_ok(a, a.gn_next_sub))) return PP_ERR_UNSUPPORTED;
   if (pp_conv_gn_wanted(a)) {      // norm -> SiLU -> conv3x3 as one launch (no silent fallback: pp_conv_gn_supported() tells)
     const int sk = pp_conv_gn_splitk(a);
     if (sk <= 0) return PP_ERR_UNSUPPORTED;

@@ -660,7 +660,9 @@ __global__ __launch_bounds__(128) void embed_splice_kernel(const unsigned char* 
   const V* sv = (const V*)src;
   V* dv = (V*)(out + (long long)r * row_bytes);
   const int nv = (int)(row_bytes / (long long)sizeof(V));
-  for (int i = threadIdx.x; i < nv; i += blockDim.x) dv[i] = sv[i];
+  // (gridDim.y blocks share a row: the denoise loop copies ONE 113 KB time-embedding row per step -- a single 128-thread
+  //  block took 18.7 us for it, profiles/r04_step_timeline.txt)
+  for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < nv; i += gridDim.y * blockDim.x) dv[i] = sv[i];
 }
 }  // namespace
 
@@ -673,12 +675,19 @@ extern "C" int pp_embed_splice(const void* table, const void* ext, const int32_t
   const unsigned long long al = (unsigned long long)(uintptr_t)t | (unsigned long long)(uintptr_t)e |
                                 (unsigned long long)(uintptr_t)o | (unsigned long long)row_bytes;
   hipStream_t st = (hipStream_t)stream;
+  // blocks per row: one per 4 KB of the row, as many as keep the whole launch near 256 blocks
+  auto per_row = [&](long long elem) -> unsigned {
+    long long want = (row_bytes / elem + 255) / 256, cap = 256 / (n_rows < 256 ? n_rows : 256);
+    if (want > cap) want = cap;
+    return (unsigned)(want < 1 ? 1 : want);
+  };
   if ((al & 15) == 0)
-    hipLaunchKernelGGL(embed_splice_kernel<uint4>, dim3(n_rows), dim3(128), 0, st, t, e, src_row, o, row_bytes);
+    hipLaunchKernelGGL(embed_splice_kernel<uint4>, dim3(n_rows, per_row(16)), dim3(128), 0, st, t, e, src_row, o, row_bytes);
   else if ((al & 3) == 0)
-    hipLaunchKernelGGL(embed_splice_kernel<unsigned int>, dim3(n_rows), dim3(128), 0, st, t, e, src_row, o, row_bytes);
+    hipLaunchKernelGGL(embed_splice_kernel<unsigned int>, dim3(n_rows, per_row(4)), dim3(128), 0, st, t, e, src_row, o,
+                       row_bytes);
   else
-    hipLaunchKernelGGL(embed_splice_kernel<unsigned char>, dim3(n_rows), dim3(128), 0, st, t, e, src_row, o,
+    hipLaunchKernelGGL(embed_splice_kernel<unsigned char>, dim3(n_rows, per_row(1)), dim3(128), 0, st, t, e, src_row, o,
                        row_bytes);
   PP_CHECK_LAUNCH("embed_splice_kernel");
   return PP_OK;

@@ -36,6 +36,9 @@ def _lab_switch(name: str) -> bool:
 
 # (lab) PP_GN_EPILOGUE=0: every GroupNorm keeps its own statistics launch
 GN_STATS_IN_EPILOGUE = _lab_switch("PP_GN_EPILOGUE")
+# A GroupNorm apply behind a split-K launch at the 16x16 / 8x8 levels rides in that launch's combine (PPGemmArgs.gn_next_*).
+# (lab) PP_GN_NEXT=0: the separate apply launch
+GN_NEXT_IN_COMBINE = _lab_switch("PP_GN_NEXT")
 # ResnetBlock2D's norm -> SiLU -> conv3x3 as ONE launch (csrc/conv_gn.hip).  (lab) PP_FUSE_GN_CONV=0: apply launch + conv
 FUSE_GN_CONV = _lab_switch("PP_FUSE_GN_CONV")
 
@@ -250,6 +253,7 @@ class Builder:
             a.workspace = self.alloc(ws)
         self.plan.keep.append(a)
         self.last_gemm = a
+        a._arena_top = self.arena.off       # everything this launch reads or scratches lies below (see _apply_in_producer_combine)
         self.plan.add(name, self.lib.pp_gemm_bf16, C.byref(a))
         self.plan.count(name, 2.0 * a.M * a.N * a.K)
 
@@ -331,9 +335,12 @@ class Builder:
                 a.gn_in_acc, a.gn_in_gb, a.gn_in_groups, a.gn_in_silu = None, None, 0, 0
                 gamma, beta, gb, eps, groups = gn_in
                 self.release(m)
-                xn = self.new_act(x.B, x.H, x.W, x.C + c2)
-                self.plan.add("groupnorm_apply", self.lib.pp_groupnorm_apply_acc, x.ptr, x.C, x2.ptr if x2 is not None else None,
-                              c2, x.B, x.H * x.W, groups, eps, gamma, beta, fused[0], 1, xn.ptr, self.dt)
+                xn = self._apply_in_producer_combine(x, fused[0], gamma, beta, eps, True, None) if x2 is None else None
+                if xn is None:
+                    xn = self.new_act(x.B, x.H, x.W, x.C + c2)
+                    self.plan.add("groupnorm_apply", self.lib.pp_groupnorm_apply_acc, x.ptr, x.C,
+                                  x2.ptr if x2 is not None else None, c2, x.B, x.H * x.W, groups, eps, gamma, beta, fused[0],
+                                  1, xn.ptr, self.dt)
                 m = self.mark()
                 a.x1, a.x2, a.c1, a.c2 = xn.ptr, None, x.C + c2, 0
         self._gemm(a, name)
@@ -346,10 +353,15 @@ class Builder:
         c2 = x2.C if x2 is not None else 0
         Ct = x.C + c2
         hw = x.H * x.W
-        if out is None:
-            out = self.new_act(x.B, x.H, x.W, Ct)
+        out_given = out
         x2p = x2.ptr if x2 is not None else None
         acc = self._subscribe_gn_stats(x, x2, groups)
+        if acc and x2 is None:
+            fused = self._apply_in_producer_combine(x, acc, gamma, beta, eps, silu, out_given)
+            if fused is not None:
+                return fused
+        if out is None:
+            out = self.new_act(x.B, x.H, x.W, Ct)
         if acc:
             # the statistics arrive from the epilogues of the launches that produced x (and x2): no stats launch
             self.plan.add("groupnorm_apply", self.lib.pp_groupnorm_apply_acc, x.ptr, x.C, x2p, c2, x.B, hw, groups, eps,
@@ -362,6 +374,32 @@ class Builder:
         self.plan.add("groupnorm_apply", self.lib.pp_groupnorm_apply, x.ptr, x.C, x2p, c2, x.B, hw, groups, eps,
                       gamma, beta, ws, int(silu), out.ptr, self.dt)
         self.release(m)
+        return out
+
+    def _apply_in_producer_combine(self, x: Act, acc: int, gamma: int, beta: int, eps: float, silu: bool,
+                                   out: Optional[Act]) -> Optional[Act]:
+        """The apply of a single-tensor GroupNorm whose input was written by the launch right in front of it in the plan: if
+        that launch ends in the split-K combine that owns whole (batch item, group) populations (pp_gemm_gn_next_ok: the
+        16x16 and 8x8 levels), the combine writes the normalised tensor as well and no apply launch is added.  `acc` = the
+        statistics subscription of this norm (its accumulators are still filled)."""
+        a = x.producer
+        if not GN_NEXT_IN_COMBINE or a is None or not acc or not self.plan.calls or a.gn_next_out:
+            return None
+        last = self.plan.calls[-1][1]
+        if not last or getattr(last[0], "_obj", None) is not a:      # something ran in between: its scratch may alias
+            return None
+        sub = 0 if a.gn_acc[0] == acc else 1 if a.gn_acc[1] == acc else -1
+        if sub < 0 or not self.lib.pp_gemm_gn_next_ok(C.byref(a), sub):
+            return None
+        if out is None:
+            # the producer's combine writes this tensor while it still reads its split-K slabs and residuals -- scratch the
+            # caller has RELEASED by now: allocate above everything that was live when the producer was recorded
+            self.arena.off = max(self.arena.off, getattr(a, "_arena_top", self.arena.off))
+            out = self.new_act(x.B, x.H, x.W, x.C)
+        elif out.ptr < self.arena.base + getattr(a, "_arena_top", 0):
+            return None                                     # (a caller-provided buffer that may alias that scratch)
+        a.gn_next_out, a.gn_next_gamma, a.gn_next_beta = out.ptr, gamma, beta
+        a.gn_next_eps, a.gn_next_silu, a.gn_next_sub = eps, int(silu), sub
         return out
 
     def _subscribe_gn_stats(self, x: Act, x2: Optional[Act], groups: int) -> int:

@@ -120,11 +120,12 @@ def _conv_args(x, cout, stride, up, x2, x3, x4):
 
 def conv3x3(x: torch.Tensor, w: torch.Tensor, bias=None, stride: int = 1, up: bool = False, x2=None, rowvec=None,
             res1=None, res2=None, scale: float = 1.0, tile: int = 0, splitk: int = 0, gn=None, x3=None, x4=None,
-            gn_in=None):
+            gn_in=None, gn_next=None):
     """x NHWC bf16 [B,H,W,C1] (+x2 [B,H,W,C2]); w bf16 [Cout, 9*(C1+C2)] (k = (ky*3+kx)*C + c) -> NHWC bf16.
     gn_in = (acc int64 [B][groups][2], gamma_beta fp32 [C1+C2][2], groups, eps): GroupNorm + SiLU of concat(x, x2) fused
     into the loader (x, x2 are then the RAW tensors); raises PPError(PP_ERR_UNSUPPORTED) where conv_gn_supported() is
-    False."""
+    False.  gn_next = (gamma, beta, eps, silu, sub): the GroupNorm that consumes the OUTPUT (its statistics subscription
+    is gn[sub]) applied by the split-K combine (PPGemmArgs.gn_next_*) -> returns (out, normalised)."""
     lib = L.lib()
     B, H, W, C1 = x.shape
     C2 = x2.shape[3] if x2 is not None else 0
@@ -147,6 +148,12 @@ def conv3x3(x: torch.Tensor, w: torch.Tensor, bias=None, stride: int = 1, up: bo
     a.scale, a.act, a.out, a.ldo = scale, 0, _p(out), cout
     a.tile, a.splitk = tile, splitk
     _set_gn(a, gn, ho * wo)
+    ynext = None
+    if gn_next is not None:
+        g_, b_, eps_, silu_, sub_ = gn_next
+        ynext = torch.empty_like(out)
+        a.gn_next_out, a.gn_next_gamma, a.gn_next_beta = _p(ynext), _p(g_), _p(b_)
+        a.gn_next_eps, a.gn_next_silu, a.gn_next_sub = eps_, int(silu_), sub_
     if gn_in is not None:
         acc, gb, groups, eps = gn_in
         assert gb.dtype == torch.float32 and gb.shape == (C1 + C2, 2) and gb.is_contiguous()
@@ -154,8 +161,10 @@ def conv3x3(x: torch.Tensor, w: torch.Tensor, bias=None, stride: int = 1, up: bo
     ws = lib.pp_gemm_workspace_bytes(C.byref(a))
     wsb = torch.empty(max(ws, 4) // 4, dtype=torch.float32, device=x.device) if ws else None
     a.workspace = _p(wsb)
+    if gn_next is not None and not lib.pp_gemm_gn_next_ok(C.byref(a), a.gn_next_sub):
+        raise L.PPError("pp_gemm_gn_next_ok() = 0 for this launch (PP_ERR_UNSUPPORTED)")
     L.check(lib.pp_gemm_bf16(C.byref(a), _s()), "pp_gemm_bf16(conv)")
-    return out
+    return (out, ynext) if gn_next is not None else out
 
 
 def groupnorm(x: torch.Tensor, gamma, beta, eps: float, silu: bool, groups: int = 32, x2=None):

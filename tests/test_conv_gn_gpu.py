@@ -171,3 +171,47 @@ def test_conv_gn_benchmark_shape_full_batch():
     """The launch configuration of the headline benchmark: batch 8 at 64x64, C = 320 (256 workgroups, one per CU)."""
     run_case(8, 64, 64, 320, 0, 320, epi=True, gn_out=True, seed=70)
     run_case(8, 64, 64, 640, 320, 320, seed=80)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("H,C,Cout,silu,fused_in", [(8, 1280, 1280, True, False), (16, 640, 1280, False, True), (16, 320, 320, True, True),
+                                                   (8, 256, 640, False, False), (8, 320, 320, True, True)])
+def test_groupnorm_apply_inside_the_splitk_combine(H, C, Cout, silu, fused_in, dtype):
+    """PPGemmArgs.gn_next_* (ABI v17): the GroupNorm (+ SiLU) that consumes a split-K conv's output, applied by the combine
+    at the levels where one workgroup owns a whole (batch item, 160-column tile).  Bit-identical to pp_groupnorm_apply_acc on
+    the raw output with the accumulators the same launch filled; the raw output and the accumulators themselves are those of
+    the plain split-K launch.  Producer = the tap-major conv (8x8 level) or the fused norm -> SiLU -> conv (16x16)."""
+    B, groups = 3, 32
+    x = (rnd(B, H, H, C, seed=1, scale=1.3) + 0.2).to(dtype)
+    K = 9 * C
+    w = rnd(Cout, K, seed=2, scale=K ** -0.5).to(dtype).contiguous()
+    bias, rv = rnd(Cout, seed=3), rnd(B, Cout, seed=4)
+    res = rnd(B, H, H, Cout, seed=5).to(dtype)
+    g2, b2 = rnd(Cout, seed=6) * 0.3 + 1.0, rnd(Cout, seed=7) * 0.3
+    kw = dict(rowvec=rv, res1=res, splitk=2)
+    if fused_in:
+        gi, bi = rnd(C, seed=8) * 0.3 + 1.0, rnd(C, seed=9) * 0.3
+        kw["gn_in"] = (gn_acc(x), ops.gn_gamma_beta(gi, bi), groups, 1e-5)
+    acc_a = [torch.zeros(B, groups, 2, dtype=torch.int64, device=DEV) for _ in range(2)]
+    acc_b = [torch.zeros(B, groups, 2, dtype=torch.int64, device=DEV) for _ in range(2)]
+    sub = lambda A: [(A[0], (Cout + 64) // groups, 64, groups), (A[1], Cout // groups, 0, groups)]   # noqa: E731
+    out, y = ops.conv3x3(x, w, bias, gn=sub(acc_a), gn_next=(g2, b2, 1e-5, silu, 1), **kw)
+    old = ops.conv3x3(x, w, bias, gn=sub(acc_b), **kw)
+    assert torch.equal(out, old), "raw output differs from the plain split-K launch"
+    for k in range(2):
+        assert torch.equal(acc_a[k], acc_b[k]), f"accumulators of subscription {k} differ"
+    y_ref = ops.groupnorm_apply_acc(old, acc_b[1], g2, b2, 1e-5, silu)
+    assert torch.equal(y, y_ref), f"normalised tensor differs: max {float((y.float() - y_ref.float()).abs().max()):.4g}"
+    yt = F.group_norm(old.float().permute(0, 3, 1, 2), groups, g2, b2, 1e-5)
+    yt = (F.silu(yt) if silu else yt).permute(0, 2, 3, 1)
+    tol = 1.0 if dtype == torch.bfloat16 else 0.25
+    close(y, yt, 3e-2 * tol, 1.2e-2 * tol, "combine + apply vs fp32 torch")
+
+
+def test_groupnorm_apply_in_combine_is_refused_where_it_cannot_run():
+    x = rnd(2, 32, 32, 128).to(torch.bfloat16)          # 1024 rows per batch item: no workgroup owns a group's population
+    w = rnd(320, 9 * 128, scale=0.03).to(torch.bfloat16)
+    acc = torch.zeros(2, 32, 2, dtype=torch.int64, device=DEV)
+    with pytest.raises(L.PPError):
+        ops.conv3x3(x, w, None, splitk=2, gn=[(acc, 10, 0, 32)],
+                    gn_next=(torch.ones(320, device=DEV), torch.zeros(320, device=DEV), 1e-5, True, 0))

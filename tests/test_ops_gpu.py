@@ -329,7 +329,7 @@ def test_layernorm(C):
 # ------------------------------------------------------------------------------------------------ attention
 @pytest.mark.parametrize("d,nq,nk", [(40, 256, 256), (80, 256, 256), (160, 64, 64), (40, 1024, 77), (80, 200, 77),
                                      (160, 256, 77), (40, 4096, 4096), (40, 200, 192), (40, 128, 128), (40, 64, 64),
-                                     (40, 1000, 960),
+                                     (40, 1000, 960), (80, 1024, 1024), (80, 1000, 960),
                                      # key-tail paths of attn_fwd_kernel: a last tile with <= 32 live keys computes only
                                      # its first 32-key block (77 = 64 + 13, 96 = 64 + exactly 32, 16 / 32: first tile),
                                      # 33 / 97 / 100 keep the masked full tile

@@ -1,10 +1,11 @@
 #!/bin/bash
 # Evidence run on the GPU box (one gpurun call:  gpurun --timeout 2400 -- bash tools/evidence.sh [tests|profiles]): GPU test suite (arg "tests": + the slow config-parity file), smoke, rocprofv3
 # kernel trace + HBM-traffic counters of the headline command, headline bench with cpu_baseline + live roofline,
-# configs 3 / 4 / 5 and fp16.  -> gpurun_out/r03/ ; the profiles the judge reads are copied to profiles/ by hand.
+# configs 3 / 4 / 5 and fp16.  -> gpurun_out/$ROUND/ (default r04); the profiles the judge reads are copied to profiles/ by hand.
 set -u
 cd "$(dirname "$0")/.."
-O=gpurun_out/r03
+R=${ROUND:-r04}
+O=gpurun_out/$R
 mkdir -p $O
 export TMPDIR=/tmp
 rm -f gpurun_out/parity_achieved.txt
@@ -17,9 +18,11 @@ else
 fi
 [ "${1:-}" = "profiles" ] || { timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?"; tail -2 $O/smoke.log; }
 (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d /root/repo/$O/prof -o r -- python /root/repo/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline > /root/repo/$O/prof.log 2>&1; echo "prof rc=$?")
-python tools/prof_summary.py $(find $O/prof -name "*.db" | head -1) $O/kernel_stats.txt "bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline" > /dev/null 2>&1; rm -rf $O/prof; head -14 $O/kernel_stats.txt
+DB=$(find $O/prof -name "*.db" | head -1)
+python tools/prof_summary.py $DB $O/kernel_stats.txt "bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline" > /dev/null 2>&1
+python tools/step_timeline.py $DB $O/step_timeline.txt > /dev/null 2>&1; rm -rf $O/prof; head -14 $O/kernel_stats.txt; head -3 $O/step_timeline.txt
 bash tools/hbm_traffic.sh > $O/hbm.log 2>&1; cp gpurun_out/hbm_traffic.json $O/hbm_traffic.json
-cp $O/kernel_stats.txt profiles/r03_kernel_stats.txt; cp $O/hbm_traffic.json profiles/r03_hbm_traffic.json     # (bench.py reads these)
+cp $O/kernel_stats.txt profiles/${R}_kernel_stats.txt; cp $O/hbm_traffic.json profiles/${R}_hbm_traffic.json     # (bench.py reads these)
 timeout 400 python bench.py --dump-launches $O/launches.json > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"; tail -c 1800 $O/bench.json
 timeout 600 python bench.py --config v2 --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_v2.json 2>> $O/bench.err; echo "v2 rc=$?"
 timeout 600 python bench.py --config controlnet --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_controlnet.json 2>> $O/bench.err; echo "cn rc=$?"

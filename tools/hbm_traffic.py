@@ -30,6 +30,10 @@ def per_kernel(dbdir, counter):
 
 
 def family(kn):
+    if "pp_conv_gn_kernel" in kn:       # round 4: the halo-tile conv with GroupNorm + SiLU in its loader (csrc/conv_gn.hip)
+        return "conv3x3 implicit GEMM"
+    if "xattn_" in kn:
+        return "fused cross-attention block"
     if "pp_gemm_kernel" in kn:
         args = kn.split("<")[1].split(">")[0].replace(" ", "").split(",")
         conv = args[4] == "1"
