@@ -53,11 +53,18 @@ def test_full_size_plans_and_flop_accounting():
         from powerpaint_amd.engine import GN_STATS_IN_EPILOGUE
         fused_out = 1 if (kind == "unet" and SDNet.fuse_conv_out and GN_STATS_IN_EPILOGUE) else 0
         # ... and the two norms of every ResnetBlock2D (22 / 22 / 10 blocks) run in the loader of the conv that consumes them
-        # (csrc/conv_gn.hip, PPGemmArgs.gn_in_*): at 64x64 latents every level has a tile of whole image rows
-        from powerpaint_amd.engine import FUSE_GN_CONV
-        n_cg = {"unet": 44, "brushnet": 44, "controlnet": 20}[kind] if (FUSE_GN_CONV and GN_STATS_IN_EPILOGUE) else 0
+        # (csrc/conv_gn.hip, PPGemmArgs.gn_in_*) wherever pp_conv_gn_preferred says the fused launch is the faster one: every
+        # level but the 8x8 one (7 / 7 / 4 blocks there; round 4, profiles/r04_conv_gn_variants.txt)
+        from powerpaint_amd.engine import FUSE_GN_CONV, GN_NEXT_IN_COMBINE
+        n_cg = {"unet": 30, "brushnet": 30, "controlnet": 12}[kind] if (FUSE_GN_CONV and GN_STATS_IN_EPILOGUE) else 0
         assert sum(1 for a in rt.step_plan.keep if getattr(a, "gn_in_acc", None)) == n_cg
-        assert names.count("groupnorm_apply") == n_gn - fused_out - n_cg
+        # ... and a single-tensor norm right behind a split-K launch at the 16x16 / 8x8 levels is applied by that launch's
+        # combine (PPGemmArgs.gn_next_*): the non-concatenated resnet norms of the 8x8 level and the transformer norms of
+        # the 16x16 level and of the mid block
+        n_next = ({"unet": 17, "brushnet": 17, "controlnet": 11}[kind]
+                  if (GN_NEXT_IN_COMBINE and FUSE_GN_CONV and GN_STATS_IN_EPILOGUE) else 0)
+        assert sum(1 for a in rt.step_plan.keep if getattr(a, "gn_next_out", None)) == n_next
+        assert names.count("groupnorm_apply") == n_gn - fused_out - n_cg - n_next
         if fused_out:
             assert names.count("conv_out") == 1
         # GroupNorm statistics come out of the producing GEMMs' epilogues -- every producer is a GEMM-family launch
@@ -67,12 +74,13 @@ def test_full_size_plans_and_flop_accounting():
             assert n_stats == 0 and names.count("zero_u64") == 1 and "conv3x3_direct" not in names
         else:
             assert n_stats == n_gn
-        # ... and the C = 320 cross-attention sub-blocks (to_q -> attention -> to_out) are one pp_xattn_block launch each,
-        # their K / V folded into the projections by pp_xattn_fold in the setup plan
+        # ... and the C = 320 and (round 4) C = 640 cross-attention sub-blocks (to_q -> attention -> to_out) are one
+        # pp_xattn_block launch each, their K / V folded into the projections by pp_xattn_fold in the setup plan
         n_x = names.count("xattn_block")
-        assert n_x == ({"unet": 5, "brushnet": 5, "controlnet": 2}[kind] if SDNet.fuse_xattn else 0)
+        per_width = {"unet": 5, "brushnet": 5, "controlnet": 2}[kind]
+        assert n_x == ((per_width * (2 if SDNet.fuse_xattn_wide else 1)) if SDNet.fuse_xattn else 0)
         assert [c[2] for c in rt.setup_plan.calls].count("xattn_fold") == n_x
-        assert len(names) == exp[kind][1] - (n_gn - n_stats) + names.count("zero_u64") - fused_out - 2 * n_x - n_cg
+        assert len(names) == exp[kind][1] - (n_gn - n_stats) + names.count("zero_u64") - fused_out - 2 * n_x - n_cg - n_next
         assert len(rt.setup_plan.calls) >= 15
 
 
