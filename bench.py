@@ -348,6 +348,8 @@ def roofline_report(pipe, dump_launches=None, peak=MFMA_PEAK_TFLOPS, profile_mat
     out = {"roofline": {"bound": "mfma", "kernel": "pp_conv_gn_kernel<...> (halo-tile implicit-GEMM 3x3 conv, GroupNorm + SiLU in the loader) / "
                                                             "pp_gemm_kernel_v2<...,XMODE=1,...> (tap-major implicit GEMM) + split-K combines",
                         "achieved": ach_live, "peak": peak, "unit": "TFLOP/s", "frac": ach_live / peak,
+                        "note": "FLOPs = the convolutions' MACs only; since round 4 the launches of this family also carry the "
+                                "GroupNorm + SiLU of their inputs (30 of 44 resnet norms per UNet forward: separate launches before)",
                         "time_base": "live: the family's launches replayed as their own hipGraph between one HIP event "
                                      "pair in this run (launch boundaries and split-K combines included)",
                         "avg_launch_us": live_us / n_live,
