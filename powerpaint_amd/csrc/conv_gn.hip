@@ -689,8 +689,20 @@ CGChoice cg_choose(const PPGemmArgs& a) {
   // explicit tile request (PP_TILE_256x160 / 128x160 / 64x160), else: the largest tile that still fills the chip;
   // failing that the largest tile, split over the channel chunks
   const int want = a.tile == PP_TILE_256x160 ? 256 : a.tile == PP_TILE_128x160 ? 128 : a.tile == PP_TILE_64x160 ? 64 : 0;
+  const int nch0 = (a.c1 + a.c2) / 64;
+  // long K on half a chip's worth of 256-row tiles: two K splits of the 256-row tile (40 MFMAs per wave and K step, one
+  // halo strip in three normalised per output row less) beat one pass of 128-row tiles from ~13 chunks on, combine
+  // included -- 179 against 211 us at K = 17280, 135 / 147 at 11520, 105 / 116 at 8640, a draw at 5760 (32x32 level,
+  // profiles/r04_rejected_experiments.txt item 8).  (lab) PP_CONV_GN_SK2 = the chunk count from which, 0 = never
+  static const int sk2_from = pp_lab_env("PP_CONV_GN_SK2", 12);
   if (want && cg_shape_ok(a, want)) c.bm = want;
   else if (cg_shape_ok(a, 256) && tiles(256) >= 224) c.bm = 256;
+  else if (sk2_from > 0 && nch0 >= sk2_from && a.splitk <= 0 && cg_shape_ok(a, 256) && tiles(256) * 2 >= 224 &&
+           tiles(256) < 224 && cg_shape_ok(a, 128) && tiles(128) >= 224) {
+    c.bm = 256;
+    c.splitk = 2;
+    return c;
+  }
   else if (cg_shape_ok(a, 128) && tiles(128) >= 224) c.bm = 128;
   else if (cg_shape_ok(a, 256)) c.bm = 256;
   else if (cg_shape_ok(a, 128)) c.bm = 128;

@@ -62,10 +62,14 @@ def main():
     ap.add_argument("--out", default="")
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--tile", type=int, default=0)
+    ap.add_argument("--splitk", type=int, default=0)
+    ap.add_argument("--only-h", type=int, default=0, help="only the shapes of this latent size")
     args = ap.parse_args()
     dev, dt, B = "cuda", torch.bfloat16, args.batch
     rows, tot = [], {"fused": 0.0, "conv": 0.0, "apply": 0.0}
     for (H, C1, C2, Cout, C3, C4, cnt) in SHAPES:
+        if args.only_h and H != args.only_h:
+            continue
         g = torch.Generator("cpu").manual_seed(H + C1 + C2)
         mk = lambda *s: torch.randn(*s, generator=g).to(dev).to(dt)  # noqa: E731
         x1 = mk(B, H, H, C1)
@@ -80,7 +84,7 @@ def main():
         acc = gn_acc(torch.cat([x1, x2], -1) if C2 else x1)
         gb = ops.gn_gamma_beta(gam, bet)
         y = ops.groupnorm_apply_acc(x1, acc, gam, bet, 1e-5, True, x2=x2)
-        t_f = timed(lambda: ops.conv3x3(x1, w, bias, x2=x2, x3=x3, x4=x4, gn_in=(acc, gb, 32, 1e-5), tile=args.tile), args.rep) \
+        t_f = timed(lambda: ops.conv3x3(x1, w, bias, x2=x2, x3=x3, x4=x4, gn_in=(acc, gb, 32, 1e-5), tile=args.tile, splitk=args.splitk), args.rep) \
             if ops.conv_gn_supported(x1, Cout, x2=x2, x3=x3, x4=x4) else float("nan")
         t_c = timed(lambda: ops.conv3x3(y, w, bias, x3=x3, x4=x4), args.rep)
         t_a = timed(lambda: ops.groupnorm_apply_acc(x1, acc, gam, bet, 1e-5, True, x2=x2), args.rep)
