@@ -196,13 +196,16 @@ __global__ void __launch_bounds__(CG_T, 2) pp_conv_gn_kernel(const PPGemmArgs a,
           o[2 * h] = sv;
           o[2 * h + 1] = gbv[2 * h + 1] - mr[0] * sv;
         }
-        // (every lane stores: the eight lanes that share a k-slot write the same bytes to the same address -- an 8-way
-        //  serialised LDS store, 2.4 M bank-conflict cycles per launch in profiles/r04_gemm_pmc.txt, ~2 % of the kernel.
-        //  Letting ONE lane per k-slot store makes the table a cross-lane hand-off inside the wave: hipcc then sinks the
-        //  whole computation into the storing lanes' branch and runs the other lanes' table reads BEFORE it -- stale
-        //  (scale, shift), caught by the op tests.  A lane reads only what it wrote itself.)
-        *reinterpret_cast<f32x4_t*>(smem + CG_T_SCSH + kslot * 64 + q * 16) = o;
+        // One lane per k-slot stores (lrow == 0): the eight lanes that share a k-slot hold the same bytes for the same
+        // address, an 8-way serialised LDS store (2.4 M bank-conflict cycles per launch in profiles/r04_gemm_pmc.txt).
+        // That makes the table a CROSS-LANE hand-off inside the wave, so the stores are fenced from the table reads that
+        // follow by the asm statement behind this function's loop: without it hipcc sank the computation into the storing
+        // lanes' branch and ran the other lanes' reads first (stale coefficients; the op tests caught it).
+        if (lrow == 0) *reinterpret_cast<f32x4_t*>(smem + CG_T_SCSH + kslot * 64 + q * 16) = o;
       }
+      // every lane, after the storing lanes' branch: the wave's LDS operations execute in order, the compiler may not move
+      // a later table read above this statement
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     };
     // in-place normalisation of this lane's 16 bytes of halo strip (wave + 8 j) in buffer hbuf: what the lane's own DMA
     // wrote (ordered by the wave's vmcnt), rounded exactly as pp_groupnorm_apply_acc stores it; pixels outside the image

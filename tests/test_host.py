@@ -1,5 +1,6 @@
 """CPU: host logic of the product (plan compilation, parameter packing, schedulers' coefficient tables, sharding and
 the world-size-2 weight broadcast over gloo).  No kernel is launched here."""
+import ctypes as C
 import os
 import sys
 
@@ -518,3 +519,47 @@ def test_time_embedding_chain_is_where_the_loop_expects_it():
         assert names == ["timestep_embedding", "linear_skinny", "linear_skinny", "linear_skinny"], (kind, names)
         assert info["total"] == net.temb_total and tuple(info["table"].shape) == (7, net.temb_total)
         assert sum(c[2] in ("timestep_embedding", "linear_skinny") for c in rt.step_plan.calls) == 4
+
+
+def test_apply_inside_the_combine_never_aliases_what_the_producer_still_reads():
+    """PPGemmArgs.gn_next_out is written by the producer's split-K combine WHILE that kernel reads the split-K slabs and the
+    residual operands -- scratch the launch-plan compiler has released by the time the consuming norm is compiled.  The
+    engine therefore places the normalised tensor above everything that was live when the producer was recorded
+    (Builder._apply_in_producer_combine); this walks the full-size plans of all three networks and checks that no such
+    output overlaps an operand of its own launch, and that it is consumed (as a conv / linear input) later in the plan."""
+    from powerpaint_amd.engine import GN_NEXT_IN_COMBINE
+    if not GN_NEXT_IN_COMBINE:
+        pytest.skip("PP_GN_NEXT=0")
+
+    def span(ptr, nbytes):
+        return (int(ptr), int(ptr) + int(nbytes)) if ptr else None
+
+    def overlap(a, b):
+        return a is not None and b is not None and a[0] < b[1] and b[0] < a[1]
+
+    for kind, cin, tot, nk in (("unet", 9, 9, {}), ("brushnet", 4, 9, dict(conditioning_channels=5)),
+                               ("controlnet", 4, 4, dict(conditioning_channels=3))):
+        net = SDNet(kind, cin, **nk)
+        net.load_state_dict(net.synthetic_state_dict(meta=True), "cpu", materialize=False)
+        rt = NetRuntime(net, "cpu")
+        rt.ensure(8, 64, 64, 77, tot, ("plain",), cond_hw=(512, 512))
+        keep = list(rt.step_plan.keep)
+        n = 0
+        for i, a in enumerate(keep):
+            if not a.gn_next_out:
+                continue
+            n += 1
+            out = span(a.gn_next_out, a.M * a.N * 2)
+            from powerpaint_amd import _lib as L_
+            sk = L_.lib().pp_gemm_workspace_bytes(C.byref(a))
+            assert sk > 0, "gn_next_out on a launch without a split-K combine"
+            hw_in = a.batch * a.hin * a.win if a.x_mode else a.M
+            operands = {"workspace": span(a.workspace, sk), "out": span(a.out, a.M * a.ldo * 2),
+                        "res1": span(a.res1, a.M * a.ldres1 * 2), "res2": span(a.res2, a.M * a.ldres2 * 2),
+                        "x1": span(a.x1, hw_in * a.c1 * 2), "x2": span(a.x2, hw_in * a.c2 * 2),
+                        "x3": span(a.x3, a.M * a.c3 * 2), "x4": span(a.x4, a.M * a.c4 * 2)}
+            for name, sp in operands.items():
+                assert not overlap(out, sp), (kind, i, name, out, sp)
+            # ... and somebody reads it: the next launches' x1
+            assert any(b.x1 == a.gn_next_out for b in keep[i + 1:i + 4]), (kind, i, "normalised tensor is never consumed")
+        assert n == {"unet": 17, "brushnet": 17, "controlnet": 11}[kind]
