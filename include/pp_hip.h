@@ -29,7 +29,7 @@ extern "C" {
 #define PP_ERR_LAUNCH (-3)       /* hipLaunchKernel / hipFuncSetAttribute failed                  */
 #define PP_ERR_WORKSPACE (-4)    /* workspace pointer null or too small                           */
 
-#define PP_ABI_VERSION 17
+#define PP_ABI_VERSION 18
 /* 16-bit storage format of activations and matrix weights ("dtype" arguments; the same codes pp_nchw_to_nhwc uses for
  * its source): bf16 or fp16 -- the reference's default is fp16 (/root/reference/app.py:548,559).  MFMA accumulation,
  * norm statistics, softmax, biases and latents are fp32 with either. */
@@ -331,6 +331,22 @@ int pp_cfg_sched_step(const float* eps2, int cfg, float guidance, float* latents
 int pp_ddim_variance_noise(float* latents, const float* noise, int n, const float* coef_table, const int32_t* step_dev,
                            void* stream);
 
+/* (ABI v18) Front end of Transformer2DModel at C = 320 in one launch (csrc/tfront.hip):
+ *     hs = proj_in(GroupNorm(x)),   q | k | v = to_q / to_k / to_v(LayerNorm1(hs))
+ * i.e. `hidden_states = self.norm(hidden_states); hidden_states = self.proj_in(hidden_states)` of diffusers 0.27
+ * Transformer2DModel.forward plus `norm_hidden_states = self.norm1(hidden_states)` and the attn1 projections of
+ * BasicTransformerBlock.forward (ctor site /root/reference/powerpaint/models/unet_2d_blocks.py:1289-1300).  x: raw rows
+ * [M][c]; gn_acc: the (sum, sum of squares) accumulators of x in the format of PPGemmArgs.gn_acc, complete before the launch;
+ * w1 / b1: proj_in [c][c] ([out][in]) and bias; w2p: the QKV weight [3c][c] with LayerNorm1's gamma folded in AND its input
+ * index permuted inside every group of 32 (position 8 kg + j holds index 16 (j >> 2) + 4 kg + (j & 3): the MFMA
+ * accumulator layout of the first GEMM is then the B-operand layout of the second); cs2 / b2: its column sums and W beta.
+ * Outputs: hs [M][c] (the residual of attn1.to_out), qk [M][>= 2c] = Q | K, vt [batch][c][ldvt] = V transposed -- what
+ * pp_attention_fwd reads.  Arithmetic = pp_groupnorm_apply_acc -> pp_gemm_bf16(row_stats_out) -> pp_gemm_bf16(ln_stats)
+ * up to the fp32 summation order.  pp_tfront_supported() = 1 for c = 320, 128-row tiles inside one batch item. */
+int pp_tfront_supported(int M, int c, int rows_per_batch, int gn_groups);
+int pp_tfront(const void* x, int ldx, const void* gn_acc, const float* gn_gamma, const float* gn_beta, float gn_eps, int gn_groups,
+              const void* w1, const float* b1, const void* w2p, const float* cs2, const float* b2, float ln_eps, void* hs,
+              int ldhs, void* qk, int ldqk, void* vt, int ldvt, int M, int c, int rows_per_batch, int dtype, void* stream);
 /* Fused cross-attention sub-block of BasicTransformerBlock (norm2 -> attn2 -> residual) for C = 320, 8 heads, <= 80
  * context tokens -- the three launches `to_q` (pp_gemm_bf16, LayerNorm folded) -> pp_attention_fwd -> `to_out`
  * (pp_gemm_bf16 + residual + row moments) of the 64x64 level as ONE (ctor site /root/reference/powerpaint/models/

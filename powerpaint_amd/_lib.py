@@ -16,7 +16,7 @@ PP_ACT_NONE, PP_ACT_GEGLU, PP_ACT_SILU = 0, 1, 2
 PP_TILE_AUTO, PP_TILE_128x160, PP_TILE_64x160, PP_TILE_256x160 = 0, 1, 2, 3
 PP_DT_F32, PP_DT_BF16, PP_DT_F16 = 0, 1, 2      # dtype codes of the C ABI (include/pp_hip.h)
 PP_ATTN_AUTO, PP_ATTN_PHASED, PP_ATTN_PIPE_Q32, PP_ATTN_PIPE_Q64 = 0, 1, 2, 3   # pp_attention_fwd_variant
-ABI_VERSION = 17                                  # PP_ABI_VERSION of include/pp_hip.h this binding was written against
+ABI_VERSION = 18                                  # PP_ABI_VERSION of include/pp_hip.h this binding was written against
 PP_ERR = {0: "PP_OK", -1: "PP_ERR_BAD_ARG", -2: "PP_ERR_UNSUPPORTED", -3: "PP_ERR_LAUNCH", -4: "PP_ERR_WORKSPACE"}
 
 vp, i32, f32, sz = C.c_void_p, C.c_int32, C.c_float, C.c_size_t
@@ -92,6 +92,9 @@ SIGNATURES = {
     "pp_gn_conv3x3_smallcout_supported": (C.c_int, [C.c_int] * 3),
     "pp_gn_conv3x3_smallcout": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, vp, vp, vp, vp, vp,
                                           C.c_int, vp, C.c_int, vp]),
+    "pp_tfront_supported": (C.c_int, [C.c_int] * 4),
+    "pp_tfront": (C.c_int, [vp, C.c_int, vp, vp, vp, C.c_float, C.c_int, vp, vp, vp, vp, vp, C.c_float, vp, C.c_int, vp, C.c_int,
+                            vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "pp_xattn_block_supported": (C.c_int, [C.c_int] * 5),
     "pp_xattn_fold": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, C.c_float,
                                 vp, vp, vp, vp, C.c_int, vp]),

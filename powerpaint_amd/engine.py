@@ -478,6 +478,19 @@ def _conv_igemm_cpad(w: torch.Tensor, cpad: int) -> torch.Tensor:
     return _conv_igemm(w)
 
 
+def _kperm(w: torch.Tensor) -> torch.Tensor:
+    """[N][K] -> the input index permuted inside every group of 32: storage position 8 kg + j holds index
+    16 (j >> 2) + 4 kg + (j & 3).  A lane's 16-byte A fragment (k-group kg) of a GEMM whose B operand comes straight out of
+    the previous GEMM's MFMA accumulators (four consecutive columns per register quad) then lines up with it: the layout
+    csrc/tfront.hip and csrc/xattn_fused.hip chain two GEMMs with."""
+    K = w.shape[-1]
+    assert K % 32 == 0
+    kp = torch.arange(K)
+    s32, kg, j = kp // 32, (kp // 8) % 4, kp % 8
+    kk = 32 * s32 + 16 * (j // 4) + 4 * kg + (j % 4)
+    return w[..., kk]
+
+
 def _geglu_interleave(w: torch.Tensor) -> torch.Tensor:
     """GEGLU proj rows [h(0..F) ; g(0..F)] -> groups of four rows (h_{2q}, h_{2q+1}, g_{2q}, g_{2q+1})."""
     F2 = w.shape[0]
@@ -507,6 +520,9 @@ class SDNet:
     # launch each, K / V folded into the projections once per prompt (pp_xattn_fold in the setup plan): 55 against 66 us
     # per block at 64x64, step -0.55 % (profiles/r03_xattn_fused_ab.txt).  (lab) PP_XATTN_FUSED=0: the three-launch chain
     fuse_xattn = _lab_switch("PP_XATTN_FUSED")
+    # round 4: Transformer2DModel.norm -> proj_in -> LayerNorm1-folded QKV at C = 320 as ONE launch (csrc/tfront.hip;
+    # three launches and two activation round trips before).  (lab) PP_TFRONT=0: the chain
+    fuse_tfront = _lab_switch("PP_TFRONT")
     # round 4: the same for C = 640 / 1280 (64-row tiles x 320-column groups, xattn_wide_kernel).  (lab) PP_XATTN_WIDE=0
     # keeps the chain at those levels
     fuse_xattn_wide = _lab_switch("PP_XATTN_WIDE")
@@ -773,6 +789,10 @@ class SDNet:
                     pk.add(f"{name}.bias", t, f32)
 
                 fold(f"{tb_}.attn1.qkv", wqkv, "norm1")
+                if wqkv.shape[1] == 320 and self.fuse_tfront:
+                    # the same folded weight with its input index permuted: second GEMM of the fused front end (csrc/tfront.hip)
+                    g_ = W(f"{tb_}.norm1.weight")
+                    pk.add(f"{tb_}.attn1.qkv.weight_kp", _kperm(wqkv * g_[None, :]), bf)
                 fold(f"{tb_}.attn2.to_q", W(f"{tb_}.attn2.to_q.weight"), "norm2")
                 fold(f"{tb_}.ff1", wff1, "norm3", bff1, il=True)
             else:
@@ -859,13 +879,33 @@ class SDNet:
             xn = pb.layernorm(h, rows, Cc, P[f"{tb}.{nrm}.weight"], P[f"{tb}.{nrm}.bias"])
             return xn, (dict(bias=P[f"{tb}.{lin}.bias"]) if lin == "ff1" else {})
 
-        st = producer()
-        n = pb.groupnorm(x, P[f"{pre}.norm.weight"], P[f"{pre}.norm.bias"], 1e-6, False, groups=self.groups)
-        hs = pb.linear(n.ptr, rows, Cc, P[f"{pre}.proj_in.weight"], Cc, P[f"{pre}.proj_in.bias"], row_stats_out=st,
-                       name="conv1x1")
-        # self-attention: fused QKV GEMM, V written transposed by the epilogue
-        ln, kw = normed(hs, st, "norm1", "attn1.qkv")
-        if hw % 8 == 0:
+        front = None
+        if fold and self.fuse_tfront and f"{tb}.attn1.qkv.weight_kp" in P and \
+                pb.lib.pp_tfront_supported(rows, Cc, hw, self.groups):
+            acc = pb._subscribe_gn_stats(x, None, self.groups)
+            if acc:
+                hs = pb.alloc(rows * Cc * 2)
+                vt = pb.alloc(x.B * Cc * hw * 2)
+                qk = pb.alloc(rows * 2 * Cc * 2)
+                pb.plan.add("tfront", pb.lib.pp_tfront, x.ptr, Cc, acc, P[f"{pre}.norm.weight"], P[f"{pre}.norm.bias"], 1e-6,
+                            self.groups, P[f"{pre}.proj_in.weight"], P[f"{pre}.proj_in.bias"],
+                            P[f"{tb}.attn1.qkv.weight_kp"], P[f"{tb}.attn1.qkv.colsum"], P[f"{tb}.attn1.qkv.bias"], 1e-5, hs, Cc,
+                            qk, 2 * Cc, vt, hw, rows, Cc, hw, pb.dt)
+                pb.plan.count("conv1x1", 2.0 * rows * Cc * Cc)           # (the FLOPs of the launches it stands for)
+                pb.plan.count("linear", 2.0 * rows * 3 * Cc * Cc)
+                front = pb.attention(qk, 2 * Cc, qk + 2 * Cc, 2 * Cc, vt, hw, x.B, self.heads, hw, hw, d)
+        if front is not None:
+            a = front
+        else:
+            st = producer()
+            n = pb.groupnorm(x, P[f"{pre}.norm.weight"], P[f"{pre}.norm.bias"], 1e-6, False, groups=self.groups)
+            hs = pb.linear(n.ptr, rows, Cc, P[f"{pre}.proj_in.weight"], Cc, P[f"{pre}.proj_in.bias"], row_stats_out=st,
+                           name="conv1x1")
+            # self-attention: fused QKV GEMM, V written transposed by the epilogue
+            ln, kw = normed(hs, st, "norm1", "attn1.qkv")
+        if front is not None:
+            pass
+        elif hw % 8 == 0:
             vt = pb.alloc(x.B * Cc * hw * 2)
             qk = pb.linear(ln, rows, Cc, P[f"{tb}.attn1.qkv.weight"], 3 * Cc, out_vt=vt, vt_col0=2 * Cc, vt_ld=hw,
                            rows_per_batch=hw, name="linear", **kw)

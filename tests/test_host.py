@@ -65,7 +65,11 @@ def test_full_size_plans_and_flop_accounting():
         n_next = ({"unet": 17, "brushnet": 17, "controlnet": 11}[kind]
                   if (GN_NEXT_IN_COMBINE and FUSE_GN_CONV and GN_STATS_IN_EPILOGUE) else 0)
         assert sum(1 for a in rt.step_plan.keep if getattr(a, "gn_next_out", None)) == n_next
-        assert names.count("groupnorm_apply") == n_gn - fused_out - n_cg - n_next
+        # ... and the front end of every C = 320 transformer (norm -> proj_in -> LayerNorm1-folded QKV) is one pp_tfront launch
+        n_front = ({"unet": 5, "brushnet": 5, "controlnet": 2}[kind]
+                   if (SDNet.fuse_tfront and SDNet.fold_ln and GN_STATS_IN_EPILOGUE) else 0)
+        assert names.count("tfront") == n_front
+        assert names.count("groupnorm_apply") == n_gn - fused_out - n_cg - n_next - n_front
         if fused_out:
             assert names.count("conv_out") == 1
         # GroupNorm statistics come out of the producing GEMMs' epilogues -- every producer is a GEMM-family launch
@@ -81,7 +85,8 @@ def test_full_size_plans_and_flop_accounting():
         per_width = {"unet": 5, "brushnet": 5, "controlnet": 2}[kind]
         assert n_x == ((per_width * (2 if SDNet.fuse_xattn_wide else 1)) if SDNet.fuse_xattn else 0)
         assert [c[2] for c in rt.setup_plan.calls].count("xattn_fold") == n_x
-        assert len(names) == exp[kind][1] - (n_gn - n_stats) + names.count("zero_u64") - fused_out - 2 * n_x - n_cg - n_next
+        assert len(names) == exp[kind][1] - (n_gn - n_stats) + names.count("zero_u64") - fused_out - 2 * n_x - n_cg - n_next \
+            - 2 * n_front
         assert len(rt.setup_plan.calls) >= 15
 
 

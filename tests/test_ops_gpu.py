@@ -697,3 +697,41 @@ def test_fused_groupnorm_silu_conv_out(B, H, W, C, dtype):
     check(out, ref, 3e-2 * tol, 1e-2 * tol, "fused conv_out vs fp32")
 
 
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,hw", [(2, 1024), (1, 4096), (3, 128), (8, 4096)])
+def test_transformer_front_end_in_one_launch(B, hw, dtype):
+    """pp_tfront (csrc/tfront.hip): Transformer2DModel.norm -> proj_in -> LayerNorm1-folded QKV at C = 320 in one launch
+    against (a) the three launches it replaces (pp_groupnorm_apply_acc, pp_gemm_bf16 with row moments, pp_gemm_bf16 with the
+    folded LayerNorm and the transposed V) and (b) fp32 torch of the same modules on the same 16-bit operands."""
+    from powerpaint_amd.engine import _kperm
+    C, groups = 320, 32
+    M = B * hw
+    tol = 4.0 if dtype == torch.bfloat16 else 1.0
+    x = (rnd(M, C, seed=1, scale=1.4) + 0.3).to(dtype)
+    xf = x.float().reshape(B, hw, groups, C // groups)
+    acc = torch.stack([(xf.sum((1, 3)).double() * 2 ** 24).round().long(),
+                       ((xf * xf).sum((1, 3)).double() * 2 ** 20).round().long()], -1).contiguous()
+    gg, gb = rnd(C, seed=2) * 0.3 + 1.0, rnd(C, seed=3) * 0.2
+    w1, b1 = rnd(C, C, seed=4, scale=C ** -0.5).to(dtype).contiguous(), rnd(C, seed=5) * 0.1
+    g1, be1 = rnd(C, seed=6) * 0.3 + 1.0, rnd(C, seed=7) * 0.2
+    wqkv = rnd(3 * C, C, seed=8, scale=C ** -0.5)
+    wf = (wqkv * g1[None, :]).to(dtype).contiguous()
+    cs, tb = wf.float().sum(1).contiguous(), (wqkv @ be1).contiguous()
+    hs, qk, vt = ops.tfront(x, acc, gg, gb, w1, b1, _kperm(wf).contiguous(), cs, tb, hw)
+    # (a) the chain
+    n = ops.groupnorm_apply_acc(x.view(B, hw, 1, C), acc, gg, gb, 1e-6, False).view(M, C)
+    hs_old, st = ops.gemm(n, w1, b1, row_stats=True)
+    qk_old, vt_old = ops.gemm(hs_old, wf, bias=tb, ln_stats=st, ln_colsum=cs, ln_dim=C, vt_col0=2 * C, rows_per_batch=hw)
+    ulp = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    check(hs, hs_old, 2 * ulp, 1.5 * ulp, "hs vs groupnorm_apply + proj_in")
+    check(qk, qk_old, 1.2e-2 * tol, 4e-3 * tol, "Q | K vs the chain")
+    check(vt, vt_old, 1.2e-2 * tol, 4e-3 * tol, "V^T vs the chain")
+    # (b) fp32 torch
+    nt = F.group_norm(x.float().reshape(B, hw, C).permute(0, 2, 1), groups, gg, gb, 1e-6).permute(0, 2, 1).reshape(M, C)
+    hst = nt @ w1.float().t() + b1
+    check(hs, hst, 1.5e-2 * tol, 6e-3 * tol, "hs vs fp32")
+    qkvt = F.layer_norm(hs.float(), (C,), g1, be1, 1e-5) @ wqkv.t()        # (from the kernel's own 16-bit hs: isolates GEMM 2)
+    check(qk, qkvt[:, :2 * C], 1.5e-2 * tol, 6e-3 * tol, "Q | K vs fp32")
+    check(vt, qkvt[:, 2 * C:].reshape(B, hw, C).permute(0, 2, 1), 1.5e-2 * tol, 6e-3 * tol, "V^T vs fp32")
