@@ -109,13 +109,27 @@ __global__ void __launch_bounds__(256) xattn_fold_kernel(const uint16_t* __restr
       float s0 = 0.f, s1 = 0.f;
       if (key < nctx) {
         const uint16_t* kr = k + ((size_t)b * nctx + key) * ldk + h * D;
-        for (int j = 0; j < D; ++j) {
-          const float kv = E::to_f(kr[j]);
-          if (qcs) s0 = fmaf(kv, qcs[h * D + j], s0);
-          if (qb) s1 = fmaf(kv, qb[h * D + j], s1);
-        }
+        if (qb)
+          for (int j = 0; j < D; ++j) s1 = fmaf(E::to_f(kr[j]), qb[h * D + j], s1);
+        // The mean term of the folded LayerNorm must cancel the mean component of x . G exactly, and the kernel multiplies
+        // with G^T as STORED (rounded to 16 bits): the column sum is taken over those rounded entries (recomputed here
+        // with the arithmetic of the first branch), not contracted from the unrounded q_colsum (the
+        // residual grew with |mean| / std of the hidden rows)
+        if (qcs)
+          for (int c2 = 0; c2 < C / 2; ++c2) {
+            const uint16_t* wr = wq + (size_t)(h * D) * C + 2 * c2;
+            float g0 = 0.f, g1 = 0.f;
+            for (int j = 0; j < D; ++j) {
+              const float kv = E::to_f(kr[j]);
+              const uint32_t w2 = *reinterpret_cast<const uint32_t*>(wr + (size_t)j * C);
+              g0 = fmaf(kv, E::lo(w2), g0);
+              g1 = fmaf(kv, E::hi(w2), g1);
+            }
+            const uint32_t pk = E::pack2(g0 * qscale, g1 * qscale);
+            s0 += E::lo(pk) + E::hi(pk);
+          }
       }
-      gcs[r] = s0 * qscale;
+      gcs[r] = s0;
       gb[r] = key < nctx ? s1 * qscale : -INFINITY;
     }
   }

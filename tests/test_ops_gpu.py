@@ -659,6 +659,8 @@ def test_fused_cross_attention_block(B, hw, nctx, C, fold, dtype):
     check(rs, rs_ref, 2e-3, 1e-5, "row moments of the stored values")
     # the folded matrices themselves
     gt, gcs, gb, ht = folded
+    if fold:      # the mean term of the folded LayerNorm is the column sum of G^T AS STORED
+        check(gcs, gt.float().sum(-1), 2e-3, 1e-5, "logit colsum = sum over c of the rounded G^T")
     G = torch.einsum("bkhd,hdc->bhkc", kf, wqf.float().reshape(heads, d, C)) * (d ** -0.5 * 1.4426950408889634)
     check(gt.reshape(B, heads, 80, C)[:, :, :nctx], G, 2e-3 * tol, 4e-3 * tol, "G^T")
     assert torch.all(gt.reshape(B, heads, 80, C)[:, :, nctx:] == 0)
