@@ -51,7 +51,7 @@ PP_DEVINL void tf_static_for_impl(std::integer_sequence<int, I...>, F&& f) { (f(
 template <int N, class F>
 PP_DEVINL void tf_static_for(F&& f) { tf_static_for_impl(std::make_integer_sequence<int, N>{}, f); }
 
-template <int EDT>
+template <int EDT, int QD = TF_QD>
 __global__ void __launch_bounds__(512, 2) tfront_kernel(const TFArgs a) {
   using E = E16<EDT>;
   typedef typename E::v8 v8_t;
@@ -200,7 +200,7 @@ __global__ void __launch_bounds__(512, 2) tfront_kernel(const TFArgs a) {
     asm volatile("s_barrier" ::: "memory");
     if constexpr (t + 2 < TF_NSLAB) issue(std::integral_constant<int, t + 2>{});   // (its stage was read at step t - 1)
     const char* st = smem + (t % TF_NS) * TF_SLAB;
-    v8_t q[TF_QD + 1];
+    v8_t q[QD + 1];
     const int so0 = ((0 * 4 + g) ^ (r16 & 7)) << 4, so1 = ((1 * 4 + g) ^ (r16 & 7)) << 4;
     auto load_frag = [&](int i) __attribute__((always_inline)) -> v8_t {
       return *reinterpret_cast<const v8_t*>(st + ((i % 20) * 16 + r16) * 128 + (i < 20 ? so0 : so1));
@@ -215,12 +215,12 @@ __global__ void __launch_bounds__(512, 2) tfront_kernel(const TFArgs a) {
       }
     }
 #pragma unroll
-    for (int i = 0; i < TF_QD; ++i) q[i] = load_frag(i);
+    for (int i = 0; i < QD; ++i) q[i] = load_frag(i);
 #pragma unroll
     for (int i = 0; i < 40; ++i) {
-      if (i + TF_QD < 40) q[(i + TF_QD) % (TF_QD + 1)] = load_frag(i + TF_QD);
+      if (i + QD < 40) q[(i + QD) % (QD + 1)] = load_frag(i + QD);
       __builtin_amdgcn_sched_barrier(0);
-      acc[i % 20] = E::mfma16(q[i % (TF_QD + 1)], bfr[i / 20], acc[i % 20]);
+      acc[i % 20] = E::mfma16(q[i % (QD + 1)], bfr[i / 20], acc[i % 20]);
       __builtin_amdgcn_sched_barrier(0);
     }
     if constexpr (t == 4) finish_proj_in();
@@ -293,6 +293,14 @@ extern "C" int pp_tfront(const void* x, int ldx, const void* gn_acc, const float
     PP_CHECK_LAUNCH("tfront_kernel");
     return PP_OK;
   };
+#ifdef PP_LAB
+  if (dtype == PP_DT_BF16) switch (pp_lab_env("PP_TF_QD", TF_QD)) {      // fragment reads in flight ahead of their MFMA
+      case 4: attr_set[dtype] = false; return go(tfront_kernel<PP_DT_BF16, 4>);
+      case 12: attr_set[dtype] = false; return go(tfront_kernel<PP_DT_BF16, 12>);
+      case 16: attr_set[dtype] = false; return go(tfront_kernel<PP_DT_BF16, 16>);
+      default: break;
+    }
+#endif
   if (dtype == PP_DT_F16) return go(tfront_kernel<PP_DT_F16>);
   return go(tfront_kernel<PP_DT_BF16>);
 }
