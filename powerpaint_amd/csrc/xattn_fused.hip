@@ -111,28 +111,33 @@ __global__ void __launch_bounds__(256) xattn_fold_kernel(const uint16_t* __restr
         const uint16_t* kr = k + ((size_t)b * nctx + key) * ldk + h * D;
         if (qb)
           for (int j = 0; j < D; ++j) s1 = fmaf(E::to_f(kr[j]), qb[h * D + j], s1);
-        // The mean term of the folded LayerNorm must cancel the mean component of x . G exactly, and the kernel multiplies
-        // with G^T as STORED (rounded to 16 bits): the column sum is taken over those rounded entries (recomputed here
-        // with the arithmetic of the first branch), not contracted from the unrounded q_colsum (the
-        // residual grew with |mean| / std of the hidden rows)
-        if (qcs)
-          for (int c2 = 0; c2 < C / 2; ++c2) {
-            const uint16_t* wr = wq + (size_t)(h * D) * C + 2 * c2;
-            float g0 = 0.f, g1 = 0.f;
-            for (int j = 0; j < D; ++j) {
-              const float kv = E::to_f(kr[j]);
-              const uint32_t w2 = *reinterpret_cast<const uint32_t*>(wr + (size_t)j * C);
-              g0 = fmaf(kv, E::lo(w2), g0);
-              g1 = fmaf(kv, E::hi(w2), g1);
-            }
-            const uint32_t pk = E::pack2(g0 * qscale, g1 * qscale);
-            s0 += E::lo(pk) + E::hi(pk);
-          }
+        // (the mean term of the folded LayerNorm -- the column sum of G^T -- is taken over the entries AS STORED, by
+        //  xattn_colsum_kernel behind this launch: ADVICE round 3)
       }
-      gcs[r] = s0;
+      if (!qcs) gcs[r] = 0.f;
       gb[r] = key < nctx ? s1 * qscale : -INFINITY;
     }
   }
+}
+
+// gcs[b][n] = sum over c of G^T[b][n][c] as stored (rounded to 16 bits): the mean term of the folded LayerNorm must cancel
+// the mean component of x . G exactly, and the block kernels multiply with the stored G^T.  One wave per row.
+template <int EDT>
+__global__ void __launch_bounds__(256) xattn_colsum_kernel(const uint32_t* __restrict__ gt, float* __restrict__ gcs, long long rows,
+                                                          int C) {
+  using E = E16<EDT>;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const uint32_t* p = gt + row * (C / 2);
+  float s = 0.f;
+  for (int i = lane; i < C / 2; i += 64) {
+    const uint32_t v = p[i];
+    s += E::lo(v) + E::hi(v);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (lane == 0) gcs[row] = s;
 }
 
 // DBG (lab build only): 1 no slab DMA, 2 no MFMAs, 4 no fragment reads, 8 no softmax, 16 no epilogue, 32 no barriers
@@ -588,6 +593,12 @@ extern "C" int pp_xattn_fold(const void* k, int ldk, const void* vt, int ldvt, i
                                          (const uint16_t*)wq, q_colsum, q_bias, (const uint16_t*)wo, qscale, (uint32_t*)gt,
                                          gcs, gbias, (uint32_t*)ht, c));
   PP_CHECK_LAUNCH("xattn_fold_kernel");
+  if (q_colsum) {
+    const long long rows = (long long)batch * XA_S;
+    PP_DT_SWITCH(dtype, hipLaunchKernelGGL((xattn_colsum_kernel<EDT>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0,
+                                           (hipStream_t)stream, (const uint32_t*)gt, gcs, rows, c));
+    PP_CHECK_LAUNCH("xattn_colsum_kernel");
+  }
   return PP_OK;
 }
 
