@@ -74,6 +74,9 @@ __global__ void __launch_bounds__(256) xattn_fold_kernel(const uint16_t* __restr
       if (key < nctx) {
         const uint16_t* kr = k + ((size_t)b * nctx + key) * ldk + h * D;
         const uint16_t* wr = wq + (size_t)(h * D) * C + 2 * c2;
+        // (D = 40 / 80 / 160: whole eights -- unrolled so that eight independent loads are in flight per thread; this kernel
+        //  runs once per pipeline call and took 1.6 ms of it as a one-load-at-a-time loop)
+#pragma unroll 8
         for (int j = 0; j < D; ++j) {
           const float kv = E::to_f(kr[j]);
           const uint32_t w2 = *reinterpret_cast<const uint32_t*>(wr + (size_t)j * C);
@@ -97,6 +100,7 @@ __global__ void __launch_bounds__(256) xattn_fold_kernel(const uint16_t* __restr
         if (key < nctx) {
           const uint16_t* wr = wo + (size_t)n * C + h * D;
           const uint16_t* vr = vt + ((size_t)b * C + h * D) * ldvt + key;
+#pragma unroll 8
           for (int jj = 0; jj < D; ++jj) s = fmaf(E::to_f(wr[jj]), E::to_f(vr[(size_t)jj * ldvt]), s);
         }
         v[e] = s;
