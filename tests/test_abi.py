@@ -95,3 +95,93 @@ def test_build_id_names_the_sources_the_library_was_built_from():
     bid = _lib.build_id()
     assert re.fullmatch(r"[0-9a-f]{12}", bid), bid
     assert bid == h.hexdigest()[:12], "libpp_hip.so is stale against powerpaint_amd/csrc: run `make -C powerpaint_amd/csrc`"
+
+
+def _conv_args(B, H, W, c1, c2, cout, c3=0, c4=0, gn_in=True, splitk=0):
+    """A PP_X_CONV3X3 request with dummy (non-null) pointers: the host-side queries only look at shapes and flags."""
+    from powerpaint_amd import _lib as L
+    a = L.PPGemmArgs()
+    a.dtype = L.PP_DT_BF16
+    a.M, a.N, a.K, a.x_mode = B * H * W, cout, 9 * (c1 + c2) + c3 + c4, L.PP_X_CONV3X3
+    a.x1, a.c1 = 0x1000, c1
+    if c2:
+        a.x2, a.c2 = 0x2000, c2
+    if c3:
+        a.x3, a.c3 = 0x3000, c3
+    if c4:
+        a.x4, a.c4 = 0x4000, c4
+    a.batch, a.hin, a.win, a.hout, a.wout, a.stride, a.up = B, H, W, H, W, 1, 0
+    a.w, a.out, a.ldo, a.ldres1, a.ldres2 = 0x5000, 0x6000, cout, cout, cout
+    a.rows_per_batch, a.scale, a.splitk = H * W, 1.0, splitk
+    if gn_in:
+        a.gn_in_acc, a.gn_in_gb, a.gn_in_groups, a.gn_in_silu, a.gn_in_eps = 0x7000, 0x8000, 32, 1, 1e-5
+    return a
+
+
+def test_fused_conv_routing_and_combine_apply_queries_on_the_host():
+    """pp_conv_gn_supported / pp_conv_gn_preferred (ABI v16) and pp_gemm_gn_next_ok (ABI v17) are pure host logic: the
+    routing classes of DESIGN section 4 at the SD-1.5 shapes (batch 8), without a GPU."""
+    import ctypes as C
+    from powerpaint_amd import _lib as L
+    lib = L.lib()
+    sup = lambda a: lib.pp_conv_gn_supported(C.byref(a))       # noqa: E731
+    pref = lambda a: lib.pp_conv_gn_preferred(C.byref(a))      # noqa: E731
+    # every level has a tile of whole image rows; fused everywhere but at 8x8
+    for (H, c1, c2, cout, tail, want) in [(64, 320, 0, 320, (0, 0), 1), (64, 640, 320, 320, (0, 0), 1), (64, 320, 0, 320, (640, 320), 1),
+                                          (32, 320, 0, 640, (0, 0), 1), (32, 1280, 640, 640, (0, 0), 1), (32, 640, 0, 640, (640, 320), 1),
+                                          (16, 1280, 1280, 1280, (0, 0), 1), (16, 640, 0, 1280, (0, 0), 1),
+                                          (8, 1280, 0, 1280, (0, 0), 0), (8, 1280, 1280, 1280, (0, 0), 0)]:
+        a = _conv_args(8, H, H, c1, c2, cout, *tail)
+        assert sup(a) == 1, (H, c1, c2)
+        assert pref(a) == want, (H, c1, c2)
+    # not the fused kernel's geometry: stride 2, upsampling, channel counts off the 64 grid, no statistics
+    a = _conv_args(8, 64, 64, 320, 0, 320)
+    a.stride, a.hout, a.wout, a.M = 2, 32, 32, 8 * 32 * 32
+    assert sup(a) == 0 and pref(a) == 0
+    assert sup(_conv_args(8, 64, 64, 96, 0, 320)) == 0
+    a = _conv_args(8, 64, 64, 320, 0, 320, gn_in=False)
+    assert sup(a) == 0
+    # the apply of the CONSUMER norm inside the split-K combine: whole (batch item, group) populations per workgroup only
+    def next_ok(H, cout, splitk, cg=None, c0=0, rows=None):
+        a = _conv_args(8, H, H, 1280, 0, cout, gn_in=False, splitk=splitk)
+        a.workspace = 0x9000
+        a.gn_acc[0], a.gn_cg[0], a.gn_c0[0], a.gn_groups[0] = 0xa000, cg or cout // 32, c0, 32
+        if rows:
+            a.rows_per_batch = rows
+        return lib.pp_gemm_gn_next_ok(C.byref(a), 0)
+    assert next_ok(8, 1280, 8) == 1 and next_ok(16, 1280, 4) == 1      # 64 / 256 rows per batch item, split-K launches
+    assert next_ok(8, 1280, 1) == 0                                    # no combine behind the launch
+    assert next_ok(32, 640, 2) == 0                                    # 1024 rows per batch item
+    assert next_ok(8, 1280, 8, c0=64) == 0                             # a concatenated consumer (channel offset)
+    assert next_ok(8, 1280, 8, cg=42) == 0                             # groups that straddle the 40-column tiles
+    a = _conv_args(8, 8, 8, 1280, 0, 1280, gn_in=False, splitk=8)
+    assert lib.pp_gemm_gn_next_ok(C.byref(a), 0) == 0                  # no statistics subscription
+    # row-local fused kernels: C = 320 in 128-row tiles, wider in 64-row tiles
+    assert lib.pp_tfront_supported(32768, 320, 4096, 32) == 1 and lib.pp_tfront_supported(8192, 640, 1024, 32) == 0
+    assert lib.pp_tfront_supported(320, 320, 64, 32) == 0
+    assert lib.pp_xattn_block_supported(32768, 320, 4096, 77, 8) == 1 and lib.pp_xattn_block_supported(8192, 640, 1024, 77, 8) == 1
+    assert lib.pp_xattn_block_supported(512, 1280, 64, 77, 8) == 1 and lib.pp_xattn_block_supported(512, 960, 64, 77, 8) == 0
+    assert lib.pp_xattn_block_supported(32768, 320, 4096, 81, 8) == 0
+
+
+def test_kperm_is_the_accumulator_to_operand_layout_of_the_chained_gemms():
+    """engine._kperm (the input-index permutation of the second GEMM's weights in csrc/tfront.hip; the same map packs H^T in
+    csrc/xattn_fused.hip): lane (row m, k-group g) of a 16x16x32 MFMA holds, as accumulator quads of the FIRST GEMM, the
+    columns 16 nb + 4 g + {0..3} of its row; quads of blocks 2 s and 2 s + 1 back to back are the lane's eight B-operand
+    values of k-block s.  With the weights permuted by _kperm the second GEMM then contracts matching indices."""
+    import torch
+    from powerpaint_amd.engine import _kperm
+    K, N = 320, 48
+    g_ = torch.Generator().manual_seed(0)
+    hs, w = torch.randn(16, K, generator=g_), torch.randn(N, K, generator=g_)
+    perm = _kperm(torch.arange(K).float()[None, :])[0].long()
+    assert sorted(perm.tolist()) == list(range(K))
+    # what the lanes hand to the MFMA: position 32 s + 8 g + j of row m <- accumulator element (block 2 s + (j >> 2), quad index j & 3)
+    frag = torch.empty(16, K)
+    for s in range(K // 32):
+        for g in range(4):
+            for j in range(8):
+                nb, i = 2 * s + (j >> 2), j & 3
+                frag[:, 32 * s + 8 * g + j] = hs[:, 16 * nb + 4 * g + i]
+    assert torch.equal(frag, hs[:, perm])
+    assert torch.allclose(frag @ _kperm(w).t(), hs @ w.t(), atol=1e-4)
