@@ -465,6 +465,11 @@ def main():
         else:                                                       # other sizes: the launch plan's own count (2 * MAC)
             tflop_step = pipe._loop.program.flops / 1e12
         ms_denoise_step = ms_per_step / unet_steps
+        # FLOPs the launch plan EXECUTES per step: below the algorithmic figure where the loop runs the CFG-identical prefix
+        # of the networks (conv_in .. first self-attention) on one half of the pair (engine.SDNet.build_step, twin).  Every
+        # utilisation figure of this line is computed from executed FLOPs; the algorithmic one is reported beside it.
+        prog = getattr(getattr(pipe, "_loop", None), "program", None)
+        tflop_exec = prog.flops / 1e12 if prog is not None else tflop_step
         px = args.latent * 8
         res = {
             "metric": ("inpainted images/sec @512x512, 50-step DDIM CFG, batch4/GPU"
@@ -482,7 +487,10 @@ def main():
                        "hipgraph": not args.no_graph, "weights": "random init (no checkpoints offline)",
                        "weight_broadcast_s": round(bcast_s, 4), "ranks": rank_log},
             "ms_per_denoise_step": ms_denoise_step,
-            "unet_step_mfma_util": tflop_step / (ms_denoise_step * 1e-3) / MFMA_PEAK_TFLOPS,
+            "algorithmic_tflop_per_step": tflop_step, "executed_tflop_per_step": tflop_exec,
+            "unet_step_mfma_util": tflop_exec / (ms_denoise_step * 1e-3) / MFMA_PEAK_TFLOPS,
+            "unet_step_mfma_util_algorithmic": tflop_step / (ms_denoise_step * 1e-3) / MFMA_PEAK_TFLOPS,
+            "cfg_twin_prefix": bool(getattr(getattr(getattr(pipe, "_loop", None), "rt", None), "twin", False)),
             "launches_per_denoise_step": len(pipe._loop.program.calls) if getattr(pipe, "_loop", None) is not None
             and getattr(pipe._loop, "program", None) is not None else None,
         }

@@ -29,7 +29,7 @@ extern "C" {
 #define PP_ERR_LAUNCH (-3)       /* hipLaunchKernel / hipFuncSetAttribute failed                  */
 #define PP_ERR_WORKSPACE (-4)    /* workspace pointer null or too small                           */
 
-#define PP_ABI_VERSION 18
+#define PP_ABI_VERSION 19
 /* 16-bit storage format of activations and matrix weights ("dtype" arguments; the same codes pp_nchw_to_nhwc uses for
  * its source): bf16 or fp16 -- the reference's default is fp16 (/root/reference/app.py:548,559).  MFMA accumulation,
  * norm statistics, softmax, biases and latents are fp32 with either. */
@@ -103,7 +103,16 @@ typedef struct PPGemmArgs {
   int32_t dbg;        /* 0.  (Phase-ablation switches of the measurement scripts under tools/: honoured by -DPP_LAB builds
                        * only, libpp_hip.so ignores the field.) */
   int32_t dtype;      /* PP_DT_BF16 | PP_DT_F16: format of x*, w, res*, out (unless out_f32), out_vt */
-  int32_t reserved[2];
+  /* (ABI v19) The two halves of a classifier-free-guidance batch are bit-identical from `torch.cat([latents] * 2)`
+   * (/root/reference/powerpaint/pipelines/pipeline_PowerPaint.py:990-996) down to the first cross-attention
+   * (/root/reference/powerpaint/models/unet_2d_condition.py:1183-1236): the launches in front of it run on ONE half.
+   *   out_dup_rows   > 0: every output row m is ALSO stored at row m + out_dup_rows of `out` (the tensor has 2 M rows; its
+   *                  consumers behind the prefix -- the up-block skip concat -- see the full batch).  Single-pass 16-bit
+   *                  epilogue only (no split-K, GEGLU, V^T, fp32 output, row moments): PP_ERR_UNSUPPORTED otherwise.
+   *   res1_wrap_rows > 0: res1 has only res1_wrap_rows rows; output row m adds res1 row (m mod res1_wrap_rows)
+   *                  (requires M <= 2 * res1_wrap_rows): the first full-batch launch reads the half-batch residual. */
+  int32_t out_dup_rows;
+  int32_t res1_wrap_rows;
   /* LayerNorm folded into the GEMM (BasicTransformerBlock.norm1/2/3 -> the Linear that follows):
    *   LN(x) W^T = rstd * (x (gamma.W)^T - mean * colsum) + beta W^T, so the host packs W' = gamma (.) W, passes
    *   ln_colsum[n] = sum_k W'[n][k] and adds beta W^T to the bias; mean / rstd come from per-row moments.
@@ -152,7 +161,10 @@ typedef struct PPGemmArgs {
   int32_t gn_in_groups;
   int32_t gn_in_silu;   /* must be 1 (every GroupNorm in front of a 3x3 conv of the path is followed by SiLU) */
   float gn_in_eps;
-  int32_t reserved3;
+  /* (ABI v19) with out_dup_rows: the statistics subscriptions k whose bit is set in gn_dup_mask belong to a consumer of the
+   * FULL (duplicated) tensor -- the epilogue adds every (batch item b, group) contribution to batch item b + gn_dup_batch of
+   * gn_acc[k] as well.  A subscription without its bit is a consumer of the half batch (the next layer of the prefix). */
+  int32_t gn_dup_batch;
   /* (ABI v17) The GroupNorm (+ SiLU) that CONSUMES this launch's output, applied by the split-K combine itself: where one
    * workgroup of the combine owns a whole (batch item, 160-column tile) -- rows_per_batch <= 256, i.e. the 16 x 16 and 8 x 8
    * levels -- and the consumer's groups lie whole inside the tile, the tile's fixed-point (sum, sum of squares) ARE the
@@ -168,7 +180,7 @@ typedef struct PPGemmArgs {
   float gn_next_eps;
   int32_t gn_next_silu;
   int32_t gn_next_sub;
-  int32_t reserved4;
+  int32_t gn_dup_mask;   /* see gn_dup_batch */
 } PPGemmArgs;
 #define PP_GN_SUM_SCALE 16777216.0f /* 2^24 */
 #define PP_GN_SQ_SCALE 1048576.0f   /* 2^20 */
@@ -364,6 +376,10 @@ int pp_tfront(const void* x, int ldx, const void* gn_acc, const float* gn_gamma,
  *     p   = softmax_per_head( rstd*(x gt^T - mean*gcs) + gbias )          (exp2 domain; mean / rstd from ln_stats as in
  *                                                                           PPGemmArgs, NULL = no LayerNorm folded)
  *     out = p ht^T + bias_o + res ,   row_stats_out[m][c/160][2] = (sum, sum of squares) of the stored values.
+ * (ABI v19) src_wrap_rows > 0: x, res and ln_stats hold only src_wrap_rows rows and output row m reads row
+ * (m mod src_wrap_rows), M <= 2 * src_wrap_rows -- the two halves of a CFG batch are identical up to this sub-block (the
+ * first place the prompt enters, unet_2d_condition.py:1183-1236), so everything in front of it ran on one half; the folded
+ * operands (gt, gcs, gbias, ht) are per batch item of the FULL batch.  C = 320 only (PP_ERR_UNSUPPORTED otherwise).
  * pp_xattn_block_supported() = 1 when the shape is one this kernel takes (the caller keeps the three-launch chain
  * otherwise); both entry points return PP_ERR_UNSUPPORTED for other shapes. */
 int pp_xattn_block_supported(int M, int c, int rows_per_batch, int nctx, int heads);
@@ -372,7 +388,8 @@ int pp_xattn_fold(const void* k, int ldk, const void* vt, int ldvt, int batch, i
                   float* gbias, void* ht, int dtype, void* stream);
 int pp_xattn_block(const void* x, int ldx, const void* res, int ldres, const float* ln_stats, int ln_tiles, float ln_eps,
                    const void* gt, const float* gcs, const float* gbias, const void* ht, const float* bias_o, void* out,
-                   int ldo, float* row_stats_out, int M, int c, int rows_per_batch, int dtype, void* stream);
+                   int ldo, float* row_stats_out, int M, int c, int rows_per_batch, int src_wrap_rows, int dtype,
+                   void* stream);
 
 /* ppt-v1 with a 4-channel (non-inpainting) UNet -- the `num_channels_unet == 4` branch of the loop body,
  * pipeline_PowerPaint.py:1025-1039: after pp_cfg_sched_step of the same step

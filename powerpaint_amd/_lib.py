@@ -16,7 +16,7 @@ PP_ACT_NONE, PP_ACT_GEGLU, PP_ACT_SILU = 0, 1, 2
 PP_TILE_AUTO, PP_TILE_128x160, PP_TILE_64x160, PP_TILE_256x160 = 0, 1, 2, 3
 PP_DT_F32, PP_DT_BF16, PP_DT_F16 = 0, 1, 2      # dtype codes of the C ABI (include/pp_hip.h)
 PP_ATTN_AUTO, PP_ATTN_PHASED, PP_ATTN_PIPE_Q32, PP_ATTN_PIPE_Q64 = 0, 1, 2, 3   # pp_attention_fwd_variant
-ABI_VERSION = 18                                  # PP_ABI_VERSION of include/pp_hip.h this binding was written against
+ABI_VERSION = 19                                  # PP_ABI_VERSION of include/pp_hip.h this binding was written against
 PP_ERR = {0: "PP_OK", -1: "PP_ERR_BAD_ARG", -2: "PP_ERR_UNSUPPORTED", -3: "PP_ERR_LAUNCH", -4: "PP_ERR_WORKSPACE"}
 
 vp, i32, f32, sz = C.c_void_p, C.c_int32, C.c_float, C.c_size_t
@@ -37,15 +37,15 @@ class PPGemmArgs(C.Structure):
         ("out_vt", vp), ("vt_col0", i32), ("vt_ld", i32),
         ("splitk", i32), ("tile", i32),
         ("workspace", vp),
-        ("dbg", i32), ("dtype", i32), ("reserved", i32 * 2),
+        ("dbg", i32), ("dtype", i32), ("out_dup_rows", i32), ("res1_wrap_rows", i32),
         ("row_stats_out", vp), ("ln_stats", vp), ("ln_colsum", vp),
         ("ln_tiles", i32), ("ln_dim", i32), ("ln_eps", f32), ("reserved_w", i32),
         ("gn_acc", vp * 2), ("gn_cg", i32 * 2), ("gn_c0", i32 * 2), ("gn_groups", i32 * 2),
         ("x3", vp), ("x4", vp), ("c3", i32), ("c4", i32),
         ("gn_in_acc", vp), ("gn_in_gb", vp), ("gn_in_groups", i32), ("gn_in_silu", i32), ("gn_in_eps", f32),
-        ("reserved3", i32),
+        ("gn_dup_batch", i32),
         ("gn_next_out", vp), ("gn_next_gamma", vp), ("gn_next_beta", vp), ("gn_next_eps", f32), ("gn_next_silu", i32),
-        ("gn_next_sub", i32), ("reserved4", i32),
+        ("gn_next_sub", i32), ("gn_dup_mask", i32),
     ]
 
 
@@ -99,7 +99,7 @@ SIGNATURES = {
     "pp_xattn_fold": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, C.c_float,
                                 vp, vp, vp, vp, C.c_int, vp]),
     "pp_xattn_block": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, C.c_int, C.c_float, vp, vp, vp, vp, vp, vp, C.c_int, vp,
-                                 C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+                                 C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "pp_step_advance": (C.c_int, [vp, vp]),
     "pp_mask_prep": (C.c_int, [C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
 }

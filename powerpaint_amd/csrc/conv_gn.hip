@@ -580,7 +580,7 @@ __global__ void __launch_bounds__(CG_T, 2) pp_conv_gn_kernel(const PPGemmArgs a,
         for (int j = 0; j < EP; ++j) {
           const int row = r0 + j * ER, m = m0 + row;
           const bool ok = row < EPI_ROWS && m < a.M;
-          r1[j] = (ok && a.res1) ? *reinterpret_cast<const u32x4_t*>((const uint16_t*)a.res1 + (size_t)m * a.ldres1 + n)
+          r1[j] = (ok && a.res1) ? *reinterpret_cast<const u32x4_t*>((const uint16_t*)a.res1 + (size_t)((a.res1_wrap_rows > 0 && m >= a.res1_wrap_rows) ? m - a.res1_wrap_rows : m) * a.ldres1 + n)
                                  : u32x4_t{0u, 0u, 0u, 0u};
           r2[j] = (ok && a.res2) ? *reinterpret_cast<const u32x4_t*>((const uint16_t*)a.res2 + (size_t)m * a.ldres2 + n)
                                  : u32x4_t{0u, 0u, 0u, 0u};

@@ -45,6 +45,11 @@ PP_DEVINL void ln_row_moments(const PPGemmArgs& a, int m, float& mean, float& rs
   rstd = rsqrtf(fmaxf(q * inv - mean * mean, 0.f) + a.ln_eps);
 }
 
+// res1 of a launch whose residual holds only the first half of the batch (PPGemmArgs.res1_wrap_rows): row m reads row m mod wrap
+PP_DEVINL size_t res1_row(const PPGemmArgs& a, int m) {
+  return (size_t)((a.res1_wrap_rows > 0 && m >= a.res1_wrap_rows) ? m - a.res1_wrap_rows : m);
+}
+
 template <int BN, int EDT>
 PP_DEVINL void epilogue4(const PPGemmArgs& a, int m, int n, f32x4_t v) {
   // v holds columns n..n+3 of row m (fp32 accumulators)
@@ -69,7 +74,7 @@ PP_DEVINL void epilogue4(const PPGemmArgs& a, int m, int n, f32x4_t v) {
   }
   v *= a.scale;
   if (a.res1) {
-    const u32x2_t r = *reinterpret_cast<const u32x2_t*>((const uint16_t*)a.res1 + (size_t)m * a.ldres1 + n);
+    const u32x2_t r = *reinterpret_cast<const u32x2_t*>((const uint16_t*)a.res1 + res1_row(a, m) * a.ldres1 + n);
     v[0] += E16<EDT>::lo(r[0]); v[1] += E16<EDT>::hi(r[0]); v[2] += E16<EDT>::lo(r[1]); v[3] += E16<EDT>::hi(r[1]);
   }
   if (a.res2) {
@@ -1033,11 +1038,13 @@ pp_gemm_kernel_v2(const PPGemmArgs a, const GemmDerived d) {   // 2nd bound = wa
           }
         } else {
           u32x4_t r1[EP], r2[EP];
+          // (PPGemmArgs.res1_wrap_rows, a multiple of the 64-row pass: one wave-uniform shift per pass)
+          const int r1shift = (a.res1_wrap_rows > 0 && m0 >= a.res1_wrap_rows) ? a.res1_wrap_rows : 0;
 #pragma unroll
           for (int j = 0; j < EP; ++j) {
             const int row = r0 + j * ER, m = m0 + row;
             const bool ok = row < EPI_ROWS && m < a.M;
-            r1[j] = (ok && a.res1) ? *reinterpret_cast<const u32x4_t*>((const uint16_t*)a.res1 + (size_t)m * a.ldres1 + n)
+            r1[j] = (ok && a.res1) ? *reinterpret_cast<const u32x4_t*>((const uint16_t*)a.res1 + (size_t)(m - r1shift) * a.ldres1 + n)
                                    : u32x4_t{0u, 0u, 0u, 0u};
             r2[j] = (ok && a.res2) ? *reinterpret_cast<const u32x4_t*>((const uint16_t*)a.res2 + (size_t)m * a.ldres2 + n)
                                    : u32x4_t{0u, 0u, 0u, 0u};
@@ -1090,6 +1097,10 @@ pp_gemm_kernel_v2(const PPGemmArgs a, const GemmDerived d) {   // 2nd bound = wa
                 o[0] = E16<EDT>::pack2(v0[0], v0[1]); o[1] = E16<EDT>::pack2(v0[2], v0[3]);
                 o[2] = E16<EDT>::pack2(v1[0], v1[1]); o[3] = E16<EDT>::pack2(v1[2], v1[3]);
                 *reinterpret_cast<u32x4_t*>((uint16_t*)a.out + (size_t)m * a.ldo + n) = o;
+                if constexpr (!LNF) {        // (conv_in: never a folded-LayerNorm launch; those kernels have no registers to spare)
+                  if (a.out_dup_rows > 0)    // the twin half of a CFG batch (PPGemmArgs.out_dup_rows): same values, second copy
+                    *reinterpret_cast<u32x4_t*>((uint16_t*)a.out + ((size_t)m + a.out_dup_rows) * a.ldo + n) = o;
+                }
                 if (GNS) {   // per-column moments of the values as stored, over this thread's rows of the pass
 #pragma unroll
                   for (int jj = 0; jj < 4; ++jj) {
@@ -1161,7 +1172,7 @@ __global__ void __launch_bounds__(256) pp_splitk_reduce_kernel(const PPGemmArgs 
     }
     if (LEAN) {
       u32x4_t r1 = {0u, 0u, 0u, 0u}, r2 = {0u, 0u, 0u, 0u};
-      if (a.res1) r1 = *reinterpret_cast<const u32x4_t*>((const uint16_t*)a.res1 + (size_t)m * a.ldres1 + n);
+      if (a.res1) r1 = *reinterpret_cast<const u32x4_t*>((const uint16_t*)a.res1 + res1_row(a, m) * a.ldres1 + n);
       if (a.res2) r2 = *reinterpret_cast<const u32x4_t*>((const uint16_t*)a.res2 + (size_t)m * a.ldres2 + n);
       f32x4_t v0 = p0[0], v1 = p1[0];
 #pragma unroll
@@ -1225,7 +1236,7 @@ __global__ void __launch_bounds__(320) pp_splitk_reduce_gn_kernel(const PPGemmAr
       }
     }
     u32x4_t r1 = {0u, 0u, 0u, 0u}, r2 = {0u, 0u, 0u, 0u};
-    if (a.res1) r1 = *reinterpret_cast<const u32x4_t*>((const uint16_t*)a.res1 + (size_t)m * a.ldres1 + n);
+    if (a.res1) r1 = *reinterpret_cast<const u32x4_t*>((const uint16_t*)a.res1 + res1_row(a, m) * a.ldres1 + n);
     if (a.res2) r2 = *reinterpret_cast<const u32x4_t*>((const uint16_t*)a.res2 + (size_t)m * a.ldres2 + n);
     f32x4_t v0 = p0[0], v1 = p1[0];
 #pragma unroll
@@ -1309,7 +1320,7 @@ __global__ void __launch_bounds__(640) pp_splitk_reduce_gn_apply_kernel(const PP
       }
     }
     u32x4_t r1 = {0u, 0u, 0u, 0u}, r2 = {0u, 0u, 0u, 0u};
-    if (a.res1) r1 = *reinterpret_cast<const u32x4_t*>((const uint16_t*)a.res1 + (size_t)m * a.ldres1 + n);
+    if (a.res1) r1 = *reinterpret_cast<const u32x4_t*>((const uint16_t*)a.res1 + res1_row(a, m) * a.ldres1 + n);
     if (a.res2) r2 = *reinterpret_cast<const u32x4_t*>((const uint16_t*)a.res2 + (size_t)m * a.ldres2 + n);
     f32x4_t v0 = p0[0], v1 = p1[0];
 #pragma unroll
@@ -1647,6 +1658,22 @@ int validate(const PPGemmArgs& a) {
   if (a.ln_stats && (!a.ln_colsum || a.ln_tiles <= 0 || a.ln_dim <= 0)) return PP_ERR_BAD_ARG;
   if (a.row_stats_out && (a.out_f32 || a.out_vt || a.act == PP_ACT_GEGLU || !v2_ok(a))) return PP_ERR_UNSUPPORTED;
   if ((a.gn_acc[0] || a.gn_acc[1]) && !gn_stats_supported(a)) return PP_ERR_UNSUPPORTED;
+  // the CFG-twin prefix (ABI v19): half-batch residual read with wrap, output written for both halves
+  if (a.res1_wrap_rows < 0 || a.out_dup_rows < 0 || a.gn_dup_batch < 0 || (a.gn_dup_mask & ~3)) return PP_ERR_BAD_ARG;
+  if (a.res1_wrap_rows > 0 && (!a.res1 || a.M > 2 * a.res1_wrap_rows || a.res1_wrap_rows % 64)) return PP_ERR_BAD_ARG;
+  if (a.out_dup_rows > 0) {
+    if (a.out_dup_rows < a.M) return PP_ERR_BAD_ARG;                 // (the copy must not overlap the rows this launch writes)
+    if (a.out_f32 || a.out_vt || a.act == PP_ACT_GEGLU || a.row_stats_out || a.ln_stats || a.gn_next_out || a.gn_in_acc ||
+        !v2_ok(a))
+      return PP_ERR_UNSUPPORTED;
+  }
+  if (a.gn_dup_mask) {
+    if (a.out_dup_rows <= 0 || a.gn_dup_batch <= 0 || a.rows_per_batch <= 0 ||
+        a.gn_dup_batch * a.rows_per_batch != a.out_dup_rows)
+      return PP_ERR_BAD_ARG;
+    for (int k = 0; k < 2; ++k)
+      if ((a.gn_dup_mask >> k & 1) && !a.gn_acc[k]) return PP_ERR_BAD_ARG;
+  }
   return PP_OK;
 }
 
@@ -1693,6 +1720,7 @@ extern "C" int pp_gemm_gn_stats_ok(const PPGemmArgs* args) {
   if (!args) return 0;
   PPGemmArgs a = *args;
   a.gn_acc[0] = a.gn_acc[1] = nullptr;
+  a.gn_dup_mask = 0;
   if (validate(a) != PP_OK || !gn_stats_supported(a)) return 0;
   if (pp_conv_gn_wanted(a)) return pp_conv_gn_splitk(a) > 0 ? 1 : 0;
   const Choice c = choose(a);
@@ -1740,6 +1768,7 @@ extern "C" int pp_gemm_bf16(const PPGemmArgs* args, void* stream) {
   const Choice c = choose(a);
   if (c.splitk > 1 && !a.workspace) return PP_ERR_WORKSPACE;
   if (c.tile > 10 && !v2_ok(a)) return PP_ERR_BAD_ARG;
+  if (a.out_dup_rows > 0 && (c.tile < 10 || c.splitk > 1)) return PP_ERR_UNSUPPORTED;   // single-pass staged epilogue only
   if ((a.row_stats_out || a.gn_acc[0] || a.gn_acc[1] || (a.x_mode == PP_X_CONV3X3 && a.c3 > 0)) &&
       c.tile < 10)
     return PP_ERR_UNSUPPORTED;

@@ -34,6 +34,11 @@ PP_DEVINL void gn_flush(const PPGemmArgs& a, unsigned long long* slots, int m0, 
       unsigned long long* sl = slots + (k * GN_SLOTS + gl) * 2;
       __hip_atomic_fetch_add(dst, sl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_fetch_add(dst + 1, sl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (a.gn_dup_mask >> k & 1) {      // the twin half of a CFG batch holds the same values (PPGemmArgs.out_dup_rows)
+        unsigned long long* dup = dst + (size_t)a.gn_dup_batch * a.gn_groups[k] * 2;
+        __hip_atomic_fetch_add(dup, sl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(dup + 1, sl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
       sl[0] = 0ull;
       sl[1] = 0ull;
     }

@@ -47,6 +47,7 @@ struct XAArgs {
   uint16_t* out; int ldo;
   float* row_stats_out;
   int M, rows_per_batch;
+  int src_wrap;          // > 0: x / res / ln_stats hold src_wrap rows, row m reads row m mod src_wrap (CFG twin, pp_hip.h)
 };
 
 template <int... I, class F>
@@ -166,11 +167,12 @@ __global__ void __launch_bounds__(512, 2) xattn_block_kernel(const XAArgs a) {
   const int m_blk = lid * XA_BM;
   const int b = m_blk / a.rows_per_batch;
   const int m = m_blk + wave * 16 + r16;                 // this lane's row: MFMA B column / accumulator column
+  const int ms = (a.src_wrap > 0 && m >= a.src_wrap) ? m - a.src_wrap : m;      // ... and the row its inputs come from
 
   // ---- the wave's 16 input rows as B fragments (k-group g: eight consecutive channels), straight from global memory
   v8_t xf[10];
   {
-    const uint16_t* xr = a.x + (size_t)m * a.ldx + g * 8;
+    const uint16_t* xr = a.x + (size_t)ms * a.ldx + g * 8;
 #pragma unroll
     for (int s = 0; s < 10; ++s) xf[s] = *reinterpret_cast<const v8_t*>(xr + 32 * s);
   }
@@ -178,7 +180,7 @@ __global__ void __launch_bounds__(512, 2) xattn_block_kernel(const XAArgs a) {
     tabs[i] = i < XA_S ? a.gcs[(size_t)b * XA_S + i] : a.gbias[(size_t)b * XA_S + i - XA_S];
   float mean = 0.f, rstd = 1.f;
   if (a.ln_stats) {
-    const f32x2_t* pm = reinterpret_cast<const f32x2_t*>(a.ln_stats) + (size_t)m * a.ln_tiles;
+    const f32x2_t* pm = reinterpret_cast<const f32x2_t*>(a.ln_stats) + (size_t)ms * a.ln_tiles;
     float sm = 0.f, sq = 0.f;
     for (int t = 0; t < a.ln_tiles; ++t) { const f32x2_t v = pm[t]; sm += v[0]; sq += v[1]; }
     mean = sm * (1.0f / XA_C);
@@ -260,7 +262,7 @@ __global__ void __launch_bounds__(512, 2) xattn_block_kernel(const XAArgs a) {
   };
 
   // residual of the epilogue: fetched under the last slab's MFMAs (after stores nothing could be hoisted)
-  const uint16_t* rr = a.res ? a.res + (size_t)m * a.ldres : nullptr;
+  const uint16_t* rr = a.res ? a.res + (size_t)ms * a.ldres : nullptr;
   u32x2_t rv[20];
   f32x4_t bo[20];
   __syncthreads();                                        // the tables are in LDS
@@ -609,9 +611,11 @@ extern "C" int pp_xattn_fold(const void* k, int ldk, const void* vt, int ldvt, i
 extern "C" int pp_xattn_block(const void* x, int ldx, const void* res, int ldres, const float* ln_stats, int ln_tiles,
                               float ln_eps, const void* gt, const float* gcs, const float* gbias, const void* ht,
                               const float* bias_o, void* out, int ldo, float* row_stats_out, int M, int c,
-                              int rows_per_batch, int dtype, void* stream) {
+                              int rows_per_batch, int src_wrap_rows, int dtype, void* stream) {
   if (!x || !gt || !gcs || !gbias || !ht || !out || !pp_dt_ok(dtype)) return PP_ERR_BAD_ARG;
   if (!pp_xattn_block_supported(M, c, rows_per_batch, XA_KP, XA_HEADS)) return PP_ERR_UNSUPPORTED;
+  if (src_wrap_rows < 0 || (src_wrap_rows > 0 && (M > 2 * src_wrap_rows || src_wrap_rows % rows_per_batch))) return PP_ERR_BAD_ARG;
+  if (src_wrap_rows > 0 && c != XA_C) return PP_ERR_UNSUPPORTED;
   if (ldx < c || (ldx & 7) || ldo < c || (ldo & 3) || (res && (ldres < c || (ldres & 3)))) return PP_ERR_BAD_ARG;
   if (ln_stats && ln_tiles <= 0) return PP_ERR_BAD_ARG;
   XAArgs a;
@@ -623,6 +627,7 @@ extern "C" int pp_xattn_block(const void* x, int ldx, const void* res, int ldres
   a.out = (uint16_t*)out; a.ldo = ldo;
   a.row_stats_out = row_stats_out;
   a.M = M; a.rows_per_batch = rows_per_batch;
+  a.src_wrap = src_wrap_rows;
   if (c != XA_C) {
     static bool wattr[2][3] = {{false, false, false}, {false, false, false}};
     auto gow = [&](auto kern, int ci, int grid) -> int {

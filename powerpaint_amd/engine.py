@@ -41,6 +41,9 @@ GN_STATS_IN_EPILOGUE = _lab_switch("PP_GN_EPILOGUE")
 GN_NEXT_IN_COMBINE = _lab_switch("PP_GN_NEXT")
 # ResnetBlock2D's norm -> SiLU -> conv3x3 as ONE launch (csrc/conv_gn.hip).  (lab) PP_FUSE_GN_CONV=0: apply launch + conv
 FUSE_GN_CONV = _lab_switch("PP_FUSE_GN_CONV")
+# round 5: the CFG-identical prefix of a forward pass (conv_in .. first self-attention) on ONE half of the batch where the
+# caller vouches for identical halves (SDNet.build_step(twin=True)).  (lab) PP_TWIN=0: the whole batch everywhere
+TWIN_PREFIX = _lab_switch("PP_TWIN")
 
 
 class Arena:
@@ -146,6 +149,8 @@ class Act:
     W: int
     C: int
     producer: object = None   # PPGemmArgs of the launch that writes this tensor (GroupNorm statistics subscribe to it)
+    dup_half: int = 0         # > 0: the producer computed batch items [0, dup_half) and stored every row twice (the CFG twin
+    #                           prefix, PPGemmArgs.out_dup_rows); this Act is the full-batch view of that tensor
 
     @property
     def rows(self) -> int:
@@ -262,9 +267,10 @@ class Builder:
                ldres2: int = 0, scale: float = 1.0, act: int = 0, out: int = 0, ldo: Optional[int] = None,
                rowvec: int = 0, ld_rowvec: int = 0, rows_per_batch: int = 0, out_vt: int = 0, vt_col0: int = 0,
                vt_ld: int = 0, out_f32: bool = False, row_stats_out: int = 0, ln_stats: int = 0, ln_colsum: int = 0,
-               ln_tiles: int = 0, ln_dim: int = 0, ln_eps: float = 1e-5, name: str = "gemm") -> int:
+               ln_tiles: int = 0, ln_dim: int = 0, ln_eps: float = 1e-5, name: str = "gemm", res1_wrap: int = 0) -> int:
         """out[rows][N] = epilogue(X[rows][K(+K2)] @ W[N][K+K2]^T).  Returns the output pointer.
-        row_stats_out / ln_*: LayerNorm folded across two GEMMs (see include/pp_hip.h)."""
+        row_stats_out / ln_*: LayerNorm folded across two GEMMs (see include/pp_hip.h).  res1_wrap: res1 holds only that
+        many rows (one half of a CFG pair), row m adds row m mod res1_wrap."""
         n_out = N // 2 if act == L.PP_ACT_GEGLU else (vt_col0 if out_vt else N)
         if ldo is None:
             ldo = n_out
@@ -278,6 +284,7 @@ class Builder:
         a.w, a.bias = w, bias or None
         a.rowvec, a.ld_rowvec, a.rows_per_batch = rowvec or None, ld_rowvec, rows_per_batch
         a.res1, a.ldres1 = res1 or None, ldres1 or N
+        a.res1_wrap_rows = res1_wrap
         a.res2, a.ldres2 = res2 or None, ldres2 or N
         a.scale, a.act = scale, act
         a.out, a.ldo, a.out_f32 = out, ldo, int(out_f32)
@@ -292,10 +299,12 @@ class Builder:
     def conv3x3(self, x: Act, w: int, cout: int, bias: int = 0, stride: int = 1, up: bool = False,
                 x2: Optional[Act] = None, rowvec: int = 0, res1: int = 0, res2: int = 0, scale: float = 1.0,
                 out: Optional[Act] = None, x3: Optional[Act] = None, x4: Optional[Act] = None,
-                name: str = "conv3x3", gn_in: Optional[Tuple[int, int, int, float, int]] = None) -> Act:
+                name: str = "conv3x3", gn_in: Optional[Tuple[int, int, int, float, int]] = None, dup: bool = False) -> Act:
         """gn_in = (gamma, beta, gamma_beta_interleaved, eps, groups): the conv input is SiLU(GroupNorm(concat(x, x2))).
         Where the statistics arrive from the producers' epilogues and the shape suits csrc/conv_gn.hip the norm runs in
-        the conv's loader (ONE launch, the normalised activation is never written); else pp_groupnorm_apply(_acc) + conv."""
+        the conv's loader (ONE launch, the normalised activation is never written); else pp_groupnorm_apply(_acc) + conv.
+        dup: x is ONE half of a CFG pair whose halves are identical; the launch stores every output row twice and the
+        returned Act is the full batch (PPGemmArgs.out_dup_rows, Act.dup_half)."""
         if gn_in is not None:
             gamma, beta, gb, eps, groups = gn_in
             acc = self._subscribe_gn_stats(x, x2, groups) if FUSE_GN_CONV else 0
@@ -308,6 +317,10 @@ class Builder:
             fused = None
         hv, wv = (x.H * 2, x.W * 2) if up else (x.H, x.W)
         ho, wo = (hv + 2 - 3) // stride + 1, (wv + 2 - 3) // stride + 1
+        if dup:
+            assert out is None and gn_in is None
+            out = self.new_act(2 * x.B, ho, wo, cout)
+            out.dup_half = x.B
         if out is None:
             out = self.new_act(x.B, ho, wo, cout)
         m = self.mark()
@@ -327,6 +340,11 @@ class Builder:
         a.res1, a.ldres1, a.res2, a.ldres2 = res1 or None, cout, res2 or None, cout
         a.scale, a.act = scale, 0
         a.out, a.ldo, a.out_f32 = out.ptr, cout, 0
+        if dup:
+            a.out_dup_rows = a.M
+            a.dtype = self.dt
+            if self.lib.pp_gemm_workspace_bytes(C.byref(a)):      # (split-K: the combine does not write twins)
+                raise L.PPError("twin-prefix conv would run split-K; the caller must not request dup for this shape")
         if fused is not None:
             a.gn_in_acc, a.gn_in_gb, a.gn_in_groups, a.gn_in_eps, a.gn_in_silu = fused[0], fused[1], fused[2], fused[3], 1
             a.dtype = self.dt
@@ -432,6 +450,8 @@ class Builder:
             k = 0 if not a.gn_acc[0] else 1
             a.rows_per_batch = hw
             a.gn_acc[k], a.gn_cg[k], a.gn_c0[k], a.gn_groups[k] = acc, Ct // groups, c0, groups
+            if t.dup_half:       # this consumer sees the full (twice-stored) tensor: both halves' accumulators get the sums
+                a.gn_dup_batch, a.gn_dup_mask = t.dup_half, a.gn_dup_mask | (1 << k)
         return acc
 
     def layernorm(self, x: int, rows: int, Cc: int, gamma: int, beta: int, eps: float = 1e-5) -> int:
@@ -857,19 +877,25 @@ class SDNet:
         pb.release(m)
         return out
 
-    def _transformer(self, pb: Builder, pre: str, x: Act, kv: Tuple[int, int, int, int], res2: int = 0) -> Act:
-        """kv = (k_ptr, ldk, vt_ptr, ldvt) of the hoisted cross-attention K / V^T; nk = ctx tokens in self._nctx."""
+    def _transformer(self, pb: Builder, pre: str, x: Act, kv: Tuple[int, int, int, int], res2: int = 0,
+                     twin: bool = False) -> Act:
+        """kv = (k_ptr, ldk, vt_ptr, ldvt) of the hoisted cross-attention K / V^T; nk = ctx tokens in self._nctx.
+        twin: x is ONE half of a CFG pair whose halves are identical up to here (build_step): norm / proj_in / attn1 run on
+        that half, the fused cross-attention block -- the first consumer that mixes the prompt in -- reads it with batch-wrap
+        addressing, and everything behind it (and the returned Act) is the full batch."""
         P = self.P
         Cc, rows, hw = x.C, x.rows, x.H * x.W
         d = Cc // self.heads
         tb = f"{pre}.transformer_blocks.0"
-        out = pb.new_act(x.B, x.H, x.W, Cc)
+        Bo = 2 * x.B if twin else x.B          # batch / rows behind the first cross-attention
+        rows_o = Bo * hw
+        out = pb.new_act(Bo, x.H, x.W, Cc)
         m = pb.mark()
         fold = self.fold_ln
         tiles = (Cc + 159) // 160
 
-        def producer():     # row-moment buffer written by the GEMM that produces the next LayerNorm's input
-            return pb.alloc(rows * tiles * 8) if fold else 0
+        def producer(r=None):     # row-moment buffer written by the GEMM that produces the next LayerNorm's input
+            return pb.alloc((r or rows) * tiles * 8) if fold else 0
 
         def normed(h, st, nrm, lin):
             """-> (x pointer, kwargs) for the Linear `lin` applied to LayerNorm_nrm(h)."""
@@ -923,15 +949,17 @@ class SDNet:
         # cross-attention (K / V^T hoisted out of the step: encoder_hidden_states are step-invariant)
         ln, kw = normed(hs, st, "norm2", "attn2.to_q")
         xa = getattr(self, "xa", {}).get(pre)
-        if xa is not None and pb.lib.pp_xattn_block_supported(rows, Cc, hw, self._nctx, self.heads):
-            st2 = producer()
-            o = pb.alloc(rows * Cc * 2)
+        if xa is not None and pb.lib.pp_xattn_block_supported(rows_o, Cc, hw, self._nctx, self.heads):
+            st2 = producer(rows_o)
+            o = pb.alloc(rows_o * Cc * 2)
             pb.plan.add("xattn_block", pb.lib.pp_xattn_block, ln, Cc, hs, Cc, kw.get("ln_stats"), tiles if fold else 0,
-                        1e-5, xa[0], xa[1], xa[2], xa[3], P[f"{tb}.attn2.to_out.bias"], o, Cc, st2 or None, rows, Cc, hw,
-                        pb.dt)
+                        1e-5, xa[0], xa[1], xa[2], xa[3], P[f"{tb}.attn2.to_out.bias"], o, Cc, st2 or None, rows_o, Cc, hw,
+                        rows if twin else 0, pb.dt)
             # (the FLOPs of the chain it stands for: the folded form multiplies twice as much)
-            pb.plan.count("xattn_block", 4.0 * rows * Cc * Cc + 4.0 * rows * self._nctx * Cc)
+            pb.plan.count("xattn_block", 4.0 * rows_o * Cc * Cc + 4.0 * rows_o * self._nctx * Cc)
             hs, st = o, st2
+        elif twin:
+            raise L.PPError("twin prefix without the fused cross-attention block (build_step checks _twin_ok first)")
         else:
             q = pb.linear(ln, rows, Cc, P[f"{tb}.attn2.to_q.weight"], Cc, name="linear", **kw)
             a = pb.attention(q, Cc, kv[0], kv[1], kv[2], kv[3], x.B, self.heads, hw, self._nctx, d)
@@ -939,16 +967,18 @@ class SDNet:
             hs = pb.linear(a, rows, Cc, P[f"{tb}.attn2.to_out.weight"], Cc, P[f"{tb}.attn2.to_out.bias"], res1=hs,
                            row_stats_out=st, name="linear")
         # feed-forward: GEGLU fused into the first GEMM's epilogue
+        rows_h, rows = rows, rows_o           # (from here on: the full batch)
+        wrap = rows_h if twin else 0          # the transformer's input (the proj_out residual) holds one half only
         ln, kw = normed(hs, st, "norm3", "ff1")
         g = pb.linear(ln, rows, Cc, P[f"{tb}.ff1.weight"], 8 * Cc, act=L.PP_ACT_GEGLU, name="linear_geglu", **kw)
         if self.merge_ff2_proj_out:
             pb.linear(g, rows, 4 * Cc, P[f"{pre}.ff2_proj_out.weight"], Cc, P[f"{pre}.ff2_proj_out.bias"], x2=hs, K2=Cc,
-                      ldx2=Cc, res1=x.ptr, res2=res2, out=out.ptr, name="linear")
+                      ldx2=Cc, res1=x.ptr, res1_wrap=wrap, res2=res2, out=out.ptr, name="linear")
             out.producer = pb.last_gemm
         else:
             hs = pb.linear(g, rows, 4 * Cc, P[f"{tb}.ff2.weight"], Cc, P[f"{tb}.ff2.bias"], res1=hs, name="linear")
-            pb.linear(hs, rows, Cc, P[f"{pre}.proj_out.weight"], Cc, P[f"{pre}.proj_out.bias"], res1=x.ptr, res2=res2,
-                      out=out.ptr, name="conv1x1")
+            pb.linear(hs, rows, Cc, P[f"{pre}.proj_out.weight"], Cc, P[f"{pre}.proj_out.bias"], res1=x.ptr, res1_wrap=wrap,
+                      res2=res2, out=out.ptr, name="conv1x1")
             out.producer = pb.last_gemm
         pb.release(m)
         return out
@@ -1001,21 +1031,38 @@ class SDNet:
             self.cond_emb = dconv(e, "conv_out", self.boc[0], 1, 0)
 
     # ---------------------------------------------------------------- step plan
+    def twin_prefix_ok(self, lib, B: int, H: int, W: int, nctx: int, brush: bool = False) -> bool:
+        """Can build_step(twin=True) run the CFG-identical prefix of this network on one half of the batch?  Needs the
+        fused cross-attention block at the first level (it is the launch that reads the half batch with wrap addressing)
+        and an input that nothing prompt-dependent touches before it: no BrushNet adds inside the down path."""
+        pre = "down_blocks.0.attentions.0"
+        return (TWIN_PREFIX and not brush and B >= 2 and B % 2 == 0 and self.L >= 1 and self.boc[0] == 320 and
+                self.down_types[0] == "CrossAttnDownBlock2D" and pre in getattr(self, "xa", {}) and (H * W) % 128 == 0 and
+                bool(lib.pp_xattn_block_supported(B * H * W, 320, H * W, nctx, self.heads)))
+
     def build_step(self, pb: Builder, x_in: Act, t_dev: int, add_down: Optional[List[int]] = None,
                    add_mid: int = 0, add_up: Optional[List[int]] = None, ctrl_down: Optional[List[int]] = None,
-                   ctrl_mid: int = 0, scale: float = 1.0, pad_uncond: bool = False) -> Dict[str, object]:
+                   ctrl_mid: int = 0, scale: float = 1.0, pad_uncond: bool = False, twin: bool = False) -> Dict[str, object]:
         """Append one forward pass.  x_in: NHWC bf16 input (already channel-concatenated).  Returns outputs:
         unet -> {"eps": ptr fp32 NCHW}; brushnet -> {"down": [Act], "mid": Act, "up": [Act]}; controlnet likewise.
         pad_uncond (side networks): the pipelines' guess mode runs the side branch on the conditional half of a CFG pair
         only and hands the UNet `cat([zeros_like(d), d])` (pipeline_PowerPaint_Brushnet_CA.py:1421-1425,
         pipeline_PowerPaint_ControlNet.py:1697-1702): the residuals are written into the second half of tensors with
-        twice the batch whose first half one launch per step zeroes."""
+        twice the batch whose first half one launch per step zeroes.
+        twin: the caller GUARANTEES that batch items [B/2, B) of x_in (and of the ControlNet conditioning) equal items
+        [0, B/2) -- the loop builds the pair as `torch.cat([latents] * 2)` (pipeline_PowerPaint.py:990-996) over CFG-duplicated
+        mask / masked-image latents.  The two halves of the forward pass are then bit-identical until the prompt enters at the
+        first cross-attention (unet_2d_condition.py:1183-1236): conv_in, down_blocks.0.resnets.0 and the first transformer's
+        norm / proj_in / self-attention run on ONE half (conv_in stores its rows twice -- the skip tensor's consumers in the
+        up path see the full batch -- and the fused cross-attention block and the transformer's last GEMM read the half
+        batch with wrap addressing).  Where twin_prefix_ok() says no, the flag changes nothing."""
         P, lib = self.P, pb.lib
         B, H, W = x_in.B, x_in.H, x_in.W
         boc = self.boc
         brush = add_down is not None
         add_down = list(add_down) if brush else None
         add_up = list(add_up) if brush else None
+        twin = bool(twin) and not pad_uncond and self.twin_prefix_ok(lib, B, H, W, self._nctx, brush)
 
         def pop(lst):
             return lst.pop(0) if lst is not None else 0
@@ -1041,8 +1088,9 @@ class SDNet:
             raise L.PPError(f"network input buffer has {x_in.C} channels, conv_in expects {self.cin_pad} (zero-padded)")
 
         def conv_in(add_ptr) -> Act:
-            o = pb.conv3x3(x_in, P["conv_in.weight"], boc[0], P["conv_in.bias"], res2=add_ptr or 0, name="conv3x3")
-            pb.plan.count("conv3x3", -2.0 * B * H * W * boc[0] * 9 * (x_in.C - self.cin0))   # (count the real MACs)
+            x = Act(x_in.ptr, B // 2, H, W, x_in.C) if twin else x_in
+            o = pb.conv3x3(x, P["conv_in.weight"], boc[0], P["conv_in.bias"], res2=add_ptr or 0, name="conv3x3", dup=twin)
+            pb.plan.count("conv3x3", -2.0 * x.B * H * W * boc[0] * 9 * (x_in.C - self.cin0))   # (count the real MACs)
             return o
 
         if self.kind == "controlnet":
@@ -1053,6 +1101,8 @@ class SDNet:
             skips = [s]                       # captured BEFORE the BrushNet add (unet_2d_condition.py:1220-1223)
             if brush:
                 s = conv_in(pop(add_down))
+        if twin:                              # the half the prefix goes on with (skips[0] stays the full, twice-stored tensor)
+            s = Act(s.ptr, B // 2, s.H, s.W, s.C, producer=s.producer)
 
         # 3. down
         for i, typ in enumerate(self.down_types):
@@ -1063,7 +1113,7 @@ class SDNet:
                 s = self._resnet(pb, pre, s, boc[i], temb_all, res2=0 if has_attn else r2)
                 if has_attn:
                     ap = f"down_blocks.{i}.attentions.{j}"
-                    s = self._transformer(pb, ap, s, self.kv[ap], res2=r2)
+                    s = self._transformer(pb, ap, s, self.kv[ap], res2=r2, twin=twin and i == 0 and j == 0)
                 skips.append(s)
             if i != len(boc) - 1:
                 pre = f"down_blocks.{i}.downsamplers.0.conv"

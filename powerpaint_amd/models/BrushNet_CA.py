@@ -63,7 +63,7 @@ class BrushNetModel(_HipModel):
         return bn.load_state_dict(new)
 
     def prepare(self, sample_shape, encoder_hidden_states, conditioning_scale=1.0, guess_mode: bool = False,
-                pad_uncond: bool = False):
+                pad_uncond: bool = False, twin: bool = False):
         """pad_uncond: outputs laid out as `cat([zeros_like(d), d])` for a UNet running the CFG pair (the pipeline's guess
         mode, pipeline_PowerPaint_Brushnet_CA.py:1421-1425)."""
         B, Cin, H, W = sample_shape
@@ -72,7 +72,7 @@ class BrushNetModel(_HipModel):
             n = len(self.net._zero_conv_specs())
             scale = [float(s) * conditioning_scale for s in torch.logspace(-1, 0, n)]
         self.rt.ensure(B, H, W, self._nctx(encoder_hidden_states), Cin + self.config.conditioning_channels,
-                       ("plain",), scale=scale, pad_uncond=pad_uncond)
+                       ("plain",), scale=scale, pad_uncond=pad_uncond, twin=twin)
         self.rt.set_context(encoder_hidden_states)
         return self.rt
 

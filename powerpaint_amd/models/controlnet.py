@@ -33,7 +33,7 @@ class ControlNetModel(_HipModel):
             global_pool_conditions=False)
 
     def prepare(self, sample_shape, encoder_hidden_states, controlnet_cond, conditioning_scale=1.0,
-                guess_mode: bool = False, pad_uncond: bool = False):
+                guess_mode: bool = False, pad_uncond: bool = False, twin: bool = False):
         """pad_uncond: outputs laid out as `cat([zeros_like(d), d])` for a UNet running the CFG pair (the pipeline's guess
         mode, pipeline_PowerPaint_ControlNet.py:1697-1702)."""
         B, Cin, H, W = sample_shape
@@ -42,7 +42,7 @@ class ControlNetModel(_HipModel):
             n = len(self.net._zero_conv_specs())
             scale = [float(s) * conditioning_scale for s in torch.logspace(-1, 0, n)]
         self.rt.ensure(B, H, W, self._nctx(encoder_hidden_states), Cin, ("plain",),
-                       cond_hw=tuple(controlnet_cond.shape[-2:]), scale=scale, pad_uncond=pad_uncond)
+                       cond_hw=tuple(controlnet_cond.shape[-2:]), scale=scale, pad_uncond=pad_uncond, twin=twin)
         self.rt.set_cond(controlnet_cond)
         self.rt.set_context(encoder_hidden_states)
         return self.rt

@@ -53,14 +53,18 @@ class UNet2DConditionModel(_HipModel):
         return ("plain",)
 
     def prepare(self, sample_shape, encoder_hidden_states, down_block_add_samples=None, mid_block_add_sample=None,
-                up_block_add_samples=None, down_block_additional_residuals=None, mid_block_additional_residual=None):
-        """Compile (or reuse) the launch plan for this shape / residual wiring and bind the inputs."""
+                up_block_add_samples=None, down_block_additional_residuals=None, mid_block_additional_residual=None,
+                twin: bool = False):
+        """Compile (or reuse) the launch plan for this shape / residual wiring and bind the inputs.  twin: the caller (the
+        fused denoising loop) vouches that the second half of the batch is a copy of the first (`torch.cat([latents] * 2)`
+        over CFG-duplicated mask / masked-image latents, pipeline_PowerPaint.py:990-996): the prompt-independent prefix of
+        the forward pass then runs on one half (NetRuntime.ensure).  `forward` never sets it."""
         B, Cin, H, W = sample_shape
         if Cin != self.config.in_channels:
             raise ValueError(f"sample has {Cin} channels, unet.config.in_channels = {self.config.in_channels}")
         wiring = self._wiring(down_block_add_samples, mid_block_add_sample, up_block_add_samples,
                               down_block_additional_residuals, mid_block_additional_residual)
-        self.rt.ensure(B, H, W, self._nctx(encoder_hidden_states), Cin, wiring)
+        self.rt.ensure(B, H, W, self._nctx(encoder_hidden_states), Cin, wiring, twin=twin)
         if wiring[0] != "plain":
             groups = {"down": down_block_add_samples if wiring[0] == "brushnet" else down_block_additional_residuals,
                       "mid": [mid_block_add_sample if wiring[0] == "brushnet" else mid_block_additional_residual]}

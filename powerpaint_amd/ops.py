@@ -45,8 +45,9 @@ def groupnorm_apply_acc(x: torch.Tensor, acc: torch.Tensor, gamma, beta, eps: fl
 def gemm(x: torch.Tensor, w: torch.Tensor, bias=None, x2=None, res1=None, res2=None, scale: float = 1.0, act: int = 0,
          rowvec=None, rows_per_batch: int = 0, out_f32: bool = False, vt_col0: int = 0, tile: int = 0,
          splitk: int = 0, row_stats: bool = False, ln_stats=None, ln_colsum=None, ln_dim: int = 0,
-         ln_eps: float = 1e-5, gn=None):
+         ln_eps: float = 1e-5, gn=None, res1_wrap: int = 0):
     """x [M,K1] (+ x2 [M,K2]) bf16, w [N,K1+K2] bf16 -> out [M,N] (or [M,N/2] for GEGLU; (out, vt) when vt_col0).
+    res1_wrap: res1 holds that many rows only, row m adds res1[m mod res1_wrap] (PPGemmArgs.res1_wrap_rows).
     row_stats=True additionally returns the per-row (sum, sumsq) partials [M, ceil(N/160), 2] fp32;
     ln_stats (that layout) + ln_colsum [N] fp32 apply the folded-LayerNorm correction (see include/pp_hip.h)."""
     lib = L.lib()
@@ -61,6 +62,7 @@ def gemm(x: torch.Tensor, w: torch.Tensor, bias=None, x2=None, res1=None, res2=N
     a.ld_rowvec = rowvec.stride(0) if (rowvec is not None and rowvec.dim() == 2 and rowvec.shape[0] > 1) else 0
     a.rows_per_batch = rows_per_batch
     a.res1, a.ldres1 = _p(res1), (res1.stride(0) if res1 is not None else N)
+    a.res1_wrap_rows = res1_wrap
     a.res2, a.ldres2 = _p(res2), (res2.stride(0) if res2 is not None else N)
     a.scale, a.act = scale, act
     n_out = N // 2 if act == L.PP_ACT_GEGLU else (vt_col0 if vt_col0 else N)
@@ -120,8 +122,10 @@ def _conv_args(x, cout, stride, up, x2, x3, x4):
 
 def conv3x3(x: torch.Tensor, w: torch.Tensor, bias=None, stride: int = 1, up: bool = False, x2=None, rowvec=None,
             res1=None, res2=None, scale: float = 1.0, tile: int = 0, splitk: int = 0, gn=None, x3=None, x4=None,
-            gn_in=None, gn_next=None):
+            gn_in=None, gn_next=None, dup: bool = False, gn_dup_mask: int = 0, res1_wrap: int = 0):
     """x NHWC bf16 [B,H,W,C1] (+x2 [B,H,W,C2]); w bf16 [Cout, 9*(C1+C2)] (k = (ky*3+kx)*C + c) -> NHWC bf16.
+    dup: every output row is stored twice -> out [2B, ...] (PPGemmArgs.out_dup_rows: the CFG twin prefix); gn_dup_mask:
+    which of the `gn` subscriptions hold [2B][groups][2] accumulators that receive both halves' sums.
     gn_in = (acc int64 [B][groups][2], gamma_beta fp32 [C1+C2][2], groups, eps): GroupNorm + SiLU of concat(x, x2) fused
     into the loader (x, x2 are then the RAW tensors); raises PPError(PP_ERR_UNSUPPORTED) where conv_gn_supported() is
     False.  gn_next = (gamma, beta, eps, silu, sub): the GroupNorm that consumes the OUTPUT (its statistics subscription
@@ -132,7 +136,7 @@ def conv3x3(x: torch.Tensor, w: torch.Tensor, bias=None, stride: int = 1, up: bo
     cout = w.shape[0]
     hv, wv = (2 * H, 2 * W) if up else (H, W)
     ho, wo = (hv - 1) // stride + 1, (wv - 1) // stride + 1
-    out = torch.empty(B, ho, wo, cout, dtype=x.dtype, device=x.device)
+    out = torch.empty(2 * B if dup else B, ho, wo, cout, dtype=x.dtype, device=x.device)
     a = L.PPGemmArgs()
     a.dtype = L.dtype_code(x.dtype)
     C3 = x3.shape[3] if x3 is not None else 0
@@ -145,6 +149,11 @@ def conv3x3(x: torch.Tensor, w: torch.Tensor, bias=None, stride: int = 1, up: bo
     if rowvec is not None and rowvec.dim() == 2 and rowvec.shape[0] > 1:
         a.ld_rowvec = rowvec.stride(0)
     a.res1, a.ldres1, a.res2, a.ldres2 = _p(res1), cout, _p(res2), cout
+    a.res1_wrap_rows = res1_wrap
+    if dup:
+        a.out_dup_rows = a.M
+        if gn_dup_mask:
+            a.gn_dup_batch, a.gn_dup_mask = B, gn_dup_mask
     a.scale, a.act, a.out, a.ldo = scale, 0, _p(out), cout
     a.tile, a.splitk = tile, splitk
     _set_gn(a, gn, ho * wo)
@@ -249,16 +258,19 @@ def xattn_fold(k: torch.Tensor, vt: torch.Tensor, batch: int, nctx: int, heads: 
 
 
 def xattn_block(x: torch.Tensor, folded, bias_o=None, res=None, ln_stats=None, ln_eps: float = 1e-5,
-                rows_per_batch: int = 0, row_stats: bool = False):
-    """out = softmax_per_head(LNfold(x) gt^T) ht^T + bias_o + res  (pp_xattn_block); x [M, c], folded = xattn_fold(...)."""
+                rows_per_batch: int = 0, row_stats: bool = False, twin: bool = False):
+    """out = softmax_per_head(LNfold(x) gt^T) ht^T + bias_o + res  (pp_xattn_block); x [M, c], folded = xattn_fold(...).
+    twin: x / res / ln_stats hold ONE half of a CFG pair (M rows) whose other half is identical; the output has 2 M rows
+    (src_wrap_rows = M) and `folded` is per batch item of the full batch."""
     gt, gcs, gb, ht = folded
-    M, c = x.shape
+    wrap = x.shape[0] if twin else 0
+    M, c = x.shape[0] * (2 if twin else 1), x.shape[1]
     out = torch.empty(M, c, dtype=x.dtype, device=x.device)
     st = torch.zeros(M, c // 160, 2, dtype=torch.float32, device=x.device) if row_stats else None
     L.check(L.lib().pp_xattn_block(_p(x), x.stride(0), _p(res), res.stride(0) if res is not None else 0, _p(ln_stats),
                                    ln_stats.shape[1] if ln_stats is not None else 0, ln_eps, _p(gt), _p(gcs), _p(gb), _p(ht),
-                                   _p(bias_o), _p(out), c, _p(st), M, c, rows_per_batch or M, L.dtype_code(x.dtype), _s()),
-            "pp_xattn_block")
+                                   _p(bias_o), _p(out), c, _p(st), M, c, rows_per_batch or M, wrap, L.dtype_code(x.dtype),
+                                   _s()), "pp_xattn_block")
     return (out, st) if row_stats else out
 
 

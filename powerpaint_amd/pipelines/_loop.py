@@ -103,6 +103,21 @@ class DenoiseLoop:
         if guess_mode and self.side is not None and not self.side.config.global_pool_conditions:
             self._guess_ramp = [float(v) for v in torch.logspace(-1, 0, len(self.side.net._zero_conv_specs()))]
         Bs = B if half else Be
+
+        # The CFG pair is built here, as `cat([latents] * 2)` (pipeline_PowerPaint.py:990): where every other network input
+        # is CFG-duplicated as well, the two halves of a forward pass are identical until the prompt enters and the
+        # networks run that prefix once (`twin`, SDNet.build_step).  A static input counts as duplicated when it arrives
+        # with the un-duplicated batch (load_input copies it to both halves) or when its halves compare equal.
+        def halves_equal(t):
+            if t is None or not torch.is_tensor(t):
+                return False
+            if t.shape[0] == B:
+                return True
+            return t.shape[0] == 2 * B and bool(torch.equal(t[:B], t[B:]))
+
+        twin_u = bool(do_cfg) and all(halves_equal(t) for t, _ in static_inputs)
+        twin_s = bool(do_cfg) and not half and all(halves_equal(t) for t, _ in side_static_inputs) and \
+            (self.side_kind == "brushnet" or halves_equal(controlnet_cond))
         if self.side is not None and self.side.dtype != self.unet.dtype:
             # the fused loop hands the side network's residuals to the UNet as raw NHWC arena pointers, every step: both
             # must store activations in the same 16-bit format (the reference raises a dtype error in its first conv)
@@ -112,15 +127,16 @@ class DenoiseLoop:
             if half and prompt_embeds_side.shape[0] == Be:
                 prompt_embeds_side = prompt_embeds_side.chunk(2)[1]
             if self.side_kind == "brushnet":
-                side_rt = self.side.prepare((Bs, Cl, h, w), prompt_embeds_side, side_scale, bool(guess_mode), half)
+                side_rt = self.side.prepare((Bs, Cl, h, w), prompt_embeds_side, side_scale, bool(guess_mode), half,
+                                            twin=twin_s)
                 d, m, u = self.side.outputs()
                 wiring_kw = dict(down_block_add_samples=d, mid_block_add_sample=m, up_block_add_samples=u)
             else:
                 side_rt = self.side.prepare((Bs, Cl, h, w), prompt_embeds_side, controlnet_cond, side_scale,
-                                            bool(guess_mode), half)
+                                            bool(guess_mode), half, twin=twin_s)
                 d, m = self.side.outputs()
                 wiring_kw = dict(down_block_additional_residuals=d, mid_block_additional_residual=m)
-        rt = self.unet.prepare((Be, cin, h, w), prompt_embeds, **wiring_kw)
+        rt = self.unet.prepare((Be, cin, h, w), prompt_embeds, twin=twin_u, **wiring_kw)
         # one-time (per call) static channels of the UNet / side inputs
         rt.load_input(list(static_inputs))
         if side_rt is not None and side_static_inputs:

@@ -34,7 +34,7 @@ class NetRuntime:
         self.gemm_splitk = 0
 
     # ------------------------------------------------------------------ build
-    def _build(self, arena: Arena, B, H, W, nctx, cin_total, wiring, cond_hw, scale, pad_uncond=False):
+    def _build(self, arena: Arena, B, H, W, nctx, cin_total, wiring, cond_hw, scale, pad_uncond=False, twin=False):
         net = self.net
         pb_setup = Builder(arena, dtype=net.dtype)
         pb_setup.gemm_tile, pb_setup.gemm_splitk = self.gemm_tile, self.gemm_splitk
@@ -83,7 +83,7 @@ class NetRuntime:
             if net.kind == "unet":
                 raise L.PPError("pad_uncond is an output layout of the side networks (BrushNet / ControlNet)")
             kw["pad_uncond"] = True
-        outs = net.build_step(pb, lay["x_in"], lay["t_dev"], scale=1.0, **kw)
+        outs = net.build_step(pb, lay["x_in"], lay["t_dev"], scale=1.0, twin=twin, **kw)
         if pb.gn_acc_used:
             pb.plan.calls.insert(0, (L.lib().pp_zero_u64, (lay["gn_acc"], pb.gn_acc_used // 8), "zero_u64"))
         return lay, pb_setup.plan, pb.plan, outs
@@ -113,13 +113,17 @@ class NetRuntime:
         return out
 
     def ensure(self, B: int, H: int, W: int, nctx: int, cin_total: int, wiring=("plain",), cond_hw=None,
-               scale: float = 1.0, pad_uncond: bool = False):
+               scale: float = 1.0, pad_uncond: bool = False, twin: bool = False):
+        """twin: the caller vouches that the second half of every network input (x_in, ControlNet conditioning) equals the
+        first -- a CFG pair built from one tensor; the step plan then runs the prompt-independent prefix on one half
+        (SDNet.build_step)."""
         def freeze(w):
             if len(w) == 1:
                 return w
             return (w[0], tuple((k, tuple(v)) for k, v in sorted(w[1].items())))
 
-        key = (B, H, W, nctx, cin_total, freeze(wiring), cond_hw, self.gemm_tile, self.gemm_splitk, bool(pad_uncond))
+        key = (B, H, W, nctx, cin_total, freeze(wiring), cond_hw, self.gemm_tile, self.gemm_splitk, bool(pad_uncond),
+               bool(twin))
         if isinstance(scale, (list, tuple)):
             scale = tuple(float(v) for v in scale)       # (one representation: a list never equals the stored tuple)
         if key == self.key:
@@ -129,10 +133,11 @@ class NetRuntime:
         if H % (2 ** (len(self.net.boc) - 1)) or W % (2 ** (len(self.net.boc) - 1)):
             raise L.PPError(f"latent size {H}x{W} must be divisible by {2 ** (len(self.net.boc) - 1)}")
         dry = Arena()
-        self._build(dry, B, H, W, nctx, cin_total, wiring, cond_hw, scale, pad_uncond)
+        self._build(dry, B, H, W, nctx, cin_total, wiring, cond_hw, scale, pad_uncond, twin)
         self.arena = Arena(_align(dry.peak, 4096), self.device)
         self.lay, self.setup_plan, self.step_plan, self.outputs = self._build(
-            self.arena, B, H, W, nctx, cin_total, wiring, cond_hw, scale, pad_uncond)
+            self.arena, B, H, W, nctx, cin_total, wiring, cond_hw, scale, pad_uncond, twin)
+        self.twin = bool(twin)
         self.key = key
         self._scale = 1.0
         if scale != 1.0:

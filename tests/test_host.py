@@ -496,7 +496,7 @@ def test_runtime_scale_schedule_representation_is_stable():
             self._scale = tuple(float(v) for v in scale) if isinstance(scale, (list, tuple)) else scale
 
     rt = RT()
-    rt.key = (2, 8, 8, 77, 9, ("plain",), None, 0, 0, False)
+    rt.key = (2, 8, 8, 77, 9, ("plain",), None, 0, 0, False, False)
     rt.ensure(2, 8, 8, 77, 9, scale=[0.1, 0.5, 1.0])
     rt.ensure(2, 8, 8, 77, 9, scale=[0.1, 0.5, 1.0])
     rt.ensure(2, 8, 8, 77, 9, scale=(0.1, 0.5, 1.0))
@@ -568,3 +568,45 @@ def test_apply_inside_the_combine_never_aliases_what_the_producer_still_reads():
             # ... and somebody reads it: the next launches' x1
             assert any(b.x1 == a.gn_next_out for b in keep[i + 1:i + 4]), (kind, i, "normalised tensor is never consumed")
         assert n == {"unet": 17, "brushnet": 17, "controlnet": 11}[kind]
+
+
+def test_twin_prefix_plans_at_the_headline_shapes():
+    """Round 5: with `twin` (the loop vouches for a CFG pair built from one latents tensor) the launches in front of the
+    first cross-attention run on half the rows -- conv_in (which stores its rows twice: out_dup_rows, and feeds the
+    up-block concat norm's statistics for both halves), down_blocks.0.resnets.0, the first transformer's front end,
+    self-attention and to_out -- the fused cross-attention block reads the half batch with wrap addressing and the
+    transformer's last GEMM its half-batch residual.  Same launch count, fewer executed FLOPs; BrushNet adds inside the
+    down path switch it off."""
+    from powerpaint_amd.engine import TWIN_PREFIX
+    if not (TWIN_PREFIX and SDNet.fuse_xattn):
+        pytest.skip("lab switches")
+    for kind, cin, tot, nk in (("unet", 9, 9, {}), ("brushnet", 4, 9, dict(conditioning_channels=5)),
+                               ("controlnet", 4, 4, dict(conditioning_channels=3))):
+        net = SDNet(kind, cin, **nk)
+        net.load_state_dict(net.synthetic_state_dict(meta=True), "cpu", materialize=False)
+        rt = NetRuntime(net, "cpu")
+        rt.ensure(8, 64, 64, 77, tot, ("plain",), cond_hw=(512, 512))
+        f0, names0 = rt.step_plan.flops, [c[2] for c in rt.step_plan.calls]
+        rt.ensure(8, 64, 64, 77, tot, ("plain",), cond_hw=(512, 512), twin=True)
+        f1, names1 = rt.step_plan.flops, [c[2] for c in rt.step_plan.calls]
+        assert names0 == names1
+        # conv_in (real channels only) + 2 resnet convs + proj_in + QKV + self-attention + to_out, on 4 x 4096 rows
+        rows, hw, C = 4 * 4096, 4096, 320
+        saved = 2.0 * rows * C * (9 * tot + 2 * 9 * C + C + 3 * C + C) + 4.0 * 4 * 8 * hw * hw * 40
+        assert abs((f0 - f1) - saved) / saved < 1e-6, (kind, f0 - f1, saved)
+        dup = [a for a in rt.step_plan.keep if a.out_dup_rows]
+        assert len(dup) == 1 and (dup[0].M, dup[0].N, dup[0].K, dup[0].out_dup_rows) == (rows, C, 576, rows)
+        # the skip tensor's second consumer (the last up-block resnet's concat norm) gets both halves' sums
+        assert (dup[0].gn_dup_batch, dup[0].gn_dup_mask) == ((4, 2) if kind != "controlnet" else (0, 0))
+        wrap = [a for a in rt.step_plan.keep if a.res1_wrap_rows]
+        assert len(wrap) == 1 and (wrap[0].M, wrap[0].K, wrap[0].res1_wrap_rows) == (2 * rows, 1600, rows)
+        i = names1.index("xattn_block")
+        args = rt.step_plan.calls[i][1]
+        assert args[15] == 2 * rows and args[18] == rows                  # M, src_wrap_rows
+        assert all(rt.step_plan.calls[j][1][18] == 0 for j, n in enumerate(names1) if n == "xattn_block" and j != i)
+    net = SDNet("unet", 4)
+    net.load_state_dict(net.synthetic_state_dict(meta=True), "cpu", materialize=False)
+    rt = NetRuntime(net, "cpu")
+    shapes = rt._residual_shapes(8, 64, 64, True)
+    rt.ensure(8, 64, 64, 77, 4, ("brushnet", {k: [0] * len(v) for k, v in shapes.items()}), twin=True)
+    assert not [a for a in rt.step_plan.keep if a.out_dup_rows or a.res1_wrap_rows]
