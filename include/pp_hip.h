@@ -391,6 +391,29 @@ int pp_xattn_block(const void* x, int ldx, const void* res, int ldres, const flo
                    int ldo, float* row_stats_out, int M, int c, int rows_per_batch, int src_wrap_rows, int dtype,
                    void* stream);
 
+/* (ABI v19) FeedForward + proj_out of a C = 320 transformer in ONE launch (csrc/ff_fused.hip):
+ *     out = epilogue2( [ h (.) gelu_erf(g) | hs ] W2'^T ),    h | g = rstd (hs W1^T - mean colsum1) + bias1   (interleaved)
+ * i.e. `ff(norm3(hidden_states)) + hidden_states` of diffusers 0.27 BasicTransformerBlock.forward (FeedForward with GEGLU)
+ * followed by Transformer2DModel.proj_out + the block residual (ctor site /root/reference/powerpaint/models/
+ * unet_2d_blocks.py:1289-1300): the two launches pp_gemm_bf16(act = PP_ACT_GEGLU, folded LayerNorm) -> pp_gemm_bf16 over the
+ * K-concatenation [g | hs] -- without the [M][1280] GEGLU tensor ever being written: the hidden dimension is streamed in
+ * chunks of 64 units against persistent fp32 accumulators of the second GEMM.
+ *   g2 : the SECOND GEMM exactly as pp_gemm_bf16 would take it (x_mode PLAIN, N = 320, c1 = 1280, c2 = 320, K = 1600):
+ *        x2 / ldx2 = hs (raw rows: LayerNorm3 is folded), w = [W_po W_ff2 | W_po] ([320][1600], 16-bit) with the HIDDEN index
+ *        (the first 1280 columns) permuted inside every group of 32 -- storage position 8 kg + 2 q + e holds unit
+ *        8 q + 2 kg + e -- so that the GEGLU values in the first GEMM's accumulator registers are the second GEMM's B
+ *        fragments; bias, scale, res1 (+ res1_wrap_rows), res2, out / ldo, dtype and the gn_acc subscriptions are honoured as
+ *        in pp_gemm_bf16; x1 is NOT read (the tensor it would name does not exist).  rowvec, GEGLU / V^T / fp32 outputs, row
+ *        moments, gn_next_*, out_dup_rows: PP_ERR_UNSUPPORTED.
+ *   w1 : [2560][320] 16-bit, rows interleaved (h0, h1, g0, g1) as PP_ACT_GEGLU takes them, LayerNorm gamma folded in;
+ *   b1 / cs1 : [2560] fp32 bias (incl. W beta) and column sums of w1 (cs1 may be NULL when ln_stats is NULL);
+ *   ln_stats : row moments of hs in the layout of PPGemmArgs.ln_stats (ln_tiles partials per row) or NULL (no LayerNorm folded).
+ * Arithmetic = the two-launch chain up to the fp32 summation order of the second GEMM (the GEGLU values are rounded to the
+ * 16-bit format exactly where the chain stores them).  pp_ff_fused_supported(): c == 320, M and rows_per_batch multiples of 128. */
+int pp_ff_fused_supported(int M, int c, int rows_per_batch);
+int pp_ff_fused(const PPGemmArgs* g2, const void* w1, const float* b1, const float* cs1, const float* ln_stats, int ln_tiles,
+                float ln_eps, void* stream);
+
 /* ppt-v1 with a 4-channel (non-inpainting) UNet -- the `num_channels_unet == 4` branch of the loop body,
  * pipeline_PowerPaint.py:1025-1039: after pp_cfg_sched_step of the same step
  *     latents[b] = (1 - mask) * (a * image_latents + b * noise[b]) + mask * latents[b]

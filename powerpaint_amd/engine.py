@@ -401,7 +401,8 @@ class Builder:
         16x16 and 8x8 levels), the combine writes the normalised tensor as well and no apply launch is added.  `acc` = the
         statistics subscription of this norm (its accumulators are still filled)."""
         a = x.producer
-        if not GN_NEXT_IN_COMBINE or a is None or not acc or not self.plan.calls or a.gn_next_out:
+        if not GN_NEXT_IN_COMBINE or a is None or not acc or not self.plan.calls or a.gn_next_out or \
+                getattr(a, "_fused_ff", False):
             return None
         last = self.plan.calls[-1][1]
         if not last or getattr(last[0], "_obj", None) is not a:      # something ran in between: its scratch may alias
@@ -469,6 +470,33 @@ class Builder:
         self.plan.count("attention", 4.0 * B * heads * nq * nk * d)
         return out
 
+    def ff_fused(self, hs: int, rows: int, Cc: int, hw: int, w1: int, b1: int, cs1: int, ln_stats: int, ln_tiles: int,
+                 w2: int, bias2: int, out: int, res1: int = 0, res1_wrap: int = 0, res2: int = 0):
+        """FeedForward (GEGLU) + FF2 . proj_out of a C = 320 transformer as ONE launch (csrc/ff_fused.hip, pp_ff_fused): the
+        [rows][4C] GEGLU tensor is never written.  The launch record is the PPGemmArgs of the SECOND GEMM (what the two-launch
+        plan hands pp_gemm_bf16 for `[g | hs] [W_po W_ff2 | W_po]^T`), so GroupNorm-statistics subscriptions of the consumer
+        patch it exactly as they patch a GEMM.  Returns that record."""
+        a = L.PPGemmArgs()
+        a.M, a.N, a.K, a.x_mode = rows, Cc, 5 * Cc, L.PP_X_PLAIN
+        a.x1, a.x2, a.c1, a.c2 = hs, hs, 4 * Cc, Cc          # (x1 is never read: the tensor it would name does not exist)
+        a.ldx1, a.ldx2 = 4 * Cc, Cc
+        a.w, a.bias = w2, bias2 or None
+        a.res1, a.ldres1, a.res1_wrap_rows = res1 or None, Cc, res1_wrap
+        a.res2, a.ldres2 = res2 or None, Cc
+        a.scale, a.act = 1.0, 0
+        a.out, a.ldo, a.out_f32 = out, Cc, 0
+        a.rows_per_batch = hw
+        a.splitk, a.tile = 1, 0
+        a.dtype = self.dt
+        a._fused_ff = True                  # (no split-K combine behind this launch: _apply_in_producer_combine keeps off)
+        self.plan.keep.append(a)
+        self.last_gemm = a
+        a._arena_top = self.arena.off
+        self.plan.add("ff_fused", self.lib.pp_ff_fused, C.byref(a), w1, b1, cs1 or None, ln_stats or None, ln_tiles, 1e-5)
+        self.plan.count("linear_geglu", 2.0 * rows * 8 * Cc * Cc)      # (the FLOPs of the two launches it stands for)
+        self.plan.count("linear", 2.0 * rows * Cc * 5 * Cc)
+        return a
+
     def add(self, a: int, b: int, out: int, n: int):
         self.plan.add("add", self.lib.pp_add_bf16, a, b, out, n, self.dt)
 
@@ -511,6 +539,19 @@ def _kperm(w: torch.Tensor) -> torch.Tensor:
     return w[..., kk]
 
 
+def _kperm_geglu(w: torch.Tensor) -> torch.Tensor:
+    """[N][K] -> the input (hidden-unit) index permuted inside every group of 32: storage position 8 kg + 2 q + e holds unit
+    8 q + 2 kg + e.  The GEGLU of an MFMA accumulator quad (h0, h1, g0, g1) is two hidden units (2 kg, 2 kg + 1 of the
+    16-column block q), so a lane's four quads of a 64-column chunk ARE its 16-byte B fragment of a GEMM whose A operand is
+    packed like this: how csrc/ff_fused.hip chains FF1 -> GEGLU -> FF2 in registers."""
+    K = w.shape[-1]
+    assert K % 32 == 0
+    sp = torch.arange(K)
+    s32, r = sp // 32, sp % 32
+    kg, q, e = r // 8, (r // 2) % 4, r % 2
+    return w[..., 32 * s32 + 8 * q + 2 * kg + e]
+
+
 def _geglu_interleave(w: torch.Tensor) -> torch.Tensor:
     """GEGLU proj rows [h(0..F) ; g(0..F)] -> groups of four rows (h_{2q}, h_{2q+1}, g_{2q}, g_{2q+1})."""
     F2 = w.shape[0]
@@ -543,6 +584,9 @@ class SDNet:
     # round 4: Transformer2DModel.norm -> proj_in -> LayerNorm1-folded QKV at C = 320 as ONE launch (csrc/tfront.hip;
     # three launches and two activation round trips before).  (lab) PP_TFRONT=0: the chain
     fuse_tfront = _lab_switch("PP_TFRONT")
+    # round 5: FeedForward (GEGLU) + FF2 . proj_out at C = 320 as ONE launch with the hidden dimension streamed
+    # (csrc/ff_fused.hip; two launches and the [M][4C] GEGLU round trip before).  (lab) PP_FF_FUSED=0: the two launches
+    fuse_ff = _lab_switch("PP_FF_FUSED")
     # round 4: the same for C = 640 / 1280 (64-row tiles x 320-column groups, xattn_wide_kernel).  (lab) PP_XATTN_WIDE=0
     # keeps the chain at those levels
     fuse_xattn_wide = _lab_switch("PP_XATTN_WIDE")
@@ -788,6 +832,9 @@ class SDNet:
                 w_f2, b_f2 = W(f"{pre}.transformer_blocks.0.ff.net.2.weight"), W(f"{pre}.transformer_blocks.0.ff.net.2.bias")
                 pk.add(f"{pre}.ff2_proj_out.weight", torch.cat([w_po @ w_f2, w_po], 1), bf)
                 pk.add(f"{pre}.ff2_proj_out.bias", w_po @ b_f2 + b_po, f32)
+                if c == 320 and self.fuse_ff and self.fold_ln:
+                    # the same matrix with its hidden index permuted: second GEMM of the fused feed-forward (csrc/ff_fused.hip)
+                    pk.add(f"{pre}.ff2_proj_out.weight_kp", torch.cat([_kperm_geglu(w_po @ w_f2), w_po], 1), bf)
             else:
                 pk.add(f"{pre}.proj_out.weight", w_po, bf)
                 pk.add(f"{pre}.proj_out.bias", b_po, f32)
@@ -969,6 +1016,13 @@ class SDNet:
         # feed-forward: GEGLU fused into the first GEMM's epilogue
         rows_h, rows = rows, rows_o           # (from here on: the full batch)
         wrap = rows_h if twin else 0          # the transformer's input (the proj_out residual) holds one half only
+        if fold and self.fuse_ff and self.merge_ff2_proj_out and f"{pre}.ff2_proj_out.weight_kp" in P and \
+                pb.lib.pp_ff_fused_supported(rows, Cc, hw):
+            out.producer = pb.ff_fused(hs, rows, Cc, hw, P[f"{tb}.ff1.weight"], P[f"{tb}.ff1.bias"], P[f"{tb}.ff1.colsum"],
+                                       st, tiles, P[f"{pre}.ff2_proj_out.weight_kp"], P[f"{pre}.ff2_proj_out.bias"], out.ptr,
+                                       res1=x.ptr, res1_wrap=wrap, res2=res2)
+            pb.release(m)
+            return out
         ln, kw = normed(hs, st, "norm3", "ff1")
         g = pb.linear(ln, rows, Cc, P[f"{tb}.ff1.weight"], 8 * Cc, act=L.PP_ACT_GEGLU, name="linear_geglu", **kw)
         if self.merge_ff2_proj_out:

@@ -274,6 +274,28 @@ def xattn_block(x: torch.Tensor, folded, bias_o=None, res=None, ln_stats=None, l
     return (out, st) if row_stats else out
 
 
+def ff_fused(hs: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2kp: torch.Tensor, bias2=None, cs1=None, ln_stats=None,
+             ln_eps: float = 1e-5, res1=None, res2=None, res1_wrap: int = 0, rows_per_batch: int = 0, gn=None):
+    """pp_ff_fused: out = [h (.) gelu(g) | hs] w2kp^T + bias2 + res1 + res2 with h | g = FF1(LayerNorm-folded hs), one launch.
+    hs [M, 320]; w1 [2560, 320] (GEGLU-interleaved rows, gamma folded); w2kp [320, 1600] (hidden index permuted:
+    engine._kperm_geglu); ln_stats [M, 2, 2] row moments of hs or None; gn: GroupNorm subscriptions as ops.gemm takes them."""
+    M, Cc = hs.shape
+    a = L.PPGemmArgs()
+    a.M, a.N, a.K, a.x_mode = M, Cc, 5 * Cc, L.PP_X_PLAIN
+    a.x1, a.x2, a.c1, a.c2, a.ldx1, a.ldx2 = _p(hs), _p(hs), 4 * Cc, Cc, 4 * Cc, hs.stride(0)
+    a.w, a.bias = _p(w2kp), _p(bias2)
+    a.res1, a.ldres1, a.res1_wrap_rows = _p(res1), (res1.stride(0) if res1 is not None else Cc), res1_wrap
+    a.res2, a.ldres2 = _p(res2), (res2.stride(0) if res2 is not None else Cc)
+    a.scale, a.act = 1.0, 0
+    out = torch.empty(M, Cc, dtype=hs.dtype, device=hs.device)
+    a.out, a.ldo, a.dtype = _p(out), Cc, L.dtype_code(hs.dtype)
+    a.rows_per_batch = rows_per_batch
+    _set_gn(a, gn, rows_per_batch)
+    L.check(L.lib().pp_ff_fused(C.byref(a), _p(w1), _p(b1), _p(cs1), _p(ln_stats),
+                                ln_stats.shape[1] if ln_stats is not None else 0, ln_eps, _s()), "pp_ff_fused")
+    return out
+
+
 def gn_conv3x3_smallcout(x, acc, gamma, beta, eps: float, w, bias, groups: int = 32):
     """conv_norm_out + SiLU + conv_out in one launch: x NHWC 16-bit [B,H,W,Cin], acc int64 [B,groups,2] (the producers'
     GroupNorm accumulators), w [4, 9*Cin] -> fp32 NCHW [B,4,H,W]."""

@@ -85,8 +85,12 @@ def test_full_size_plans_and_flop_accounting():
         per_width = {"unet": 5, "brushnet": 5, "controlnet": 2}[kind]
         assert n_x == ((per_width * (2 if SDNet.fuse_xattn_wide else 1)) if SDNet.fuse_xattn else 0)
         assert [c[2] for c in rt.setup_plan.calls].count("xattn_fold") == n_x
+        # ... and (round 5) the feed-forward of every C = 320 transformer (FF1 + GEGLU, FF2 . proj_out) is one pp_ff_fused launch
+        n_ff = ({"unet": 5, "brushnet": 5, "controlnet": 2}[kind]
+                if (SDNet.fuse_ff and SDNet.fold_ln and SDNet.merge_ff2_proj_out) else 0)
+        assert names.count("ff_fused") == n_ff
         assert len(names) == exp[kind][1] - (n_gn - n_stats) + names.count("zero_u64") - fused_out - 2 * n_x - n_cg - n_next \
-            - 2 * n_front
+            - 2 * n_front - n_ff
         assert len(rt.setup_plan.calls) >= 15
 
 
@@ -598,7 +602,7 @@ def test_twin_prefix_plans_at_the_headline_shapes():
         assert len(dup) == 1 and (dup[0].M, dup[0].N, dup[0].K, dup[0].out_dup_rows) == (rows, C, 576, rows)
         # the skip tensor's second consumer (the last up-block resnet's concat norm) gets both halves' sums
         assert (dup[0].gn_dup_batch, dup[0].gn_dup_mask) == ((4, 2) if kind != "controlnet" else (0, 0))
-        wrap = [a for a in rt.step_plan.keep if a.res1_wrap_rows]
+        wrap = [a for a in rt.step_plan.keep if a.res1_wrap_rows]     # (the second GEMM of the feed-forward, fused or not)
         assert len(wrap) == 1 and (wrap[0].M, wrap[0].K, wrap[0].res1_wrap_rows) == (2 * rows, 1600, rows)
         i = names1.index("xattn_block")
         args = rt.step_plan.calls[i][1]

@@ -1,0 +1,60 @@
+#!/usr/bin/env python
+"""Fused feed-forward (pp_ff_fused) against the two launches it replaces, hot, at the UNet's 64x64 level (M = 32768 rows) and
+at config 5's 128x128 level.  usage: python tools/ff_one.py [M ...]   (GPU box; lab switches of the library apply)"""
+import sys
+import torch
+sys.path.insert(0, ".")
+from powerpaint_amd import _lib as L, ops
+from powerpaint_amd.engine import _geglu_interleave, _kperm_geglu
+
+C = 320
+dev = "cuda"
+
+
+def main():
+    Ms = [int(a) for a in sys.argv[1:]] or [32768, 131072]
+    for M in Ms:
+        g = torch.Generator("cpu").manual_seed(0)
+        r = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(dev)
+        hs = r(M, C).to(torch.bfloat16)
+        w1 = _geglu_interleave(r(8 * C, C, sc=C ** -0.5)).to(torch.bfloat16).contiguous()
+        b1 = r(8 * C, sc=0.1)
+        cs1 = w1.float().sum(1).contiguous()
+        hf = hs.float()
+        st = torch.stack([hf.reshape(M, 2, 160).sum(-1), (hf * hf).reshape(M, 2, 160).sum(-1)], -1).contiguous()
+        w2 = r(C, 5 * C, sc=(5 * C) ** -0.5).to(torch.bfloat16).contiguous()
+        w2kp = torch.cat([_kperm_geglu(w2[:, :4 * C]), w2[:, 4 * C:]], 1).contiguous()
+        b2 = r(C, sc=0.1)
+        res = r(M, C).to(torch.bfloat16)
+        acc = torch.zeros(M // 4096 if M >= 4096 else 1, 32, 2, dtype=torch.int64, device=dev)
+        rpb = 4096 if M >= 4096 else M
+        gn = [(acc, 10, 0, 32)]
+
+        def fused():
+            return ops.ff_fused(hs, w1, b1, w2kp, b2, cs1=cs1, ln_stats=st, res1=res, rows_per_batch=rpb, gn=gn)
+
+        def chain():
+            gg = ops.gemm(hs, w1, bias=b1, act=L.PP_ACT_GEGLU, ln_stats=st, ln_colsum=cs1, ln_dim=C)
+            return ops.gemm(gg, w2, bias=b2, x2=hs, res1=res, rows_per_batch=rpb, gn=gn)
+
+        a, b = fused(), chain()
+        d = (a.float() - b.float()).abs()
+        print(f"M={M}: max |fused - chain| {float(d.max()):.4g}, differing {float((d > 0).float().mean()):.4f}")
+        for name, fn in (("fused", fused), ("chain", chain), ("fused", fused), ("chain", chain)):
+            for _ in range(5):
+                fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            n = 50
+            e0.record()
+            for _ in range(n):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 1e3 / n
+            fl = 2.0 * M * C * (8 * C + 5 * C)
+            print(f"  {name}: {us:8.1f} us   {fl / us / 1e6:7.1f} TFLOP/s")
+
+
+if __name__ == "__main__":
+    main()
