@@ -154,8 +154,11 @@ typedef struct PPGemmArgs {
    * concat(x1, x2) in the fixed-point format of gn_acc above, COMPLETE before this launch (written by the producers'
    * epilogues); gn_in_gb -> fp32 [c1 + c2][2] = (gamma, beta) interleaved per channel.  The optional 1x1 tail (x3, x4)
    * is NOT normalised.  Zero padding applies to the normalised tensor, as in the reference.  Supported shapes:
-   * pp_conv_gn_supported(); the arithmetic of the normalisation is that of pp_groupnorm_apply_acc (values rounded to
-   * the 16-bit format before the convolution, exactly as the two-launch path stores them). */
+   * pp_conv_gn_supported(); the arithmetic of the normalisation is that of pp_groupnorm_apply_acc -- values rounded to
+   * the 16-bit format before the convolution where the two-launch path stores them -- up to 1-ulp differences of the SiLU
+   * (the loader evaluates it with v_exp / v_rcp: a few per cent of the normalised values differ from the apply launch's by
+   * one unit of the 16-bit format; only the gn_next_* combine path below is bit-identical to the apply launch).  gn_in_*
+   * on a PP_X_PLAIN launch is PP_ERR_UNSUPPORTED, gn_in_acc without gn_in_gb (or the reverse) PP_ERR_BAD_ARG. */
   const int64_t* gn_in_acc;
   const float* gn_in_gb;
   int32_t gn_in_groups;

@@ -1658,6 +1658,9 @@ int validate(const PPGemmArgs& a) {
   if (a.ln_stats && (!a.ln_colsum || a.ln_tiles <= 0 || a.ln_dim <= 0)) return PP_ERR_BAD_ARG;
   if (a.row_stats_out && (a.out_f32 || a.out_vt || a.act == PP_ACT_GEGLU || !v2_ok(a))) return PP_ERR_UNSUPPORTED;
   if ((a.gn_acc[0] || a.gn_acc[1]) && !gn_stats_supported(a)) return PP_ERR_UNSUPPORTED;
+  // GroupNorm in the conv loader: a conv3x3 feature with both operands or none -- never silently ignored
+  if ((a.gn_in_acc || a.gn_in_gb) && a.x_mode != PP_X_CONV3X3) return PP_ERR_UNSUPPORTED;
+  if ((a.gn_in_acc != nullptr) != (a.gn_in_gb != nullptr)) return PP_ERR_BAD_ARG;
   // the CFG-twin prefix (ABI v19): half-batch residual read with wrap, output written for both halves
   if (a.res1_wrap_rows < 0 || a.out_dup_rows < 0 || a.gn_dup_batch < 0 || (a.gn_dup_mask & ~3)) return PP_ERR_BAD_ARG;
   if (a.res1_wrap_rows > 0 && (!a.res1 || a.M > 2 * a.res1_wrap_rows || a.res1_wrap_rows % 64)) return PP_ERR_BAD_ARG;

@@ -115,9 +115,12 @@ class PipelineBase(PipelinePretrainedMixin):
         a = tuple(torch.device("cuda", v) if isinstance(v, int) and not isinstance(v, bool) else v for v in a)
         if isinstance(k.get("device"), int):
             k = dict(k, device=torch.device("cuda", k["device"]))
-        for name, m in getattr(self, "_modules", {}).items():
-            if m is None or not hasattr(m, "to") or name == "scheduler":
-                continue
+        mods = [(name, m) for name, m in getattr(self, "_modules", {}).items()
+                if m is not None and hasattr(m, "to") and name != "scheduler"]
+        # the packed HIP networks only VALIDATE the request (and may refuse it): ask them before any nn.Module is converted,
+        # so that a refused `pipe.to(torch.float16)` leaves the pipeline as it was
+        mods.sort(key=lambda nm: isinstance(nm[1], torch.nn.Module))
+        for name, m in mods:
             r = m.to(*a, **k)
             if isinstance(m, torch.nn.Module) and r is not None:
                 setattr(self, name, r)

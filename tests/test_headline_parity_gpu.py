@@ -35,7 +35,14 @@ KEEP = (9, 19, 29, 39, 49)
 
 
 def fixture():
-    return torch.load(os.path.join(ROOT, "tests", "golden", "headline_ref.pt"), weights_only=False)
+    fx = torch.load(os.path.join(ROOT, "tests", "golden", "headline_ref.pt"), weights_only=False)
+    # the fixture matches only if torch.manual_seed + the nn initialisers reproduce the oracle's weights on THIS torch build
+    # (ADVICE round 4): say so instead of failing an opaque parity gate after an upgrade
+    tv = fx.get("torch_version") if isinstance(fx, dict) else None
+    if tv is not None and str(tv).split("+")[0] != torch.__version__.split("+")[0]:
+        pytest.skip(f"tests/golden/headline_ref.pt was generated with torch {tv}, this is {torch.__version__}: regenerate it "
+                    f"(tests/golden/make_headline_ref.py) or run with PP_HEADLINE_LIVE=1")
+    return fx
 
 
 def record(line: str):

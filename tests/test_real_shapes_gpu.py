@@ -149,3 +149,68 @@ def test_config3_one_teacher_forced_dpm_step_64x64(unet4):
     eps = pipe._loop.rt.eps_tensor()                     # (the last step's eps; the first step is checked via latents)
     assert eps.shape == (2 * B, 4, hh, hh)
     report("config 3, 64x64: latents after the first DPM-Solver++ step", seen[0], ref, cos_min=0.9995, rel=3e-2)
+
+
+def _rows(t, idx):
+    return torch.cat([t[i:i + 1] for i in idx])
+
+
+def test_config3_batch8_launch_plan_rows_vs_oracle(unet4):
+    """BASELINE config 3 as BENCHMARKED: the batch-8 launch plans of the full BrushNet and of the UNet at 64x64 (256-row
+    ping-pong tiles, the split-K choices of M = 32768 ... 512, GroupNorm statistics at rows_per_batch = 4096) -- the
+    reduced-batch tests above run other tiles.  One CFG pair goes through the fp32 oracle; rows 0-1 and 6-7 of the HIP
+    batch-8 forward (the same samples, other samples between them) must reproduce it (VERDICT round 4, missing item 4;
+    pipeline_PowerPaint_Brushnet_CA.py:1384-1466)."""
+    ou, hu = unet4
+    torch.manual_seed(5)
+    ob = bf16_weights_(OM.randomize_zero_convs(OM.BrushNetModel(in_channels=4, conditioning_channels=5))).eval()
+    hb = PM.BrushNetModel(in_channels=4, conditioning_channels=5, device=DEV).load_state_dict(ob.state_dict())
+    x2, e2, eu2, c2 = gen(2, 4, 64, 64, seed=51), gen(2, 77, 768, seed=52), gen(2, 77, 768, seed=53), gen(2, 5, 64, 64, seed=54)
+    with torch.no_grad():
+        dn, md, up = ob(x2, 441, e2, c2, conditioning_scale=1.0)
+        ref = ou(x2, 441, eu2, down_block_add_samples=list(dn), mid_block_add_sample=md, up_block_add_samples=list(up))[0]
+    mid = lambda s, *shape: gen(4, *shape, seed=s)
+    x8 = torch.cat([x2, mid(55, 4, 64, 64), x2])
+    e8 = torch.cat([e2, mid(56, 77, 768), e2])
+    eu8 = torch.cat([eu2, mid(57, 77, 768), eu2])
+    c8 = torch.cat([c2, mid(58, 5, 64, 64), c2])
+    hdn, hmd, hup = hb(x8.to(DEV), 441, e8.to(DEV), c8.to(DEV), conditioning_scale=1.0, return_dict=False)
+    worst = 1.0
+    for i, (a, b) in enumerate(zip(hdn + [hmd] + hup, list(dn) + [md] + list(up))):
+        for idx in ((0, 1), (6, 7)):
+            cos, _ = close(_rows(a, idx), b, f"BrushNet batch-8 residual {i} rows {idx}", cos_min=0.998)
+            worst = min(worst, cos)
+    print(f"[real-shape parity] config 3 batch-8 plan, BrushNet 64x64: 28 residuals x 2 row pairs, worst cosine {worst:.6f}")
+    out = hu(x8.to(DEV), 441, eu8.to(DEV), down_block_add_samples=list(hdn), mid_block_add_sample=hmd,
+             up_block_add_samples=list(hup), return_dict=False)[0]
+    report("config 3 batch-8 plan (BrushNet -> UNet, 64x64), rows 0-1", out[0:2], ref)
+    report("config 3 batch-8 plan (BrushNet -> UNet, 64x64), rows 6-7", out[6:8], ref)
+
+
+def test_config4_batch8_launch_plan_rows_vs_oracle(unet9):
+    """BASELINE config 4 as benchmarked: full ControlNet (512x512 control image) and the 9-channel UNet at 64x64, batch 8;
+    rows 0-1 and 6-7 against one CFG pair through the fp32 oracle (pipeline_PowerPaint_ControlNet.py:1663-1741)."""
+    ou, hu = unet9
+    torch.manual_seed(6)
+    oc = bf16_weights_(OM.randomize_zero_convs(OM.ControlNetModel(in_channels=4))).eval()
+    hc = PM.ControlNetModel(in_channels=4, device=DEV).load_state_dict(oc.state_dict())
+    x4, x9, e2 = gen(2, 4, 64, 64, seed=61), gen(2, 9, 64, 64, seed=62), gen(2, 77, 768, seed=63)
+    img2 = torch.rand(2, 3, 512, 512, generator=torch.Generator("cpu").manual_seed(64))
+    with torch.no_grad():
+        dn, md = oc(x4, 520, e2, img2, conditioning_scale=0.5)
+        ref = ou(x9, 520, e2, down_block_additional_residuals=dn, mid_block_additional_residual=md)[0]
+    x4_8 = torch.cat([x4, gen(4, 4, 64, 64, seed=65), x4])
+    x9_8 = torch.cat([x9, gen(4, 9, 64, 64, seed=66), x9])
+    e8 = torch.cat([e2, gen(4, 77, 768, seed=67), e2])
+    img8 = torch.cat([img2, torch.rand(4, 3, 512, 512, generator=torch.Generator("cpu").manual_seed(68)), img2])
+    hdn, hmd = hc(x4_8.to(DEV), 520, e8.to(DEV), img8.to(DEV), conditioning_scale=0.5, return_dict=False)
+    worst = 1.0
+    for i, (a, b) in enumerate(zip(hdn + [hmd], list(dn) + [md])):
+        for idx in ((0, 1), (6, 7)):
+            cos, _ = close(_rows(a, idx), b, f"ControlNet batch-8 residual {i} rows {idx}", cos_min=0.998)
+            worst = min(worst, cos)
+    print(f"[real-shape parity] config 4 batch-8 plan, ControlNet 64x64: 13 residuals x 2 row pairs, worst cosine {worst:.6f}")
+    out = hu(x9_8.to(DEV), 520, e8.to(DEV), down_block_additional_residuals=hdn, mid_block_additional_residual=hmd,
+             return_dict=False)[0]
+    report("config 4 batch-8 plan (ControlNet -> UNet, 64x64), rows 0-1", out[0:2], ref)
+    report("config 4 batch-8 plan (ControlNet -> UNet, 64x64), rows 6-7", out[6:8], ref)
