@@ -379,6 +379,14 @@ int pp_tfront(const void* x, int ldx, const void* gn_acc, const float* gn_gamma,
  *     p   = softmax_per_head( rstd*(x gt^T - mean*gcs) + gbias )          (exp2 domain; mean / rstd from ln_stats as in
  *                                                                           PPGemmArgs, NULL = no LayerNorm folded)
  *     out = p ht^T + bias_o + res ,   row_stats_out[m][c/160][2] = (sum, sum of squares) of the stored values.
+ * (ABI v19) pre_w != NULL (C = 320): the Linear in FRONT of the sub-block rides in the same launch --
+ *     h = x pre_w^T + pre_b + res     (BasicTransformerBlock: `attn1(norm1(h0)) + h0`, i.e. attn1.to_out applied to the
+ *     self-attention output x, residual res = h0; pre_w [c][c] 16-bit ([out][in]), pre_b fp32 or NULL),
+ * then the sub-block on h (rounded to 16 bits where the separate launch stored it): h is the logits' input, the source of
+ * the LayerNorm row moments (computed in the kernel; ln_stats is ignored, ln_tiles > 0 = "a LayerNorm is folded into gt")
+ * and the residual of the output.  The logits' B operand then comes out of the first GEMM's accumulators, so gt must be
+ * packed with its channel index permuted inside every group of 32: pp_xattn_fold(kperm = 1) (position 8 kg + j holds
+ * channel 16 (j >> 2) + 4 kg + (j & 3), the permutation pp_tfront uses).
  * (ABI v19) src_wrap_rows > 0: x, res and ln_stats hold only src_wrap_rows rows and output row m reads row
  * (m mod src_wrap_rows), M <= 2 * src_wrap_rows -- the two halves of a CFG batch are identical up to this sub-block (the
  * first place the prompt enters, unet_2d_condition.py:1183-1236), so everything in front of it ran on one half; the folded
@@ -388,11 +396,11 @@ int pp_tfront(const void* x, int ldx, const void* gn_acc, const float* gn_gamma,
 int pp_xattn_block_supported(int M, int c, int rows_per_batch, int nctx, int heads);
 int pp_xattn_fold(const void* k, int ldk, const void* vt, int ldvt, int batch, int nctx, int heads, int c, const void* wq,
                   const float* q_colsum, const float* q_bias, const void* wo, float scale, void* gt, float* gcs,
-                  float* gbias, void* ht, int dtype, void* stream);
+                  float* gbias, void* ht, int kperm, int dtype, void* stream);
 int pp_xattn_block(const void* x, int ldx, const void* res, int ldres, const float* ln_stats, int ln_tiles, float ln_eps,
                    const void* gt, const float* gcs, const float* gbias, const void* ht, const float* bias_o, void* out,
-                   int ldo, float* row_stats_out, int M, int c, int rows_per_batch, int src_wrap_rows, int dtype,
-                   void* stream);
+                   int ldo, float* row_stats_out, int M, int c, int rows_per_batch, int src_wrap_rows, const void* pre_w,
+                   const float* pre_b, int dtype, void* stream);
 
 /* (ABI v19) FeedForward + proj_out of a C = 320 transformer in ONE launch (csrc/ff_fused.hip):
  *     out = epilogue2( [ h (.) gelu_erf(g) | hs ] W2'^T ),    h | g = rstd (hs W1^T - mean colsum1) + bias1   (interleaved)

@@ -97,9 +97,9 @@ SIGNATURES = {
                             vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "pp_xattn_block_supported": (C.c_int, [C.c_int] * 5),
     "pp_xattn_fold": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, C.c_float,
-                                vp, vp, vp, vp, C.c_int, vp]),
+                                vp, vp, vp, vp, C.c_int, C.c_int, vp]),
     "pp_xattn_block": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, C.c_int, C.c_float, vp, vp, vp, vp, vp, vp, C.c_int, vp,
-                                 C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+                                 C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, vp]),
     "pp_ff_fused_supported": (C.c_int, [C.c_int] * 3),
     "pp_ff_fused": (C.c_int, [C.POINTER(PPGemmArgs), vp, vp, vp, vp, C.c_int, C.c_float, vp]),
     "pp_step_advance": (C.c_int, [vp, vp]),

@@ -350,7 +350,9 @@ attn_pipe_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __rest
           const int sb = es >> 3, eq = sb / JB, ej = sb % JB, u = (es >> 2) & 1, e = es & 3;
           const f32x2_t s2 = {sc[eq][ej][8 * u + 2 * e], sc[eq][ej][8 * u + 2 * e + 1]};
           f32x2_t e2;
-          if (OPT & 2) {
+          if (OPT & 32) {                                   // (lab, timing only) no exponent arithmetic: what a logit that leaves
+            e2 = s2;                                        //  the MFMA as an exp2 exponent would cost
+          } else if (OPT & 2) {
             float e0 = __builtin_fmaf(s2[0], scale_log2e, nm2[eq][0]), e1 = __builtin_fmaf(s2[1], scale_log2e, nm2[eq][1]);
             asm volatile("" : "+v"(e0), "+v"(e1));        // (keeps LLVM's SLP vectoriser from re-packing the pair)
             e2 = f32x2_t{e0, e1};
@@ -547,6 +549,7 @@ int pp_attention_pipe_launch(const void* q, int ldq, const void* k, int ldk, con
       case 13: return launch_pipe<32, 0, PP_DT_BF16, 4, 2, 13>(PP_ARGS);
       case 21: return launch_pipe<32, 0, PP_DT_BF16, 4, 2, 21>(PP_ARGS);
       case 29: return launch_pipe<32, 0, PP_DT_BF16, 4, 2, 29>(PP_ARGS);
+      case 61: return launch_pipe<32, 0, PP_DT_BF16, 4, 2, 61>(PP_ARGS);
       case 15: return launch_pipe<32, 0, PP_DT_BF16, 4, 2, 15>(PP_ARGS);
       default: return PP_ERR_BAD_ARG;
     }

@@ -455,6 +455,13 @@ extern "C" int pp_ff_fused(const PPGemmArgs* g2, const void* w1, const float* b1
 #ifdef PP_LAB
   if (a.dtype == PP_DT_BF16) switch (pp_lab_env("PP_FF_DBG", 0)) {      // tools/ff_one.py: time the loop with parts removed
       case 8: attr_set[a.dtype] = false; return go(ff_fused_kernel<PP_DT_BF16, 8>);
+      case 9: attr_set[a.dtype] = false; return go(ff_fused_kernel<PP_DT_BF16, 9>);
+      case 12: attr_set[a.dtype] = false; return go(ff_fused_kernel<PP_DT_BF16, 12>);
+      case 13: attr_set[a.dtype] = false; return go(ff_fused_kernel<PP_DT_BF16, 13>);
+      case 24: attr_set[a.dtype] = false; return go(ff_fused_kernel<PP_DT_BF16, 24>);
+      case 29: attr_set[a.dtype] = false; return go(ff_fused_kernel<PP_DT_BF16, 29>);
+      case 21: attr_set[a.dtype] = false; return go(ff_fused_kernel<PP_DT_BF16, 21>);
+      case 108: attr_set[a.dtype] = false; return go(ff_fused_kernel<PP_DT_BF16, 8, 8, false>);
       case 16: attr_set[a.dtype] = false; return go(ff_fused_kernel<PP_DT_BF16, 16>);
       default: break;
     }

@@ -33,7 +33,7 @@ constexpr int XA_C = 320, XA_HEADS = 8, XA_KP = 80, XA_S = XA_HEADS * XA_KP;   /
 constexpr int XA_BM = 128;
 constexpr int XA_SLAB = 320 * 128, XA_NS = 3, XA_NSLAB = 20;
 constexpr int XA_TAB = XA_NS * XA_SLAB;                   // (logit colsum | logit bias) of the batch item, fp32 [2][640]
-constexpr int XA_LDS = XA_TAB + 2 * XA_S * 4;
+constexpr int XA_LDS = XA_TAB + 2 * XA_S * 4 + XA_C * 4;   // (+ the bias of the Linear in front, PRE)
 constexpr int XA_QD = 8;                                  // fragment reads kept in flight ahead of their MFMA
 
 typedef __attribute__((address_space(3))) void* xa_lds_ptr_t;
@@ -48,6 +48,8 @@ struct XAArgs {
   float* row_stats_out;
   int M, rows_per_batch;
   int src_wrap;          // > 0: x / res / ln_stats hold src_wrap rows, row m reads row m mod src_wrap (CFG twin, pp_hip.h)
+  const uint16_t* pre_w; // != NULL (C = 320): a Linear in FRONT of the sub-block, h = x pre_w^T + pre_b + res (attn1.to_out)
+  const float* pre_b;
 };
 
 template <int... I, class F>
@@ -62,7 +64,7 @@ __global__ void __launch_bounds__(256) xattn_fold_kernel(const uint16_t* __restr
                                                         const uint16_t* __restrict__ wq, const float* __restrict__ qcs,
                                                         const float* __restrict__ qb, const uint16_t* __restrict__ wo,
                                                         float qscale, uint32_t* __restrict__ gt, float* __restrict__ gcs,
-                                                        float* __restrict__ gb, uint32_t* __restrict__ ht, int C) {
+                                                        float* __restrict__ gb, uint32_t* __restrict__ ht, int C, int kperm) {
   using E = E16<EDT>;
   const int D = C / XA_HEADS;
   const long long n_g = (long long)batch * XA_S * (C / 2), n_h = (long long)batch * C * (XA_S / 2),
@@ -72,9 +74,17 @@ __global__ void __launch_bounds__(256) xattn_fold_kernel(const uint16_t* __restr
       const int c2 = (int)(i % (C / 2)), n = (int)((i / (C / 2)) % XA_S), b = (int)(i / ((long long)(C / 2) * XA_S));
       const int h = n / XA_KP, key = n % XA_KP;
       float s0 = 0.f, s1 = 0.f;
+      // kperm: storage position 8 kg + j of every group of 32 channels holds channel 16 (j >> 2) + 4 kg + (j & 3) (the pair
+      // (j, j + 1), j even, stays a pair of neighbours) -- the logits' B operand then comes out of the accumulators of the
+      // Linear in front (pre_w), as in tfront.hip
+      int ch = 2 * c2;
+      if (kperm) {
+        const int s32 = ch >> 5, kg = (ch >> 3) & 3, j = ch & 7;
+        ch = 32 * s32 + 16 * (j >> 2) + 4 * kg + (j & 3);
+      }
       if (key < nctx) {
         const uint16_t* kr = k + ((size_t)b * nctx + key) * ldk + h * D;
-        const uint16_t* wr = wq + (size_t)(h * D) * C + 2 * c2;
+        const uint16_t* wr = wq + (size_t)(h * D) * C + ch;
         // (D = 40 / 80 / 160: whole eights -- unrolled so that eight independent loads are in flight per thread; this kernel
         //  runs once per pipeline call and took 1.6 ms of it as a one-load-at-a-time loop)
 #pragma unroll 8
@@ -146,7 +156,11 @@ __global__ void __launch_bounds__(256) xattn_colsum_kernel(const uint32_t* __res
 }
 
 // DBG (lab build only): 1 no slab DMA, 2 no MFMAs, 4 no fragment reads, 8 no softmax, 16 no epilogue, 32 no barriers
-template <int EDT, int DBG = 0, int QD = XA_QD>
+// PRE: five more slabs in front -- h = x pre_w^T + pre_b + res (BasicTransformerBlock.attn1.to_out + residual, the launch
+// that used to produce this kernel's input) on the same accumulators; h (rounded to 16 bits, as that launch stored it) is
+// at once the logits' B operand (G^T packed with its channel index permuted: pp_xattn_fold(kperm = 1)), the source of the
+// LayerNorm row moments and the residual of the epilogue.  25 slabs instead of 20, one launch and the h round trip less.
+template <int EDT, int DBG = 0, int QD = XA_QD, bool PRE = false>
 __global__ void __launch_bounds__(512, 2) xattn_block_kernel(const XAArgs a) {
   using E = E16<EDT>;
   typedef typename E::v8 v8_t;
@@ -178,8 +192,9 @@ __global__ void __launch_bounds__(512, 2) xattn_block_kernel(const XAArgs a) {
   }
   for (int i = tid; i < 2 * XA_S; i += 512)
     tabs[i] = i < XA_S ? a.gcs[(size_t)b * XA_S + i] : a.gbias[(size_t)b * XA_S + i - XA_S];
+  if (PRE && tid < XA_C) tabs[2 * XA_S + tid] = a.pre_b ? a.pre_b[tid] : 0.f;
   float mean = 0.f, rstd = 1.f;
-  if (a.ln_stats) {
+  if (!PRE && a.ln_stats) {
     const f32x2_t* pm = reinterpret_cast<const f32x2_t*>(a.ln_stats) + (size_t)ms * a.ln_tiles;
     float sm = 0.f, sq = 0.f;
     for (int t = 0; t < a.ln_tiles; ++t) { const f32x2_t v = pm[t]; sm += v[0]; sq += v[1]; }
@@ -199,11 +214,18 @@ __global__ void __launch_bounds__(512, 2) xattn_block_kernel(const XAArgs a) {
   }
   const __amdgpu_buffer_rsrc_t rs_g = make_rsrc(a.gt + (size_t)b * XA_S * XA_C, XA_S * XA_C * 2);
   const __amdgpu_buffer_rsrc_t rs_h = make_rsrc(a.ht + (size_t)b * XA_C * XA_S, XA_C * XA_S * 2);
+  const __amdgpu_buffer_rsrc_t rs_p = make_rsrc(PRE ? a.pre_w : a.gt, PRE ? XA_C * XA_C * 2 : 0);
+  constexpr int NPRE = PRE ? 5 : 0, NSLAB = XA_NSLAB + NPRE;
   auto issue = [&](auto T) __attribute__((always_inline)) {
-    constexpr int t = decltype(T)::value;
+    constexpr int tt = decltype(T)::value, t = tt - NPRE;      // tt: slab of this launch, t: slab of the sub-block proper
     if constexpr (DBG & 1) return;
-    char* st = smem + (t % XA_NS) * XA_SLAB + wave * 1024;
-    if constexpr (t < 10) {                               // G^T rows (t / 5) * 320 .., channels (t % 5) * 64 ..
+    char* st = smem + (tt % XA_NS) * XA_SLAB + wave * 1024;
+    if constexpr (t < 0) {                                // pre_w rows 0 .. 319, input channels 64 tt ..
+      constexpr int so = tt * 64 * 2;
+#pragma unroll
+      for (int j = 0; j < 5; ++j)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_p, (xa_lds_ptr_t)(st + j * 8192), 16, vg[j], so, 0, 0);
+    } else if constexpr (t < 10) {                        // G^T rows (t / 5) * 320 .., channels (t % 5) * 64 ..
       constexpr int so = ((t / 5) * 320 * XA_C + (t % 5) * 64) * 2;
 #pragma unroll
       for (int j = 0; j < 5; ++j)
@@ -218,8 +240,47 @@ __global__ void __launch_bounds__(512, 2) xattn_block_kernel(const XAArgs a) {
 
   f32x4_t acc[20];
   uint32_t pf[20][4];                                     // probabilities as B fragments of the second GEMM
+  uint32_t hq[10][4];                                     // PRE: h as B fragments of the logits (and the epilogue's residual)
 #pragma unroll
   for (int nb = 0; nb < 20; ++nb) acc[nb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  // PRE, after the five pre_w slabs: + bias + residual, rounded to 16 bits; row moments of the rounded values (LayerNorm)
+  u32x2_t rv[20];
+  f32x4_t bo[20];
+  // (its residual and bias: fetched one slab early, under the MFMAs of pre_w's fourth slab)
+  auto prefetch_pre = [&]() __attribute__((always_inline)) {
+    const uint16_t* rp = a.res ? a.res + (size_t)ms * a.ldres : nullptr;
+#pragma unroll
+    for (int nb = 0; nb < 20; ++nb) {
+      const int n = nb * 16 + 4 * g;
+      rv[nb] = rp ? *reinterpret_cast<const u32x2_t*>(rp + n) : u32x2_t{0u, 0u};
+    }
+  };
+  auto finish_pre = [&]() __attribute__((always_inline)) {
+    float sm = 0.f, sq = 0.f;
+#pragma unroll
+    for (int nb = 0; nb < 20; ++nb) {
+      const int n = nb * 16 + 4 * g;
+      const u32x2_t r = rv[nb];
+      const f32x4_t bb = *reinterpret_cast<const f32x4_t*>(tabs + 2 * XA_S + n);
+      const f32x4_t v = acc[nb] + bb + f32x4_t{E::lo(r[0]), E::hi(r[0]), E::lo(r[1]), E::hi(r[1])};
+      const uint32_t o0 = E::pack2(v[0], v[1]), o1 = E::pack2(v[2], v[3]);
+      const float r0 = E::lo(o0), r1 = E::hi(o0), r2 = E::lo(o1), r3 = E::hi(o1);
+      sm += (r0 + r1) + (r2 + r3);
+      sq += (r0 * r0 + r1 * r1) + (r2 * r2 + r3 * r3);
+      hq[nb >> 1][(nb & 1) * 2 + 0] = o0;
+      hq[nb >> 1][(nb & 1) * 2 + 1] = o1;
+      // h is also the residual of the epilogue, fifteen slabs from here: parked in this lane's own piece of `out` (40 more
+      // live registers would spill) and read back by the same lane under the last slab
+      *reinterpret_cast<u32x2_t*>(a.out + (size_t)m * a.ldo + n) = u32x2_t{o0, o1};
+      acc[nb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
+    if (a.ln_tiles > 0) {                                  // (LayerNorm folded into the logits: ln_tiles > 0 says so)
+      sm += __shfl_xor(sm, 16, 64); sq += __shfl_xor(sq, 16, 64);
+      sm += __shfl_xor(sm, 32, 64); sq += __shfl_xor(sq, 32, 64);
+      mean = sm * (1.0f / XA_C);
+      rstd = rsqrtf(fmaxf(sq * (1.0f / XA_C) - mean * mean, 0.f) + a.ln_eps);
+    }
+  };
 
   // softmax of the four heads whose logits the accumulators hold (half hf of the 640 columns): head hh = blocks 5 hh ..
   // 5 hh + 4, a row's 80 keys spread over 20 registers x the four lanes that share r16
@@ -262,27 +323,26 @@ __global__ void __launch_bounds__(512, 2) xattn_block_kernel(const XAArgs a) {
   };
 
   // residual of the epilogue: fetched under the last slab's MFMAs (after stores nothing could be hoisted)
-  const uint16_t* rr = a.res ? a.res + (size_t)ms * a.ldres : nullptr;
-  u32x2_t rv[20];
-  f32x4_t bo[20];
+  const uint16_t* rr = PRE ? a.out + (size_t)m * a.ldo : (a.res ? a.res + (size_t)ms * a.ldres : nullptr);
   __syncthreads();                                        // the tables are in LDS
   issue(std::integral_constant<int, 0>{});
   issue(std::integral_constant<int, 1>{});
-  xa_static_for<XA_NSLAB>([&](auto T) __attribute__((always_inline)) {
-    constexpr int t = decltype(T)::value;
-    // this wave's five pieces of slab t have landed (slab t + 1's five may still be in flight), then everybody's
-    if constexpr (t + 1 < XA_NSLAB) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+  xa_static_for<NSLAB>([&](auto T) __attribute__((always_inline)) {
+    constexpr int tt = decltype(T)::value, t = tt - NPRE;
+    // this wave's five pieces of slab tt have landed (slab tt + 1's five may still be in flight), then everybody's
+    if constexpr (tt + 1 < NSLAB) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if constexpr (!(DBG & 32)) asm volatile("s_barrier" ::: "memory");
-    if constexpr (t + 2 < XA_NSLAB) issue(std::integral_constant<int, t + 2>{});   // (its stage was read at step t - 1)
-    if constexpr (t + 1 == XA_NSLAB) {
+    if constexpr (tt + 2 < NSLAB) issue(std::integral_constant<int, tt + 2>{});   // (its stage was read at step tt - 1)
+    if constexpr (PRE && tt == 3) prefetch_pre();
+    if constexpr (tt + 1 == NSLAB) {
 #pragma unroll
       for (int nb = 0; nb < 20; ++nb) {
         const int n = nb * 16 + 4 * g;
         rv[nb] = rr ? *reinterpret_cast<const u32x2_t*>(rr + n) : u32x2_t{0u, 0u};
       }
     }
-    const char* st = smem + (t % XA_NS) * XA_SLAB;
+    const char* st = smem + (tt % XA_NS) * XA_SLAB;
     // the slab's 40 weight fragments (ks 0 / 1 x 20 blocks) as a hand-made software pipeline: eight ds_read_b128 stay in
     // flight ahead of the MFMA that consumes the oldest (left to itself the compiler keeps ~5 reads ahead of an MFMA that
     // depends on each of them, with nothing else to issue); nine rotating fragment registers
@@ -294,8 +354,12 @@ __global__ void __launch_bounds__(512, 2) xattn_block_kernel(const XAArgs a) {
     v8_t bfr[2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      if constexpr (t < 10) bfr[ks] = xf[(t % 5) * 2 + ks];
-      else {
+      if constexpr (t < 0) bfr[ks] = xf[tt * 2 + ks];
+      else if constexpr (t < 10) {
+        constexpr int f = (t % 5) * 2;
+        if constexpr (PRE) bfr[ks] = __builtin_bit_cast(v8_t, u32x4_t{hq[f + ks][0], hq[f + ks][1], hq[f + ks][2], hq[f + ks][3]});
+        else bfr[ks] = xf[f + ks];
+      } else {
         constexpr int f = (t - 10) * 2;
         bfr[ks] = __builtin_bit_cast(v8_t, u32x4_t{pf[f + ks][0], pf[f + ks][1], pf[f + ks][2], pf[f + ks][3]});
       }
@@ -315,11 +379,13 @@ __global__ void __launch_bounds__(512, 2) xattn_block_kernel(const XAArgs a) {
       else acc[i % 20] = E::mfma16(af, bfr[i / 20], acc[i % 20]);
       if constexpr (!(DBG & 4)) __builtin_amdgcn_sched_barrier(0);
     }
+    if constexpr (PRE && t == -1) finish_pre();
     if constexpr (!(DBG & 8)) {
       if constexpr (t == 4) softmax_half(std::integral_constant<int, 0>{});
       if constexpr (t == 9) softmax_half(std::integral_constant<int, 1>{});
     }
   });
+
 
   // ---- epilogue: + bias + residual, 16-bit stores, row moments of the stored values per 160-column tile
   if constexpr (DBG & 16) {
@@ -587,17 +653,18 @@ extern "C" int pp_xattn_block_supported(int M, int c, int rows_per_batch, int nc
 
 extern "C" int pp_xattn_fold(const void* k, int ldk, const void* vt, int ldvt, int batch, int nctx, int heads, int c,
                              const void* wq, const float* q_colsum, const float* q_bias, const void* wo, float scale,
-                             void* gt, float* gcs, float* gbias, void* ht, int dtype, void* stream) {
+                             void* gt, float* gcs, float* gbias, void* ht, int kperm, int dtype, void* stream) {
   if (!k || !vt || !wq || !wo || !gt || !gcs || !gbias || !ht || batch <= 0 || !pp_dt_ok(dtype)) return PP_ERR_BAD_ARG;
   if (!pp_xattn_block_supported(XA_BM, c, XA_BM, nctx, heads)) return PP_ERR_UNSUPPORTED;
   if (ldk < c || ldvt < nctx || (c & 1)) return PP_ERR_BAD_ARG;
+  if (kperm && c != XA_C) return PP_ERR_UNSUPPORTED;      // (only the C = 320 block kernel chains a Linear in front)
   const long long total = (long long)batch * XA_S * (c / 2) * 2 + (long long)batch * XA_S;
   const unsigned grid = (unsigned)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
   const float qscale = scale * 1.44269504088896340736f;   // the softmax runs in the exp2 domain
   PP_DT_SWITCH(dtype, hipLaunchKernelGGL((xattn_fold_kernel<EDT>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
                                          (const uint16_t*)k, ldk, (const uint16_t*)vt, ldvt, batch, nctx,
                                          (const uint16_t*)wq, q_colsum, q_bias, (const uint16_t*)wo, qscale, (uint32_t*)gt,
-                                         gcs, gbias, (uint32_t*)ht, c));
+                                         gcs, gbias, (uint32_t*)ht, c, kperm ? 1 : 0));
   PP_CHECK_LAUNCH("xattn_fold_kernel");
   if (q_colsum) {
     const long long rows = (long long)batch * XA_S;
@@ -611,11 +678,14 @@ extern "C" int pp_xattn_fold(const void* k, int ldk, const void* vt, int ldvt, i
 extern "C" int pp_xattn_block(const void* x, int ldx, const void* res, int ldres, const float* ln_stats, int ln_tiles,
                               float ln_eps, const void* gt, const float* gcs, const float* gbias, const void* ht,
                               const float* bias_o, void* out, int ldo, float* row_stats_out, int M, int c,
-                              int rows_per_batch, int src_wrap_rows, int dtype, void* stream) {
+                              int rows_per_batch, int src_wrap_rows, const void* pre_w, const float* pre_b, int dtype,
+                              void* stream) {
   if (!x || !gt || !gcs || !gbias || !ht || !out || !pp_dt_ok(dtype)) return PP_ERR_BAD_ARG;
   if (!pp_xattn_block_supported(M, c, rows_per_batch, XA_KP, XA_HEADS)) return PP_ERR_UNSUPPORTED;
   if (src_wrap_rows < 0 || (src_wrap_rows > 0 && (M > 2 * src_wrap_rows || src_wrap_rows % rows_per_batch))) return PP_ERR_BAD_ARG;
   if (src_wrap_rows > 0 && c != XA_C) return PP_ERR_UNSUPPORTED;
+  if (pre_w && c != XA_C) return PP_ERR_UNSUPPORTED;
+  if (pre_b && !pre_w) return PP_ERR_BAD_ARG;
   if (ldx < c || (ldx & 7) || ldo < c || (ldo & 3) || (res && (ldres < c || (ldres & 3)))) return PP_ERR_BAD_ARG;
   if (ln_stats && ln_tiles <= 0) return PP_ERR_BAD_ARG;
   XAArgs a;
@@ -628,6 +698,7 @@ extern "C" int pp_xattn_block(const void* x, int ldx, const void* res, int ldres
   a.row_stats_out = row_stats_out;
   a.M = M; a.rows_per_batch = rows_per_batch;
   a.src_wrap = src_wrap_rows;
+  a.pre_w = (const uint16_t*)pre_w; a.pre_b = pre_b;
   if (c != XA_C) {
     static bool wattr[2][3] = {{false, false, false}, {false, false, false}};
     auto gow = [&](auto kern, int ci, int grid) -> int {
@@ -684,6 +755,24 @@ extern "C" int pp_xattn_block(const void* x, int ldx, const void* res, int ldres
       default: break;
     }
 #endif
+  if (pre_w) {
+    static bool pattr[3] = {false, false, false};
+    auto gop = [&](auto kern) -> int {
+      if (!pattr[dtype]) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, XA_LDS) !=
+            hipSuccess) {
+          pp_set_last_error("hipFuncSetAttribute(xattn block, pre)", hipGetLastError());
+          return PP_ERR_LAUNCH;
+        }
+        pattr[dtype] = true;
+      }
+      hipLaunchKernelGGL(kern, dim3(M / XA_BM), dim3(512), XA_LDS, (hipStream_t)stream, a);
+      PP_CHECK_LAUNCH("xattn_block_kernel(pre)");
+      return PP_OK;
+    };
+    if (dtype == PP_DT_F16) return gop(xattn_block_kernel<PP_DT_F16, 0, XA_QD, true>);
+    return gop(xattn_block_kernel<PP_DT_BF16, 0, XA_QD, true>);
+  }
   if (dtype == PP_DT_F16) return go(xattn_block_kernel<PP_DT_F16>, PP_DT_F16);
   return go(xattn_block_kernel<PP_DT_BF16>, PP_DT_BF16);
 }

@@ -584,6 +584,9 @@ class SDNet:
     # round 4: Transformer2DModel.norm -> proj_in -> LayerNorm1-folded QKV at C = 320 as ONE launch (csrc/tfront.hip;
     # three launches and two activation round trips before).  (lab) PP_TFRONT=0: the chain
     fuse_tfront = _lab_switch("PP_TFRONT")
+    # round 5: BasicTransformerBlock.attn1.to_out (+ residual) rides in front of the fused cross-attention block at C = 320
+    # (five more weight slabs in pp_xattn_block, one launch and one hidden-state round trip less).  (lab) PP_XATTN_PRE=0
+    fuse_xattn_pre = _lab_switch("PP_XATTN_PRE")
     # round 5: FeedForward (GEGLU) + FF2 . proj_out at C = 320 as ONE launch with the hidden dimension streamed
     # (csrc/ff_fused.hip; two launches and the [M][4C] GEGLU round trip before).  (lab) PP_FF_FUSED=0: the two launches
     fuse_ff = _lab_switch("PP_FF_FUSED")
@@ -990,24 +993,42 @@ class SDNet:
             qkv = pb.linear(ln, rows, Cc, P[f"{tb}.attn1.qkv.weight"], 3 * Cc, name="linear", **kw)
             pb.plan.add("transpose_v", pb.lib.pp_transpose_v, qkv + 4 * Cc, 3 * Cc, x.B, hw, Cc, vt, ldvt)
             a = pb.attention(qkv, 3 * Cc, qkv + 2 * Cc, 3 * Cc, vt, ldvt, x.B, self.heads, hw, hw, d)
-        st = producer()
-        hs = pb.linear(a, rows, Cc, P[f"{tb}.attn1.to_out.weight"], Cc, P[f"{tb}.attn1.to_out.bias"], res1=hs,
-                       row_stats_out=st, name="linear")
-        # cross-attention (K / V^T hoisted out of the step: encoder_hidden_states are step-invariant)
-        ln, kw = normed(hs, st, "norm2", "attn2.to_q")
         xa = getattr(self, "xa", {}).get(pre)
-        if xa is not None and pb.lib.pp_xattn_block_supported(rows_o, Cc, hw, self._nctx, self.heads):
+        if xa is not None and len(xa) > 4 and xa[4] and fold and \
+                pb.lib.pp_xattn_block_supported(rows_o, Cc, hw, self._nctx, self.heads):
+            # attn1.to_out + residual in front of the cross-attention sub-block, same launch (G^T was folded with kperm = 1)
+            st2 = producer(rows_o)
+            o = pb.alloc(rows_o * Cc * 2)
+            pb.plan.add("xattn_block", pb.lib.pp_xattn_block, a, Cc, hs, Cc, None, tiles, 1e-5, xa[0], xa[1], xa[2], xa[3],
+                        P[f"{tb}.attn2.to_out.bias"], o, Cc, st2 or None, rows_o, Cc, hw, rows if twin else 0,
+                        P[f"{tb}.attn1.to_out.weight"], P[f"{tb}.attn1.to_out.bias"], pb.dt)
+            pb.plan.count("linear", 2.0 * rows_o * Cc * Cc)
+            pb.plan.count("xattn_block", 4.0 * rows_o * Cc * Cc + 4.0 * rows_o * self._nctx * Cc)
+            hs, st = o, st2
+            xa = "done"
+        else:
+            st = producer()
+            hs = pb.linear(a, rows, Cc, P[f"{tb}.attn1.to_out.weight"], Cc, P[f"{tb}.attn1.to_out.bias"], res1=hs,
+                           row_stats_out=st, name="linear")
+        # cross-attention (K / V^T hoisted out of the step: encoder_hidden_states are step-invariant)
+        if xa == "done":
+            pass
+        elif xa is not None and len(xa) > 4 and xa[4]:
+            raise L.PPError("G^T was folded for the chained cross-attention block, which this shape does not take")
+        elif xa is not None and pb.lib.pp_xattn_block_supported(rows_o, Cc, hw, self._nctx, self.heads):
+            ln, kw = normed(hs, st, "norm2", "attn2.to_q")
             st2 = producer(rows_o)
             o = pb.alloc(rows_o * Cc * 2)
             pb.plan.add("xattn_block", pb.lib.pp_xattn_block, ln, Cc, hs, Cc, kw.get("ln_stats"), tiles if fold else 0,
                         1e-5, xa[0], xa[1], xa[2], xa[3], P[f"{tb}.attn2.to_out.bias"], o, Cc, st2 or None, rows_o, Cc, hw,
-                        rows if twin else 0, pb.dt)
+                        rows if twin else 0, None, None, pb.dt)
             # (the FLOPs of the chain it stands for: the folded form multiplies twice as much)
             pb.plan.count("xattn_block", 4.0 * rows_o * Cc * Cc + 4.0 * rows_o * self._nctx * Cc)
             hs, st = o, st2
         elif twin:
             raise L.PPError("twin prefix without the fused cross-attention block (build_step checks _twin_ok first)")
         else:
+            ln, kw = normed(hs, st, "norm2", "attn2.to_q")
             q = pb.linear(ln, rows, Cc, P[f"{tb}.attn2.to_q.weight"], Cc, name="linear", **kw)
             a = pb.attention(q, Cc, kv[0], kv[1], kv[2], kv[3], x.B, self.heads, hw, self._nctx, d)
             st = producer()
@@ -1038,11 +1059,21 @@ class SDNet:
         return out
 
     # ---------------------------------------------------------------- setup plan: step-invariant work
-    def build_setup(self, pb: Builder, B: int, nctx: int, ehs: int, cond: Optional[Act] = None):
+    def build_setup(self, pb: Builder, B: int, nctx: int, ehs: int, cond: Optional[Act] = None,
+                    hw0: Optional[Tuple[int, int]] = None):
         """Cross-attention K and V^T for every transformer from encoder_hidden_states (bf16 [B*nctx][ctx_dim] at
-        `ehs`); for ControlNet also the conditioning embedding of `cond` (NHWC bf16 image)."""
+        `ehs`); for ControlNet also the conditioning embedding of `cond` (NHWC bf16 image).  hw0 = (H, W) of the latents the
+        step plan will be built for (the folded cross-attention operands of a transformer depend on which kernel runs it)."""
         self._nctx = nctx
         ldvt = _align(nctx, 8)
+        pre_hw: Dict[str, bool] = {}        # transformer -> the fused block kernel takes its step geometry
+        if hw0 is not None:
+            nl = len(self.boc)
+            for pre, c in self._attn_specs():
+                part = pre.split(".")
+                lvl = int(part[1]) if part[0] == "down_blocks" else (nl - 1 if part[0] == "mid_block" else nl - 1 - int(part[1]))
+                hw = (hw0[0] >> lvl) * (hw0[1] >> lvl)
+                pre_hw[pre] = hw > 0 and bool(pb.lib.pp_xattn_block_supported(B * hw, c, hw, nctx, self.heads))
         self.kv: Dict[str, Tuple[int, int, int, int]] = {}
         self.xa: Dict[str, Tuple[int, int, int, int]] = {}       # folded cross-attention operands (pp_xattn_fold)
         for pre, c in self._attn_specs():
@@ -1058,11 +1089,15 @@ class SDNet:
                 gt, ht = pb.alloc(B * S * c * 2), pb.alloc(B * c * S * 2)
                 gcs, gb = pb.alloc(B * S * 4), pb.alloc(B * S * 4)
                 fold = self.fold_ln
+                # C = 320: attn1.to_out runs in front of the sub-block in the same launch, whose logits then take their B
+                # operand from that GEMM's accumulators -> G^T with its channel index permuted (pre_hw: the step geometry
+                # must be one the block kernel takes, else the step plan keeps the chain and the plain layout)
+                kperm = bool(c == 320 and fold and self.fuse_xattn_pre and pre_hw.get(pre))
                 pb.plan.add("xattn_fold", pb.lib.pp_xattn_fold, k, c, vt, ldvt, B, nctx, self.heads, c,
                             self.P[f"{tbq}.weight"], self.P[f"{tbq}.colsum"] if fold else None,
                             self.P[f"{tbq}.bias"] if fold else None, self.P[f"{tb}.attn2.to_out.weight"],
-                            float(c // self.heads) ** -0.5, gt, gcs, gb, ht, pb.dt)
-                self.xa[pre] = (gt, gcs, gb, ht)
+                            float(c // self.heads) ** -0.5, gt, gcs, gb, ht, int(kperm), pb.dt)
+                self.xa[pre] = (gt, gcs, gb, ht, kperm)
         self.cond_emb = None
         if self.kind == "controlnet":
             assert cond is not None

@@ -242,7 +242,7 @@ def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, batch: int, he
 
 
 def xattn_fold(k: torch.Tensor, vt: torch.Tensor, batch: int, nctx: int, heads: int, wq: torch.Tensor, wo: torch.Tensor,
-               q_colsum=None, q_bias=None, scale: Optional[float] = None):
+               q_colsum=None, q_bias=None, scale: Optional[float] = None, kperm: bool = False):
     """Once per prompt (pp_xattn_fold): k [batch*nctx, >=c], vt [batch, c, ldvt], wq / wo [c, c] ([out][in]) ->
     (gt [batch, heads*80, c], gcs [batch, heads*80] fp32, gbias [batch, heads*80] fp32, ht [batch, c, heads*80])."""
     c = wq.shape[0]
@@ -253,12 +253,13 @@ def xattn_fold(k: torch.Tensor, vt: torch.Tensor, batch: int, nctx: int, heads: 
     gb = torch.empty(batch, heads * 80, dtype=torch.float32, device=dev)
     L.check(L.lib().pp_xattn_fold(_p(k), k.stride(0), _p(vt), vt.stride(1), batch, nctx, heads, c, _p(wq), _p(q_colsum),
                                   _p(q_bias), _p(wo), scale if scale is not None else (c // heads) ** -0.5, _p(gt),
-                                  _p(gcs), _p(gb), _p(ht), L.dtype_code(dt), _s()), "pp_xattn_fold")
+                                  _p(gcs), _p(gb), _p(ht), int(kperm), L.dtype_code(dt), _s()), "pp_xattn_fold")
     return gt, gcs, gb, ht
 
 
 def xattn_block(x: torch.Tensor, folded, bias_o=None, res=None, ln_stats=None, ln_eps: float = 1e-5,
-                rows_per_batch: int = 0, row_stats: bool = False, twin: bool = False):
+                rows_per_batch: int = 0, row_stats: bool = False, twin: bool = False, pre_w=None, pre_b=None,
+                ln_fold: bool = False):
     """out = softmax_per_head(LNfold(x) gt^T) ht^T + bias_o + res  (pp_xattn_block); x [M, c], folded = xattn_fold(...).
     twin: x / res / ln_stats hold ONE half of a CFG pair (M rows) whose other half is identical; the output has 2 M rows
     (src_wrap_rows = M) and `folded` is per batch item of the full batch."""
@@ -267,10 +268,13 @@ def xattn_block(x: torch.Tensor, folded, bias_o=None, res=None, ln_stats=None, l
     M, c = x.shape[0] * (2 if twin else 1), x.shape[1]
     out = torch.empty(M, c, dtype=x.dtype, device=x.device)
     st = torch.zeros(M, c // 160, 2, dtype=torch.float32, device=x.device) if row_stats else None
+    # pre_w / pre_b: the Linear in front (h = x pre_w^T + pre_b + res) in the same launch; `folded` must come from
+    # xattn_fold(kperm=True); ln_fold = a LayerNorm of h is folded into `folded` (row moments are computed in the kernel)
+    tiles = ln_stats.shape[1] if ln_stats is not None else (c // 160 if (pre_w is not None and ln_fold) else 0)
     L.check(L.lib().pp_xattn_block(_p(x), x.stride(0), _p(res), res.stride(0) if res is not None else 0, _p(ln_stats),
-                                   ln_stats.shape[1] if ln_stats is not None else 0, ln_eps, _p(gt), _p(gcs), _p(gb), _p(ht),
-                                   _p(bias_o), _p(out), c, _p(st), M, c, rows_per_batch or M, wrap, L.dtype_code(x.dtype),
-                                   _s()), "pp_xattn_block")
+                                   tiles, ln_eps, _p(gt), _p(gcs), _p(gb), _p(ht),
+                                   _p(bias_o), _p(out), c, _p(st), M, c, rows_per_batch or M, wrap, _p(pre_w), _p(pre_b),
+                                   L.dtype_code(x.dtype), _s()), "pp_xattn_block")
     return (out, st) if row_stats else out
 
 

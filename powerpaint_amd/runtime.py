@@ -63,7 +63,7 @@ class NetRuntime:
             slots = {k: [Act(arena.alloc(b * h * w * c * 2), b, h, w, c) for (b, c, h, w) in v]
                      for k, v in shapes.items()}
         lay["slots"] = slots
-        net.build_setup(pb_setup, B, nctx, lay["ehs"], cond)
+        net.build_setup(pb_setup, B, nctx, lay["ehs"], cond, hw0=(H, W))
         pb = Builder(arena, dtype=net.dtype)
         pb.gemm_tile, pb.gemm_splitk = self.gemm_tile, self.gemm_splitk
         pb.gn_acc_base, pb.gn_acc_cap = lay["gn_acc"], gn_cap

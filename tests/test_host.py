@@ -89,8 +89,12 @@ def test_full_size_plans_and_flop_accounting():
         n_ff = ({"unet": 5, "brushnet": 5, "controlnet": 2}[kind]
                 if (SDNet.fuse_ff and SDNet.fold_ln and SDNet.merge_ff2_proj_out) else 0)
         assert names.count("ff_fused") == n_ff
+        # ... and attn1.to_out (+ residual) of the C = 320 transformers rides in front of their fused cross-attention block
+        n_pre = ({"unet": 5, "brushnet": 5, "controlnet": 2}[kind]
+                 if (SDNet.fuse_xattn and SDNet.fuse_xattn_pre and SDNet.fold_ln) else 0)
+        assert sum(1 for c in rt.step_plan.calls if c[2] == "xattn_block" and c[1][19]) == n_pre
         assert len(names) == exp[kind][1] - (n_gn - n_stats) + names.count("zero_u64") - fused_out - 2 * n_x - n_cg - n_next \
-            - 2 * n_front - n_ff
+            - 2 * n_front - n_ff - n_pre
         assert len(rt.setup_plan.calls) >= 15
 
 
@@ -596,7 +600,9 @@ def test_twin_prefix_plans_at_the_headline_shapes():
         assert names0 == names1
         # conv_in (real channels only) + 2 resnet convs + proj_in + QKV + self-attention + to_out, on 4 x 4096 rows
         rows, hw, C = 4 * 4096, 4096, 320
-        saved = 2.0 * rows * C * (9 * tot + 2 * 9 * C + C + 3 * C + C) + 4.0 * 4 * 8 * hw * hw * 40
+        # (attn1.to_out rides in the full-batch cross-attention launch when SDNet.fuse_xattn_pre: not halved then)
+        to_out = 0 if (SDNet.fuse_xattn_pre and SDNet.fold_ln) else C
+        saved = 2.0 * rows * C * (9 * tot + 2 * 9 * C + C + 3 * C + to_out) + 4.0 * 4 * 8 * hw * hw * 40
         assert abs((f0 - f1) - saved) / saved < 1e-6, (kind, f0 - f1, saved)
         dup = [a for a in rt.step_plan.keep if a.out_dup_rows]
         assert len(dup) == 1 and (dup[0].M, dup[0].N, dup[0].K, dup[0].out_dup_rows) == (rows, C, 576, rows)

@@ -190,3 +190,45 @@ def test_twin_is_ignored_where_the_prefix_cannot_be_split():
     assert not [a for a in rt.step_plan.keep if getattr(a, "out_dup_rows", 0)]
     rt.ensure(2, 16, 16, 77, 9, ("plain",), twin=True)
     assert [a for a in rt.step_plan.keep if getattr(a, "out_dup_rows", 0)]
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("twin", [False, True])
+@pytest.mark.parametrize("Bh,hw,nctx", [(2, 256, 77), (1, 1024, 80), (3, 128, 5)])
+def test_attn1_to_out_in_front_of_the_cross_attention_block(Bh, hw, nctx, twin, dtype):
+    """pp_xattn_block(pre_w, pre_b): BasicTransformerBlock `attn1(norm1(h0)) + h0` (the to_out Linear + residual) in the
+    launch of the cross-attention sub-block, G^T folded with kperm = 1, against the two launches it replaces -- pp_gemm_bf16
+    (to_out + residual + row moments) -> pp_xattn_block -- with and without the CFG-twin wrap addressing.  h is rounded to
+    16 bits in both paths; only the fp32 order of the LayerNorm row moments differs."""
+    C, heads = 320, 8
+    B = 2 * Bh if twin else Bh
+    Mh = Bh * hw
+    ao = rnd(Mh, C, seed=1, dtype=dtype)                          # self-attention output (one half when twin)
+    h0 = rnd(Mh, C, seed=2, scale=1.5, dtype=dtype)
+    w1 = rnd(C, C, seed=3, scale=C ** -0.5, dtype=dtype)
+    b1 = rnd(C, seed=4, scale=0.1, dtype=torch.float32)
+    k = rnd(B * nctx, C, seed=5, dtype=dtype)
+    vt = rnd(B, C, 80, seed=6, dtype=dtype)
+    wq = rnd(C, C, seed=7, scale=C ** -0.5, dtype=dtype)
+    wo = rnd(C, C, seed=8, scale=C ** -0.5, dtype=dtype)
+    bo = rnd(C, seed=9, scale=0.1, dtype=torch.float32)
+    qcs = wq.float().sum(1).contiguous()
+    qb = rnd(C, seed=10, scale=0.1, dtype=torch.float32)
+    plain = ops.xattn_fold(k, vt, B, nctx, heads, wq, wo, q_colsum=qcs, q_bias=qb)
+    perm = ops.xattn_fold(k, vt, B, nctx, heads, wq, wo, q_colsum=qcs, q_bias=qb, kperm=True)
+    h1, st = ops.gemm(ao, w1, bias=b1, res1=h0, row_stats=True)
+    ref, rs_ref = ops.xattn_block(h1, plain, bias_o=bo, res=h1, ln_stats=st, rows_per_batch=hw, row_stats=True, twin=twin)
+    out, rs = ops.xattn_block(ao, perm, bias_o=bo, res=h0, rows_per_batch=hw, row_stats=True, twin=twin, pre_w=w1, pre_b=b1,
+                              ln_fold=True)
+    assert out.shape == ref.shape == (B * hw, C) and torch.isfinite(out.float()).all()
+    d = (out.float() - ref.float()).abs()
+    ulp = 2.0 ** (-7 if dtype == torch.bfloat16 else -10)
+    assert float((d > 0).float().mean()) < 0.05 and bool((d <= 2 * ulp * ref.float().abs().clamp(min=1.0)).all()), \
+        (float((d > 0).float().mean()), float(d.max()))
+    assert torch.allclose(rs, rs_ref, rtol=2e-3, atol=0.5)
+    # the permuted G^T is the plain one with its channel index shuffled inside every group of 32; everything else equal
+    kp = torch.arange(C)
+    s32, kg, j = kp // 32, (kp // 8) % 4, kp % 8
+    src = (32 * s32 + 16 * (j // 4) + 4 * kg + (j % 4)).to(DEV)
+    assert torch.equal(perm[0], plain[0][:, :, src]) and torch.equal(perm[2], plain[2]) and torch.equal(perm[3], plain[3])
+    assert torch.allclose(perm[1], plain[1], rtol=1e-5, atol=1e-5)       # (column sums of the stored G^T: another fp32 order)
