@@ -423,7 +423,7 @@ int pp_xattn_block(const void* x, int ldx, const void* res, int ldres, const flo
  * 16-bit format exactly where the chain stores them).  pp_ff_fused_supported(): c == 320, M and rows_per_batch multiples of 128. */
 int pp_ff_fused_supported(int M, int c, int rows_per_batch);
 int pp_ff_fused(const PPGemmArgs* g2, const void* w1, const float* b1, const float* cs1, const float* ln_stats, int ln_tiles,
-                float ln_eps, void* stream);
+                float ln_eps, int w2_kperm, void* stream);
 
 /* ppt-v1 with a 4-channel (non-inpainting) UNet -- the `num_channels_unet == 4` branch of the loop body,
  * pipeline_PowerPaint.py:1025-1039: after pp_cfg_sched_step of the same step

@@ -101,7 +101,7 @@ SIGNATURES = {
     "pp_xattn_block": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, C.c_int, C.c_float, vp, vp, vp, vp, vp, vp, C.c_int, vp,
                                  C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, vp]),
     "pp_ff_fused_supported": (C.c_int, [C.c_int] * 3),
-    "pp_ff_fused": (C.c_int, [C.POINTER(PPGemmArgs), vp, vp, vp, vp, C.c_int, C.c_float, vp]),
+    "pp_ff_fused": (C.c_int, [C.POINTER(PPGemmArgs), vp, vp, vp, vp, C.c_int, C.c_float, C.c_int, vp]),
     "pp_step_advance": (C.c_int, [vp, vp]),
     "pp_mask_prep": (C.c_int, [C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
 }

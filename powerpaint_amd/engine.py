@@ -471,7 +471,7 @@ class Builder:
         return out
 
     def ff_fused(self, hs: int, rows: int, Cc: int, hw: int, w1: int, b1: int, cs1: int, ln_stats: int, ln_tiles: int,
-                 w2: int, bias2: int, out: int, res1: int = 0, res1_wrap: int = 0, res2: int = 0):
+                 w2: int, bias2: int, out: int, res1: int = 0, res1_wrap: int = 0, res2: int = 0, w2_kperm: bool = False):
         """FeedForward (GEGLU) + FF2 . proj_out of a C = 320 transformer as ONE launch (csrc/ff_fused.hip, pp_ff_fused): the
         [rows][4C] GEGLU tensor is never written.  The launch record is the PPGemmArgs of the SECOND GEMM (what the two-launch
         plan hands pp_gemm_bf16 for `[g | hs] [W_po W_ff2 | W_po]^T`), so GroupNorm-statistics subscriptions of the consumer
@@ -492,7 +492,8 @@ class Builder:
         self.plan.keep.append(a)
         self.last_gemm = a
         a._arena_top = self.arena.off
-        self.plan.add("ff_fused", self.lib.pp_ff_fused, C.byref(a), w1, b1, cs1 or None, ln_stats or None, ln_tiles, 1e-5)
+        self.plan.add("ff_fused", self.lib.pp_ff_fused, C.byref(a), w1, b1, cs1 or None, ln_stats or None, ln_tiles, 1e-5,
+                      int(w2_kperm))
         self.plan.count("linear_geglu", 2.0 * rows * 8 * Cc * Cc)      # (the FLOPs of the two launches it stands for)
         self.plan.count("linear", 2.0 * rows * Cc * 5 * Cc)
         return a
@@ -590,6 +591,9 @@ class SDNet:
     # round 5: FeedForward (GEGLU) + FF2 . proj_out at C = 320 as ONE launch with the hidden dimension streamed
     # (csrc/ff_fused.hip; two launches and the [M][4C] GEGLU round trip before).  (lab) PP_FF_FUSED=0: the two launches
     fuse_ff = _lab_switch("PP_FF_FUSED")
+    # ... as the 8-wave kernel (two waves per SIMD, GEGLU values exchanged through LDS, W2' in natural hidden order).
+    # (lab) PP_FF_W8=0: the 4-wave kernel (one wave per SIMD, GEGLU chained in registers, W2' hidden index permuted)
+    ff_w8 = _lab_switch("PP_FF_W8")
     # round 4: the same for C = 640 / 1280 (64-row tiles x 320-column groups, xattn_wide_kernel).  (lab) PP_XATTN_WIDE=0
     # keeps the chain at those levels
     fuse_xattn_wide = _lab_switch("PP_XATTN_WIDE")
@@ -835,8 +839,8 @@ class SDNet:
                 w_f2, b_f2 = W(f"{pre}.transformer_blocks.0.ff.net.2.weight"), W(f"{pre}.transformer_blocks.0.ff.net.2.bias")
                 pk.add(f"{pre}.ff2_proj_out.weight", torch.cat([w_po @ w_f2, w_po], 1), bf)
                 pk.add(f"{pre}.ff2_proj_out.bias", w_po @ b_f2 + b_po, f32)
-                if c == 320 and self.fuse_ff and self.fold_ln:
-                    # the same matrix with its hidden index permuted: second GEMM of the fused feed-forward (csrc/ff_fused.hip)
+                if c == 320 and self.fuse_ff and self.fold_ln and not self.ff_w8:
+                    # the same matrix with its hidden index permuted: second GEMM of the 4-wave fused feed-forward
                     pk.add(f"{pre}.ff2_proj_out.weight_kp", torch.cat([_kperm_geglu(w_po @ w_f2), w_po], 1), bf)
             else:
                 pk.add(f"{pre}.proj_out.weight", w_po, bf)
@@ -1037,11 +1041,11 @@ class SDNet:
         # feed-forward: GEGLU fused into the first GEMM's epilogue
         rows_h, rows = rows, rows_o           # (from here on: the full batch)
         wrap = rows_h if twin else 0          # the transformer's input (the proj_out residual) holds one half only
-        if fold and self.fuse_ff and self.merge_ff2_proj_out and f"{pre}.ff2_proj_out.weight_kp" in P and \
-                pb.lib.pp_ff_fused_supported(rows, Cc, hw):
+        w2n = f"{pre}.ff2_proj_out.weight" + ("" if self.ff_w8 else "_kp")
+        if fold and self.fuse_ff and self.merge_ff2_proj_out and w2n in P and pb.lib.pp_ff_fused_supported(rows, Cc, hw):
             out.producer = pb.ff_fused(hs, rows, Cc, hw, P[f"{tb}.ff1.weight"], P[f"{tb}.ff1.bias"], P[f"{tb}.ff1.colsum"],
-                                       st, tiles, P[f"{pre}.ff2_proj_out.weight_kp"], P[f"{pre}.ff2_proj_out.bias"], out.ptr,
-                                       res1=x.ptr, res1_wrap=wrap, res2=res2)
+                                       st, tiles, P[w2n], P[f"{pre}.ff2_proj_out.bias"], out.ptr,
+                                       res1=x.ptr, res1_wrap=wrap, res2=res2, w2_kperm=not self.ff_w8)
             pb.release(m)
             return out
         ln, kw = normed(hs, st, "norm3", "ff1")

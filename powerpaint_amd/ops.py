@@ -279,10 +279,12 @@ def xattn_block(x: torch.Tensor, folded, bias_o=None, res=None, ln_stats=None, l
 
 
 def ff_fused(hs: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2kp: torch.Tensor, bias2=None, cs1=None, ln_stats=None,
-             ln_eps: float = 1e-5, res1=None, res2=None, res1_wrap: int = 0, rows_per_batch: int = 0, gn=None):
+             ln_eps: float = 1e-5, res1=None, res2=None, res1_wrap: int = 0, rows_per_batch: int = 0, gn=None,
+             w2_kperm: bool = True):
     """pp_ff_fused: out = [h (.) gelu(g) | hs] w2kp^T + bias2 + res1 + res2 with h | g = FF1(LayerNorm-folded hs), one launch.
-    hs [M, 320]; w1 [2560, 320] (GEGLU-interleaved rows, gamma folded); w2kp [320, 1600] (hidden index permuted:
-    engine._kperm_geglu); ln_stats [M, 2, 2] row moments of hs or None; gn: GroupNorm subscriptions as ops.gemm takes them."""
+    hs [M, 320]; w1 [2560, 320] (GEGLU-interleaved rows, gamma folded); w2kp [320, 1600]: w2_kperm=True -> hidden index
+    permuted (engine._kperm_geglu; the 4-wave kernel that chains the GEGLU in registers), False -> natural order (the 8-wave
+    kernel, activations exchanged through LDS); ln_stats [M, 2, 2] row moments of hs or None; gn: as ops.gemm takes them."""
     M, Cc = hs.shape
     a = L.PPGemmArgs()
     a.M, a.N, a.K, a.x_mode = M, Cc, 5 * Cc, L.PP_X_PLAIN
@@ -296,7 +298,7 @@ def ff_fused(hs: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2kp: torch.T
     a.rows_per_batch = rows_per_batch
     _set_gn(a, gn, rows_per_batch)
     L.check(L.lib().pp_ff_fused(C.byref(a), _p(w1), _p(b1), _p(cs1), _p(ln_stats),
-                                ln_stats.shape[1] if ln_stats is not None else 0, ln_eps, _s()), "pp_ff_fused")
+                                ln_stats.shape[1] if ln_stats is not None else 0, ln_eps, int(w2_kperm), _s()), "pp_ff_fused")
     return out
 
 

@@ -26,6 +26,13 @@ def rnd(*shape, seed=0, scale=1.0):
     return (torch.randn(*shape, generator=g) * scale).to(DEV)
 
 
+W8 = [True, False]      # the 8-wave kernel (W2' natural) and the 4-wave kernel (hidden index permuted)
+
+
+def _w2(k, w8):
+    return dict(w2kp=k["w2"] if w8 else k["w2kp"], w2_kperm=not w8)
+
+
 def _case(M, dtype, fold, seed=0):
     """Weights of one transformer's feed-forward in the layouts the engine packs, plus the fp32 meaning of the op."""
     hs = (rnd(M, C, seed=seed + 1, scale=2.0) + 0.5).to(dtype)
@@ -75,11 +82,13 @@ def _close(out, ref, dtype, what):
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("fold", [True, False])
 @pytest.mark.parametrize("M", [128, 640, 4096])
-def test_fused_feed_forward_vs_fp32_and_vs_the_chain(M, fold, dtype):
+@pytest.mark.parametrize("w8", W8)
+def test_fused_feed_forward_vs_fp32_and_vs_the_chain(w8, M, fold, dtype):
     k = _case(M, dtype, fold, seed=M)
     res1 = rnd(M, C, seed=91).to(dtype)
     res2 = rnd(M, C, seed=92).to(dtype)
-    out = ops.ff_fused(k["hs"], k["w1"], k["b1"], k["w2kp"], k["bias2"], cs1=k["cs1"], ln_stats=k["st"], res1=res1, res2=res2)
+    out = ops.ff_fused(k["hs"], k["w1"], k["b1"], bias2=k["bias2"], cs1=k["cs1"], ln_stats=k["st"], res1=res1, res2=res2,
+                       **_w2(k, w8))
     ref = k["ref"] + res1.float() + res2.float()
     _close(out, ref, dtype, "fused feed-forward vs fp32")
     chain = _chain(k, res1, res2)
@@ -92,7 +101,8 @@ def test_fused_feed_forward_vs_fp32_and_vs_the_chain(M, fold, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-def test_fused_feed_forward_epilogue_statistics_and_wrap(dtype):
+@pytest.mark.parametrize("w8", W8)
+def test_fused_feed_forward_epilogue_statistics_and_wrap(w8, dtype):
     """The second GEMM's epilogue as the engine uses it: GroupNorm statistics of the output for two consumers (own 32-group
     norm; a 640-channel concat norm with this tensor at channel offset 320) and the half-batch residual of the CFG twin
     prefix (res1_wrap_rows) -- both bit-equal to what the chain's second launch produces from the same stored values."""
@@ -102,8 +112,8 @@ def test_fused_feed_forward_epilogue_statistics_and_wrap(dtype):
     res_half = rnd(M // 2, C, seed=93).to(dtype)
     a1 = torch.zeros(B, 32, 2, dtype=torch.int64, device=DEV)
     a2 = torch.zeros(B, 32, 2, dtype=torch.int64, device=DEV)
-    out = ops.ff_fused(k["hs"], k["w1"], k["b1"], k["w2kp"], k["bias2"], cs1=k["cs1"], ln_stats=k["st"], res1=res_half,
-                       res1_wrap=M // 2, rows_per_batch=hw, gn=[(a1, 10, 0, 32), (a2, 20, 320, 32)])
+    out = ops.ff_fused(k["hs"], k["w1"], k["b1"], bias2=k["bias2"], cs1=k["cs1"], ln_stats=k["st"], res1=res_half,
+                       res1_wrap=M // 2, rows_per_batch=hw, gn=[(a1, 10, 0, 32), (a2, 20, 320, 32)], **_w2(k, w8))
     ref = k["ref"] + torch.cat([res_half, res_half]).float()
     _close(out, ref, dtype, "fused feed-forward with a wrapped residual")
     # statistics = moments of the values AS STORED
@@ -119,13 +129,13 @@ def test_fused_feed_forward_epilogue_statistics_and_wrap(dtype):
         got_s, got_q = acc[..., 0].double() / 2 ** 24, acc[..., 1].double() / 2 ** 20
         assert torch.allclose(got_s, exp_s, rtol=1e-4, atol=1e-2) and torch.allclose(got_q, exp_q, rtol=1e-4, atol=1e-2)
     again = torch.zeros_like(a1)
-    out2 = ops.ff_fused(k["hs"], k["w1"], k["b1"], k["w2kp"], k["bias2"], cs1=k["cs1"], ln_stats=k["st"], res1=res_half,
-                        res1_wrap=M // 2, rows_per_batch=hw, gn=[(again, 10, 0, 32)])
+    out2 = ops.ff_fused(k["hs"], k["w1"], k["b1"], bias2=k["bias2"], cs1=k["cs1"], ln_stats=k["st"], res1=res_half,
+                        res1_wrap=M // 2, rows_per_batch=hw, gn=[(again, 10, 0, 32)], **_w2(k, w8))
     assert torch.equal(out, out2) and torch.equal(again, a1)            # deterministic, order-independent accumulation
 
 
 def test_fused_feed_forward_refuses_what_it_does_not_implement():
     k = _case(128, torch.bfloat16, True)
     with pytest.raises(L.PPError):
-        ops.ff_fused(k["hs"][:64], k["w1"], k["b1"], k["w2kp"], k["bias2"], cs1=k["cs1"], ln_stats=k["st"][:64])   # M % 128
+        ops.ff_fused(k["hs"][:64], k["w1"], k["b1"], k["w2kp"], bias2=k["bias2"], cs1=k["cs1"], ln_stats=k["st"][:64])   # M % 128
     assert L.lib().pp_ff_fused_supported(256, 640, 256) == 0 and L.lib().pp_ff_fused_supported(32768, 320, 4096) == 1

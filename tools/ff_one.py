@@ -30,8 +30,11 @@ def main():
         rpb = 4096 if M >= 4096 else M
         gn = [(acc, 10, 0, 32)]
 
-        def fused():
-            return ops.ff_fused(hs, w1, b1, w2kp, b2, cs1=cs1, ln_stats=st, res1=res, rows_per_batch=rpb, gn=gn)
+        def fused():      # the 8-wave kernel (W2' natural order)
+            return ops.ff_fused(hs, w1, b1, w2, b2, cs1=cs1, ln_stats=st, res1=res, rows_per_batch=rpb, gn=gn, w2_kperm=False)
+
+        def fused4():     # the 4-wave kernel (hidden index permuted)
+            return ops.ff_fused(hs, w1, b1, w2kp, b2, cs1=cs1, ln_stats=st, res1=res, rows_per_batch=rpb, gn=gn, w2_kperm=True)
 
         def chain():
             gg = ops.gemm(hs, w1, bias=b1, act=L.PP_ACT_GEGLU, ln_stats=st, ln_colsum=cs1, ln_dim=C)
@@ -40,7 +43,9 @@ def main():
         a, b = fused(), chain()
         d = (a.float() - b.float()).abs()
         print(f"M={M}: max |fused - chain| {float(d.max()):.4g}, differing {float((d > 0).float().mean()):.4f}")
-        for name, fn in (("fused", fused), ("chain", chain), ("fused", fused), ("chain", chain)):
+        d4 = (fused4().float() - b.float()).abs()
+        print(f"M={M}: max |fused4 - chain| {float(d4.max()):.4g}, differing {float((d4 > 0).float().mean()):.4f}")
+        for name, fn in (("fused", fused), ("fused4", fused4), ("chain", chain), ("fused", fused), ("fused4", fused4), ("chain", chain)):
             for _ in range(5):
                 fn()
             torch.cuda.synchronize()
