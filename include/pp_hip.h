@@ -435,6 +435,14 @@ int pp_ff_fused(const PPGemmArgs* g2, const void* w1, const float* b1, const flo
 int pp_latent_blend(float* latents, const float* image_latents, const float* mask, const float* noise,
                     const float* renoise_table, const int32_t* step_dev, int batch, int channels, int hw, void* stream);
 
+/* (ABI v19) The head of a captured denoising step as ONE launch -- what pp_embed_splice (one row), pp_nchw_to_nhwc and
+ * pp_zero_u64 did in three (each a launch floor of 5-6 us): temb_out[0 .. row_floats) = temb_table[step][:] (the per-schedule
+ * table of the time-embedding chain's output, unet_2d_condition.py:1155-1156: it depends on the timestep alone);
+ * x_in[b][p][c0 + j] = latents[b mod src_batch_mod][j][p] for j < c (fp32 NCHW -> 16-bit NHWC: `torch.cat([latents] * 2)`,
+ * pipeline_PowerPaint.py:990, without the copy); zero_dst[0 .. n_zero) = 0 (64-bit words: the GroupNorm accumulators). */
+int pp_step_head(const float* temb_table, const int32_t* step_dev, float* temb_out, int row_floats, const float* latents,
+                 int batch, int c, int hw, int src_batch_mod, void* x_in, int ldc, int c0, int dtype, void* zero_dst,
+                 long long n_zero, void* stream);
 /* t_out[0] = timesteps[step]; used at the top of a captured step.  advance: ++step. */
 int pp_step_select_t(const float* timesteps, const int32_t* step_dev, float* t_out, void* stream);
 int pp_step_advance(int32_t* step_dev, void* stream);

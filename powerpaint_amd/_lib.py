@@ -102,6 +102,8 @@ SIGNATURES = {
                                  C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, vp]),
     "pp_ff_fused_supported": (C.c_int, [C.c_int] * 3),
     "pp_ff_fused": (C.c_int, [C.POINTER(PPGemmArgs), vp, vp, vp, vp, C.c_int, C.c_float, C.c_int, vp]),
+    "pp_step_head": (C.c_int, [vp, vp, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp,
+                              C.c_longlong, vp]),
     "pp_step_advance": (C.c_int, [vp, vp]),
     "pp_mask_prep": (C.c_int, [C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
 }

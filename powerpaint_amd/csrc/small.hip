@@ -645,6 +645,53 @@ extern "C" int pp_zero_u64(void* dst, long long n, void* stream) {
   return PP_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ head of a denoising step
+// The three bookkeeping launches in front of a network's step plan as one (each was 5-6 us of pure launch floor):
+//   blocks [0, nb_t)            temb_out[:] = temb_table[step][:]            (the time-embedding rows of this timestep)
+//   blocks [nb_t, nb_t + nb_x)  x_in[b][p][c0 + j] = latents[b mod wrap][j][p]   (fp32 NCHW -> 16-bit NHWC, CFG duplication)
+//   the rest                    acc[:] = 0                                    (GroupNorm-statistics accumulators)
+namespace {
+template <int EDT>
+__global__ void __launch_bounds__(256) step_head_kernel(const float* __restrict__ table, const int32_t* __restrict__ step_dev,
+                                                       float* __restrict__ temb_out, int row_floats, int nb_t,
+                                                       const float* __restrict__ lat, int batch, int c, int hw, int bmod,
+                                                       uint16_t* __restrict__ dst, int ldc, int c0, int nb_x,
+                                                       unsigned long long* __restrict__ zdst, long long nz) {
+  const int bid = blockIdx.x;
+  if (bid < nb_t) {
+    const float* row = table + (size_t)step_dev[0] * row_floats;
+    for (int i = bid * 256 + threadIdx.x; i < row_floats; i += nb_t * 256) temb_out[i] = row[i];
+  } else if (bid < nb_t + nb_x) {
+    const long long total = (long long)batch * hw;
+    for (long long i = (long long)(bid - nb_t) * 256 + threadIdx.x; i < total; i += (long long)nb_x * 256) {
+      const int b = (int)(i / hw), p = (int)(i - (long long)b * hw);
+      const int sb = bmod > 0 ? b % bmod : b;
+      for (int j = 0; j < c; ++j) dst[(size_t)i * ldc + c0 + j] = E16<EDT>::from_f(lat[((size_t)sb * c + j) * hw + p]);
+    }
+  } else {
+    const int nb_z = gridDim.x - nb_t - nb_x;
+    for (long long i = (long long)(bid - nb_t - nb_x) * 256 + threadIdx.x; i < nz; i += (long long)nb_z * 256) zdst[i] = 0ull;
+  }
+}
+}  // namespace
+
+extern "C" int pp_step_head(const float* temb_table, const int32_t* step_dev, float* temb_out, int row_floats,
+                            const float* latents, int batch, int c, int hw, int src_batch_mod, void* x_in, int ldc, int c0,
+                            int dtype, void* zero_dst, long long n_zero, void* stream) {
+  if (!temb_table || !step_dev || !temb_out || row_floats <= 0 || !latents || !x_in || batch <= 0 || c <= 0 || hw <= 0 ||
+      c0 < 0 || c0 + c > ldc || !pp_dt_ok(dtype) || !zero_dst || n_zero <= 0)
+    return PP_ERR_BAD_ARG;
+  int nb_t = (row_floats + 255) / 256, nb_x = (int)(((long long)batch * hw + 255) / 256), nb_z = (int)((n_zero + 255) / 256);
+  if (nb_t > 64) nb_t = 64;
+  if (nb_x > 256) nb_x = 256;
+  if (nb_z > 256) nb_z = 256;
+  PP_DT_SWITCH(dtype, hipLaunchKernelGGL(step_head_kernel<EDT>, dim3(nb_t + nb_x + nb_z), dim3(256), 0, (hipStream_t)stream,
+                                         temb_table, step_dev, temb_out, row_floats, nb_t, latents, batch, c, hw, src_batch_mod,
+                                         (uint16_t*)x_in, ldc, c0, nb_x, (unsigned long long*)zero_dst, n_zero));
+  PP_CHECK_LAUNCH("step_head_kernel");
+  return PP_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ embedding splice
 // One workgroup per output row; the row is a plain byte copy from one of two tables, so the kernel is dtype-agnostic
 // (fp32 / fp16 / bf16 token embeddings) and bit-exact by construction.

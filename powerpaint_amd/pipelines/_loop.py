@@ -2,6 +2,7 @@
 
 Per step (reference: /root/reference/powerpaint/pipelines/pipeline_PowerPaint.py:988-1041,
 pipeline_PowerPaint_Brushnet_CA.py:1384-1466, pipeline_PowerPaint_ControlNet.py:1663-1741):
+    (round 5: the next two lines and the zeroing of the GroupNorm accumulators are ONE launch, pp_step_head)
     temb_all     <- temb_table[step]                                  (one row copy, pp_embed_splice indexed by the device
                                                                        step counter: the sinusoid -> time_embedding MLP ->
                                                                        every resnet's time_emb_proj chain depends on t
@@ -175,20 +176,32 @@ class DenoiseLoop:
         hw = h * w
         mod = B if do_cfg else 0
         self._temb = {}
+        head_skip = {}
         for r in ([side_rt] if side_rt is not None else []) + [rt]:
             info = self._temb_split(r, ts) if _temb_table_enabled() else None
+            x = r.lay["x_in"]
+            nb_r = Bs if r is side_rt else Be                    # (guess mode: the side network takes `latents` as is)
+            calls = r.step_plan.calls
+            zero = calls[0] if (calls and calls[0][2] == "zero_u64") else None
+            if info is not None and zero is not None:
+                # time-embedding row + network input + accumulator zeroing: ONE launch at the head of the step (pp_step_head)
+                self._temb[id(r)] = info
+                head_skip[id(r)] = {0}
+                prog.add("step_head", lib.pp_step_head, info["table"].data_ptr(), step.data_ptr(), info["out"], info["total"],
+                         src.data_ptr(), nb_r, Cl, hw, mod if nb_r != B else 0, x.ptr, x.C, 0, L.dtype_code(r.net.dtype),
+                         zero[1][0], zero[1][1])
+                continue
             if info is not None:
                 self._temb[id(r)] = info
                 prog.add("temb_row", lib.pp_embed_splice, info["table"].data_ptr(), None, step.data_ptr(), info["out"], 1,
                          info["total"] * 4)
             else:
                 prog.add("step_select_t", lib.pp_step_select_t, ts.data_ptr(), step.data_ptr(), r.lay["t_dev"])
-            x = r.lay["x_in"]
-            nb_r = Bs if r is side_rt else Be                    # (guess mode: the side network takes `latents` as is)
             prog.add("nchw_to_nhwc", lib.pp_nchw_to_nhwc, src.data_ptr(), 0, nb_r, Cl, hw, mod if nb_r != B else 0,
                      x.ptr, x.C, 0, L.dtype_code(r.net.dtype))
         for r in ([side_rt] if side_rt is not None else []) + [rt]:
-            skip = set(self._temb[id(r)]["idx"]) if id(r) in self._temb else ()
+            skip = set(self._temb[id(r)]["idx"]) if id(r) in self._temb else set()
+            skip |= head_skip.get(id(r), set())
             prog.calls += [c for i, c in enumerate(r.step_plan.calls) if i not in skip]
             prog.flops += r.step_plan.flops
         if not self.foreign:

@@ -737,3 +737,22 @@ def test_transformer_front_end_in_one_launch(B, hw, dtype):
     qkvt = F.layer_norm(hs.float(), (C,), g1, be1, 1e-5) @ wqkv.t()        # (from the kernel's own 16-bit hs: isolates GEMM 2)
     check(qk, qkvt[:, :2 * C], 1.5e-2 * tol, 6e-3 * tol, "Q | K vs fp32")
     check(vt, qkvt[:, 2 * C:].reshape(B, hw, C).permute(0, 2, 1), 1.5e-2 * tol, 6e-3 * tol, "V^T vs fp32")
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_step_head_is_the_three_launches_it_replaces(dtype):
+    """pp_step_head = pp_embed_splice (one row of the time-embedding table, indexed by the device step counter) +
+    pp_nchw_to_nhwc (fp32 NCHW latents -> 16-bit NHWC input buffer with the CFG duplication) + pp_zero_u64, bit for bit."""
+    B, C, h, ldc, rows, steps = 4, 4, 24, 64, 20160, 7
+    table = rnd(steps, rows, seed=1)
+    lat = rnd(B, C, h, h, seed=2)
+    step = torch.tensor([5], dtype=torch.int32, device=DEV)
+    temb = torch.full((rows,), -1.0, device=DEV)
+    x = torch.full((2 * B, h * h, ldc), 3.0, device=DEV).to(dtype)
+    acc = torch.full((999,), 7, dtype=torch.int64, device=DEV)
+    L.check(L.lib().pp_step_head(table.data_ptr(), step.data_ptr(), temb.data_ptr(), rows, lat.data_ptr(), 2 * B, C, h * h, B,
+                                 x.data_ptr(), ldc, 0, L.dtype_code(dtype), acc.data_ptr(), acc.numel(),
+                                 torch.cuda.current_stream().cuda_stream), "pp_step_head")
+    assert torch.equal(temb, table[5]) and int(acc.abs().sum()) == 0
+    ref = torch.cat([lat, lat]).permute(0, 2, 3, 1).reshape(2 * B, h * h, C).to(dtype)
+    assert torch.equal(x[:, :, :C], ref) and bool((x[:, :, C:] == 3.0).all())          # (pad channels untouched)
