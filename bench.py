@@ -325,6 +325,7 @@ def cpu_baseline(budget_s: float = 40.0):
 
 
 HBM_PEAK_GBS = 6290.0            # measured float4 copy, /opt/skills/guides/MI355X_MICROARCH.md ("6.29 TB/s measured")
+HBM_SPEC_GBS = 8000.0            # the part's HBM3E specification (fractions are quoted against both)
 
 
 def roofline_report(pipe, dump_launches=None, peak=MFMA_PEAK_TFLOPS, profile_matches=True) -> dict:
@@ -379,14 +380,15 @@ def roofline_report(pipe, dump_launches=None, peak=MFMA_PEAK_TFLOPS, profile_mat
         if us:
             gbs = nbytes / (us * 1e-6) / 1e9
             hbm[fam] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(gbs / HBM_PEAK_GBS, 4), "launches": n, "avg_launch_us": round(us / n, 2),
+                        "frac": round(gbs / HBM_PEAK_GBS, 4), "peak_spec": HBM_SPEC_GBS,
+                        "frac_of_spec": round(gbs / HBM_SPEC_GBS, 4), "launches": n, "avg_launch_us": round(us / n, 2),
                         "alg_MB_per_step": round(nbytes / 1e6, 1), "time_base": "live hipGraph replay of the family"}
             if fam.startswith("linear"):
                 fl = flops.get("linear", 0.0) + flops.get("conv1x1", 0.0)
                 hbm[fam]["tflops"] = round(fl / 1e12 / (us * 1e-6), 1)
     out["hbm_roofline"] = hbm
     fam_us = {}
-    for fam in ("attention", "linear_geglu"):
+    for fam in ("attention", "linear_geglu", "ff_fused", "xattn_block", "tfront"):
         us, n = family_replay_us(pipe, (fam,))
         if us:
             fam_us[fam] = {"us_per_step": round(us, 1), "launches": n,

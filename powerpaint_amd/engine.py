@@ -494,8 +494,7 @@ class Builder:
         a._arena_top = self.arena.off
         self.plan.add("ff_fused", self.lib.pp_ff_fused, C.byref(a), w1, b1, cs1 or None, ln_stats or None, ln_tiles, 1e-5,
                       int(w2_kperm))
-        self.plan.count("linear_geglu", 2.0 * rows * 8 * Cc * Cc)      # (the FLOPs of the two launches it stands for)
-        self.plan.count("linear", 2.0 * rows * Cc * 5 * Cc)
+        self.plan.count("ff_fused", 2.0 * rows * 8 * Cc * Cc + 2.0 * rows * Cc * 5 * Cc)   # (FF1 + [g | hs] W2'^T)
         return a
 
     def add(self, a: int, b: int, out: int, n: int):
@@ -971,8 +970,7 @@ class SDNet:
                             self.groups, P[f"{pre}.proj_in.weight"], P[f"{pre}.proj_in.bias"],
                             P[f"{tb}.attn1.qkv.weight_kp"], P[f"{tb}.attn1.qkv.colsum"], P[f"{tb}.attn1.qkv.bias"], 1e-5, hs, Cc,
                             qk, 2 * Cc, vt, hw, rows, Cc, hw, pb.dt)
-                pb.plan.count("conv1x1", 2.0 * rows * Cc * Cc)           # (the FLOPs of the launches it stands for)
-                pb.plan.count("linear", 2.0 * rows * 3 * Cc * Cc)
+                pb.plan.count("tfront", 2.0 * rows * Cc * Cc + 2.0 * rows * 3 * Cc * Cc)     # (proj_in + QKV)
                 front = pb.attention(qk, 2 * Cc, qk + 2 * Cc, 2 * Cc, vt, hw, x.B, self.heads, hw, hw, d)
         if front is not None:
             a = front
@@ -1006,8 +1004,7 @@ class SDNet:
             pb.plan.add("xattn_block", pb.lib.pp_xattn_block, a, Cc, hs, Cc, None, tiles, 1e-5, xa[0], xa[1], xa[2], xa[3],
                         P[f"{tb}.attn2.to_out.bias"], o, Cc, st2 or None, rows_o, Cc, hw, rows if twin else 0,
                         P[f"{tb}.attn1.to_out.weight"], P[f"{tb}.attn1.to_out.bias"], pb.dt)
-            pb.plan.count("linear", 2.0 * rows_o * Cc * Cc)
-            pb.plan.count("xattn_block", 4.0 * rows_o * Cc * Cc + 4.0 * rows_o * self._nctx * Cc)
+            pb.plan.count("xattn_block", 6.0 * rows_o * Cc * Cc + 4.0 * rows_o * self._nctx * Cc)   # (+ attn1.to_out)
             hs, st = o, st2
             xa = "done"
         else:
