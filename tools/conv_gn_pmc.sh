@@ -2,11 +2,12 @@
 # Issue / LDS / matrix-pipe counters of the fused norm -> SiLU -> conv kernel (csrc/conv_gn.hip) at the 64x64 level
 # (batch 8, 320 -> 320: 256 workgroups of 256x160, five channel chunks) and on a long-K shape (640 + 320 -> 320), one counter
 # group per pass; the same passes on the skeleton without the normalisation (lab build, PP_CONV_GN_NMODE=2).
-# -> gpurun_out/conv_gn_pmc.txt (copy to profiles/r04_gemm_pmc.txt)
+# -> gpurun_out/conv_gn_pmc.txt (copy to profiles/rNN_gemm_pmc.txt); the header carries pp_build_id of the library it ran
 cd /tmp && export TMPDIR=/tmp
 R=/root/repo
 OUT=$R/gpurun_out/conv_gn_pmc.txt
 : > $OUT
+echo "# tools/conv_gn_pmc.sh; lib_sha16: $(cd $R && python -c 'from powerpaint_amd import _lib; print(_lib.build_id())')  (shipping library; the nm2 passes run libpp_hip_lab.so of the same sources)" >> $OUT
 for shape in "64 320 0 320" "64 640 320 320"; do
  for variant in ship nm2; do
   if [ $variant = nm2 ]; then export PP_LAB=1 PP_LIB=$R/powerpaint_amd/libpp_hip_lab.so PP_CONV_GN_NMODE=2; else unset PP_LAB PP_LIB PP_CONV_GN_NMODE; fi

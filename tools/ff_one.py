@@ -12,6 +12,11 @@ dev = "cuda"
 
 
 def main():
+    only = None
+    if "--only" in sys.argv:                     # (rocprofv3 --pmc passes: run ONE of fused / fused4 / chain)
+        i = sys.argv.index("--only")
+        only = sys.argv[i + 1]
+        del sys.argv[i:i + 2]
     Ms = [int(a) for a in sys.argv[1:]] or [32768, 131072]
     for M in Ms:
         g = torch.Generator("cpu").manual_seed(0)
@@ -40,6 +45,12 @@ def main():
             gg = ops.gemm(hs, w1, bias=b1, act=L.PP_ACT_GEGLU, ln_stats=st, ln_colsum=cs1, ln_dim=C)
             return ops.gemm(gg, w2, bias=b2, x2=hs, res1=res, rows_per_batch=rpb, gn=gn)
 
+        if only:
+            fn = {"fused": fused, "fused4": fused4, "chain": chain}[only]
+            for _ in range(6):
+                fn()
+            torch.cuda.synchronize()
+            continue
         a, b = fused(), chain()
         d = (a.float() - b.float()).abs()
         print(f"M={M}: max |fused - chain| {float(d.max()):.4g}, differing {float((d > 0).float().mean()):.4f}")
