@@ -29,7 +29,7 @@ extern "C" {
 #define PP_ERR_LAUNCH (-3)       /* hipLaunchKernel / hipFuncSetAttribute failed                  */
 #define PP_ERR_WORKSPACE (-4)    /* workspace pointer null or too small                           */
 
-#define PP_ABI_VERSION 19
+#define PP_ABI_VERSION 20
 /* 16-bit storage format of activations and matrix weights ("dtype" arguments; the same codes pp_nchw_to_nhwc uses for
  * its source): bf16 or fp16 -- the reference's default is fp16 (/root/reference/app.py:548,559).  MFMA accumulation,
  * norm statistics, softmax, biases and latents are fp32 with either. */
@@ -265,11 +265,18 @@ int pp_attention_fwd(const void* q, int ldq, const void* k, int ldk, const void*
  *   PP_ATTN_PIPE_Q32 attn_pipe_kernel  (software-pipelined, 32 queries per wave, 64-key tiles; d = 40, nk % 64 == 0, nk >= 256)
  *   PP_ATTN_PIPE_Q64 attn_pipe_kernel  (64 queries per wave on 32-key tiles; same shapes; AUTO takes it when
  *                                       batch * heads * ceil(nq / 256) >= 512, i.e. the 64x64 and 128x128 latents)
+ *   PP_ATTN_PIPE_LOG2 (ABI v20) the pipelined kernel AUTO would take, for a q that already holds Q * scale * log2(e) (the
+ *                                       producing GEMM's epilogue multiplies: pp_tfront q_scale): the running softmax
+ *                                       reference enters as the initial accumulator of the QK^T MFMAs, a score leaves the
+ *                                       matrix pipe as the exp2 argument (no VALU multiply-add per score); `scale` is NOT
+ *                                       applied.  Shapes: pp_attention_log2_ok(); never chosen by AUTO.
  * A named kernel that does not cover the shape returns PP_ERR_UNSUPPORTED. */
 #define PP_ATTN_AUTO 0
 #define PP_ATTN_PHASED 1
 #define PP_ATTN_PIPE_Q32 2
 #define PP_ATTN_PIPE_Q64 3
+#define PP_ATTN_PIPE_LOG2 4
+int pp_attention_log2_ok(int nq, int nk, int d);
 int pp_attention_fwd_variant(const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt, void* o, int ldo,
                              int batch, int heads, int nq, int nk, int d, float scale, int dtype, int variant,
                              void* stream);
@@ -335,10 +342,13 @@ int pp_add_bf16(const void* a, const void* b, void* out, long long n, int dtype,
  *             rows are 16 floats {sigma_t, alpha_t, use_corr, k_last, k_m1, k_m2, k_m3, k_x0, p_xc, p_x0, p_m1, p_m2};
  *             x0 = (x - sigma_t eps) / alpha_t;  xc = use_corr ? k . (last, m1, m2, m3, x0) : x;
  *             x_next = p . (xc, x0, m1, m2);  state [4][n] fp32 <- (xc, x0, m1, m2), zero before the first step.
- * `step_dev` (int32 on device) selects the row; it is NOT incremented here (pp_step_advance does).
+ * `step_dev` (int32 on device) selects the row.  advance_ticket == NULL: it is NOT incremented here (pp_step_advance
+ * does).  advance_ticket != NULL (ABI v20; a zero-initialised device word that belongs to this call site): this launch is
+ * the step's last reader of the counter and moves it on itself -- the block that finishes last does step_dev[0] += 1
+ * and returns the ticket to zero; no pp_step_advance launch behind it.
  */
 int pp_cfg_sched_step(const float* eps2, int cfg, float guidance, float* latents, float* m_prev, int n, int kind,
-                      const float* coef_table, const int32_t* step_dev, void* stream);
+                      const float* coef_table, int32_t* step_dev, uint32_t* advance_ticket, void* stream);
 /* Stochastic DDIM, `eta > 0` (the pipelines' `eta` argument, pipeline_PowerPaint.py:736-745 / 1023: it reaches
  * `DDIMScheduler.step` only): after pp_cfg_sched_step of the same step,  latents += std_dev_t * noise  with
  * std_dev_t = coef[step][4] of the kind-0 table (eta * sqrt((1-a_prev)/(1-a_t) * (1-a_t/a_prev)); column 3 then holds
@@ -357,11 +367,14 @@ int pp_ddim_variance_noise(float* latents, const float* noise, int n, const floa
  * accumulator layout of the first GEMM is then the B-operand layout of the second); cs2 / b2: its column sums and W beta.
  * Outputs: hs [M][c] (the residual of attn1.to_out), qk [M][>= 2c] = Q | K, vt [batch][c][ldvt] = V transposed -- what
  * pp_attention_fwd reads.  Arithmetic = pp_groupnorm_apply_acc -> pp_gemm_bf16(row_stats_out) -> pp_gemm_bf16(ln_stats)
- * up to the fp32 summation order.  pp_tfront_supported() = 1 for c = 320, 128-row tiles inside one batch item. */
+ * up to the fp32 summation order.  pp_tfront_supported() = 1 for c = 320, 128-row tiles inside one batch item.
+ * q_scale (ABI v20): the Q third is multiplied by it in fp32 before its one rounding to 16 bits -- 1.0 for
+ * pp_attention_fwd, head_dim^-0.5 * log2(e) for PP_ATTN_PIPE_LOG2. */
 int pp_tfront_supported(int M, int c, int rows_per_batch, int gn_groups);
 int pp_tfront(const void* x, int ldx, const void* gn_acc, const float* gn_gamma, const float* gn_beta, float gn_eps, int gn_groups,
               const void* w1, const float* b1, const void* w2p, const float* cs2, const float* b2, float ln_eps, void* hs,
-              int ldhs, void* qk, int ldqk, void* vt, int ldvt, int M, int c, int rows_per_batch, int dtype, void* stream);
+              int ldhs, void* qk, int ldqk, void* vt, int ldvt, int M, int c, int rows_per_batch, float q_scale, int dtype,
+              void* stream);
 /* Fused cross-attention sub-block of BasicTransformerBlock (norm2 -> attn2 -> residual) for C = 320, 8 heads, <= 80
  * context tokens -- the three launches `to_q` (pp_gemm_bf16, LayerNorm folded) -> pp_attention_fwd -> `to_out`
  * (pp_gemm_bf16 + residual + row moments) of the 64x64 level as ONE (ctor site /root/reference/powerpaint/models/

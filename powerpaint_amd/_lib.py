@@ -15,8 +15,8 @@ PP_X_PLAIN, PP_X_CONV3X3 = 0, 1
 PP_ACT_NONE, PP_ACT_GEGLU, PP_ACT_SILU = 0, 1, 2
 PP_TILE_AUTO, PP_TILE_128x160, PP_TILE_64x160, PP_TILE_256x160 = 0, 1, 2, 3
 PP_DT_F32, PP_DT_BF16, PP_DT_F16 = 0, 1, 2      # dtype codes of the C ABI (include/pp_hip.h)
-PP_ATTN_AUTO, PP_ATTN_PHASED, PP_ATTN_PIPE_Q32, PP_ATTN_PIPE_Q64 = 0, 1, 2, 3   # pp_attention_fwd_variant
-ABI_VERSION = 19                                  # PP_ABI_VERSION of include/pp_hip.h this binding was written against
+PP_ATTN_AUTO, PP_ATTN_PHASED, PP_ATTN_PIPE_Q32, PP_ATTN_PIPE_Q64, PP_ATTN_PIPE_LOG2 = 0, 1, 2, 3, 4   # pp_attention_fwd_variant
+ABI_VERSION = 20                                  # PP_ABI_VERSION of include/pp_hip.h this binding was written against
 PP_ERR = {0: "PP_OK", -1: "PP_ERR_BAD_ARG", -2: "PP_ERR_UNSUPPORTED", -3: "PP_ERR_LAUNCH", -4: "PP_ERR_WORKSPACE"}
 
 vp, i32, f32, sz = C.c_void_p, C.c_int32, C.c_float, C.c_size_t
@@ -85,7 +85,7 @@ SIGNATURES = {
     "pp_nchw_to_nhwc": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp]),
     "pp_nhwc_to_nchw": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp]),
     "pp_add_bf16": (C.c_int, [vp, vp, vp, C.c_longlong, C.c_int, vp]),
-    "pp_cfg_sched_step": (C.c_int, [vp, C.c_int, f32, vp, vp, C.c_int, C.c_int, vp, vp, vp]),
+    "pp_cfg_sched_step": (C.c_int, [vp, C.c_int, f32, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp]),
     "pp_step_select_t": (C.c_int, [vp, vp, vp, vp]),
     "pp_ddim_variance_noise": (C.c_int, [vp, vp, C.c_int, vp, vp, vp]),
     "pp_latent_blend": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
@@ -94,7 +94,8 @@ SIGNATURES = {
                                           C.c_int, vp, C.c_int, vp]),
     "pp_tfront_supported": (C.c_int, [C.c_int] * 4),
     "pp_tfront": (C.c_int, [vp, C.c_int, vp, vp, vp, C.c_float, C.c_int, vp, vp, vp, vp, vp, C.c_float, vp, C.c_int, vp, C.c_int,
-                            vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+                            vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, vp]),
+    "pp_attention_log2_ok": (C.c_int, [C.c_int] * 3),
     "pp_xattn_block_supported": (C.c_int, [C.c_int] * 5),
     "pp_xattn_fold": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, C.c_float,
                                 vp, vp, vp, vp, C.c_int, C.c_int, vp]),

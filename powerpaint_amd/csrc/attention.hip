@@ -380,7 +380,7 @@ extern "C" int pp_attention_fwd_variant(const void* q, int ldq, const void* k, i
                                         int variant, void* stream) {
   if (!q || !k || !vt || !o || batch <= 0 || heads <= 0 || nq <= 0 || nk <= 0 || !pp_dt_ok(dtype)) return PP_ERR_BAD_ARG;
   if (ldq % 8 || ldk % 8 || ldvt % 8 || ldo % 4 || ldvt < nk) return PP_ERR_BAD_ARG;
-  if (variant < PP_ATTN_AUTO || variant > PP_ATTN_PIPE_Q64) return PP_ERR_BAD_ARG;
+  if (variant < PP_ATTN_AUTO || variant > PP_ATTN_PIPE_LOG2) return PP_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)stream;
   const float sl2 = scale * 1.4426950408889634f;
   bool use_pipe = variant != PP_ATTN_PHASED;
@@ -396,6 +396,9 @@ extern "C" int pp_attention_fwd_variant(const void* q, int ldq, const void* k, i
     default: return PP_ERR_UNSUPPORTED;
   }
 }
+
+// shapes of the software-pipelined kernels = shapes PP_ATTN_PIPE_LOG2 covers (a producer asks before it pre-multiplies Q)
+extern "C" int pp_attention_log2_ok(int nq, int nk, int d) { return (nq > 0 && d == 40 && nk % 64 == 0 && nk >= 4 * 64) ? 1 : 0; }
 
 extern "C" int pp_attention_fwd(const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt, void* o,
                                 int ldo, int batch, int heads, int nq, int nk, int d, float scale, int dtype,

@@ -76,6 +76,13 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 //      the v_cvt_pk of an exp step is issued one step LATER (behind the next step's v_exp pair: no `s_nop` for the
 //      transcendental-result hazard, 13 per stage before), and the deferred-rescale factor exp2(m_old - m_new) is
 //      evaluated inside the (rare) rescale branch instead of on every stage.
+//  64  (round 5) LOG2 form: q holds Q * scale * log2(e) (the producer's epilogue pre-multiplies: pp_tfront q_scale), and the
+//      running reference -m is the INITIAL ACCUMULATOR of the first QK^T MFMA of a block instead of zero, so a score leaves
+//      the matrix pipe as the exp2 argument itself: no v_fma per score (32 of ~120 VALU instructions per 32-key stage; the
+//      kernel is VALU-issue bound, profiles/r03_attention_pmc.txt).  For that the stage runs its PV MFMAs FIRST and the
+//      QK^T ones behind the running-max phase (the reference S(t+1) is baked with is the one P(t) uses), and the rare
+//      reference update (a lane's tile maximum more than RESCALE_THR above its reference; always at the first tile) fixes
+//      up the 16 scores per lane and block it arrived too late for, in a wave-uniform branch.  Needs bit 8.
 template <int D, int KB, int dbg, int EDT, int NW, int QB, int OPT>
 __global__ void __launch_bounds__(64 * NW, (KB == 32 && QB == 1 ? 4 : 2))
 attn_pipe_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __restrict__ k, int ldk,
@@ -85,6 +92,8 @@ attn_pipe_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __rest
   // 8 no LDS fragment reads
   constexpr int SUBS = (OPT & 16) ? 2 : 1;
   constexpr int KT = KB * SUBS;
+  constexpr bool BAKE = (OPT & 64) != 0;
+  static_assert(!BAKE || (OPT & 8), "the LOG2 form keeps the rescale exponent in alpha[] (OPT bit 8)");
   using C = PCfg<D, KB, NW, SUBS>;
   using E = E16<EDT>;
   typedef typename E::v8 v8_t;
@@ -193,6 +202,14 @@ attn_pipe_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __rest
 #pragma unroll
   for (int qb = 0; qb < QB; ++qb) { m_run[qb] = -1.0e30f; alpha[qb] = (OPT & 8) ? 0.0f : 1.0f; }
   bool pend = false;            // wave-uniform: some alpha != 1 somewhere
+  // (LOG2 form) -reference of every query of the lane, as the accumulator the first QK^T MFMA of a block starts from;
+  // the reference starts at 0 and the first tile always replaces it by that tile's row maximum
+  f32x16_t cinit[BAKE ? QB : 1];
+#pragma unroll
+  for (int qb = 0; qb < (BAKE ? QB : 1); ++qb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cinit[qb][r] = 0.f;
+  bool first = true;            // wave-uniform
 
   // plain (non-interleaved) pieces: prologue S(0) and the drain PV
   auto qk = [&](const char* ks, f32x16_t (&sn)[QB][JB]) {
@@ -233,7 +250,7 @@ attn_pipe_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __rest
   // the softmax VALU work, and every QB-th slot the LDS read of the fragment FDF fragments ahead (a fragment feeds the QB
   // consecutive MFMAs of the wave's q-blocks).  sched_barrier(0) between slots keeps the compiler from regrouping (left
   // alone it emits all MFMAs back to back, then the VALU block: zero overlap).
-  auto stage = [&](auto sub_tag, const f32x16_t (&sc)[QB][JB], f32x16_t (&sn)[QB][JB], v8_t (&pc)[QB][JB][2],
+  auto stage = [&](auto sub_tag, f32x16_t (&sc)[QB][JB], f32x16_t (&sn)[QB][JB], v8_t (&pc)[QB][JB][2],
                    const v8_t (&pp)[QB][JB][2]) {
     constexpr int sub = decltype(sub_tag)::value;       // t & 1
     // SUBS = 2: `sub` = t & 1 is a compile-time constant of the two stage instantiations (the loop is unrolled by two).
@@ -272,6 +289,9 @@ attn_pipe_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __rest
     constexpr int NQK = NKF * QB, NM = NF * QB;                  // QK^T slots / all slots
     constexpr int FDF = (dbg >> 4) ? (dbg >> 4) : ((OPT & 4) ? 2 : (QB == 1 ? 2 : 1));   // fragment prefetch distance, in fragments
     //                                       (= two slots either way; QB = 2 with FDF 2 measured the same)
+    constexpr int NVF = NF - NKF;
+    // slot order: QK^T fragments first, then PV; LOG2 form: PV first (S(t+1) must see the reference this stage settles)
+    auto fk = [](int kk) { return BAKE ? (kk < NVF ? NKF + kk : kk - NVF) : kk; };
     constexpr int SB = QB * JB;                  // 32 x 32 score blocks per stage
     constexpr int MAXSLOTS = 2 * SB;             // slots carrying the running-max phase (8 scores each)
     constexpr int NES = 8 * SB;                  // exp steps (2 scores each)
@@ -288,7 +308,7 @@ attn_pipe_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __rest
       }
     };
 #pragma unroll
-    for (int k = 0; k < FDF; ++k) fetch(k);
+    for (int k = 0; k < FDF; ++k) fetch(fk(k));
     float tmax[QB];
     f32x2_t c2 = {scale_log2e, scale_log2e}, nm2[QB];
 #pragma unroll
@@ -299,9 +319,10 @@ attn_pipe_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __rest
     int es = 0;                                  // exp steps done (compile-time after unrolling)
 #pragma unroll
     for (int f = 0; f < NM; ++f) {
-      const int k = f / QB, qb = f % QB;         // fragment of this slot, q-block it multiplies
-      if (qb == 0 && k + FDF < NF) {
-        fetch(k + FDF);
+      const int kk = f / QB, qb = f % QB;        // fragment of this slot (in slot order), q-block it multiplies
+      const int k = fk(kk);
+      if (qb == 0 && kk + FDF < NF) {
+        fetch(fk(kk + FDF));
         if (OPT & 4) __builtin_amdgcn_sched_barrier(0);   // the read leaves at the head of the slot
       }
       if (dbg & 1) {
@@ -309,7 +330,8 @@ attn_pipe_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __rest
       } else if (k < NKF) {
         const int j = k / C::DS, sidx = k % C::DS;
         const f32x16_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        sn[qb][j] = E::mfma32(frag[k], __builtin_bit_cast(v8_t, qraw[qb][sidx]), sidx == 0 ? zero : sn[qb][j], 0, 0, 0);
+        sn[qb][j] = E::mfma32(frag[k], __builtin_bit_cast(v8_t, qraw[qb][sidx]),
+                              sidx == 0 ? (BAKE ? cinit[BAKE ? qb : 0] : zero) : sn[qb][j], 0, 0, 0);
       } else {
         const int g = k - NKF, ju = g / C::DT, dt = g % C::DT;
         oacc[qb][dt] = E::mfma32(frag[k], pp[qb][ju >> 1][ju & 1], oacc[qb][dt], 0, 0, 0);
@@ -333,6 +355,22 @@ attn_pipe_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __rest
           } else {
             tm = fmaxf(tmax[mq], __shfl_xor(tmax[mq], 32, 64));
           }
+          if constexpr (BAKE) {
+            // tm = this tile's row maximum MINUS the lane's reference (the scores carry it already)
+            const bool need = first || !__all(tm <= RESCALE_THR);
+            alpha[mq] = 0.f;
+            if (need) {
+              const float dlt = first ? tm : fmaxf(tm, 0.f);      // the reference moves up by dlt (first tile: to the maximum)
+#pragma unroll
+              for (int jj = 0; jj < JB; ++jj)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sc[mq][jj][r] -= dlt;
+#pragma unroll
+              for (int r = 0; r < 16; ++r) cinit[mq][r] -= dlt;
+              alpha[mq] = first ? 0.f : -dlt;                     // (O is still zero at the first tile)
+              any = true;
+            }
+          } else {
           const float ts = tm * scale_log2e;
           const bool need = !__all(ts - m_run[mq] <= RESCALE_THR);
           const float m_new = need ? fmaxf(m_run[mq], ts) : m_run[mq];
@@ -340,8 +378,9 @@ attn_pipe_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __rest
           any = any || need;
           m_run[mq] = m_new;
           nm2[mq] = f32x2_t{-m_new, -m_new};
+          }
         }
-        if (f == MAXSLOTS - 1) pend = any;
+        if (f == MAXSLOTS - 1) { pend = any; first = false; }
       } else {                                   // exp steps: 2 scores each (pk_fma, 2 x exp2, cvt_pk)
         const int kk = f - MAXSLOTS;
         const int upto = (NES * (kk + 1) + ESLOTS - 1) / ESLOTS;
@@ -350,8 +389,8 @@ attn_pipe_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __rest
           const int sb = es >> 3, eq = sb / JB, ej = sb % JB, u = (es >> 2) & 1, e = es & 3;
           const f32x2_t s2 = {sc[eq][ej][8 * u + 2 * e], sc[eq][ej][8 * u + 2 * e + 1]};
           f32x2_t e2;
-          if (OPT & 32) {                                   // (lab, timing only) no exponent arithmetic: what a logit that leaves
-            e2 = s2;                                        //  the MFMA as an exp2 exponent would cost
+          if (BAKE || (OPT & 32)) {                         // LOG2 form: the score IS the exponent  (32: lab timing probe of
+            e2 = s2;                                        //  the same without the reference, results garbage)
           } else if (OPT & 2) {
             float e0 = __builtin_fmaf(s2[0], scale_log2e, nm2[eq][0]), e1 = __builtin_fmaf(s2[1], scale_log2e, nm2[eq][1]);
             asm volatile("" : "+v"(e0), "+v"(e1));        // (keeps LLVM's SLP vectoriser from re-packing the pair)
@@ -534,7 +573,17 @@ int pp_attention_pipe_launch(const void* q, int ldq, const void* k, int ldk, con
   // per query): 319 us against 338 us at N = 4096 hot, -0.5 % on the UNet step.  Needs two 256-query workgroups per CU
   // to be worth it.
   const long long wg2 = (long long)batch * heads * ((nq + 255) / 256);
-  const bool q64 = variant == PP_ATTN_PIPE_Q64 || (variant == PP_ATTN_AUTO && wg2 >= 512);
+  const bool log2q = variant == PP_ATTN_PIPE_LOG2;      // q = Q * scale * log2(e): same kernel choice as AUTO, OPT bit 64
+  const bool q64 = variant == PP_ATTN_PIPE_Q64 || ((variant == PP_ATTN_AUTO || log2q) && wg2 >= 512);
+  if (log2q) {
+    constexpr int O64 = PP_ATTN_OPT_DEFAULT | 64, O32 = (PP_ATTN_OPT_DEFAULT & ~16) | 64;
+    if (q64) {
+      if (dtype == PP_DT_F16) return launch_pipe<32, 0, PP_DT_F16, 4, 2, O64>(PP_ARGS);
+      return launch_pipe<32, 0, PP_DT_BF16, 4, 2, O64>(PP_ARGS);
+    }
+    if (dtype == PP_DT_F16) return launch_pipe<64, 0, PP_DT_F16, 4, 1, O32>(PP_ARGS);
+    return launch_pipe<64, 0, PP_DT_BF16, 4, 1, O32>(PP_ARGS);
+  }
 #ifdef PP_LAB
   if (q64 && dtype == PP_DT_BF16 && pp_lab_env("PP_ATTN_OPT", -1) >= 0) {      // A/B of the round-3 loop changes
     switch (pp_lab_env("PP_ATTN_OPT", 0)) {

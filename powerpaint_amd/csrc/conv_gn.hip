@@ -698,6 +698,16 @@ CGChoice cg_choose(const PPGemmArgs& a) {
   // included -- 179 against 211 us at K = 17280, 135 / 147 at 11520, 105 / 116 at 8640, a draw at 5760 (32x32 level,
   // profiles/r04_rejected_experiments.txt item 8).  (lab) PP_CONV_GN_SK2 = the chunk count from which, 0 = never
   static const int sk2_from = pp_lab_env("PP_CONV_GN_SK2", 12);
+#ifdef PP_LAB
+  // (lab) PP_CONV_GN_W16 = 10 * BM + splits: the tile / split-K form of the 16x16-level launches (ships: 256 rows x 4 splits)
+  static const int w16 = pp_lab_env("PP_CONV_GN_W16", 0);
+  if (w16 > 0 && a.win == 16 && !want && a.splitk <= 0 && cg_shape_ok(a, w16 / 10)) {
+    c.bm = w16 / 10;
+    c.splitk = w16 % 10;
+    if (c.splitk > nch0) c.splitk = nch0;
+    return c;
+  }
+#endif
   if (want && cg_shape_ok(a, want)) c.bm = want;
   else if (cg_shape_ok(a, 256) && tiles(256) >= 224) c.bm = 256;
   else if (sk2_from > 0 && nch0 >= sk2_from && a.splitk <= 0 && cg_shape_ok(a, 256) && tiles(256) * 2 >= 224 &&
@@ -707,6 +717,12 @@ CGChoice cg_choose(const PPGemmArgs& a) {
     return c;
   }
   else if (cg_shape_ok(a, 128) && tiles(128) >= 224) c.bm = 128;
+  // a quarter of the chip's worth of 256-row tiles or less (the 16x16 level at batch 8: 64 tiles x 4 splits) and a SHORT K:
+  // 128-row tiles with half the splits (half the fp32 slabs to write and combine, the same 256 workgroups) -- 53 against
+  // 57 us at K = 5760.  From K = 11520 on the 256-row tile wins on a fast box of the pool (77 / 83, 123 / 143 us at
+  // K = 23040; step 8.73 against 8.83 ms) and LOSES on a slow one (10.76 against 10.62 ms): profiles/r05_w16_tiles.txt.
+  // (lab) PP_CONV_GN_W16 = 10 * rows + splits forces a form at W = 16
+  else if (cg_shape_ok(a, 256) && cg_shape_ok(a, 128) && tiles(256) * 4 <= 256 && nch0 <= 10 && a.splitk <= 0) c.bm = 128;
   else if (cg_shape_ok(a, 256)) c.bm = 256;
   else if (cg_shape_ok(a, 128)) c.bm = 128;
   else c.bm = 64;

@@ -292,10 +292,9 @@ __global__ void __launch_bounds__(256) add_bf16_kernel(const uint16_t* __restric
 }
 
 // ------------------------------------------------------------------------------------------ CFG + scheduler step
-__global__ void __launch_bounds__(256) cfg_sched_step_kernel(const float* __restrict__ eps2, int cfg, float g,
-                                                            float* __restrict__ x, float* __restrict__ m_prev, int n,
-                                                            int kind, const float* __restrict__ coef,
-                                                            const int32_t* __restrict__ step_dev) {
+PP_DEVINL void cfg_sched_step_body(const float* __restrict__ eps2, int cfg, float g, float* __restrict__ x,
+                                   float* __restrict__ m_prev, int n, int kind, const float* __restrict__ coef,
+                                   const int32_t* step_dev) {
   if (kind == 2) {
     // PNDM / PLMS: table row (16 floats) = w0..w3 (linear multistep weights over eps, h1, h2, h3), a (sample coefficient),
     // b (model-output coefficient), then as floats: ring slots of h1, h2, h3, the slot this eps is pushed to (-1: not
@@ -384,6 +383,23 @@ __global__ void __launch_bounds__(256) cfg_sched_step_kernel(const float* __rest
       const float d1 = c5 * (x0 - m_prev[i]);
       x[i] = c2 * xv - c3 * x0 - c4 * d1;
       m_prev[i] = x0;
+    }
+  }
+}
+
+// ticket != NULL (ABI v20): the launch is the last reader of the step counter in its step and moves it on itself -- the
+// block that takes the last ticket does `step[0] += 1` (every other block has read the counter before it drew its ticket;
+// the ticket returns to zero for the next step).  One launch less per denoise step than pp_step_advance behind it.
+__global__ void __launch_bounds__(256) cfg_sched_step_kernel(const float* __restrict__ eps2, int cfg, float g,
+                                                            float* __restrict__ x, float* __restrict__ m_prev, int n,
+                                                            int kind, const float* __restrict__ coef, int32_t* step_dev,
+                                                            unsigned* ticket) {
+  cfg_sched_step_body(eps2, cfg, g, x, m_prev, n, kind, coef, step_dev);
+  if (ticket) {
+    __syncthreads();
+    if (threadIdx.x == 0 && atomicAdd(ticket, 1u) == gridDim.x - 1) {
+      *ticket = 0u;
+      step_dev[0] += 1;
     }
   }
 }
@@ -574,11 +590,12 @@ extern "C" int pp_add_bf16(const void* a, const void* b, void* out, long long n,
 }
 
 extern "C" int pp_cfg_sched_step(const float* eps2, int cfg, float guidance, float* latents, float* m_prev, int n,
-                                 int kind, const float* coef_table, const int32_t* step_dev, void* stream) {
+                                 int kind, const float* coef_table, int32_t* step_dev, uint32_t* advance_ticket,
+                                 void* stream) {
   if (!eps2 || !latents || !coef_table || !step_dev || n <= 0 || kind < 0 || kind > 3) return PP_ERR_BAD_ARG;
   if (kind >= 1 && !m_prev) return PP_ERR_BAD_ARG;
   hipLaunchKernelGGL(cfg_sched_step_kernel, dim3(grid_for_host(n)), dim3(256), 0, (hipStream_t)stream, eps2, cfg,
-                     guidance, latents, m_prev, n, kind, coef_table, step_dev);
+                     guidance, latents, m_prev, n, kind, coef_table, step_dev, (unsigned*)advance_ticket);
   PP_CHECK_LAUNCH("cfg_sched_step_kernel");
   return PP_OK;
 }

@@ -44,6 +44,7 @@ struct TFArgs {
   uint16_t* qk; int ldqk;
   uint16_t* vt; int ldvt;
   int M, rows_per_batch;
+  float q_scale;
 };
 
 template <int... I, class F>
@@ -186,6 +187,7 @@ __global__ void __launch_bounds__(512, 2) tfront_kernel(const TFArgs a) {
       f32x4_t v;
 #pragma unroll
       for (int i = 0; i < 4; ++i) v[i] = rstd * (acc[nb][i] - mean * cs[i]) + bb[i];
+      if constexpr (p == 0) v *= a.q_scale;      // (1.0, or head_dim^-0.5 * log2 e for PP_ATTN_PIPE_LOG2)
       const uint32_t o0 = E::pack2(v[0], v[1]), o1 = E::pack2(v[2], v[3]);
       if constexpr (p < 2) *reinterpret_cast<u32x2_t*>(orow + nb * 16 + 4 * g) = u32x2_t{o0, o1};
       else { vkeep[nb][0] = o0; vkeep[nb][1] = o1; }
@@ -265,10 +267,11 @@ extern "C" int pp_tfront_supported(int M, int c, int rows_per_batch, int gn_grou
 extern "C" int pp_tfront(const void* x, int ldx, const void* gn_acc, const float* gn_gamma, const float* gn_beta, float gn_eps,
                          int gn_groups, const void* w1, const float* b1, const void* w2p, const float* cs2, const float* b2,
                          float ln_eps, void* hs, int ldhs, void* qk, int ldqk, void* vt, int ldvt, int M, int c,
-                         int rows_per_batch, int dtype, void* stream) {
+                         int rows_per_batch, float q_scale, int dtype, void* stream) {
   if (!x || !gn_acc || !gn_gamma || !gn_beta || !w1 || !b1 || !w2p || !cs2 || !b2 || !hs || !qk || !vt || !pp_dt_ok(dtype))
     return PP_ERR_BAD_ARG;
   if (!pp_tfront_supported(M, c, rows_per_batch, gn_groups)) return PP_ERR_UNSUPPORTED;
+  if (!(q_scale > 0.f)) return PP_ERR_BAD_ARG;
   if (ldx < c || (ldx & 7) || ldhs < c || (ldhs & 3) || ldqk < 2 * c || (ldqk & 3) || ldvt < rows_per_batch || (ldvt & 7))
     return PP_ERR_BAD_ARG;
   TFArgs a;
@@ -280,6 +283,7 @@ extern "C" int pp_tfront(const void* x, int ldx, const void* gn_acc, const float
   a.qk = (uint16_t*)qk; a.ldqk = ldqk;
   a.vt = (uint16_t*)vt; a.ldvt = ldvt;
   a.M = M; a.rows_per_batch = rows_per_batch;
+  a.q_scale = q_scale;
   static bool attr_set[3] = {false, false, false};
   auto go = [&](auto kern) -> int {
     if (!attr_set[dtype]) {

@@ -461,12 +461,17 @@ class Builder:
         return out
 
     def attention(self, q: int, ldq: int, k: int, ldk: int, vt: int, ldvt: int, B: int, heads: int, nq: int,
-                  nk: int, d: int, out: int = 0, ldo: int = 0) -> int:
+                  nk: int, d: int, out: int = 0, ldo: int = 0, log2q: bool = False) -> int:
+        """log2q: q already holds Q * d^-0.5 * log2(e) (pp_tfront q_scale) -> the PP_ATTN_PIPE_LOG2 kernel."""
         Cc = heads * d
         if not out:
             out, ldo = self.alloc(B * nq * Cc * 2), Cc
-        self.plan.add("attention", self.lib.pp_attention_fwd, q, ldq, k, ldk, vt, ldvt, out, ldo, B, heads, nq, nk,
-                      d, float(d) ** -0.5, self.dt)
+        if log2q:
+            self.plan.add("attention", self.lib.pp_attention_fwd_variant, q, ldq, k, ldk, vt, ldvt, out, ldo, B, heads, nq,
+                          nk, d, float(d) ** -0.5, self.dt, L.PP_ATTN_PIPE_LOG2)
+        else:
+            self.plan.add("attention", self.lib.pp_attention_fwd, q, ldq, k, ldk, vt, ldvt, out, ldo, B, heads, nq, nk,
+                          d, float(d) ** -0.5, self.dt)
         self.plan.count("attention", 4.0 * B * heads * nq * nk * d)
         return out
 
@@ -593,6 +598,9 @@ class SDNet:
     # ... as the 8-wave kernel (two waves per SIMD, GEGLU values exchanged through LDS, W2' in natural hidden order).
     # (lab) PP_FF_W8=0: the 4-wave kernel (one wave per SIMD, GEGLU chained in registers, W2' hidden index permuted)
     ff_w8 = _lab_switch("PP_FF_W8")
+    # round 5: the fused front end hands Q over pre-multiplied by d^-0.5 * log2(e) and self-attention runs the
+    # PP_ATTN_PIPE_LOG2 form of the pipelined kernel (no multiply-add per score).  (lab) PP_ATTN_LOG2=0: plain Q
+    attn_log2 = _lab_switch("PP_ATTN_LOG2")
     # round 4: the same for C = 640 / 1280 (64-row tiles x 320-column groups, xattn_wide_kernel).  (lab) PP_XATTN_WIDE=0
     # keeps the chain at those levels
     fuse_xattn_wide = _lab_switch("PP_XATTN_WIDE")
@@ -966,12 +974,15 @@ class SDNet:
                 hs = pb.alloc(rows * Cc * 2)
                 vt = pb.alloc(x.B * Cc * hw * 2)
                 qk = pb.alloc(rows * 2 * Cc * 2)
+                # (round 5) Q leaves the front end as Q * d^-0.5 * log2(e) where the pipelined attention kernel covers the
+                # shape: its scores then come out of the MFMA as exp2 arguments (PP_ATTN_PIPE_LOG2)
+                log2q = bool(self.attn_log2 and pb.lib.pp_attention_log2_ok(hw, hw, d))
                 pb.plan.add("tfront", pb.lib.pp_tfront, x.ptr, Cc, acc, P[f"{pre}.norm.weight"], P[f"{pre}.norm.bias"], 1e-6,
                             self.groups, P[f"{pre}.proj_in.weight"], P[f"{pre}.proj_in.bias"],
                             P[f"{tb}.attn1.qkv.weight_kp"], P[f"{tb}.attn1.qkv.colsum"], P[f"{tb}.attn1.qkv.bias"], 1e-5, hs, Cc,
-                            qk, 2 * Cc, vt, hw, rows, Cc, hw, pb.dt)
+                            qk, 2 * Cc, vt, hw, rows, Cc, hw, (float(d) ** -0.5) * 1.4426950408889634 if log2q else 1.0, pb.dt)
                 pb.plan.count("tfront", 2.0 * rows * Cc * Cc + 2.0 * rows * 3 * Cc * Cc)     # (proj_in + QKV)
-                front = pb.attention(qk, 2 * Cc, qk + 2 * Cc, 2 * Cc, vt, hw, x.B, self.heads, hw, hw, d)
+                front = pb.attention(qk, 2 * Cc, qk + 2 * Cc, 2 * Cc, vt, hw, x.B, self.heads, hw, hw, d, log2q=log2q)
         if front is not None:
             a = front
         else:

@@ -375,9 +375,10 @@ def linear_skinny(x: torch.Tensor, w: torch.Tensor, bias=None, act_in: int = 0, 
 
 
 def tfront(x: torch.Tensor, acc: torch.Tensor, gamma, beta, w1: torch.Tensor, b1, w2p: torch.Tensor, cs2, b2, rows_per_batch: int,
-           gn_eps: float = 1e-6, ln_eps: float = 1e-5, groups: int = 32):
+           gn_eps: float = 1e-6, ln_eps: float = 1e-5, groups: int = 32, q_scale: float = 1.0):
     """pp_tfront: hs = proj_in(GroupNorm(x)); q | k | v = QKV(LayerNorm1(hs)), V transposed.  x [M, 320] raw rows, acc the
-    int64 GroupNorm accumulators of x, w2p the gamma-folded QKV weight with engine._kperm applied.  -> (hs, qk [M, 640], vt)."""
+    int64 GroupNorm accumulators of x, w2p the gamma-folded QKV weight with engine._kperm applied.  -> (hs, qk [M, 640], vt).
+    q_scale multiplies the Q third before its rounding (head_dim^-0.5 * log2 e for L.PP_ATTN_PIPE_LOG2)."""
     M, c = x.shape
     nb = M // rows_per_batch
     hs = torch.empty(M, c, dtype=x.dtype, device=x.device)
@@ -385,5 +386,5 @@ def tfront(x: torch.Tensor, acc: torch.Tensor, gamma, beta, w1: torch.Tensor, b1
     vt = torch.empty(nb, c, rows_per_batch, dtype=x.dtype, device=x.device)
     L.check(L.lib().pp_tfront(_p(x), x.stride(0), _p(acc), _p(gamma), _p(beta), gn_eps, groups, _p(w1), _p(b1), _p(w2p), _p(cs2),
                               _p(b2), ln_eps, _p(hs), c, _p(qk), 2 * c, _p(vt), rows_per_batch, M, c, rows_per_batch,
-                              L.dtype_code(x.dtype), _s()), "pp_tfront")
+                              float(q_scale), L.dtype_code(x.dtype), _s()), "pp_tfront")
     return hs, qk, vt

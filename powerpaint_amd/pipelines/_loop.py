@@ -14,7 +14,8 @@ pipeline_PowerPaint_Brushnet_CA.py:1384-1466, pipeline_PowerPaint_ControlNet.py:
     eps          <- UNet(x_in, t, ctx, residuals)
     latents      <- scheduler.step(eps_u + g (eps_c - eps_u), t, latents)   (pp_cfg_sched_step, fp32)
     [latents     <- (1 - m) add_noise(x0, noise, t_next) + m latents]       (pp_latent_blend; ppt-v1 with a 4-channel UNet)
-    step         <- step + 1                                          (pp_step_advance)
+    step         <- step + 1                                          (pp_step_advance; round 5: by the last block of
+                                                                       pp_cfg_sched_step when nothing behind it reads the counter)
 No host->device traffic and no host synchronisation inside the loop.
 
 A scheduler that is not one of powerpaint_amd.schedulers (any object with the diffusers protocol the reference
@@ -22,6 +23,7 @@ duck-types: `.timesteps`, `.scale_model_input`, `.step(...)`, e.g. the UniPC sch
 the way the reference drives it: the network part of the step is the same captured launch program, the guidance
 combine and the scheduler's own `.step` run as that object's tensor code on the device, once per step.
 """
+import os
 from typing import Callable, List, Optional
 
 import torch
@@ -33,7 +35,6 @@ from ..schedulers import _SchedulerBase, variance_noise
 
 def _temb_table_enabled() -> bool:
     """(lab) PP_LAB=1 PP_TEMB_TABLE=0: every step runs the time-embedding chain again."""
-    import os
     return not (os.environ.get("PP_LAB") == "1" and os.environ.get("PP_TEMB_TABLE", "1") == "0")
 
 
@@ -204,10 +205,16 @@ class DenoiseLoop:
             skip |= head_skip.get(id(r), set())
             prog.calls += [c for i, c in enumerate(r.step_plan.calls) if i not in skip]
             prog.flops += r.step_plan.flops
+        # (round 5) where pp_cfg_sched_step is the step's last reader of the counter, its last block moves the counter on:
+        # no pp_step_advance launch behind it
+        fold_advance = (not self.foreign) and not (self._eta > 0) and self._blend is None and \
+            not (os.environ.get("PP_LAB") == "1" and os.environ.get("PP_FOLD_ADVANCE", "1") == "0")     # (lab: the two launches)
         if not self.foreign:
+            if fold_advance and (getattr(self, "_ticket", None) is None or self._ticket.device != lat.device):
+                self._ticket = torch.zeros(1, dtype=torch.int32, device=lat.device)
             prog.add("cfg_sched_step", lib.pp_cfg_sched_step, rt.outputs["eps"], int(do_cfg), float(guidance_scale),
                      lat.data_ptr(), mp.data_ptr() if mp is not None else None, lat.numel(), sch.kind,
-                     sch.coef_table().data_ptr(), step.data_ptr())
+                     sch.coef_table().data_ptr(), step.data_ptr(), self._ticket.data_ptr() if fold_advance else None)
             if self._eta > 0:
                 if getattr(self, "_var_noise", None) is None or tuple(self._var_noise.shape) != tuple(latents_shape):
                     self._var_noise = torch.zeros(latents_shape, dtype=torch.float32, device=dev)
@@ -217,7 +224,8 @@ class DenoiseLoop:
                 x0, mk, nz = self._blend
                 prog.add("latent_blend", lib.pp_latent_blend, lat.data_ptr(), x0.data_ptr(), mk.data_ptr(), nz.data_ptr(),
                          sch.renoise_table().data_ptr(), step.data_ptr(), B, Cl, hw)
-        prog.add("step_advance", lib.pp_step_advance, step.data_ptr())
+        if not fold_advance:
+            prog.add("step_advance", lib.pp_step_advance, step.data_ptr())
         self.program = prog
         self.rt, self.side_rt = rt, side_rt
         self.graph = None

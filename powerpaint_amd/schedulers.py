@@ -190,7 +190,7 @@ class _SchedulerBase:
         step = torch.full((1,), i, dtype=torch.int32, device=x.device)
         mp = self.m_prev(x) if self.kind >= 1 else None
         L.check(L.lib().pp_cfg_sched_step(e.data_ptr(), 0, 0.0, x.data_ptr(), mp.data_ptr() if mp is not None else None,
-                                           x.numel(), self.kind, self._coef_dev.data_ptr(), step.data_ptr(),
+                                           x.numel(), self.kind, self._coef_dev.data_ptr(), step.data_ptr(), None,
                                            torch.cuda.current_stream().cuda_stream), "pp_cfg_sched_step")
         if self.kind == 0 and self.eta > 0:
             z = variance_noise(model_output.shape, generator, x.device, model_output.dtype)

@@ -93,6 +93,8 @@ def sdpa_fp32_chunked(q, k, v, B, Hh, nq, nk, d):
     (torch.bfloat16, 2, 4096, L.PP_ATTN_PIPE_Q32, "attn_pipe_kernel<40, QB=1> bf16 N=4096 B=2"),
     (torch.bfloat16, 2, 4096, L.PP_ATTN_PHASED, "attn_fwd_kernel<40> bf16 N=4096 B=2"),
     (torch.bfloat16, 8, 4096, L.PP_ATTN_AUTO, "AUTO (what the pipelines run) bf16 N=4096 B=8"),
+    (torch.bfloat16, 8, 4096, L.PP_ATTN_PIPE_LOG2, "attn_pipe_kernel<40, QB=2, LOG2> bf16 N=4096 B=8 (config 2-4 behind pp_tfront, as benchmarked)"),
+    (torch.float16, 4, 16384, L.PP_ATTN_PIPE_LOG2, "attn_pipe_kernel<40, QB=2, LOG2> fp16 N=16384 B=4 (config 5 behind pp_tfront)"),
 ])
 def test_attention_shipping_kernels_at_benchmark_shapes(dtype, B, n, variant, name):
     Hh, d = 8, 40
@@ -102,7 +104,12 @@ def test_attention_shipping_kernels_at_benchmark_shapes(dtype, B, n, variant, na
     k = torch.randn(B * n, C, generator=g).to(DEV, dtype)
     v = torch.randn(B * n, C, generator=g).to(DEV, dtype)
     vt = ops.transpose_v(v, B, n)
-    out = ops.attention(q, k, vt, B, Hh, n, n, d, variant=variant)
+    if variant == L.PP_ATTN_PIPE_LOG2:     # the producer hands over Q * d^-0.5 * log2(e), rounded once; the reference sees that q
+        q = (q.float() * (d ** -0.5 * 1.4426950408889634)).to(dtype)
+        out = ops.attention(q, k, vt, B, Hh, n, n, d, variant=variant)
+        q = (q.float() * (d ** 0.5 / 1.4426950408889634))       # fp32: exact up to 1 ulp of fp32
+    else:
+        out = ops.attention(q, k, vt, B, Hh, n, n, d, variant=variant)
     ref = sdpa_fp32_chunked(q, k, v, B, Hh, n, n, d)
     err = (out.float() - ref).abs().max().item()
     cos = F.cosine_similarity(out.float().flatten(), ref.flatten(), dim=0).item()

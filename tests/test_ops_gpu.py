@@ -365,6 +365,78 @@ def test_attention_strided_qkv_and_spike():
     check(out, ref, 2e-2, 2e-2, "attention strided+spike")
 
 
+LOG2E = 1.4426950408889634
+
+
+def _log2_ref(qs, k, v, B, Hh, nq, nk, d):
+    """softmax over exp2(q' . k) in fp32: what PP_ATTN_PIPE_LOG2 computes from a pre-multiplied q'."""
+    qh = qs.float().view(B, nq, Hh, d).transpose(1, 2)
+    kh = k.float().view(B, nk, Hh, d).transpose(1, 2)
+    vh = v.float().view(B, nk, Hh, d).transpose(1, 2)
+    s = torch.matmul(qh, kh.transpose(2, 3)) * math.log(2.0)
+    return torch.matmul(torch.softmax(s, dim=-1), vh).transpose(1, 2).reshape(B * nq, Hh * d)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,nq,nk", [(2, 256, 256),       # 32-queries-per-wave kernel, the minimum of four 64-key tiles
+                                     (1, 200, 320),       # ragged last query block, odd tile count
+                                     (2, 1024, 1024),
+                                     (8, 2048, 1024),     # 64-queries-per-wave kernel (batch * heads * ceil(nq / 256) >= 512)
+                                     (4, 4096, 4096)])    # the twin-prefix launch of the headline step
+def test_attention_log2_form(B, nq, nk, dtype):
+    """PP_ATTN_PIPE_LOG2 (round 5): q arrives as Q * d^-0.5 * log2(e), the running reference enters the QK^T MFMA as its
+    initial accumulator.  Against fp32 torch on the same 16-bit operands, and against the plain kernel on the unscaled Q
+    (the two differ by Q's second rounding here; in the product pp_tfront rounds Q once, after the multiplication)."""
+    Hh, d = 8, 40
+    C = Hh * d
+    q, k, v = rnd(B * nq, C, seed=1), rnd(B * nk, C, seed=2).to(dtype), rnd(B * nk, C, seed=3).to(dtype)
+    qs = (q * (d ** -0.5 * LOG2E)).to(dtype)
+    vt = ops.transpose_v(v, B, nk)
+    assert L.lib().pp_attention_log2_ok(nq, nk, d) == 1
+    out = ops.attention(qs, k, vt, B, Hh, nq, nk, d, variant=L.PP_ATTN_PIPE_LOG2)
+    check(out, _log2_ref(qs, k, v, B, Hh, nq, nk, d), 2e-2 if dtype == torch.bfloat16 else 3e-3, 2e-2, "attention LOG2 vs fp32")
+    plain = ops.attention(q.to(dtype), k, vt, B, Hh, nq, nk, d)
+    check(out, plain, 3e-2 if dtype == torch.bfloat16 else 6e-3, 2e-2, "attention LOG2 vs the plain kernel")
+
+
+@pytest.mark.parametrize("B", [1, 8])
+@pytest.mark.parametrize("case", ["spike", "cold_start", "ramp"])
+def test_attention_log2_reference_updates(case, B):
+    """The rare paths of the LOG2 form: a late dominant key (the reference jumps, scores already baked with the old one are
+    fixed up), a first tile far BELOW zero for every query (the first tile always replaces the initial reference 0), and
+    scores that climb through every tile (an update every few stages)."""
+    Hh, d, n = 8, 40, 1024
+    C = Hh * d
+    q, k, v = rnd(B * n, C, seed=1), rnd(B * n, C, seed=2), rnd(B * n, C, seed=3)
+    if case == "spike":
+        k[300, :d] = 30.0
+        q[5, :d] = 4.0
+        k[n - 1, d:2 * d] = -25.0
+        q[n - 7, d:2 * d] = -5.0
+    elif case == "cold_start":            # every score of head 0 strongly negative, those of the first tile most of all
+        q[:, :d] = q[:, :d].abs() + 1.0
+        k[:, :d] = -(k[:, :d].abs() + 1.0)
+        k[:64, :d] *= 6.0
+    else:                                  # key t scores ~ t / 16 for every query of head 1
+        q[:, d:2 * d] = 1.0
+        k[:, d:2 * d] = (torch.arange(B * n, device=DEV) % n)[:, None].float() / 16.0 / d * (d ** 0.5) / LOG2E
+    qs = (q * (d ** -0.5 * LOG2E)).to(torch.bfloat16)
+    k, v = bf(k), bf(v)
+    vt = ops.transpose_v(v, B, n)
+    out = ops.attention(qs, k, vt, B, Hh, n, n, d, variant=L.PP_ATTN_PIPE_LOG2)
+    check(out, _log2_ref(qs, k, v, B, Hh, n, n, d), 2e-2, 2e-2, f"attention LOG2 {case}")
+
+
+def test_attention_log2_refuses_what_it_does_not_cover():
+    B, Hh, n = 1, 8, 256
+    for d, nk in ((80, 256), (40, 192), (40, 128)):
+        assert L.lib().pp_attention_log2_ok(n, nk, d) == 0
+        q = torch.zeros(B * n, Hh * d, dtype=torch.bfloat16, device=DEV)
+        kk = torch.zeros(B * nk, Hh * d, dtype=torch.bfloat16, device=DEV)
+        with pytest.raises(L.PPError, match="UNSUPPORTED"):
+            ops.attention(q, kk, ops.transpose_v(kk, B, nk), B, Hh, n, nk, d, variant=L.PP_ATTN_PIPE_LOG2)
+
+
 def test_transpose_v():
     B, nk, cols = 2, 77, 320
     v = bf(rnd(B * nk, cols, seed=1))
@@ -464,12 +536,17 @@ def test_scheduler_step_kernel(kind, N):
     mp = torch.zeros_like(x)
     lib = L.lib()
     sch.reset()
+    ticket = torch.zeros(1, dtype=torch.int32, device=DEV)
     for i in range(N):
         e = eps[i].to(DEV)
+        # even steps: the counter moves on inside the launch (advance_ticket, ABI v20); odd steps: pp_step_advance behind it
         L.check(lib.pp_cfg_sched_step(e.data_ptr(), 1, gs, x.data_ptr(), mp.data_ptr(), x.numel(), sch.kind,
                                       sch.coef_table().data_ptr(), sch.step_counter().data_ptr(),
+                                      ticket.data_ptr() if i % 2 == 0 else None,
                                       torch.cuda.current_stream().cuda_stream), "step")
-        L.check(lib.pp_step_advance(sch.step_counter().data_ptr(), torch.cuda.current_stream().cuda_stream), "adv")
+        if i % 2:
+            L.check(lib.pp_step_advance(sch.step_counter().data_ptr(), torch.cuda.current_stream().cuda_stream), "adv")
+        assert int(sch.step_counter()) == i + 1 and int(ticket) == 0
     comb = [(e[:2] + gs * (e[2:] - e[:2])).double().numpy() for e in eps]
     if kind == "ddim":
         ref = x0.double().numpy()
@@ -737,6 +814,12 @@ def test_transformer_front_end_in_one_launch(B, hw, dtype):
     qkvt = F.layer_norm(hs.float(), (C,), g1, be1, 1e-5) @ wqkv.t()        # (from the kernel's own 16-bit hs: isolates GEMM 2)
     check(qk, qkvt[:, :2 * C], 1.5e-2 * tol, 6e-3 * tol, "Q | K vs fp32")
     check(vt, qkvt[:, 2 * C:].reshape(B, hw, C).permute(0, 2, 1), 1.5e-2 * tol, 6e-3 * tol, "V^T vs fp32")
+    # (c) q_scale (ABI v20): only the Q third changes -- multiplied in fp32 before its one rounding
+    qs = 40 ** -0.5 * LOG2E
+    hs2, qk2, vt2 = ops.tfront(x, acc, gg, gb, w1, b1, _kperm(wf).contiguous(), cs, tb, hw, q_scale=qs)
+    assert torch.equal(hs2, hs) and torch.equal(vt2, vt) and torch.equal(qk2[:, C:], qk[:, C:])
+    check(qk2[:, :C], qkvt[:, :C] * qs, 1.5e-2 * tol * qs, 6e-3 * tol, "pre-multiplied Q vs fp32")
+    check(qk2[:, :C], qk[:, :C].float() * qs, 2 * ulp, 2 * ulp, "pre-multiplied Q vs the rounded plain Q")
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
