@@ -371,7 +371,8 @@ def roofline_report(pipe, dump_launches=None, peak=MFMA_PEAK_TFLOPS, profile_mat
         if name in ("linear", "conv1x1") and isinstance(a, L.PPGemmArgs):
             # algorithmic bytes: X once, W once, output once, residual operands once (16-bit), row moments ignored
             out_cols = a.N
-            lin_bytes += 2.0 * a.M * a.K + 2.0 * a.N * a.K + 2.0 * a.M * out_cols
+            nw = a.M // a.rows_per_batch if a.w_batch_stride > 0 else 1      # (one weight matrix per batch item)
+            lin_bytes += 2.0 * a.M * a.K + 2.0 * a.N * a.K * nw + 2.0 * a.M * out_cols
             lin_bytes += (2.0 * a.M * a.N if a.res1 else 0.0) + (2.0 * a.M * a.N if a.res2 else 0.0)
             lin_n += 1
     for fam, names, nbytes in (("linear + conv1x1 (plain GEMMs)", ("linear", "conv1x1"), lin_bytes),

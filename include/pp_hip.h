@@ -72,6 +72,12 @@ const char* pp_last_error(void);
 #define PP_ACT_NONE 0
 #define PP_ACT_GEGLU 1
 #define PP_ACT_SILU 2
+/* (ABI v20) softmax over every group of 80 consecutive output columns, in the exp2 domain (the weights carry log2 e); a
+ * -inf bias entry masks its column.  16-bit output [M][N], N % 80 == 0.  With the folded LayerNorm on the input side and
+ * per-item weights (w_batch_stride / vec_batch_stride) this is the FIRST of the two GEMMs the cross-attention sub-block
+ * becomes once K and V are folded into its projections (pp_xattn_fold): probabilities = softmax_h(LN2(h) G_h); the second,
+ * plain GEMM multiplies them with H = V Wo^T.  No residuals / row vector / statistics / split-K on this launch. */
+#define PP_ACT_SOFTMAX80 3
 
 typedef struct PPGemmArgs {
   int32_t M, N, K;
@@ -126,7 +132,10 @@ typedef struct PPGemmArgs {
   int32_t ln_tiles;
   int32_t ln_dim;
   float ln_eps;
-  int32_t reserved_w;   /* 0 (was w_batch_stride, ABI v12-v14: a rejected experiment) */
+  /* (ABI v20; the slot of ABI v12-v14's experiment of the same name) > 0: PP_X_PLAIN only -- batch item b = m / rows_per_batch
+   * multiplies with the [N][K] matrix at w + b * w_batch_stride elements (rows_per_batch % 64 == 0: 64-row tiles inside
+   * one item).  The encoder hidden states are step-invariant, so pp_xattn_fold leaves one G^T / H^T per prompt. */
+  int32_t w_batch_stride;
   /* GroupNorm statistics of the OUTPUT, accumulated by the epilogue (the stats launch of the consuming GroupNorm
    * disappears).  Up to two consumers per tensor (a UNet skip tensor feeds the next layer's norm and, concatenated,
    * an up-block norm):  gn_acc[k] -> int64 [batch][gn_groups[k]][2] = (sum, sum of squares) of the stored bf16 values
@@ -184,6 +193,8 @@ typedef struct PPGemmArgs {
   int32_t gn_next_silu;
   int32_t gn_next_sub;
   int32_t gn_dup_mask;   /* see gn_dup_batch */
+  /* (ABI v20) with w_batch_stride and act = PP_ACT_SOFTMAX80: bias and ln_colsum advance by this many floats per batch item */
+  int32_t vec_batch_stride;
 } PPGemmArgs;
 #define PP_GN_SUM_SCALE 16777216.0f /* 2^24 */
 #define PP_GN_SQ_SCALE 1048576.0f   /* 2^20 */
@@ -405,7 +416,13 @@ int pp_tfront(const void* x, int ldx, const void* gn_acc, const float* gn_gamma,
  * first place the prompt enters, unet_2d_condition.py:1183-1236), so everything in front of it ran on one half; the folded
  * operands (gt, gcs, gbias, ht) are per batch item of the FULL batch.  C = 320 only (PP_ERR_UNSUPPORTED otherwise).
  * pp_xattn_block_supported() = 1 when the shape is one this kernel takes (the caller keeps the three-launch chain
- * otherwise); both entry points return PP_ERR_UNSUPPORTED for other shapes. */
+ * otherwise); both entry points return PP_ERR_UNSUPPORTED for other shapes.
+ * (ABI v20) pp_xattn_fold(kperm = 2) stores ht with its contraction index in NATURAL order (column h * 80 + key): the
+ * operands of the two-GEMM form of the same sub-block, where the row-local kernels lose (C = 1280: M <= 2048 rows) --
+ *     P   = pp_gemm_bf16(x, w = gt, w_batch_stride = 640 c, bias = gbias, ln_colsum = gcs, vec_batch_stride = 640,
+ *                        ln_stats, act = PP_ACT_SOFTMAX80)                          [M][640] probabilities
+ *     out = pp_gemm_bf16(P, w = ht, w_batch_stride = 640 c, bias = bias_o, res1 = h, row_stats_out)
+ * with half the multiplications of the chain at C = 1280 (2 x 640 c per row instead of 2 c^2 + 4 * 77 c). */
 int pp_xattn_block_supported(int M, int c, int rows_per_batch, int nctx, int heads);
 int pp_xattn_fold(const void* k, int ldk, const void* vt, int ldvt, int batch, int nctx, int heads, int c, const void* wq,
                   const float* q_colsum, const float* q_bias, const void* wo, float scale, void* gt, float* gcs,

@@ -12,7 +12,7 @@ if os.environ.get("PP_LAB") == "1" and os.environ.get("PP_LIB"):      # lab: A/B
     LIB_PATH = os.path.abspath(os.environ["PP_LIB"])
 
 PP_X_PLAIN, PP_X_CONV3X3 = 0, 1
-PP_ACT_NONE, PP_ACT_GEGLU, PP_ACT_SILU = 0, 1, 2
+PP_ACT_NONE, PP_ACT_GEGLU, PP_ACT_SILU, PP_ACT_SOFTMAX80 = 0, 1, 2, 3
 PP_TILE_AUTO, PP_TILE_128x160, PP_TILE_64x160, PP_TILE_256x160 = 0, 1, 2, 3
 PP_DT_F32, PP_DT_BF16, PP_DT_F16 = 0, 1, 2      # dtype codes of the C ABI (include/pp_hip.h)
 PP_ATTN_AUTO, PP_ATTN_PHASED, PP_ATTN_PIPE_Q32, PP_ATTN_PIPE_Q64, PP_ATTN_PIPE_LOG2 = 0, 1, 2, 3, 4   # pp_attention_fwd_variant
@@ -39,13 +39,13 @@ class PPGemmArgs(C.Structure):
         ("workspace", vp),
         ("dbg", i32), ("dtype", i32), ("out_dup_rows", i32), ("res1_wrap_rows", i32),
         ("row_stats_out", vp), ("ln_stats", vp), ("ln_colsum", vp),
-        ("ln_tiles", i32), ("ln_dim", i32), ("ln_eps", f32), ("reserved_w", i32),
+        ("ln_tiles", i32), ("ln_dim", i32), ("ln_eps", f32), ("w_batch_stride", i32),
         ("gn_acc", vp * 2), ("gn_cg", i32 * 2), ("gn_c0", i32 * 2), ("gn_groups", i32 * 2),
         ("x3", vp), ("x4", vp), ("c3", i32), ("c4", i32),
         ("gn_in_acc", vp), ("gn_in_gb", vp), ("gn_in_groups", i32), ("gn_in_silu", i32), ("gn_in_eps", f32),
         ("gn_dup_batch", i32),
         ("gn_next_out", vp), ("gn_next_gamma", vp), ("gn_next_beta", vp), ("gn_next_eps", f32), ("gn_next_silu", i32),
-        ("gn_next_sub", i32), ("gn_dup_mask", i32),
+        ("gn_next_sub", i32), ("gn_dup_mask", i32), ("vec_batch_stride", i32),
     ]
 
 

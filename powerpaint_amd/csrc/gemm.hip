@@ -359,7 +359,7 @@ pp_gemm_kernel_v2(const PPGemmArgs a, const GemmDerived d) {   // 2nd bound = wa
   // four only for the 8-wave 128x160x2 tile (two co-resident workgroups = 16 waves per CU); the 4-wave 64x160 and
   // 128x160 tiles are limited to two workgroups per CU by their LDS, i.e. two waves per SIMD whatever the registers
   typedef typename E16<EDT>::v8 v8_t;
-  constexpr bool LNF = EPI == 1 || EPI == 2;
+  constexpr bool LNF = EPI == 1 || EPI == 2 || EPI == 5;   // (5: softmax over 80-column groups, PP_ACT_SOFTMAX80)
   constexpr bool GNS = EPI == 4;
   constexpr int T = WM * WN * 64;
   constexpr int MI = BM / WM / 16;
@@ -435,7 +435,10 @@ pp_gemm_kernel_v2(const PPGemmArgs a, const GemmDerived d) {   // 2nd bound = wa
                            : (XMODE == PP_X_PLAIN ? (uint32_t)a.M * (uint32_t)a.ldx2 * 2u
                                                   : (uint32_t)a.batch * (uint32_t)a.hin * (uint32_t)a.win * (uint32_t)a.c2 * 2u);
   const uint32_t wbytes = (uint32_t)a.N * (uint32_t)a.K * 2u;
-  const void* const w_base = a.w;
+  // (ABI v20) one weight matrix per batch item (the cross-attention operands folded per prompt): a tile lies inside ONE
+  // item (host-checked: rows_per_batch % BM == 0)
+  const int bitem = a.w_batch_stride > 0 ? m_blk / a.rows_per_batch : 0;
+  const void* const w_base = reinterpret_cast<const uint16_t*>(a.w) + (size_t)bitem * (size_t)a.w_batch_stride;
 
   // ---- per-lane offsets.  PLAIN: vx1/vx2 = byte offset of (row m, k-slot) in source 1 / 2 (OOB if m >= M), fixed.
   //      CONV : pixel coordinates kept in (xa, xb, xc); vx1 recomputed when the (tap, source) pair changes.
@@ -584,13 +587,14 @@ pp_gemm_kernel_v2(const PPGemmArgs a, const GemmDerived d) {   // 2nd bound = wa
   const bool ln = LNF && a.ln_stats != nullptr;
   const bool ln_lds = ln && a.ln_tiles <= LN_TMAX;
   if (LNF) {   // older than every tile load -> covered by the counted vmcnt waits below
+    const size_t voff = (size_t)bitem * (size_t)a.vec_batch_stride;     // (per-item bias / column sums: PP_ACT_SOFTMAX80)
     if (wave == 0) {
-      const __amdgpu_buffer_rsrc_t rb = make_rsrc(a.bias ? (const void*)a.bias : (const void*)a.w, a.bias ? (uint32_t)a.N * 4u : 0u);
+      const __amdgpu_buffer_rsrc_t rb = make_rsrc(a.bias ? (const void*)(a.bias + voff) : (const void*)a.w, a.bias ? (uint32_t)a.N * 4u : 0u);
       const int vo = n_blk * 4 + lane * 16;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr_t)(smem + PRE_B), 16, vo, 0, 0, 0);
     }
     if (wave == 1) {
-      const __amdgpu_buffer_rsrc_t rc = make_rsrc(ln ? (const void*)a.ln_colsum : (const void*)a.w, ln ? (uint32_t)a.N * 4u : 0u);
+      const __amdgpu_buffer_rsrc_t rc = make_rsrc(ln ? (const void*)(a.ln_colsum + voff) : (const void*)a.w, ln ? (uint32_t)a.N * 4u : 0u);
       const int vo = n_blk * 4 + lane * 16;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rc, (lds_ptr_t)(smem + PRE_C), 16, vo, 0, 0, 0);
     }
@@ -930,6 +934,71 @@ pp_gemm_kernel_v2(const PPGemmArgs a, const GemmDerived d) {   // 2nd bound = wa
       if (m < a.M && n < a.N)
         *reinterpret_cast<u32x4_t*>((uint16_t*)a.out + (size_t)m * a.ldo + (n >> 1)) =
             *reinterpret_cast<const u32x4_t*>(smem + row * GLD + c * 16);
+    }
+    return;
+  } else if constexpr (EPI == 5) {
+    // PP_ACT_SOFTMAX80: out[m][80 g .. 80 g + 79] = softmax over the group's 80 logits in the exp2 domain (the caller's
+    // weights carry log2 e; -inf bias entries mask padding columns).  The fp32 tile (bias / folded-LayerNorm correction
+    // applied in the accumulator layout) is staged once; one thread per (row, group) then runs the three passes.
+    static_assert(BN % 80 == 0, "whole groups per tile");
+    constexpr int SLN = BM * EPI_LD;                   // (mean, rstd) table behind the staged tile
+    static_assert(SLN + BM * 8 <= NS * STAGE, "softmax staging must fit in the pipeline stages");
+    asm volatile("s_barrier" ::: "memory");            // main loop done with LDS
+    if (ln) {
+      if (tid < BM) *reinterpret_cast<f32x2_t*>(smem + SLN + tid * 8) = ln_mr;
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    const int q4 = 4 * (lane >> 4);
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int nl = wn * (NI * 16) + ni * 16 + q4;
+      const f32x4_t bs = *reinterpret_cast<const f32x4_t*>(smem + PRE_B + nl * 4);   // (prefetched; zero where absent / n >= N)
+      const f32x4_t cs = *reinterpret_cast<const f32x4_t*>(smem + PRE_C + nl * 4);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        const int row = wm * (MI * 16) + mi * 16 + (lane & 15);
+        f32x4_t v = acc[ni][mi];
+        if (ln) {
+          const f32x2_t mr = *reinterpret_cast<const f32x2_t*>(smem + SLN + row * 8);
+          v = (v - cs * mr[0]) * mr[1];
+        }
+        v += bs;
+        *reinterpret_cast<f32x4_t*>(smem + row * EPI_LD + nl * 4) = v;
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    constexpr int G = BN / 80;
+    for (int q = tid; q < BM * G; q += T) {
+      const int row = q % BM, gi = q / BM;
+      const int m = m_blk + row, n0 = n_blk + gi * 80;
+      if (m >= a.M || n0 >= a.N) continue;
+      const char* src = smem + row * EPI_LD + gi * 320;
+      float mx = -INFINITY;
+#pragma unroll 5
+      for (int j = 0; j < 20; ++j) {
+        const f32x4_t v = *reinterpret_cast<const f32x4_t*>(src + j * 16);
+        mx = fmaxf(fmaxf(fmaxf(mx, v[0]), fmaxf(v[1], v[2])), v[3]);
+      }
+      if (mx == -INFINITY) mx = 0.f;                   // (a fully masked group stays all zero instead of NaN)
+      float sum = 0.f;
+#pragma unroll 5
+      for (int j = 0; j < 20; ++j) {
+        const f32x4_t v = *reinterpret_cast<const f32x4_t*>(src + j * 16);
+        sum += (__builtin_amdgcn_exp2f(v[0] - mx) + __builtin_amdgcn_exp2f(v[1] - mx)) +
+               (__builtin_amdgcn_exp2f(v[2] - mx) + __builtin_amdgcn_exp2f(v[3] - mx));
+      }
+      const float inv = sum > 0.f ? 1.0f / sum : 0.f;
+      uint16_t* dst = (uint16_t*)a.out + (size_t)m * a.ldo + n0;
+#pragma unroll 2
+      for (int j = 0; j < 10; ++j) {
+        const f32x4_t v0 = *reinterpret_cast<const f32x4_t*>(src + j * 32), v1 = *reinterpret_cast<const f32x4_t*>(src + j * 32 + 16);
+        u32x4_t o;
+        o[0] = E16<EDT>::pack2(__builtin_amdgcn_exp2f(v0[0] - mx) * inv, __builtin_amdgcn_exp2f(v0[1] - mx) * inv);
+        o[1] = E16<EDT>::pack2(__builtin_amdgcn_exp2f(v0[2] - mx) * inv, __builtin_amdgcn_exp2f(v0[3] - mx) * inv);
+        o[2] = E16<EDT>::pack2(__builtin_amdgcn_exp2f(v1[0] - mx) * inv, __builtin_amdgcn_exp2f(v1[1] - mx) * inv);
+        o[3] = E16<EDT>::pack2(__builtin_amdgcn_exp2f(v1[2] - mx) * inv, __builtin_amdgcn_exp2f(v1[3] - mx) * inv);
+        *reinterpret_cast<u32x4_t*>(dst + j * 8) = o;
+      }
     }
     return;
   } else {
@@ -1433,6 +1502,8 @@ Choice choose(const PPGemmArgs& a) {
   //   ~ 1 block per CU               : 128x160 x 3 stages, split-K 2 only for very long conv K;
   //   less                           : 64x160 x 3 stages when that fills the chip, else split-K over 256-row tiles.
   // Tensors the 16-byte staged epilogue cannot address fall back to the register-staged v1 kernel.
+  // per-item weight matrices / the group softmax: 64-row tiles (a tile inside one batch item down to the 8x8 level), one pass
+  if (a.w_batch_stride > 0 || a.act == PP_ACT_SOFTMAX80) return Choice{32, 1};
   Choice c{a.tile, a.splitk};
   const int tn = (a.N + 159) / 160;
   auto blocks = [&](int bm) { return ((a.M + bm - 1) / bm) * tn; };
@@ -1571,10 +1642,14 @@ int launch2(const PPGemmArgs& a, int splitk, hipStream_t st) {
     if ((a.gn_acc[0] || a.gn_acc[1]) && splitk == 1) return launch2<BM, BN, WM, WN, XMODE, NS, 4, PP, EDT>(a, splitk, st);
   }
   if constexpr (XMODE == PP_X_PLAIN && EPI == 0) {
+    if (a.act == PP_ACT_SOFTMAX80) {                   // (one instantiation: the 64 x 160 x 3-stage tile choose() sends it to)
+      if constexpr (BM == 64 && NS == 3 && !PP) return launch2<BM, BN, WM, WN, XMODE, NS, 5, PP, EDT>(a, splitk, st);
+      else return PP_ERR_UNSUPPORTED;
+    }
     if (a.act == PP_ACT_GEGLU && splitk == 1) return launch2<BM, BN, WM, WN, XMODE, NS, 2, PP, EDT>(a, splitk, st);
     if (a.ln_stats || a.row_stats_out) return launch2<BM, BN, WM, WN, XMODE, NS, 1, PP, EDT>(a, splitk, st);
   }
-  constexpr bool LNF = EPI == 1 || EPI == 2;
+  constexpr bool LNF = EPI == 1 || EPI == 2 || EPI == 5;
   constexpr int T = WM * WN * 64;
   // + epilogue-operand prefetch (LNF)
   constexpr int LDS = NS * (BM + BN) * 128 + (LNF ? 2048 + BM * 32 : 0);
@@ -1654,6 +1729,20 @@ int validate(const PPGemmArgs& a) {
   if ((uint64_t)a.N * (uint64_t)a.K * 2u >= 0x80000000ull) return PP_ERR_UNSUPPORTED;
   if ((a.rowvec || a.out_vt) && a.rows_per_batch <= 0) return PP_ERR_BAD_ARG;
   if (a.act == PP_ACT_GEGLU && (a.out_f32 || a.out_vt || a.x_mode != PP_X_PLAIN)) return PP_ERR_BAD_ARG;
+  // (ABI v20) per-item weights and the 80-column group softmax: the folded cross-attention as two GEMMs
+  if (a.w_batch_stride < 0 || a.vec_batch_stride < 0) return PP_ERR_BAD_ARG;
+  if (a.w_batch_stride > 0) {
+    if (a.x_mode != PP_X_PLAIN || a.rows_per_batch <= 0 || a.rows_per_batch % 64 || a.M % a.rows_per_batch || (a.w_batch_stride & 7))
+      return PP_ERR_BAD_ARG;
+    if (a.out_vt || a.out_f32 || a.act == PP_ACT_GEGLU || a.splitk > 1 || !v2_ok(a)) return PP_ERR_UNSUPPORTED;
+  }
+  if (a.vec_batch_stride > 0 && (a.act != PP_ACT_SOFTMAX80 || a.w_batch_stride <= 0 || (a.vec_batch_stride & 3))) return PP_ERR_UNSUPPORTED;
+  if (a.act == PP_ACT_SOFTMAX80) {
+    if (a.x_mode != PP_X_PLAIN || a.N % 80 || a.ldo % 8 || a.ldo < a.N) return PP_ERR_BAD_ARG;
+    if (a.out_f32 || a.out_vt || a.res1 || a.res2 || a.rowvec || a.row_stats_out || a.gn_acc[0] || a.gn_acc[1] ||
+        a.gn_next_out || a.out_dup_rows > 0 || a.splitk > 1 || a.scale != 1.0f || !v2_ok(a))
+      return PP_ERR_UNSUPPORTED;
+  }
   if (a.out_vt && a.vt_col0 % 4 != 0) return PP_ERR_BAD_ARG;
   if (a.ln_stats && (!a.ln_colsum || a.ln_tiles <= 0 || a.ln_dim <= 0)) return PP_ERR_BAD_ARG;
   if (a.row_stats_out && (a.out_f32 || a.out_vt || a.act == PP_ACT_GEGLU || !v2_ok(a))) return PP_ERR_UNSUPPORTED;

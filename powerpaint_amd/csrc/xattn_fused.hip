@@ -58,81 +58,138 @@ template <int N, class F>
 PP_DEVINL void xa_static_for(F&& f) { xa_static_for_impl(std::make_integer_sequence<int, N>{}, f); }
 
 // ---- once per prompt: G^T [B][640][C] (16-bit), logit colsum / bias [B][640] (fp32), H^T [B][C][640] (16-bit, k-permuted)
+// Round 5: three kernels.  The first form (one thread per output pair, a D-deep loop of one 4-byte weight load per two
+// FMAs) pulled every weight row through the L2 once per key -- 330 us per launch on average, 600 at C = 1280, sixteen
+// launches per pipeline call = 5 ms per call (0.1 ms per denoise step at 50 steps: what the two-GEMM form of the C = 1280
+// sub-blocks gains per step).  Now a workgroup owns one (batch item, head): the head's K (or V) tile sits in LDS as fp32
+// [D][80 keys], a thread keeps ALL 80 keys of its two channels (G^T) / its output row (H^T) in registers and reads every
+// weight exactly once -- same FMA order per output (j ascending), so the stored bits are those of the first form.
+constexpr int XF_MAXD = 160;
 template <int EDT>
-__global__ void __launch_bounds__(256) xattn_fold_kernel(const uint16_t* __restrict__ k, int ldk,
-                                                        const uint16_t* __restrict__ vt, int ldvt, int batch, int nctx,
-                                                        const uint16_t* __restrict__ wq, const float* __restrict__ qcs,
-                                                        const float* __restrict__ qb, const uint16_t* __restrict__ wo,
-                                                        float qscale, uint32_t* __restrict__ gt, float* __restrict__ gcs,
-                                                        float* __restrict__ gb, uint32_t* __restrict__ ht, int C, int kperm) {
+__global__ void __launch_bounds__(256) xattn_fold_g_kernel(const uint16_t* __restrict__ k, int ldk, int nctx,
+                                                          const uint16_t* __restrict__ wq, float qscale,
+                                                          uint32_t* __restrict__ gt, int C, int kperm) {
   using E = E16<EDT>;
-  const int D = C / XA_HEADS;
-  const long long n_g = (long long)batch * XA_S * (C / 2), n_h = (long long)batch * C * (XA_S / 2),
-                  n_v = (long long)batch * XA_S;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n_g + n_h + n_v; i += (long long)gridDim.x * 256) {
-    if (i < n_g) {                                        // G^T[b][n = h * 80 + key][c], two c per thread
-      const int c2 = (int)(i % (C / 2)), n = (int)((i / (C / 2)) % XA_S), b = (int)(i / ((long long)(C / 2) * XA_S));
-      const int h = n / XA_KP, key = n % XA_KP;
-      float s0 = 0.f, s1 = 0.f;
-      // kperm: storage position 8 kg + j of every group of 32 channels holds channel 16 (j >> 2) + 4 kg + (j & 3) (the pair
-      // (j, j + 1), j even, stays a pair of neighbours) -- the logits' B operand then comes out of the accumulators of the
-      // Linear in front (pre_w), as in tfront.hip
-      int ch = 2 * c2;
-      if (kperm) {
-        const int s32 = ch >> 5, kg = (ch >> 3) & 3, j = ch & 7;
-        ch = 32 * s32 + 16 * (j >> 2) + 4 * kg + (j & 3);
-      }
-      if (key < nctx) {
-        const uint16_t* kr = k + ((size_t)b * nctx + key) * ldk + h * D;
-        const uint16_t* wr = wq + (size_t)(h * D) * C + ch;
-        // (D = 40 / 80 / 160: whole eights -- unrolled so that eight independent loads are in flight per thread; this kernel
-        //  runs once per pipeline call and took 1.6 ms of it as a one-load-at-a-time loop)
-#pragma unroll 8
-        for (int j = 0; j < D; ++j) {
-          const float kv = E::to_f(kr[j]);
-          const uint32_t w2 = *reinterpret_cast<const uint32_t*>(wr + (size_t)j * C);
-          s0 = fmaf(kv, E::lo(w2), s0);
-          s1 = fmaf(kv, E::hi(w2), s1);
-        }
-      }
-      gt[i] = E::pack2(s0 * qscale, s1 * qscale);
-    } else if (i < n_g + n_h) {                           // H^T[b][n][storage position kp], two kp per thread
-      const long long r = i - n_g;
-      const int p2 = (int)(r % (XA_S / 2)), n = (int)((r / (XA_S / 2)) % C), b = (int)(r / ((long long)(XA_S / 2) * C));
-      float v[2];
+  __shared__ __attribute__((aligned(16))) float ks[XF_MAXD * XA_KP];          // [j][key]
+  const int D = C / XA_HEADS, h = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
+  for (int i = tid; i < XA_KP * D; i += 256) {
+    const int key = i / D, j = i - key * D;
+    ks[j * XA_KP + key] = key < nctx ? E::to_f(k[((size_t)b * nctx + key) * ldk + h * D + j]) : 0.f;
+  }
+  __syncthreads();
+  const int c2 = blockIdx.x * 256 + tid;
+  if (c2 >= C / 2) return;
+  // kperm & 1: storage position 8 kg + j of every group of 32 channels holds channel 16 (j >> 2) + 4 kg + (j & 3) (the pair
+  // (j, j + 1), j even, stays a pair of neighbours) -- the logits' B operand then comes out of the accumulators of the
+  // Linear in front (pre_w), as in tfront.hip
+  int ch = 2 * c2;
+  if (kperm & 1) {
+    const int s32 = ch >> 5, kg = (ch >> 3) & 3, j = ch & 7;
+    ch = 32 * s32 + 16 * (j >> 2) + 4 * kg + (j & 3);
+  }
+  const uint16_t* wr = wq + (size_t)(h * D) * C + ch;
+  float a0[XA_KP], a1[XA_KP];
 #pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        // storage position kp of a 32-group holds contraction index 32 s + 16 (j >> 2) + 4 kg + (j & 3), kp = 32 s + 8 kg + j:
-        // a lane's 16-byte A fragment (k-group kg) then lines up with accumulator quads of logit blocks 2s and 2s + 1
-        const int kp = 2 * p2 + e, s32 = kp >> 5, kg = (kp >> 3) & 3, j = kp & 7;
-        const int kk = 32 * s32 + 16 * (j >> 2) + 4 * kg + (j & 3);
-        const int h = kk / XA_KP, key = kk % XA_KP;
-        float s = 0.f;
-        if (key < nctx) {
-          const uint16_t* wr = wo + (size_t)n * C + h * D;
-          const uint16_t* vr = vt + ((size_t)b * C + h * D) * ldvt + key;
-#pragma unroll 8
-          for (int jj = 0; jj < D; ++jj) s = fmaf(E::to_f(wr[jj]), E::to_f(vr[(size_t)jj * ldvt]), s);
+  for (int q = 0; q < XA_KP; ++q) { a0[q] = 0.f; a1[q] = 0.f; }
+  // (D = 40 / 80 / 160: whole eights -- eight independent weight loads in flight per thread)
+#pragma unroll 1
+  for (int j0 = 0; j0 < D; j0 += 8) {
+    uint32_t w8[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) w8[u] = *reinterpret_cast<const uint32_t*>(wr + (size_t)(j0 + u) * C);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const float wl = E::lo(w8[u]), wh = E::hi(w8[u]);
+      const f32x4_t* kr = reinterpret_cast<const f32x4_t*>(ks + (j0 + u) * XA_KP);
+#pragma unroll
+      for (int q4 = 0; q4 < XA_KP / 4; ++q4) {
+        const f32x4_t kv = kr[q4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          a0[4 * q4 + e] = fmaf(kv[e], wl, a0[4 * q4 + e]);
+          a1[4 * q4 + e] = fmaf(kv[e], wh, a1[4 * q4 + e]);
         }
-        v[e] = s;
       }
-      ht[r] = E::pack2(v[0], v[1]);
-    } else {                                              // folded-LayerNorm terms of the logits; -inf masks the padded keys
-      const long long r = i - n_g - n_h;
-      const int n = (int)(r % XA_S), b = (int)(r / XA_S);
-      const int h = n / XA_KP, key = n % XA_KP;
-      float s0 = 0.f, s1 = 0.f;
-      if (key < nctx) {
-        const uint16_t* kr = k + ((size_t)b * nctx + key) * ldk + h * D;
-        if (qb)
-          for (int j = 0; j < D; ++j) s1 = fmaf(E::to_f(kr[j]), qb[h * D + j], s1);
-        // (the mean term of the folded LayerNorm -- the column sum of G^T -- is taken over the entries AS STORED, by
-        //  xattn_colsum_kernel behind this launch: ADVICE round 3)
-      }
-      if (!qcs) gcs[r] = 0.f;
-      gb[r] = key < nctx ? s1 * qscale : -INFINITY;
     }
   }
+  uint32_t* dst = gt + ((size_t)b * XA_S + h * XA_KP) * (C / 2) + c2;
+#pragma unroll
+  for (int q = 0; q < XA_KP; ++q) dst[(size_t)q * (C / 2)] = E::pack2(a0[q] * qscale, a1[q] * qscale);
+}
+
+template <int EDT>
+__global__ void __launch_bounds__(256) xattn_fold_h_kernel(const uint16_t* __restrict__ vt, int ldvt, int nctx,
+                                                          const uint16_t* __restrict__ wo, uint32_t* __restrict__ ht, int C,
+                                                          int kperm) {
+  using E = E16<EDT>;
+  __shared__ __attribute__((aligned(16))) float vs[XF_MAXD * XA_KP];          // [d][key]
+  const int D = C / XA_HEADS, h = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
+  for (int i = tid; i < XA_KP * D; i += 256) {
+    const int d = i / XA_KP, key = i - d * XA_KP;
+    vs[i] = key < nctx ? E::to_f(vt[((size_t)b * C + h * D + d) * ldvt + key]) : 0.f;
+  }
+  __syncthreads();
+  const int n = blockIdx.x * 256 + tid;
+  if (n >= C) return;
+  const uint16_t* wr = wo + (size_t)n * C + h * D;
+  float acc[XA_KP];
+#pragma unroll
+  for (int q = 0; q < XA_KP; ++q) acc[q] = 0.f;
+  // (the thread's weight row segment in 16-byte pieces: n * C + h * D is a multiple of 8 elements)
+#pragma unroll 1
+  for (int d0 = 0; d0 < D; d0 += 8) {
+    const u32x4_t w8 = *reinterpret_cast<const u32x4_t*>(wr + d0);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const float w = (u & 1) ? E::hi(w8[u >> 1]) : E::lo(w8[u >> 1]);
+      const f32x4_t* vr = reinterpret_cast<const f32x4_t*>(vs + (d0 + u) * XA_KP);
+#pragma unroll
+      for (int q4 = 0; q4 < XA_KP / 4; ++q4) {
+        const f32x4_t v = vr[q4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[4 * q4 + e] = fmaf(w, v[e], acc[4 * q4 + e]);
+      }
+    }
+  }
+  // storage position kp of a 32-group holds contraction index 32 s + 16 (j >> 2) + 4 kg + (j & 3), kp = 32 s + 8 kg + j:
+  // a lane's 16-byte A fragment (k-group kg) then lines up with accumulator quads of logit blocks 2s and 2s + 1
+  // (kperm & 2: natural order -- H^T as the weight matrix of a plain GEMM over the stored probabilities, ABI v20).
+  // Contraction indices (kk, kk + 1), kk even, are neighbours in either order: one 32-bit store per pair.
+  uint32_t* dst = ht + ((size_t)b * C + n) * (XA_S / 2);
+#pragma unroll
+  for (int q = 0; q < XA_KP; q += 2) {
+    const int kk = h * XA_KP + q;
+    int kp = kk;
+    if (!(kperm & 2)) {
+      const int r = kk & 31, j = 4 * (r >> 4) + (r & 3), kg = (r >> 2) & 3;
+      kp = (kk & ~31) + 8 * kg + j;
+    }
+    dst[kp >> 1] = E::pack2(acc[q], acc[q + 1]);
+  }
+}
+
+// folded-LayerNorm terms of the logits; -inf masks the padded keys
+template <int EDT>
+__global__ void __launch_bounds__(256) xattn_fold_vec_kernel(const uint16_t* __restrict__ k, int ldk, int batch, int nctx,
+                                                            const float* __restrict__ qcs, const float* __restrict__ qb,
+                                                            float qscale, float* __restrict__ gcs, float* __restrict__ gb,
+                                                            int C) {
+  using E = E16<EDT>;
+  const int D = C / XA_HEADS;
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= batch * XA_S) return;
+  const int n = r % XA_S, b = r / XA_S;
+  const int h = n / XA_KP, key = n % XA_KP;
+  float s1 = 0.f;
+  if (key < nctx) {
+    const uint16_t* kr = k + ((size_t)b * nctx + key) * ldk + h * D;
+    if (qb)
+      for (int j = 0; j < D; ++j) s1 = fmaf(E::to_f(kr[j]), qb[h * D + j], s1);
+    // (the mean term of the folded LayerNorm -- the column sum of G^T -- is taken over the entries AS STORED, by
+    //  xattn_colsum_kernel behind this launch: ADVICE round 3)
+  }
+  if (!qcs) gcs[r] = 0.f;
+  gb[r] = key < nctx ? s1 * qscale : -INFINITY;
 }
 
 // gcs[b][n] = sum over c of G^T[b][n][c] as stored (rounded to 16 bits): the mean term of the folded LayerNorm must cancel
@@ -657,15 +714,20 @@ extern "C" int pp_xattn_fold(const void* k, int ldk, const void* vt, int ldvt, i
   if (!k || !vt || !wq || !wo || !gt || !gcs || !gbias || !ht || batch <= 0 || !pp_dt_ok(dtype)) return PP_ERR_BAD_ARG;
   if (!pp_xattn_block_supported(XA_BM, c, XA_BM, nctx, heads)) return PP_ERR_UNSUPPORTED;
   if (ldk < c || ldvt < nctx || (c & 1)) return PP_ERR_BAD_ARG;
-  if (kperm && c != XA_C) return PP_ERR_UNSUPPORTED;      // (only the C = 320 block kernel chains a Linear in front)
-  const long long total = (long long)batch * XA_S * (c / 2) * 2 + (long long)batch * XA_S;
-  const unsigned grid = (unsigned)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+  if (kperm < 0 || kperm > 2) return PP_ERR_BAD_ARG;
+  if ((kperm & 1) && c != XA_C) return PP_ERR_UNSUPPORTED;      // (only the C = 320 block kernel chains a Linear in front)
+  if (c / XA_HEADS > XF_MAXD || (c / XA_HEADS) % 8 || nctx > XA_KP) return PP_ERR_UNSUPPORTED;
   const float qscale = scale * 1.44269504088896340736f;   // the softmax runs in the exp2 domain
-  PP_DT_SWITCH(dtype, hipLaunchKernelGGL((xattn_fold_kernel<EDT>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
-                                         (const uint16_t*)k, ldk, (const uint16_t*)vt, ldvt, batch, nctx,
-                                         (const uint16_t*)wq, q_colsum, q_bias, (const uint16_t*)wo, qscale, (uint32_t*)gt,
-                                         gcs, gbias, (uint32_t*)ht, c, kperm ? 1 : 0));
-  PP_CHECK_LAUNCH("xattn_fold_kernel");
+  hipStream_t st = (hipStream_t)stream;
+  PP_DT_SWITCH(dtype, hipLaunchKernelGGL((xattn_fold_g_kernel<EDT>), dim3((c / 2 + 255) / 256, XA_HEADS, batch), dim3(256), 0, st,
+                                         (const uint16_t*)k, ldk, nctx, (const uint16_t*)wq, qscale, (uint32_t*)gt, c, kperm));
+  PP_CHECK_LAUNCH("xattn_fold_g_kernel");
+  PP_DT_SWITCH(dtype, hipLaunchKernelGGL((xattn_fold_h_kernel<EDT>), dim3((c + 255) / 256, XA_HEADS, batch), dim3(256), 0, st,
+                                         (const uint16_t*)vt, ldvt, nctx, (const uint16_t*)wo, (uint32_t*)ht, c, kperm));
+  PP_CHECK_LAUNCH("xattn_fold_h_kernel");
+  PP_DT_SWITCH(dtype, hipLaunchKernelGGL((xattn_fold_vec_kernel<EDT>), dim3((batch * XA_S + 255) / 256), dim3(256), 0, st,
+                                         (const uint16_t*)k, ldk, batch, nctx, q_colsum, q_bias, qscale, gcs, gbias, c));
+  PP_CHECK_LAUNCH("xattn_fold_vec_kernel");
   if (q_colsum) {
     const long long rows = (long long)batch * XA_S;
     PP_DT_SWITCH(dtype, hipLaunchKernelGGL((xattn_colsum_kernel<EDT>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0,

@@ -267,10 +267,12 @@ class Builder:
                ldres2: int = 0, scale: float = 1.0, act: int = 0, out: int = 0, ldo: Optional[int] = None,
                rowvec: int = 0, ld_rowvec: int = 0, rows_per_batch: int = 0, out_vt: int = 0, vt_col0: int = 0,
                vt_ld: int = 0, out_f32: bool = False, row_stats_out: int = 0, ln_stats: int = 0, ln_colsum: int = 0,
-               ln_tiles: int = 0, ln_dim: int = 0, ln_eps: float = 1e-5, name: str = "gemm", res1_wrap: int = 0) -> int:
+               ln_tiles: int = 0, ln_dim: int = 0, ln_eps: float = 1e-5, name: str = "gemm", res1_wrap: int = 0,
+               w_batch_stride: int = 0, vec_batch_stride: int = 0) -> int:
         """out[rows][N] = epilogue(X[rows][K(+K2)] @ W[N][K+K2]^T).  Returns the output pointer.
         row_stats_out / ln_*: LayerNorm folded across two GEMMs (see include/pp_hip.h).  res1_wrap: res1 holds only that
-        many rows (one half of a CFG pair), row m adds row m mod res1_wrap."""
+        many rows (one half of a CFG pair), row m adds row m mod res1_wrap.  w_batch_stride / vec_batch_stride: one weight
+        matrix (and bias / column-sum vector) per batch item of rows_per_batch rows."""
         n_out = N // 2 if act == L.PP_ACT_GEGLU else (vt_col0 if out_vt else N)
         if ldo is None:
             ldo = n_out
@@ -282,6 +284,7 @@ class Builder:
         a.x1, a.x2, a.c1, a.c2 = x, x2 or None, K, K2
         a.ldx1, a.ldx2 = (ldx if ldx is not None else K), (ldx2 or K2)
         a.w, a.bias = w, bias or None
+        a.w_batch_stride, a.vec_batch_stride = w_batch_stride, vec_batch_stride
         a.rowvec, a.ld_rowvec, a.rows_per_batch = rowvec or None, ld_rowvec, rows_per_batch
         a.res1, a.ldres1 = res1 or None, ldres1 or N
         a.res1_wrap_rows = res1_wrap
@@ -608,6 +611,11 @@ class SDNet:
     # logits, and a 4-wave workgroup pays ~150 cycles of issue per LDS-DMA piece with no partner wave to hide it);
     # (lab) PP_XATTN_WIDE_C=1280 runs it there too
     xattn_wide_max_c = int(os.environ.get("PP_XATTN_WIDE_C", "640")) if os.environ.get("PP_LAB") == "1" else 640
+    # round 5: above that width (C = 1280: the 16x16 level and the mid block) the folded sub-block runs as TWO plain GEMMs with
+    # per-prompt weights -- logits + per-head softmax in the first one's epilogue (PP_ACT_SOFTMAX80), probabilities x H^T +
+    # residual in the second -- instead of to_q -> 77-key attention -> to_out: one launch less and half the multiplications
+    # per block.  (lab) PP_XATTN_2G=0: the three-launch chain
+    fuse_xattn_2g = _lab_switch("PP_XATTN_2G")
     # ResnetBlock2D.conv_shortcut merged into conv2 as a 1x1 K tail (needs 64-channel multiples; (lab) PP_MERGE_SHORTCUT=0 off)
     _merge_shortcut_env = _lab_switch("PP_MERGE_SHORTCUT")
 
@@ -1007,7 +1015,7 @@ class SDNet:
             pb.plan.add("transpose_v", pb.lib.pp_transpose_v, qkv + 4 * Cc, 3 * Cc, x.B, hw, Cc, vt, ldvt)
             a = pb.attention(qkv, 3 * Cc, qkv + 2 * Cc, 3 * Cc, vt, ldvt, x.B, self.heads, hw, hw, d)
         xa = getattr(self, "xa", {}).get(pre)
-        if xa is not None and len(xa) > 4 and xa[4] and fold and \
+        if xa is not None and len(xa) > 4 and xa[4] == 1 and fold and \
                 pb.lib.pp_xattn_block_supported(rows_o, Cc, hw, self._nctx, self.heads):
             # attn1.to_out + residual in front of the cross-attention sub-block, same launch (G^T was folded with kperm = 1)
             st2 = producer(rows_o)
@@ -1025,7 +1033,20 @@ class SDNet:
         # cross-attention (K / V^T hoisted out of the step: encoder_hidden_states are step-invariant)
         if xa == "done":
             pass
-        elif xa is not None and len(xa) > 4 and xa[4]:
+        elif xa is not None and len(xa) > 4 and xa[4] == 2 and hw % 64 == 0 and not twin:
+            # the folded sub-block as two GEMMs with one (G^T, H^T) per batch item (setup plan: pp_xattn_fold(kperm = 2))
+            S = self.heads * 80
+            ln, kw = normed(hs, st, "norm2", "attn2.to_q")
+            stats = dict(ln_stats=kw["ln_stats"], ln_colsum=xa[1], ln_tiles=tiles, ln_dim=Cc, ln_eps=1e-5) if fold else {}
+            prob = pb.linear(ln, rows, Cc, xa[0], S, bias=xa[2], act=L.PP_ACT_SOFTMAX80, rows_per_batch=hw,
+                             w_batch_stride=S * Cc, vec_batch_stride=S, name="linear", **stats)
+            st = producer()
+            hs = pb.linear(prob, rows, S, xa[3], Cc, P[f"{tb}.attn2.to_out.bias"], res1=hs, row_stats_out=st,
+                           rows_per_batch=hw, w_batch_stride=Cc * S, name="linear")
+        elif xa is not None and len(xa) > 4 and xa[4] == 2:
+            raise L.PPError("H^T was folded for the two-GEMM cross-attention, which this shape does not take (build_setup "
+                            "folds it only for step geometries with whole 64-row tiles per batch item)")
+        elif xa is not None and len(xa) > 4 and xa[4] == 1:
             raise L.PPError("G^T was folded for the chained cross-attention block, which this shape does not take")
         elif xa is not None and pb.lib.pp_xattn_block_supported(rows_o, Cc, hw, self._nctx, self.heads):
             ln, kw = normed(hs, st, "norm2", "attn2.to_q")
@@ -1079,6 +1100,7 @@ class SDNet:
         self._nctx = nctx
         ldvt = _align(nctx, 8)
         pre_hw: Dict[str, bool] = {}        # transformer -> the fused block kernel takes its step geometry
+        pre_hw64: Dict[str, bool] = {}      # transformer -> whole 64-row GEMM tiles per batch item (the two-GEMM form)
         if hw0 is not None:
             nl = len(self.boc)
             for pre, c in self._attn_specs():
@@ -1086,6 +1108,7 @@ class SDNet:
                 lvl = int(part[1]) if part[0] == "down_blocks" else (nl - 1 if part[0] == "mid_block" else nl - 1 - int(part[1]))
                 hw = (hw0[0] >> lvl) * (hw0[1] >> lvl)
                 pre_hw[pre] = hw > 0 and bool(pb.lib.pp_xattn_block_supported(B * hw, c, hw, nctx, self.heads))
+                pre_hw64[pre] = hw > 0 and hw % 64 == 0
         self.kv: Dict[str, Tuple[int, int, int, int]] = {}
         self.xa: Dict[str, Tuple[int, int, int, int]] = {}       # folded cross-attention operands (pp_xattn_fold)
         for pre, c in self._attn_specs():
@@ -1095,7 +1118,9 @@ class SDNet:
                           vt_col0=c, vt_ld=ldvt, rows_per_batch=nctx, name="linear")
             self.kv[pre] = (k, c, vt, ldvt)
             tbq = f"{tb}.attn2.to_q"
-            if self.fuse_xattn and (c == 320 or (self.fuse_xattn_wide and c <= self.xattn_wide_max_c)) and \
+            two_gemm = bool(self.fuse_xattn and self.fuse_xattn_2g and c > 320 and pre_hw64.get(pre) and
+                            not (self.fuse_xattn_wide and c <= self.xattn_wide_max_c))
+            if self.fuse_xattn and (c == 320 or two_gemm or (self.fuse_xattn_wide and c <= self.xattn_wide_max_c)) and \
                     pb.lib.pp_xattn_block_supported(128, c, 128, nctx, self.heads):
                 S = self.heads * 80
                 gt, ht = pb.alloc(B * S * c * 2), pb.alloc(B * c * S * 2)
@@ -1104,7 +1129,7 @@ class SDNet:
                 # C = 320: attn1.to_out runs in front of the sub-block in the same launch, whose logits then take their B
                 # operand from that GEMM's accumulators -> G^T with its channel index permuted (pre_hw: the step geometry
                 # must be one the block kernel takes, else the step plan keeps the chain and the plain layout)
-                kperm = bool(c == 320 and fold and self.fuse_xattn_pre and pre_hw.get(pre))
+                kperm = 2 if two_gemm else int(bool(c == 320 and fold and self.fuse_xattn_pre and pre_hw.get(pre)))
                 pb.plan.add("xattn_fold", pb.lib.pp_xattn_fold, k, c, vt, ldvt, B, nctx, self.heads, c,
                             self.P[f"{tbq}.weight"], self.P[f"{tbq}.colsum"] if fold else None,
                             self.P[f"{tbq}.bias"] if fold else None, self.P[f"{tb}.attn2.to_out.weight"],

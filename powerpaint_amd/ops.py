@@ -47,14 +47,20 @@ def gemm(x: torch.Tensor, w: torch.Tensor, bias=None, x2=None, res1=None, res2=N
          splitk: int = 0, row_stats: bool = False, ln_stats=None, ln_colsum=None, ln_dim: int = 0,
          ln_eps: float = 1e-5, gn=None, res1_wrap: int = 0):
     """x [M,K1] (+ x2 [M,K2]) bf16, w [N,K1+K2] bf16 -> out [M,N] (or [M,N/2] for GEGLU; (out, vt) when vt_col0).
+    w [nb, N, K]: one matrix per batch item of rows_per_batch rows (PPGemmArgs.w_batch_stride); with act =
+    L.PP_ACT_SOFTMAX80 bias / ln_colsum may then be [nb, N] as well (vec_batch_stride).
     res1_wrap: res1 holds that many rows only, row m adds res1[m mod res1_wrap] (PPGemmArgs.res1_wrap_rows).
     row_stats=True additionally returns the per-row (sum, sumsq) partials [M, ceil(N/160), 2] fp32;
     ln_stats (that layout) + ln_colsum [N] fp32 apply the folded-LayerNorm correction (see include/pp_hip.h)."""
     lib = L.lib()
     M, K1 = x.shape
     K2 = x2.shape[1] if x2 is not None else 0
-    N = w.shape[0]
+    N = w.shape[-2]
     a = L.PPGemmArgs()
+    if w.dim() == 3:
+        a.w_batch_stride = w.stride(0)
+        if bias is not None and bias.dim() == 2:
+            a.vec_batch_stride = bias.stride(0)
     a.M, a.N, a.K, a.x_mode = M, N, K1 + K2, L.PP_X_PLAIN
     a.x1, a.x2, a.c1, a.c2, a.ldx1, a.ldx2 = _p(x), _p(x2), K1, K2, x.stride(0), (x2.stride(0) if x2 is not None else 0)
     a.w, a.bias = _p(w), _p(bias)

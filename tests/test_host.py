@@ -84,7 +84,12 @@ def test_full_size_plans_and_flop_accounting():
         n_x = names.count("xattn_block")
         per_width = {"unet": 5, "brushnet": 5, "controlnet": 2}[kind]
         assert n_x == ((per_width * (2 if SDNet.fuse_xattn_wide else 1)) if SDNet.fuse_xattn else 0)
-        assert [c[2] for c in rt.setup_plan.calls].count("xattn_fold") == n_x
+        # ... and (round 5) the C = 1280 sub-blocks (16x16 level + mid block: 6 / 6 / 3 of them) run folded too, as TWO GEMMs
+        # with per-prompt weights (PP_ACT_SOFTMAX80 + w_batch_stride): one launch less per block than the chain
+        n_2g = {"unet": 6, "brushnet": 6, "controlnet": 3}[kind] if (SDNet.fuse_xattn and SDNet.fuse_xattn_2g) else 0
+        assert sum(1 for a in rt.step_plan.keep if getattr(a, "act", 0) == 3) == n_2g      # (PP_ACT_SOFTMAX80)
+        assert sum(1 for a in rt.step_plan.keep if getattr(a, "w_batch_stride", 0) > 0) == 2 * n_2g
+        assert [c[2] for c in rt.setup_plan.calls].count("xattn_fold") == n_x + n_2g
         # ... and (round 5) the feed-forward of every C = 320 transformer (FF1 + GEGLU, FF2 . proj_out) is one pp_ff_fused launch
         n_ff = ({"unet": 5, "brushnet": 5, "controlnet": 2}[kind]
                 if (SDNet.fuse_ff and SDNet.fold_ln and SDNet.merge_ff2_proj_out) else 0)
@@ -94,7 +99,7 @@ def test_full_size_plans_and_flop_accounting():
                  if (SDNet.fuse_xattn and SDNet.fuse_xattn_pre and SDNet.fold_ln) else 0)
         assert sum(1 for c in rt.step_plan.calls if c[2] == "xattn_block" and c[1][19]) == n_pre
         assert len(names) == exp[kind][1] - (n_gn - n_stats) + names.count("zero_u64") - fused_out - 2 * n_x - n_cg - n_next \
-            - 2 * n_front - n_ff - n_pre
+            - 2 * n_front - n_ff - n_pre - n_2g
         assert len(rt.setup_plan.calls) >= 15
 
 

@@ -749,6 +749,30 @@ def test_fused_cross_attention_block(B, hw, nctx, C, fold, dtype):
     Hfull = torch.zeros(B, C, heads, 80, device=DEV)
     Hfull[..., :nctx] = H
     check(ht, Hfull.reshape(B, C, 640)[:, :, kk.to(DEV)], 2e-3 * tol, 4e-3 * tol, "H^T (k-permuted)")
+    # (c) round 5, ABI v20: the same folded sub-block as TWO plain GEMMs with one weight matrix per batch item -- logits +
+    # per-head softmax in the first one's epilogue (PP_ACT_SOFTMAX80), probabilities x H^T (natural order: kperm = 2) +
+    # bias + residual + row moments in the second.  What the engine runs at C = 1280 (whole 64-row tiles per batch item).
+    if hw % 64 == 0:
+        gt2, gcs2, gb2, ht2 = ops.xattn_fold(k, vtp, B, nctx, heads, wqf, wod, kperm=2, **kw_f)
+        assert torch.equal(gt2, gt) and torch.equal(gb2, gb) and torch.equal(gcs2, gcs)
+        check(ht2, Hfull.reshape(B, C, 640), 2e-3 * tol, 4e-3 * tol, "H^T (natural order)")
+        prob = ops.gemm(x_in, gt2, bias=gb2, act=L.PP_ACT_SOFTMAX80, rows_per_batch=hw, ln_stats=ln,
+                        ln_colsum=gcs2 if fold else None, ln_dim=C)
+        assert prob.shape == (M, 640)
+        xin_f = x_in.float().reshape(B, hw, C)
+        lg = torch.einsum("bmc,bnc->bmn", xin_f, gt2.float())
+        if fold:
+            lg = rstd.reshape(B, hw, 1) * (lg - mean.reshape(B, hw, 1) * gcs2[:, None, :])
+        lg = lg + gb2[:, None, :]
+        p_ref = torch.softmax(lg.reshape(B, hw, heads, 80) * math.log(2.0), -1).reshape(M, 640)
+        check(prob, p_ref, 4e-3 * tol, 8e-3 * tol, "PP_ACT_SOFTMAX80 probabilities")
+        assert torch.all(prob.reshape(M, heads, 80)[:, :, nctx:] == 0)
+        out2, rs2 = ops.gemm(prob, ht2, bias=bo, res1=h, row_stats=True, rows_per_batch=hw)
+        check(out2, ref, 1.0e-2 * tol, 4e-3 * tol, "two-GEMM cross-attention vs fp32")
+        check(out2, old, 1.2e-2 * tol, 4e-3 * tol, "two-GEMM cross-attention vs the three-launch chain")
+        o2 = out2.float()
+        check(rs2, torch.stack([o2.reshape(M, C // 160, 160).sum(-1), (o2 * o2).reshape(M, C // 160, 160).sum(-1)], -1),
+              2e-3, 1e-5, "row moments of the two-GEMM output")
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
