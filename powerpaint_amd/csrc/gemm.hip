@@ -1523,7 +1523,10 @@ Choice choose(const PPGemmArgs& a) {
       c.tile = 32;
       while (nb64 * sk < 128 && kt / (sk * 2) >= 24 && sk < 8) sk *= 2;
     } else if (nb64 >= 256 && kt <= 100) {
-      c.tile = 32;
+      // (round 5, tools/tile_probe.py, cold in a graph) FF2 . proj_out of the 16x16 level, M = 2048 x N = 1280 x K = 6400:
+      // 128-row tiles x 2 K splits 54 us incl. the combine against 60 - 66 for one pass of 64-row tiles
+      if (kt >= 80 && nb128 * 2 >= 256 && !conv && !a.row_stats_out && !a.out_vt && a.act == PP_ACT_NONE) { c.tile = 31; sk = 2; }
+      else c.tile = 32;
     } else if (nb256 >= 32) {
       c.tile = 33;
       while (nb256 * sk < 256 && sk < 8) sk *= 2;

@@ -183,8 +183,10 @@ __global__ void __launch_bounds__(256) xattn_fold_vec_kernel(const uint16_t* __r
   float s1 = 0.f;
   if (key < nctx) {
     const uint16_t* kr = k + ((size_t)b * nctx + key) * ldk + h * D;
-    if (qb)
+    if (qb) {
+#pragma unroll 8
       for (int j = 0; j < D; ++j) s1 = fmaf(E::to_f(kr[j]), qb[h * D + j], s1);
+    }
     // (the mean term of the folded LayerNorm -- the column sum of G^T -- is taken over the entries AS STORED, by
     //  xattn_colsum_kernel behind this launch: ADVICE round 3)
   }
