@@ -1120,7 +1120,10 @@ class SDNet:
             tbq = f"{tb}.attn2.to_q"
             two_gemm = bool(self.fuse_xattn and self.fuse_xattn_2g and c > 320 and pre_hw64.get(pre) and
                             not (self.fuse_xattn_wide and c <= self.xattn_wide_max_c))
-            if self.fuse_xattn and (c == 320 or two_gemm or (self.fuse_xattn_wide and c <= self.xattn_wide_max_c)) and \
+            # (no folded operands for a step geometry none of the folded forms takes -- they were dead weight
+            #  in the arena and in the setup plan)
+            block_ok = bool(pre_hw.get(pre)) if hw0 is not None else True
+            if self.fuse_xattn and (two_gemm or (block_ok and (c == 320 or (self.fuse_xattn_wide and c <= self.xattn_wide_max_c)))) and \
                     pb.lib.pp_xattn_block_supported(128, c, 128, nctx, self.heads):
                 S = self.heads * 80
                 gt, ht = pb.alloc(B * S * c * 2), pb.alloc(B * c * S * 2)

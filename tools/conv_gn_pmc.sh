@@ -8,7 +8,8 @@ R=/root/repo
 OUT=$R/gpurun_out/conv_gn_pmc.txt
 : > $OUT
 echo "# tools/conv_gn_pmc.sh; lib_sha16: $(cd $R && python -c 'from powerpaint_amd import _lib; print(_lib.build_id())')  (shipping library; the nm2 passes run libpp_hip_lab.so of the same sources)" >> $OUT
-for shape in "64 320 0 320" "64 640 320 320"; do
+SHAPES=("64 320 0 320" "64 640 320 320"); [ "${SHAPES_ONE:-0}" = "1" ] && SHAPES=("64 320 0 320")
+for shape in "${SHAPES[@]}"; do
  for variant in ship nm2; do
   if [ $variant = nm2 ]; then export PP_LAB=1 PP_LIB=$R/powerpaint_amd/libpp_hip_lab.so PP_CONV_GN_NMODE=2; else unset PP_LAB PP_LIB PP_CONV_GN_NMODE; fi
   echo "## shape (H C1 C2 Cout) = $shape, variant = $variant" | tee -a $OUT

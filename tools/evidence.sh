@@ -11,6 +11,8 @@ export TMPDIR=/tmp
 rm -f gpurun_out/parity_achieved.txt
 if [ "${1:-}" = "profiles" ]; then
   echo "(profiles only: test suite and smoke skipped)"
+elif [ "${1:-}" = "parity" ]; then      # only the slow config-parity file (the rest of the suite ran in another session on this build)
+  timeout 1200 python -m pytest tests/test_config_parity_gpu.py -m gpu -q -p no:cacheprovider --timeout=900 > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -3 $O/pytest_gpu.log
 elif [ "${1:-}" = "tests" ]; then
   timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider --timeout=900 > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -3 $O/pytest_gpu.log
 else
@@ -37,4 +39,12 @@ except Exception as e: print('$f', 'ERR', e)
 PY
 done
 tail -5 $O/bench.err
+if [ "${PMC:-0}" = "1" ]; then
+  # counters of the shipping fused conv (first shape of tools/conv_gn_pmc.sh: 64x64, 320 -> 320) and of the fused feed-forward,
+  # ablations of the feed-forward's lab build (PP_FF_DBG: 1 no weight DMA, 8 no GEGLU, 13 MFMAs only, 16 no barriers)
+  SHAPES_ONE=1 bash tools/conv_gn_pmc.sh > $O/conv_gn_pmc.log 2>&1; cp gpurun_out/conv_gn_pmc.txt $O/gemm_pmc.txt
+  ONLY=fused bash tools/ff_pmc.sh > $O/ff_pmc.log 2>&1; cp gpurun_out/ff_pmc.txt $O/ff_fused_pmc.txt
+  { echo "# tools/ff_one.py 32768 on libpp_hip_lab.so (same sources as $(python -c 'from powerpaint_amd import _lib; print(_lib.build_id())')), PP_FF_DBG ablations of ff_fused8_kernel; eager launches (~8 us of launch gap included)";
+    for d in 0 1 8 9 13 16; do echo "## PP_FF_DBG=$d"; PP_LAB=1 PP_LIB=powerpaint_amd/libpp_hip_lab.so PP_FF_DBG=$d timeout 100 python tools/ff_one.py 32768 2>&1 | grep -E "fused:|chain:|fused4:" | tail -3; done; } > $O/ff_fused.txt 2>&1
+fi
 cat gpurun_out/parity_achieved.txt 2>/dev/null | grep -i "free-running\|golden\|loop\|smoke" | head -40

@@ -6,7 +6,8 @@ cd /tmp && export TMPDIR=/tmp
 R=/root/repo
 OUT=$R/gpurun_out/ff_pmc.txt
 echo "# tools/ff_pmc.sh; lib_sha16: $(cd $R && python -c 'from powerpaint_amd import _lib; print(_lib.build_id())')" > $OUT
-for which in "fused ff_fused8" "fused4 ff_fused_kernel" "chain pp_gemm_kernel_v2"; do
+WHICH=("fused ff_fused8" "fused4 ff_fused_kernel" "chain pp_gemm_kernel_v2"); [ "${ONLY:-}" = "fused" ] && WHICH=("fused ff_fused8")
+for which in "${WHICH[@]}"; do
   set -- $which
   echo "## $1 (kernel filter $2)" | tee -a $OUT
   for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU" "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM"; do
