@@ -150,8 +150,8 @@ def roofline_pass(pipe):
     return per, flops, counts, alg_bytes, hbm_bytes
 
 
-TRAFFIC_PROFILE = "profiles/r04_hbm_traffic.json"         # tools/hbm_traffic.sh (two rocprofv3 --pmc passes of this bench)
-KERNEL_STATS_PROFILE = "profiles/r04_kernel_stats.txt"     # rocprofv3 --kernel-trace --stats of this bench (tools/gpu_round.sh)
+TRAFFIC_PROFILE = "profiles/r05_hbm_traffic.json"         # tools/hbm_traffic.sh (two rocprofv3 --pmc passes of this bench)
+KERNEL_STATS_PROFILE = "profiles/r05_kernel_stats.txt"     # rocprofv3 --kernel-trace --stats of this bench (tools/gpu_round.sh)
 
 
 def lib_sha16() -> str:
@@ -199,7 +199,7 @@ def family_replay_us(pipe, names, reps: int = 20):
 def measured_traffic():
     """HBM bytes per 3x3 implicit-GEMM launch from the committed PMC passes (two rocprofv3 --pmc runs of this benchmark
     cannot happen inside this process).  None if the profile is absent."""
-    for rel in (TRAFFIC_PROFILE, "profiles/r03_hbm_traffic.json"):
+    for rel in (TRAFFIC_PROFILE, "profiles/r04_hbm_traffic.json"):
         try:
             fam = json.load(open(os.path.join(ROOT, rel)))["families"]["conv3x3 implicit GEMM"]
             return fam["bytes_per_launch"], rel
@@ -214,7 +214,7 @@ def profiled_conv_launch_us():
     GEMM: 8x8 level, strided / upsampling convs) -- in the committed rocprofv3 --stats summary of this benchmark, and the
     build that summary was taken from (`# lib_sha16:` header line).  -> (us per conv launch, lib sha) or (None, None)."""
     import re
-    for rel in (KERNEL_STATS_PROFILE, "profiles/r03_kernel_stats.txt"):
+    for rel in (KERNEL_STATS_PROFILE, "profiles/r04_kernel_stats.txt"):
         try:
             calls, total_ms, sha = 0, 0.0, None
             for line in open(os.path.join(ROOT, rel)):
