@@ -1,9 +1,10 @@
 #!/usr/bin/env python
 """Fused feed-forward (pp_ff_fused) against the two launches it replaces, hot, at the UNet's 64x64 level (M = 32768 rows) and
 at config 5's 128x128 level.  usage: python tools/ff_one.py [M ...]   (GPU box; lab switches of the library apply)"""
+import os
 import sys
 import torch
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from powerpaint_amd import _lib as L, ops
 from powerpaint_amd.engine import _geglu_interleave, _kperm_geglu
 
