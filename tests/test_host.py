@@ -103,6 +103,25 @@ def test_full_size_plans_and_flop_accounting():
         assert len(rt.setup_plan.calls) >= 15
 
 
+def test_folded_cross_attention_forms_follow_the_step_geometry():
+    """Round 5: which form a cross-attention sub-block takes is decided per step geometry -- the block kernels need 128-row
+    (C = 320) / 64-row (C = 640) tiles inside one batch item, the two-GEMM form of C = 1280 whole 64-row GEMM tiles per item;
+    where none fits the chain stays and NOTHING is folded for that block in the setup plan."""
+    for (H, n_fold, n_2g, n_blk) in ((64, 16, 6, 10),     # headline: 64^2 / 32^2 block kernels, 16^2 + mid two GEMMs
+                                     (32, 15, 5, 10),     # 32^2 / 16^2 block kernels (1024 / 256 rows per item), 8^2 = 64 rows:
+                                     #                       two GEMMs at the lowest level, the 4x4 mid block keeps the chain
+                                     (16, 10, 0, 10)):    # 16^2 / 8^2 block kernels; 4x4 and 2x2 at C = 1280: the chain, no fold
+        net = SDNet("unet", 9)
+        net.load_state_dict(net.synthetic_state_dict(meta=True), "cpu", materialize=False)
+        rt = NetRuntime(net, "cpu")
+        rt.ensure(2, H, H, 77, 9, ("plain",), cond_hw=(8 * H, 8 * H))
+        names = [c[2] for c in rt.step_plan.calls]
+        folds = [c[2] for c in rt.setup_plan.calls].count("xattn_fold")
+        two = sum(1 for a in rt.step_plan.keep if getattr(a, "act", 0) == 3)              # (PP_ACT_SOFTMAX80)
+        assert (folds, two, names.count("xattn_block")) == (n_fold, n_2g, n_blk), (H, folds, two, names.count("xattn_block"))
+        assert sum(1 for a in rt.step_plan.keep if getattr(a, "w_batch_stride", 0) > 0) == 2 * two
+
+
 def test_brushnet_wiring_changes_the_unet_plan():
     net = SDNet("unet", 4, **TINY)
     net.load_state_dict(net.synthetic_state_dict(meta=True), "cpu", materialize=False)
