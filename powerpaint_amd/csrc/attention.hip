@@ -339,15 +339,9 @@ template <int D, int EDT>
 static int launch_attn(const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt, void* o, int ldo,
                        int batch, int heads, int nq, int nk, float sl2, hipStream_t st) {
   constexpr int LDS = 2 * (Cfg<D>::KBYTES + Cfg<D>::VBYTES);
-  static bool attr_set = false;
-  if (!attr_set && LDS > 64 * 1024) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<D, EDT, false>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
-      pp_set_last_error("hipFuncSetAttribute(attention)", hipGetLastError());
-      return PP_ERR_LAUNCH;
-    }
-    attr_set = true;
-  }
+  if (LDS > 64 * 1024 &&
+      pp_func_lds(reinterpret_cast<const void*>(attn_fwd_kernel<D, EDT, false>), LDS, "hipFuncSetAttribute(attention)") != PP_OK)
+    return PP_ERR_LAUNCH;
   static_assert(D > 40 || LDS <= 64 * 1024, "the d = 40 kernels run with the default dynamic LDS limit");
   // K / V reuse over query blocks (see the kernel): only where the keys fit the two LDS buffers and the launch would
   // otherwise be >= 4 rounds of workgroups (two 4-wave workgroups per CU).  PP_ATTN_QREP=1|2 forces it (A/B, tests).
@@ -398,7 +392,8 @@ extern "C" int pp_attention_fwd_variant(const void* q, int ldq, const void* k, i
 }
 
 // shapes of the software-pipelined kernels = shapes PP_ATTN_PIPE_LOG2 covers (a producer asks before it pre-multiplies Q)
-extern "C" int pp_attention_log2_ok(int nq, int nk, int d) { return (nq > 0 && d == 40 && nk % 64 == 0 && nk >= 4 * 64) ? 1 : 0; }
+bool pp_attention_pipe_keys_ok(int nk);      // attention_pipe.hip: the launcher's own shape predicate
+extern "C" int pp_attention_log2_ok(int nq, int nk, int d) { return (nq > 0 && d == 40 && pp_attention_pipe_keys_ok(nk)) ? 1 : 0; }
 
 extern "C" int pp_attention_fwd(const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt, void* o,
                                 int ldo, int batch, int heads, int nq, int nk, int d, float scale, int dtype,

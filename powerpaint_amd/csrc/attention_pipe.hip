@@ -512,15 +512,9 @@ template <int KB, int DBG, int EDT, int NW = 4, int QB = 1, int OPT = (KB == 32 
 static int launch_pipe(const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt, void* o, int ldo,
                        int batch, int heads, int nq, int nk, float sl2, hipStream_t st) {
   using C = PCfg<D, KB, NW, (OPT & 16) ? 2 : 1>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_pipe_kernel<D, KB, DBG, EDT, NW, QB, OPT>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS) != hipSuccess) {
-      pp_set_last_error("hipFuncSetAttribute(attention pipe)", hipGetLastError());
-      return PP_ERR_LAUNCH;
-    }
-    attr_set = true;
-  }
+  if (pp_func_lds(reinterpret_cast<const void*>(attn_pipe_kernel<D, KB, DBG, EDT, NW, QB, OPT>), C::LDS,
+                  "hipFuncSetAttribute(attention pipe)") != PP_OK)
+    return PP_ERR_LAUNCH;
   const dim3 grid((nq + 32 * QB * NW - 1) / (32 * QB * NW), heads, batch), block(64 * NW);
   hipLaunchKernelGGL((attn_pipe_kernel<D, KB, DBG, EDT, NW, QB, OPT>), grid, block, C::LDS, st, (const uint16_t*)q, ldq,
                      (const uint16_t*)k, ldk, (const uint16_t*)vt, ldvt, (uint16_t*)o, ldo, heads, nq, nk, sl2);
@@ -530,12 +524,16 @@ static int launch_pipe(const void* q, int ldq, const void* k, int ldk, const voi
 
 // variant (PP_ATTN_* of pp_hip.h): AUTO picks by shape; PIPE_Q32 / PIPE_Q64 force the 32- / 64-queries-per-wave kernel
 // (PP_ERR_UNSUPPORTED when the shape is outside it) -- the parity tests address each shipping kernel by name.
+// key counts the software-pipelined kernels take (64-key LDS tiles, ring depth 4): the ONE predicate behind the launcher
+// and pp_attention_log2_ok()
+bool pp_attention_pipe_keys_ok(int nk) { return nk % 64 == 0 && nk >= 4 * 64; }
+
 int pp_attention_pipe_launch(const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt, void* o, int ldo,
                              int batch, int heads, int nq, int nk, int d, float sl2, int dtype, int variant,
                              hipStream_t st) {
 #define PP_ARGS q, ldq, k, ldk, vt, ldvt, o, ldo, batch, heads, nq, nk, sl2, st
   // both tile sizes need whole tiles and at least four of them (three look-ahead issues + the prologue)
-  if (nk % 64 != 0 || nk < 4 * 64) return PP_ERR_UNSUPPORTED;
+  if (!pp_attention_pipe_keys_ok(nk)) return PP_ERR_UNSUPPORTED;
 #ifdef PP_LAB
   // d = 80 (the 32x32 level) on the pipelined loop, 32 queries per wave: measured and NOT shipped -- 38.6 against 36.5 us
   // per launch for the three-phase kernel inside the step (9.515 against 9.481 ms per step; the 96-row V^T tiles leave room

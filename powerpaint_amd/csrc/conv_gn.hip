@@ -737,16 +737,8 @@ CGChoice cg_choose(const PPGemmArgs& a) {
 
 template <int BM, int HPW, bool PP, int NMODE, int EDT>
 int cg_launch(const PPGemmArgs& a, int splitk, hipStream_t st) {
-  static bool attr_set = false;
   auto kern = pp_conv_gn_kernel<BM, HPW, PP, NMODE, EDT>;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, CG_LDS) !=
-        hipSuccess) {
-      pp_set_last_error("hipFuncSetAttribute(conv_gn)", hipGetLastError());
-      return PP_ERR_LAUNCH;
-    }
-    attr_set = true;
-  }
+  if (pp_func_lds(reinterpret_cast<const void*>(kern), CG_LDS, "hipFuncSetAttribute(conv_gn)") != PP_OK) return PP_ERR_LAUNCH;
   CGDerived d;
   d.tiles_m = a.M / BM;
   d.tiles_n = (a.N + CG_BN - 1) / CG_BN;

@@ -789,29 +789,15 @@ extern "C" int pp_ff_fused(const PPGemmArgs* g2, const void* w1, const float* b1
   fa.g = a;
   fa.w1 = (const uint16_t*)w1; fa.b1 = b1; fa.cs1 = ln_stats ? cs1 : nullptr;
   fa.ln_stats = ln_stats; fa.ln_tiles = ln_tiles; fa.ln_eps = ln_eps;
-  static bool attr_set[3] = {false, false, false};
   auto go = [&](auto kern) -> int {
-    if (!attr_set[a.dtype]) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS) != hipSuccess) {
-        pp_set_last_error("hipFuncSetAttribute(ff_fused)", hipGetLastError());
-        return PP_ERR_LAUNCH;
-      }
-      attr_set[a.dtype] = true;
-    }
+    if (pp_func_lds(reinterpret_cast<const void*>(kern), FF_LDS, "hipFuncSetAttribute(ff_fused)") != PP_OK) return PP_ERR_LAUNCH;
     hipLaunchKernelGGL(kern, dim3(a.M / FF_BM), dim3(256), FF_LDS, (hipStream_t)stream, fa);
     PP_CHECK_LAUNCH("ff_fused_kernel");
     return PP_OK;
   };
   if (!w2_kperm) {      // W2' in natural hidden order: the 8-wave kernel (activations exchanged through LDS)
-    static bool attr8[3] = {false, false, false};
-    auto go8 = [&](auto kern, bool lab) -> int {
-      if (!attr8[a.dtype] || lab) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, FF8_LDS) != hipSuccess) {
-          pp_set_last_error("hipFuncSetAttribute(ff_fused8)", hipGetLastError());
-          return PP_ERR_LAUNCH;
-        }
-        attr8[a.dtype] = !lab;
-      }
+    auto go8 = [&](auto kern, bool) -> int {
+      if (pp_func_lds(reinterpret_cast<const void*>(kern), FF8_LDS, "hipFuncSetAttribute(ff_fused8)") != PP_OK) return PP_ERR_LAUNCH;
       hipLaunchKernelGGL(kern, dim3(a.M / FF_BM), dim3(512), FF8_LDS, (hipStream_t)stream, fa);
       PP_CHECK_LAUNCH("ff_fused8_kernel");
       return PP_OK;
@@ -831,7 +817,7 @@ extern "C" int pp_ff_fused(const PPGemmArgs* g2, const void* w1, const float* b1
   }
 #ifdef PP_LAB
   if (a.dtype == PP_DT_BF16) switch (pp_lab_env("PP_FF_DBG", 0)) {      // tools/ff_one.py: time the loop with parts removed
-      case 8: attr_set[a.dtype] = false; return go(ff_fused_kernel<PP_DT_BF16, 8>);
+      case 8: return go(ff_fused_kernel<PP_DT_BF16, 8>);
       default: break;
     }
   if (a.dtype == PP_DT_BF16) switch (pp_lab_env("PP_FF_VAR", 0)) {      // FD / DSP variants

@@ -1597,16 +1597,8 @@ template <int BM, int BN, int WM, int WN, int XMODE, int EDT>
 int launch(const PPGemmArgs& a, int splitk, hipStream_t st) {
   constexpr int T = WM * WN * 64;
   constexpr int LDS = 2 * (BM + BN) * 128;
-  static bool attr_set = false;
   auto kern = pp_gemm_kernel<BM, BN, WM, WN, XMODE, EDT>;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) !=
-        hipSuccess) {
-      pp_set_last_error("hipFuncSetAttribute(gemm)", hipGetLastError());
-      return PP_ERR_LAUNCH;
-    }
-    attr_set = true;
-  }
+  if (pp_func_lds(reinterpret_cast<const void*>(kern), LDS, "hipFuncSetAttribute(gemm)") != PP_OK) return PP_ERR_LAUNCH;
   GemmDerived d;
   d.tiles_m = (a.M + BM - 1) / BM;
   d.tiles_n = (a.N + BN - 1) / BN;
@@ -1660,7 +1652,6 @@ int launch2(const PPGemmArgs& a, int splitk, hipStream_t st) {
   if constexpr (LDS > 160 * 1024) {   // 256x160 x 3 stages has no room for the prefetch: drop to 2 stages (lock-step)
     return launch2<BM, BN, WM, WN, XMODE, 2, EPI, false, EDT>(a, splitk, st);
   } else {
-  static bool attr_set = false;
   // (2-stage pipelines need their single in-flight refill as early as possible: the spread costs them time)
 #ifdef PP_LAB
   auto kern = pp_gemm_kernel_v2<BM, BN, WM, WN, XMODE, NS, EPI, false, PP, EDT>;
@@ -1670,14 +1661,7 @@ int launch2(const PPGemmArgs& a, int splitk, hipStream_t st) {
 #else
   auto kern = pp_gemm_kernel_v2<BM, BN, WM, WN, XMODE, NS, EPI, (NS >= 3 && !PP), PP, EDT>;
 #endif
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) !=
-        hipSuccess) {
-      pp_set_last_error("hipFuncSetAttribute(gemm v2)", hipGetLastError());
-      return PP_ERR_LAUNCH;
-    }
-    attr_set = true;
-  }
+  if (pp_func_lds(reinterpret_cast<const void*>(kern), LDS, "hipFuncSetAttribute(gemm v2)") != PP_OK) return PP_ERR_LAUNCH;
   GemmDerived d;
   d.tiles_m = (a.M + BM - 1) / BM;
   d.tiles_n = (a.N + BN - 1) / BN;

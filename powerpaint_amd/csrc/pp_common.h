@@ -124,6 +124,8 @@ constexpr int pp_lab_env(const char*, int dflt) { return dflt; }
 
 // Host-side error plumbing (pp_api.cpp)
 void pp_set_last_error(const char* what, hipError_t e);
+// raise a kernel's dynamic-LDS limit once per (kernel, device, size); PP_OK or PP_ERR_LAUNCH (last error set)
+int pp_func_lds(const void* kern, int bytes, const char* what);
 #define PP_CHECK_LAUNCH(what)                         \
   do {                                                \
     hipError_t e__ = hipGetLastError();               \

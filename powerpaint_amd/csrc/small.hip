@@ -397,9 +397,12 @@ __global__ void __launch_bounds__(256) cfg_sched_step_kernel(const float* __rest
   cfg_sched_step_body(eps2, cfg, g, x, m_prev, n, kind, coef, step_dev);
   if (ticket) {
     __syncthreads();
-    if (threadIdx.x == 0 && atomicAdd(ticket, 1u) == gridDim.x - 1) {
-      *ticket = 0u;
-      step_dev[0] += 1;
+    if (threadIdx.x == 0) {
+      __threadfence();      // this block's reads of the counter are performed before its ticket becomes visible
+      if (atomicAdd(ticket, 1u) == gridDim.x - 1) {
+        *ticket = 0u;
+        step_dev[0] += 1;
+      }
     }
   }
 }
@@ -496,15 +499,9 @@ extern "C" int pp_linear_skinny(const float* x, int rows, int K, const void* w, 
   do {                                                                                                            \
     const size_t lds = (size_t)(R) * K * 4;                                                                       \
     if (lds > 160 * 1024) return PP_ERR_UNSUPPORTED;                                                              \
-    static size_t attr_lds = 0;                                                                                   \
-    if (lds > 64 * 1024 && lds > attr_lds) {                                                                      \
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(linear_skinny_kernel<R, E>),                          \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {              \
-        pp_set_last_error("hipFuncSetAttribute(linear_skinny)", hipGetLastError());                               \
-        return PP_ERR_LAUNCH;                                                                                     \
-      }                                                                                                           \
-      attr_lds = lds;                                                                                             \
-    }                                                                                                             \
+    if (lds > 64 * 1024 && pp_func_lds(reinterpret_cast<const void*>(linear_skinny_kernel<R, E>), (int)lds,       \
+                                       "hipFuncSetAttribute(linear_skinny)") != PP_OK)                            \
+      return PP_ERR_LAUNCH;                                                                                       \
     hipLaunchKernelGGL((linear_skinny_kernel<R, E>), dim3(nb), dim3(256), lds, st, x, rows, K, (const uint16_t*)w, \
                        bias, N, out, ldo, act_in, act_out);                                                       \
   } while (0)

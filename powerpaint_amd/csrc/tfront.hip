@@ -284,24 +284,17 @@ extern "C" int pp_tfront(const void* x, int ldx, const void* gn_acc, const float
   a.vt = (uint16_t*)vt; a.ldvt = ldvt;
   a.M = M; a.rows_per_batch = rows_per_batch;
   a.q_scale = q_scale;
-  static bool attr_set[3] = {false, false, false};
   auto go = [&](auto kern) -> int {
-    if (!attr_set[dtype]) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, TF_LDS) != hipSuccess) {
-        pp_set_last_error("hipFuncSetAttribute(tfront)", hipGetLastError());
-        return PP_ERR_LAUNCH;
-      }
-      attr_set[dtype] = true;
-    }
+    if (pp_func_lds(reinterpret_cast<const void*>(kern), TF_LDS, "hipFuncSetAttribute(tfront)") != PP_OK) return PP_ERR_LAUNCH;
     hipLaunchKernelGGL(kern, dim3(M / TF_BM), dim3(512), TF_LDS, (hipStream_t)stream, a);
     PP_CHECK_LAUNCH("tfront_kernel");
     return PP_OK;
   };
 #ifdef PP_LAB
   if (dtype == PP_DT_BF16) switch (pp_lab_env("PP_TF_QD", TF_QD)) {      // fragment reads in flight ahead of their MFMA
-      case 4: attr_set[dtype] = false; return go(tfront_kernel<PP_DT_BF16, 4>);
-      case 12: attr_set[dtype] = false; return go(tfront_kernel<PP_DT_BF16, 12>);
-      case 16: attr_set[dtype] = false; return go(tfront_kernel<PP_DT_BF16, 16>);
+      case 4: return go(tfront_kernel<PP_DT_BF16, 4>);
+      case 12: return go(tfront_kernel<PP_DT_BF16, 12>);
+      case 16: return go(tfront_kernel<PP_DT_BF16, 16>);
       default: break;
     }
 #endif

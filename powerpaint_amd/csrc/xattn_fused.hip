@@ -764,16 +764,8 @@ extern "C" int pp_xattn_block(const void* x, int ldx, const void* res, int ldres
   a.src_wrap = src_wrap_rows;
   a.pre_w = (const uint16_t*)pre_w; a.pre_b = pre_b;
   if (c != XA_C) {
-    static bool wattr[2][3] = {{false, false, false}, {false, false, false}};
-    auto gow = [&](auto kern, int ci, int grid) -> int {
-      if (!wattr[ci][dtype]) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, XA_LDS) !=
-            hipSuccess) {
-          pp_set_last_error("hipFuncSetAttribute(xattn wide)", hipGetLastError());
-          return PP_ERR_LAUNCH;
-        }
-        wattr[ci][dtype] = true;
-      }
+    auto gow = [&](auto kern, int, int grid) -> int {
+      if (pp_func_lds(reinterpret_cast<const void*>(kern), XA_LDS, "hipFuncSetAttribute(xattn wide)") != PP_OK) return PP_ERR_LAUNCH;
       hipLaunchKernelGGL(kern, dim3(grid), dim3(256), XA_LDS, (hipStream_t)stream, a);
       PP_CHECK_LAUNCH("xattn_wide_kernel");
       return PP_OK;
@@ -784,16 +776,8 @@ extern "C" int pp_xattn_block(const void* x, int ldx, const void* res, int ldres
     return dtype == PP_DT_F16 ? gow(xattn_wide_kernel<1280, PP_DT_F16>, 1, (M / 64) * 4)
                               : gow(xattn_wide_kernel<1280, PP_DT_BF16>, 1, (M / 64) * 4);
   }
-  static bool attr_set[3] = {false, false, false};
-  auto go = [&](auto kern, int slot) -> int {
-    if (!attr_set[slot] || slot == 0) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, XA_LDS) !=
-          hipSuccess) {
-        pp_set_last_error("hipFuncSetAttribute(xattn block)", hipGetLastError());
-        return PP_ERR_LAUNCH;
-      }
-      attr_set[slot] = true;
-    }
+  auto go = [&](auto kern, int) -> int {
+    if (pp_func_lds(reinterpret_cast<const void*>(kern), XA_LDS, "hipFuncSetAttribute(xattn block)") != PP_OK) return PP_ERR_LAUNCH;
     hipLaunchKernelGGL(kern, dim3(M / XA_BM), dim3(512), XA_LDS, (hipStream_t)stream, a);
     PP_CHECK_LAUNCH("xattn_block_kernel");
     return PP_OK;
@@ -820,16 +804,8 @@ extern "C" int pp_xattn_block(const void* x, int ldx, const void* res, int ldres
     }
 #endif
   if (pre_w) {
-    static bool pattr[3] = {false, false, false};
     auto gop = [&](auto kern) -> int {
-      if (!pattr[dtype]) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, XA_LDS) !=
-            hipSuccess) {
-          pp_set_last_error("hipFuncSetAttribute(xattn block, pre)", hipGetLastError());
-          return PP_ERR_LAUNCH;
-        }
-        pattr[dtype] = true;
-      }
+      if (pp_func_lds(reinterpret_cast<const void*>(kern), XA_LDS, "hipFuncSetAttribute(xattn block, pre)") != PP_OK) return PP_ERR_LAUNCH;
       hipLaunchKernelGGL(kern, dim3(M / XA_BM), dim3(512), XA_LDS, (hipStream_t)stream, a);
       PP_CHECK_LAUNCH("xattn_block_kernel(pre)");
       return PP_OK;

@@ -1191,7 +1191,10 @@ class SDNet:
         brush = add_down is not None
         add_down = list(add_down) if brush else None
         add_up = list(add_up) if brush else None
-        twin = bool(twin) and not pad_uncond and self.twin_prefix_ok(lib, B, H, W, self._nctx, brush)
+        # (a forced tile / split-K factor -- NetRuntime.gemm_tile / gemm_splitk, a measurement knob -- may send conv_in off
+        #  the single-pass staged epilogue that stores the twin copy: the flag then changes nothing, as everywhere it cannot run)
+        twin = bool(twin) and not pad_uncond and not (pb.gemm_tile or pb.gemm_splitk) and \
+            self.twin_prefix_ok(lib, B, H, W, self._nctx, brush)
 
         def pop(lst):
             return lst.pop(0) if lst is not None else 0

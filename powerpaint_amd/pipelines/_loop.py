@@ -118,6 +118,7 @@ class DenoiseLoop:
             return t.shape[0] == 2 * B and bool(torch.equal(t[:B], t[B:]))
 
         twin_u = bool(do_cfg) and all(halves_equal(t) for t, _ in static_inputs)
+        # (the control image goes through set_cond, which accepts the un-duplicated batch as well and copies it to both halves)
         twin_s = bool(do_cfg) and not half and all(halves_equal(t) for t, _ in side_static_inputs) and \
             (self.side_kind == "brushnet" or halves_equal(controlnet_cond))
         if self.side is not None and self.side.dtype != self.unet.dtype:
@@ -316,6 +317,8 @@ class DenoiseLoop:
         if self.foreign:
             return self._run_foreign(latents, num_steps, use_graph, callback, timesteps, scale_schedule)
         self.scheduler.reset()
+        if getattr(self, "_ticket", None) is not None:
+            self._ticket.zero_()       # (an aborted launch must not leave the step counter's ticket mid-count)
         if self.scheduler.kind >= 1:
             self._keep[2].zero_()
         self._fill_temb_tables()

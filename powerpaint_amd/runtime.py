@@ -184,7 +184,13 @@ class NetRuntime:
         if ident == self._cond_id:
             return
         c = self.lay["cond"]
-        self.load_nchw(cond, c.ptr, c.C, 0, c.H * c.W)
+        # the whole batch, or one CFG half (copied to both halves, as load_input does); anything else would leave rows stale
+        if cond.shape[0] == c.B:
+            self.load_nchw(cond, c.ptr, c.C, 0, c.H * c.W)
+        elif 2 * cond.shape[0] == c.B:
+            self.load_nchw(cond, c.ptr, c.C, 0, c.H * c.W, batch=c.B, batch_mod=cond.shape[0])
+        else:
+            raise L.PPError(f"controlnet_cond has batch {cond.shape[0]}, the network runs batch {c.B}")
         self._cond_id = ident
         self._cond_keep = cond    # (same reason as _ctx_keep)
         if self._ctx_id is not None:

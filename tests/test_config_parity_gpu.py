@@ -13,7 +13,7 @@
     the same 10 steps.
 
 Gates sit at about twice the achieved error (numbers: profiles/r03_config_parity.txt, appended to
-gpurun_out/parity_r03.txt by every run).
+gpurun_out/parity.txt by every run).
 """
 import os
 
@@ -41,7 +41,7 @@ def record(line: str):
     print(line)
     try:
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-        with open(os.path.join(ROOT, "gpurun_out", "parity_r03.txt"), "a") as f:
+        with open(os.path.join(ROOT, "gpurun_out", "parity.txt"), "a") as f:
             f.write(line + "\n")
     except OSError:
         pass

@@ -12,7 +12,7 @@ beside the rest of the suite in the driver's GPU test step.  By default the expe
 tests/golden/headline_ref.pt -- the SAME oracle run once by tests/golden/make_headline_ref.py (inputs and oracle calls
 shared through tests/headline_cases.py) -- and the file runs in seconds; PP_HEADLINE_LIVE=1 runs the oracle live as well
 and checks it against the fixture (done on the GPU box in round 4: profiles/r04_parity_achieved.txt).
-Achieved numbers are appended to gpurun_out/parity_r04.txt; gates at ~2x achieved.
+Achieved numbers are appended to gpurun_out/parity.txt; gates at ~2x achieved.
 """
 import os
 
@@ -49,7 +49,7 @@ def record(line: str):
     print(line)
     try:
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-        with open(os.path.join(ROOT, "gpurun_out", "parity_r04.txt"), "a") as f:
+        with open(os.path.join(ROOT, "gpurun_out", "parity.txt"), "a") as f:
             f.write(line + "\n")
     except OSError:
         pass

@@ -214,3 +214,121 @@ def test_config4_batch8_launch_plan_rows_vs_oracle(unet9):
              return_dict=False)[0]
     report("config 4 batch-8 plan (ControlNet -> UNet, 64x64), rows 0-1", out[0:2], ref)
     report("config 4 batch-8 plan (ControlNet -> UNet, 64x64), rows 6-7", out[6:8], ref)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The plans the benchmarks actually time since round 5: the CFG-twin prefix (`cat([latents] * 2)`,
+# /root/reference/powerpaint/pipelines/pipeline_PowerPaint.py:990-996) at batch 8 -- M = 16384 prefix tiles,
+# `out_dup_rows`, the wrapped residual -- against one oracle CFG pair (missing item 4).
+
+def _twin_batch(xa, seed, *shape):
+    """half = [a, r1, r2, a]; the CFG batch is cat([half] * 2): rows (0, 4) and (3, 7) are CFG twins of sample a."""
+    half = torch.cat([xa, gen(2, *shape, seed=seed), xa])
+    return torch.cat([half, half])
+
+
+def _twin_prompts(e_neg, e_pos, seed):
+    r = gen(4, 77, 768, seed=seed)
+    return torch.cat([e_neg, r[0:2], e_neg, e_pos, r[2:4], e_pos])
+
+
+def _dup_launches(rt):
+    return [a for a in rt.step_plan.keep if getattr(a, "out_dup_rows", 0)]
+
+
+def test_config2_twin_prefix_batch8_plan_vs_oracle(unet9):
+    """BASELINE config 2 AS BENCHMARKED: the batch-8 twin-prefix plan of the full 9-channel UNet at 64x64 through
+    `prepare(twin=True)` (what DenoiseLoop.bind selects); rows (0, 4) and (3, 7) -- one sample under the negative and the
+    positive prompt, at both ends of the half batch -- against ONE oracle CFG pair; same gates as the non-twin test."""
+    o, h = unet9
+    xa, en, ep = gen(1, 9, 64, 64, seed=71), gen(1, 77, 768, seed=72), gen(1, 77, 768, seed=73)
+    with torch.no_grad():
+        ref = o(torch.cat([xa, xa]), 681, torch.cat([en, ep]))[0]
+    x8, e8 = _twin_batch(xa, 74, 9, 64, 64), _twin_prompts(en, ep, 75)
+    rt = h.prepare((8, 9, 64, 64), e8.to(DEV), twin=True)
+    assert rt.twin and len(_dup_launches(rt)) == 1 and _dup_launches(rt)[0].M == 4 * 64 * 64
+    rt.load_input([(x8.to(DEV), 0)])
+    rt.set_timestep(681)
+    rt.run_step()
+    torch.cuda.synchronize()
+    out = rt.eps_tensor().clone()
+    assert not torch.equal(out[0], out[4])                       # (the prompts differ: a plan that copied a half would not)
+    report("config 2 twin-prefix batch-8 plan, rows (0, 4)", _rows(out, (0, 4)), ref)
+    report("config 2 twin-prefix batch-8 plan, rows (3, 7)", _rows(out, (3, 7)), ref)
+
+
+def test_config3_twin_prefix_batch8_plan_vs_oracle(unet4):
+    """BASELINE config 3 as benchmarked: the BrushNet's twin-prefix batch-8 plan at 64x64 (the UNet behind it has BrushNet
+    adds inside its down path and runs the full batch), residuals and eps of the CFG twins against one oracle pair
+    (pipeline_PowerPaint_Brushnet_CA.py:1384-1466)."""
+    ou, hu = unet4
+    torch.manual_seed(7)
+    ob = bf16_weights_(OM.randomize_zero_convs(OM.BrushNetModel(in_channels=4, conditioning_channels=5))).eval()
+    hb = PM.BrushNetModel(in_channels=4, conditioning_channels=5, device=DEV).load_state_dict(ob.state_dict())
+    xa, ca = gen(1, 4, 64, 64, seed=81), gen(1, 5, 64, 64, seed=82)
+    en, ep, un, up_ = (gen(1, 77, 768, seed=s) for s in (83, 84, 85, 86))
+    with torch.no_grad():
+        dn, md, up = ob(torch.cat([xa, xa]), 441, torch.cat([en, ep]), torch.cat([ca, ca]), conditioning_scale=1.0)
+        ref = ou(torch.cat([xa, xa]), 441, torch.cat([un, up_]), down_block_add_samples=list(dn), mid_block_add_sample=md,
+                 up_block_add_samples=list(up))[0]
+    x8, c8 = _twin_batch(xa, 87, 4, 64, 64), _twin_batch(ca, 88, 5, 64, 64)
+    e8, eu8 = _twin_prompts(en, ep, 89), _twin_prompts(un, up_, 90)
+    srt = hb.prepare((8, 4, 64, 64), e8.to(DEV), 1.0, twin=True)
+    assert srt.twin and len(_dup_launches(srt)) == 1
+    srt.load_input([(x8.to(DEV), 0), (c8.to(DEV), 4)])
+    srt.set_timestep(441)
+    srt.run_step()
+    hdn, hmd, hup = hb.outputs()
+    worst = 1.0
+    for i, (a, b) in enumerate(zip(hdn + [hmd] + hup, list(dn) + [md] + list(up))):
+        for idx in ((0, 4), (3, 7)):
+            cos, _ = close(_rows(a, idx), b, f"BrushNet twin-prefix residual {i} rows {idx}", cos_min=0.998)
+            worst = min(worst, cos)
+    print(f"[real-shape parity] config 3 twin-prefix plan, BrushNet 64x64: 28 residuals x 2 twin pairs, worst cosine {worst:.6f}")
+    out = hu(x8.to(DEV), 441, eu8.to(DEV), down_block_add_samples=list(hdn), mid_block_add_sample=hmd,
+             up_block_add_samples=list(hup), return_dict=False)[0]
+    report("config 3 twin-prefix plan (BrushNet -> UNet, 64x64), rows (0, 4)", _rows(out, (0, 4)), ref)
+    report("config 3 twin-prefix plan (BrushNet -> UNet, 64x64), rows (3, 7)", _rows(out, (3, 7)), ref)
+
+
+def test_config4_twin_prefix_batch8_plan_vs_oracle(unet9):
+    """BASELINE config 4 as benchmarked: the ControlNet's twin-prefix batch-8 plan (512x512 control image, its conditioning
+    embedding on half the batch) feeding the 9-channel UNet, CFG twins against one oracle pair
+    (pipeline_PowerPaint_ControlNet.py:1663-1741)."""
+    ou, hu = unet9
+    torch.manual_seed(8)
+    oc = bf16_weights_(OM.randomize_zero_convs(OM.ControlNetModel(in_channels=4))).eval()
+    hc = PM.ControlNetModel(in_channels=4, device=DEV).load_state_dict(oc.state_dict())
+    x4a, x9a = gen(1, 4, 64, 64, seed=91), gen(1, 9, 64, 64, seed=92)
+    en, ep = gen(1, 77, 768, seed=93), gen(1, 77, 768, seed=94)
+    imga = torch.rand(1, 3, 512, 512, generator=torch.Generator("cpu").manual_seed(95))
+    with torch.no_grad():
+        dn, md = oc(torch.cat([x4a, x4a]), 520, torch.cat([en, ep]), torch.cat([imga, imga]), conditioning_scale=0.5)
+        ref = ou(torch.cat([x9a, x9a]), 520, torch.cat([en, ep]), down_block_additional_residuals=dn,
+                 mid_block_additional_residual=md)[0]
+    x4_8, x9_8 = _twin_batch(x4a, 96, 4, 64, 64), _twin_batch(x9a, 97, 9, 64, 64)
+    e8 = _twin_prompts(en, ep, 98)
+    ih = torch.cat([imga, torch.rand(2, 3, 512, 512, generator=torch.Generator("cpu").manual_seed(99)), imga])
+    img8 = torch.cat([ih, ih])
+    srt = hc.prepare((8, 4, 64, 64), e8.to(DEV), img8.to(DEV), 0.5, twin=True)
+    assert srt.twin and len(_dup_launches(srt)) == 1
+    srt.load_input([(x4_8.to(DEV), 0)])
+    srt.set_timestep(520)
+    srt.run_step()
+    hdn, hmd = hc.outputs()
+    worst = 1.0
+    for i, (a, b) in enumerate(zip(hdn + [hmd], list(dn) + [md])):
+        for idx in ((0, 4), (3, 7)):
+            cos, _ = close(_rows(a, idx), b, f"ControlNet twin-prefix residual {i} rows {idx}", cos_min=0.998)
+            worst = min(worst, cos)
+    print(f"[real-shape parity] config 4 twin-prefix plan, ControlNet 64x64: 13 residuals x 2 twin pairs, worst cosine {worst:.6f}")
+    # the UNet behind a ControlNet has no adds inside its down path: it runs ITS twin prefix as well (as DenoiseLoop binds it)
+    rt = hu.prepare((8, 9, 64, 64), e8.to(DEV), down_block_additional_residuals=hdn, mid_block_additional_residual=hmd, twin=True)
+    rt.load_input([(x9_8.to(DEV), 0)])
+    rt.set_timestep(520)
+    rt.run_step()
+    torch.cuda.synchronize()
+    out = rt.eps_tensor().clone()
+    print(f"[real-shape parity] config 4: UNet behind the ControlNet runs the twin prefix: {bool(rt.twin and _dup_launches(rt))}")
+    report("config 4 twin-prefix plan (ControlNet -> UNet, 64x64), rows (0, 4)", _rows(out, (0, 4)), ref)
+    report("config 4 twin-prefix plan (ControlNet -> UNet, 64x64), rows (3, 7)", _rows(out, (3, 7)), ref)
