@@ -29,7 +29,7 @@ extern "C" {
 #define PP_ERR_LAUNCH (-3)       /* hipLaunchKernel / hipFuncSetAttribute failed                  */
 #define PP_ERR_WORKSPACE (-4)    /* workspace pointer null or too small                           */
 
-#define PP_ABI_VERSION 20
+#define PP_ABI_VERSION 21
 /* 16-bit storage format of activations and matrix weights ("dtype" arguments; the same codes pp_nchw_to_nhwc uses for
  * its source): bf16 or fp16 -- the reference's default is fp16 (/root/reference/app.py:548,559).  MFMA accumulation,
  * norm statistics, softmax, biases and latents are fp32 with either. */
@@ -195,6 +195,19 @@ typedef struct PPGemmArgs {
   int32_t gn_dup_mask;   /* see gn_dup_batch */
   /* (ABI v20) with w_batch_stride and act = PP_ACT_SOFTMAX80: bias and ln_colsum advance by this many floats per batch item */
   int32_t vec_batch_stride;
+  /* (ABI v21) The split-K combine INSIDE the producing kernel.  tile_ctr != NULL permits it: pp_gemm_combine_ctr_bytes()
+   * bytes of device memory, zero before the first launch that uses them (every launch leaves them zero again), private to
+   * this launch within a step.  Where pp_gemm_bf16 then finds the launch eligible -- lean epilogue, an 8-wave ping-pong or
+   * fused-norm tile, tiles % 8 == 0 so that the splits of a tile share an XCD (csrc/gemm_combine.h) -- the workgroup that
+   * arrives LAST at its tile sums the tile's fp32 slabs in slab order and runs the combine's epilogue (incl. gn_acc and
+   * gn_next_*): same bits as the separate combine launch, which then does not happen.  Not eligible => the separate
+   * combine as before; tile_ctr is a permission, never a request that can fail.  combine_fault (optional): a device
+   * counter the last arriver increments if it finds that the splits of its tile did NOT run on one XCD (the slab sums
+   * may then be stale): the caller checks it at its synchronisation points and refuses the results (pp_*  never
+   * synchronises).  Replaces the combine behind the split-K convs / Linears of the 16x16 and 8x8 levels
+   * (/root/reference/powerpaint/models/unet_2d_blocks.py:1457-1500, 850-899, 2696-2770). */
+  uint64_t* tile_ctr;
+  uint32_t* combine_fault;
 } PPGemmArgs;
 #define PP_GN_SUM_SCALE 16777216.0f /* 2^24 */
 #define PP_GN_SQ_SCALE 1048576.0f   /* 2^20 */
@@ -219,6 +232,22 @@ int pp_conv_gn_preferred(const PPGemmArgs* args);
 /* (ABI v17) 1 if this launch, as pp_gemm_bf16 would configure it, ends in the split-K combine that can apply the consumer
  * GroupNorm of subscription `sub` (PPGemmArgs.gn_next_*), else 0. */
 int pp_gemm_gn_next_ok(const PPGemmArgs* args, int sub);
+/* (ABI v21) Bytes of PPGemmArgs.tile_ctr the library ADVISES for this launch: 0 = the launch does not run split-K, can never
+ * combine in-kernel (tile form, tiles % 8 != 0, epilogue not lean, placement check failed), or is one where the separate
+ * combine launch measured at least as fast on MI355X -- which, as of round 6, is EVERY launch (one workgroup pulls the tile's
+ * 0.16 .. 1.3 MB of slabs through one CU while the chip idles: +3 % on the headline step; profiles/r06_fused_combine.txt), so
+ * the shipping library returns 0 throughout and the launch plans keep the separate combine.  The mechanism stays available: a
+ * caller that sets tile_ctr anyway (8 bytes per 128-row x 160-column tile always suffice) gets the in-kernel combine, bit for
+ * bit the separate one.  Asked at plan-build time, never inside a stream capture: the first call per process may run
+ * pp_xcd_placement_ok(). */
+size_t pp_gemm_combine_ctr_bytes(const PPGemmArgs* args);
+/* (ABI v21) 1 if pp_gemm_bf16 will combine this launch in-kernel (tile_ctr set and every condition met, incl. the
+ * gn_next_* apply where requested), else 0: how many kernels the launch is. */
+int pp_gemm_combine_fused(const PPGemmArgs* args);
+/* (ABI v21) Launches a probe grid on the current device and SYNCHRONISES it (the one entry point that does): 1 if the
+ * workgroups of dim3(tiles, splits) grids are placed on the XCDs round-robin by their linear id (what the in-kernel
+ * combine's co-location rests on), else 0.  Cached per device. */
+int pp_xcd_placement_ok(void);
 
 /* Small-M ("skinny") linear in fp32 accumulate: out[b][n] = act_in(x[b][:]) . W[n][:] + bias[n], b < rows <= 16.
  * Replaces TimestepEmbedding.linear_1/linear_2 and the 22 ResnetBlock2D.time_emb_proj (batched into one call by

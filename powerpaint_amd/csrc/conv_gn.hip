@@ -25,6 +25,7 @@
 
 #include "pp_common.h"
 #include "gemm_gn.h"
+#include "gemm_combine.h"
 
 namespace {
 
@@ -653,6 +654,12 @@ __global__ void __launch_bounds__(CG_T, 2) pp_conv_gn_kernel(const PPGemmArgs a,
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     gn_flush(a, slots, m_blk, n_blk, ncols, tid);
   }
+  // (ABI v21) the split-K combine by the workgroup that arrives last at its tile (gemm_combine.h)
+  if (splitk && a.tile_ctr) {
+    static_assert(fc_lds_bytes(BM) <= CG_LDS, "fused combine staging must fit in the kernel's LDS");
+    if (splitk_arrive(a, blockIdx.x, splits, tid, reinterpret_cast<int*>(smem + fc_flag_off(BM))) == 0) return;
+    splitk_fused_combine<BM, T, EDT>(a, smem, m_blk, n_blk, splits, tid);
+  }
 }
 
 // ---- host side ----------------------------------------------------------------------------------------------------------
@@ -807,6 +814,7 @@ int cg_dispatch(const PPGemmArgs& a, const CGChoice& c, hipStream_t st) {
 // entry points used by gemm.hip's pp_gemm_bf16 / pp_gemm_workspace_bytes (one C-ABI call per conv, whichever kernel runs)
 bool pp_conv_gn_wanted(const PPGemmArgs& a) { return a.x_mode == PP_X_CONV3X3 && a.gn_in_acc != nullptr; }
 int pp_conv_gn_splitk(const PPGemmArgs& a) { return cg_supported(a) ? cg_choose(a).splitk : 0; }
+int pp_conv_gn_bm(const PPGemmArgs& a) { return cg_supported(a) ? cg_choose(a).bm : 0; }
 int pp_conv_gn_run(const PPGemmArgs& a, hipStream_t st) {
   if (!cg_supported(a)) return PP_ERR_UNSUPPORTED;
   const CGChoice c = cg_choose(a);

@@ -20,6 +20,7 @@
 //     consecutive N tiles of the same M panel, so the activation panel is fetched from HBM once per XCD.
 #include "pp_common.h"
 #include "gemm_gn.h"
+#include "gemm_combine.h"
 
 // Epilogue: accumulators staged through LDS in 64-row passes, full-row 16-byte stores.  (A register-direct epilogue was
 // built and measured in round 3 -- parity-green, +1 % on the UNet step: profiles/r03_epilogue_ab.txt, DESIGN.md section 8;
@@ -1211,6 +1212,15 @@ pp_gemm_kernel_v2(const PPGemmArgs a, const GemmDerived d) {   // 2nd bound = wa
     }
   }
   if (GNS && !splitk && !gn_per_pass) gn_fold_block(m_blk, true);
+  if constexpr (EPI == 0 && PP) {
+    // (ABI v21) the split-K combine by the workgroup that arrives last at its tile (gemm_combine.h); a.tile_ctr is set by
+    // the host only where every split of a tile runs on one XCD and the epilogue is the lean combine's
+    if (splitk && a.tile_ctr) {
+      static_assert(fc_lds_bytes(BM) <= NS * STAGE, "fused combine staging must fit in the pipeline stages");
+      if (splitk_arrive(a, blockIdx.x, gridDim.y, tid, reinterpret_cast<int*>(smem + fc_flag_off(BM))) == 0) return;
+      splitk_fused_combine<BM, T, EDT>(a, smem, m_blk, n_blk, gridDim.y, tid);
+    }
+  }
   }   // EPI != 2
 }
 
@@ -1569,6 +1579,32 @@ bool gn_next_shape_ok(const PPGemmArgs& a, int sub) {
   return hw >= 16 && hw <= 256 && hw % 16 == 0 && (hw <= 128 || hw % 128 == 0) && a.M % hw == 0 && a.ldo == a.N;
 }
 
+// (ABI v21) can the launch combine its split-K slabs in-kernel (gemm_combine.h)?  bm / tiles / pp_tile describe the form
+// pp_gemm_bf16 runs it in.  `with_consumers`: also honour what a consumer may have patched into the request (gn_next_*).
+bool fused_combine_shape_ok(const PPGemmArgs& a, int bm, int tiles, int splitk, bool pp_tile, bool with_consumers) {
+  if (splitk <= 1 || splitk > 8 || !pp_tile || !reduce_lean_ok(a)) return false;
+  if (tiles % 8) return false;                                   // every split of a tile on the XCD (tile id % 8)
+  // ONE workgroup pulls the tile's splitk x bm x 640 bytes (0.16 .. 1.3 MB) through one CU's 64 B/clk path while the rest
+  // of the chip idles: measured (tools/fc_time.py, tools/step_ab.sh; profiles/r06_fused_combine.txt) the tail costs 4-20 us
+  // MORE per launch than the separate combine (which spreads the same bytes over 256 CUs) from 128 rows x 8 splits up, and
+  // is a draw below (256 x 2, 128 x 2): headline step +3.0 % with every eligible launch combined in-kernel, +0.1 .. 0.25 %
+  // with only the small tiles.  So the library ADVISES it nowhere (pp_gemm_combine_ctr_bytes() = 0); a caller that hands
+  // counters over anyway gets it, bit-identical (tests/test_fused_combine_gpu.py).  (lab) PP_FUSED_COMBINE_ROWS = the
+  // largest splitk x rows product advised
+  static const int max_rows = pp_lab_env("PP_FUSED_COMBINE_ROWS", 0);
+  if (!with_consumers && splitk * bm > max_rows) return false;
+  if (a.M % bm || a.N % 8) return false;
+  if ((uint64_t)splitk * (uint64_t)a.M * (uint64_t)a.N * 4u >= 0x80000000ull) return false;
+  if (!with_consumers) return true;
+  if ((a.gn_acc[0] || a.gn_acc[1]) && (a.rows_per_batch <= 0 || a.rows_per_batch % 64)) return false;
+  if (a.gn_next_out) {
+    if (!gn_next_shape_ok(a, a.gn_next_sub)) return false;
+    const int hw = a.rows_per_batch, cg = a.gn_cg[a.gn_next_sub];
+    if (hw % 64 || bm % hw || 160 % cg) return false;            // whole (batch item, group) populations inside a tile
+  }
+  return true;
+}
+
 template <int EDT>
 int launch_combine(const PPGemmArgs& a, int splitk, hipStream_t st) {
   const long long total = (long long)a.M * (a.N / 8);
@@ -1672,7 +1708,7 @@ int launch2(const PPGemmArgs& a, int splitk, hipStream_t st) {
   dim3 grid(d.tiles_m * d.tiles_n, splitk, 1);
   hipLaunchKernelGGL(kern, grid, dim3(T), LDS, st, a, d);
   PP_CHECK_LAUNCH("pp_gemm_kernel_v2");
-  if (splitk > 1) return launch_combine<EDT>(a, splitk, st);
+  if (splitk > 1 && !a.tile_ctr) return launch_combine<EDT>(a, splitk, st);   // (tile_ctr: combined by the last arriver)
   return PP_OK;
   }
 }
@@ -1793,6 +1829,7 @@ int dispatch(const PPGemmArgs& a, const Choice& c, hipStream_t st) {
 // conv_gn.hip: GroupNorm + SiLU of the conv input fused into the loader (PPGemmArgs.gn_in_acc)
 bool pp_conv_gn_wanted(const PPGemmArgs& a);
 int pp_conv_gn_splitk(const PPGemmArgs& a);       // 0 = shape not supported by the fused kernel
+int pp_conv_gn_bm(const PPGemmArgs& a);           // rows of the tile it runs on (0 = not supported)
 int pp_conv_gn_run(const PPGemmArgs& a, hipStream_t st);
 
 extern "C" int pp_gemm_gn_stats_ok(const PPGemmArgs* args) {
@@ -1818,6 +1855,46 @@ extern "C" int pp_gemm_gn_next_ok(const PPGemmArgs* args, int sub) {
   return (planned_splitk(*args) > 1 && gn_next_shape_ok(*args, sub)) ? 1 : 0;
 }
 
+// the form pp_gemm_bf16 runs this request in, as the fused-combine predicate sees it
+struct PlannedForm {
+  int bm, tiles, splitk;
+  bool pp_tile;
+};
+static PlannedForm planned_form(const PPGemmArgs& a) {
+  PlannedForm f{0, 0, 1, false};
+  const int tn = (a.N + 159) / 160;
+  if (pp_conv_gn_wanted(a)) {
+    f.splitk = pp_conv_gn_splitk(a);
+    f.bm = pp_conv_gn_bm(a);
+    f.pp_tile = f.bm > 0;                        // (the shipping fused-norm kernels are all 8-wave ping-pong tiles)
+  } else {
+    const Choice c = choose(a);
+    f.splitk = c.tile > 10 ? c.splitk : 1;
+    f.pp_tile = c.tile == 53 || c.tile == 44 || c.tile == 54;
+    f.bm = c.tile == 53 ? 256 : 128;
+  }
+  if (f.bm > 0) f.tiles = ((a.M + f.bm - 1) / f.bm) * tn;
+  return f;
+}
+
+extern "C" size_t pp_gemm_combine_ctr_bytes(const PPGemmArgs* args) {
+  if (!args || validate(*args) != PP_OK) return 0;
+  const PlannedForm f = planned_form(*args);
+  if (!fused_combine_shape_ok(*args, f.bm, f.tiles, f.splitk, f.pp_tile, false)) return 0;
+  if (!pp_xcd_placement_ok()) return 0;
+  return (size_t)f.tiles * sizeof(uint64_t);
+}
+
+static bool combine_fused(const PPGemmArgs& a) {
+  if (!a.tile_ctr) return false;
+  const PlannedForm f = planned_form(a);
+  return fused_combine_shape_ok(a, f.bm, f.tiles, f.splitk, f.pp_tile, true);
+}
+
+extern "C" int pp_gemm_combine_fused(const PPGemmArgs* args) {
+  return (args && validate(*args) == PP_OK && combine_fused(*args)) ? 1 : 0;
+}
+
 extern "C" size_t pp_gemm_workspace_bytes(const PPGemmArgs* args) {
   if (!args || validate(*args) != PP_OK) return 0;
   if (pp_conv_gn_wanted(*args)) {
@@ -1831,16 +1908,20 @@ extern "C" size_t pp_gemm_workspace_bytes(const PPGemmArgs* args) {
 
 extern "C" int pp_gemm_bf16(const PPGemmArgs* args, void* stream) {
   if (!args) return PP_ERR_BAD_ARG;
-  const PPGemmArgs& a = *args;
-  const int v = validate(a);
+  const int v = validate(*args);
   if (v != PP_OK) return v;
+  // tile_ctr is a permission: the kernels see it only where the launch is eligible for the in-kernel combine
+  PPGemmArgs a_ = *args;
+  const bool fused = combine_fused(a_);
+  if (!fused) a_.tile_ctr = nullptr;
+  const PPGemmArgs& a = a_;
   if (a.gn_next_out && !(planned_splitk(a) > 1 && gn_next_shape_ok(a, a.gn_next_sub))) return PP_ERR_UNSUPPORTED;
   if (pp_conv_gn_wanted(a)) {      // norm -> SiLU -> conv3x3 as one launch (no silent fallback: pp_conv_gn_supported() tells)
     const int sk = pp_conv_gn_splitk(a);
     if (sk <= 0) return PP_ERR_UNSUPPORTED;
     if ((a.gn_acc[0] || a.gn_acc[1]) && !gn_stats_supported(a)) return PP_ERR_UNSUPPORTED;
     const int rc = pp_conv_gn_run(a, (hipStream_t)stream);
-    if (rc != PP_OK || sk == 1) return rc;
+    if (rc != PP_OK || sk == 1 || fused) return rc;
     return a.dtype == PP_DT_F16 ? launch_combine<PP_DT_F16>(a, sk, (hipStream_t)stream)
                                 : launch_combine<PP_DT_BF16>(a, sk, (hipStream_t)stream);
   }

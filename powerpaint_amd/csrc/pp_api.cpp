@@ -32,6 +32,50 @@ int pp_func_lds(const void* kern, int bytes, const char* what) {
   return PP_OK;
 }
 
+// ---- workgroup -> XCD placement probe (ABI v21; what the in-kernel split-K combine's co-location rests on, gemm_combine.h)
+__global__ void __launch_bounds__(64) pp_xcc_probe_kernel(unsigned* out) {
+  if (threadIdx.x == 0) {
+    unsigned v;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+    out[blockIdx.y * gridDim.x + blockIdx.x] = v & 7u;
+  }
+}
+
+extern "C" int pp_xcd_placement_ok(void) {
+  static std::mutex mu;
+  static std::map<int, int> verdict;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  std::lock_guard<std::mutex> g(mu);
+  auto it = verdict.find(dev);
+  if (it != verdict.end()) return it->second;
+  // two grid shapes of the split-K launches (tiles % 8 == 0): residue (linear id % 8) -> one XCC each, all eight distinct
+  int ok = 1;
+  const int shapes[2][2] = {{64, 4}, {32, 8}};
+  unsigned* d = nullptr;
+  if (hipMalloc(&d, 256 * sizeof(unsigned)) != hipSuccess) return 0;
+  for (int sh = 0; sh < 2 && ok; ++sh) {
+    const int X = shapes[sh][0], Y = shapes[sh][1];
+    unsigned h[256];
+    if (hipMemset(d, 0xff, sizeof(h)) != hipSuccess) { ok = 0; break; }
+    hipLaunchKernelGGL(pp_xcc_probe_kernel, dim3(X, Y), dim3(64), 0, 0, d);
+    if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
+        hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) { ok = 0; break; }
+    int map[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
+    for (int f = 0; f < X * Y; ++f) {
+      if (h[f] > 7u) ok = 0;
+      else if (map[f & 7] < 0) map[f & 7] = (int)h[f];
+      else if (map[f & 7] != (int)h[f]) ok = 0;
+    }
+    for (int i = 0; i < 8 && ok; ++i)
+      for (int j = i + 1; j < 8; ++j)
+        if (map[i] == map[j]) ok = 0;
+  }
+  (void)hipFree(d);
+  verdict[dev] = ok;
+  return ok;
+}
+
 #ifndef PP_BUILD_ID
 #define PP_BUILD_ID "unknown"
 #endif

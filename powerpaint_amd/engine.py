@@ -44,6 +44,9 @@ FUSE_GN_CONV = _lab_switch("PP_FUSE_GN_CONV")
 # round 5: the CFG-identical prefix of a forward pass (conv_in .. first self-attention) on ONE half of the batch where the
 # caller vouches for identical halves (SDNet.build_step(twin=True)).  (lab) PP_TWIN=0: the whole batch everywhere
 TWIN_PREFIX = _lab_switch("PP_TWIN")
+# round 6: the split-K combine inside the producing kernel, by the workgroup that arrives last at its tile
+# (csrc/gemm_combine.h, PPGemmArgs.tile_ctr).  (lab) PP_FUSED_COMBINE=0: the separate combine launches
+FUSED_COMBINE = _lab_switch("PP_FUSED_COMBINE")
 
 
 class Arena:
@@ -232,6 +235,8 @@ class Builder:
         self.gn_acc_base = 0
         self.gn_acc_cap = 0
         self.gn_acc_used = 0
+        # device word the in-kernel split-K combine counts placement violations in (NetRuntime.check_faults); 0 = none given
+        self.fault_ptr = 0
 
     # -- memory
     def alloc(self, nbytes: int) -> int:
@@ -256,6 +261,14 @@ class Builder:
         ws = self.lib.pp_gemm_workspace_bytes(C.byref(a))
         if ws:
             a.workspace = self.alloc(ws)
+            # tile counters of the in-kernel combine: persistent words of the pool the step's first launch zeroes (private to
+            # this launch; every launch also leaves them zero).  A permission: pp_gemm_bf16 decides per launch.
+            if FUSED_COMBINE and self.gn_acc_cap:
+                nctr = _align(self.lib.pp_gemm_combine_ctr_bytes(C.byref(a)), 8)
+                if nctr and self.gn_acc_used + nctr <= self.gn_acc_cap:
+                    a.tile_ctr = self.gn_acc_base + self.gn_acc_used
+                    a.combine_fault = self.fault_ptr or None
+                    self.gn_acc_used += nctr
         self.plan.keep.append(a)
         self.last_gemm = a
         a._arena_top = self.arena.off       # everything this launch reads or scratches lies below (see _apply_in_producer_combine)

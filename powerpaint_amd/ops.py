@@ -31,6 +31,47 @@ def _set_gn(a, gn, rows_per_batch):
         a.gn_acc[k], a.gn_cg[k], a.gn_c0[k], a.gn_groups[k] = acc.data_ptr(), cg, c0, groups
 
 
+# (ABI v21) the in-kernel split-K combine: `fuse_combine=True` on gemm / conv3x3 hands the launch zeroed tile counters where
+# pp_gemm_combine_ctr_bytes() asks for them.  `last_combine` describes the most recent such call: fused (did pp_gemm_bf16
+# combine in-kernel), ctr (the counters: all zero again after the launch), and combine_faults() reads the fault counter.
+last_combine = {"fused": False, "ctr": None}
+_fault_words = {}
+
+
+def _fault_word(device) -> torch.Tensor:
+    key = torch.device(device)
+    if key not in _fault_words:
+        _fault_words[key] = torch.zeros(1, dtype=torch.int32, device=device)
+    return _fault_words[key]
+
+
+def combine_faults(device) -> int:
+    """Split-K tiles whose splits did NOT share an XCD since the process started (synchronises; must stay 0)."""
+    return int(_fault_word(device).item())
+
+
+def _attach_combine(a, device, enable):
+    """enable: False / None -- no counters; True -- where pp_gemm_combine_ctr_bytes() advises them; "force" -- also where the
+    library advises the separate combine (large tiles); a tensor -- the caller's own (zeroed or re-armed) counters."""
+    last_combine["fused"], last_combine["ctr"] = False, None
+    if enable is None or enable is False:
+        return
+    bound = ((a.M + 127) // 128) * ((a.N + 159) // 160) * 8       # 8 bytes per 128 x 160 tile always suffice
+    if torch.is_tensor(enable):
+        ctr = enable
+        assert ctr.dtype == torch.int64 and ctr.numel() * 8 >= bound
+    else:
+        n = L.lib().pp_gemm_combine_ctr_bytes(C.byref(a))
+        if enable == "force":
+            n = max(n, bound)
+        if not n:
+            return
+        ctr = torch.zeros(n // 8, dtype=torch.int64, device=device)
+    a.tile_ctr, a.combine_fault = ctr.data_ptr(), _fault_word(device).data_ptr()
+    last_combine["ctr"] = ctr
+    last_combine["fused"] = bool(L.lib().pp_gemm_combine_fused(C.byref(a)))
+
+
 def groupnorm_apply_acc(x: torch.Tensor, acc: torch.Tensor, gamma, beta, eps: float, silu: bool, groups: int = 32,
                         x2=None):
     """GroupNorm(+SiLU) of concat(x, x2) from statistics accumulated by the producers (PPGemmArgs.gn_acc)."""
@@ -45,7 +86,7 @@ def groupnorm_apply_acc(x: torch.Tensor, acc: torch.Tensor, gamma, beta, eps: fl
 def gemm(x: torch.Tensor, w: torch.Tensor, bias=None, x2=None, res1=None, res2=None, scale: float = 1.0, act: int = 0,
          rowvec=None, rows_per_batch: int = 0, out_f32: bool = False, vt_col0: int = 0, tile: int = 0,
          splitk: int = 0, row_stats: bool = False, ln_stats=None, ln_colsum=None, ln_dim: int = 0,
-         ln_eps: float = 1e-5, gn=None, res1_wrap: int = 0):
+         ln_eps: float = 1e-5, gn=None, res1_wrap: int = 0, fuse_combine: bool = False):
     """x [M,K1] (+ x2 [M,K2]) bf16, w [N,K1+K2] bf16 -> out [M,N] (or [M,N/2] for GEGLU; (out, vt) when vt_col0).
     w [nb, N, K]: one matrix per batch item of rows_per_batch rows (PPGemmArgs.w_batch_stride); with act =
     L.PP_ACT_SOFTMAX80 bias / ln_colsum may then be [nb, N] as well (vec_batch_stride).
@@ -91,6 +132,7 @@ def gemm(x: torch.Tensor, w: torch.Tensor, bias=None, x2=None, res1=None, res2=N
     ws = lib.pp_gemm_workspace_bytes(C.byref(a))
     wsb = torch.empty(max(ws, 4) // 4, dtype=torch.float32, device=x.device) if ws else None
     a.workspace = _p(wsb)
+    _attach_combine(a, x.device, fuse_combine)
     L.check(lib.pp_gemm_bf16(C.byref(a), _s()), "pp_gemm_bf16")
     if row_stats:
         return out, stats
@@ -128,7 +170,8 @@ def _conv_args(x, cout, stride, up, x2, x3, x4):
 
 def conv3x3(x: torch.Tensor, w: torch.Tensor, bias=None, stride: int = 1, up: bool = False, x2=None, rowvec=None,
             res1=None, res2=None, scale: float = 1.0, tile: int = 0, splitk: int = 0, gn=None, x3=None, x4=None,
-            gn_in=None, gn_next=None, dup: bool = False, gn_dup_mask: int = 0, res1_wrap: int = 0):
+            gn_in=None, gn_next=None, dup: bool = False, gn_dup_mask: int = 0, res1_wrap: int = 0,
+            fuse_combine: bool = False):
     """x NHWC bf16 [B,H,W,C1] (+x2 [B,H,W,C2]); w bf16 [Cout, 9*(C1+C2)] (k = (ky*3+kx)*C + c) -> NHWC bf16.
     dup: every output row is stored twice -> out [2B, ...] (PPGemmArgs.out_dup_rows: the CFG twin prefix); gn_dup_mask:
     which of the `gn` subscriptions hold [2B][groups][2] accumulators that receive both halves' sums.
@@ -178,6 +221,7 @@ def conv3x3(x: torch.Tensor, w: torch.Tensor, bias=None, stride: int = 1, up: bo
     a.workspace = _p(wsb)
     if gn_next is not None and not lib.pp_gemm_gn_next_ok(C.byref(a), a.gn_next_sub):
         raise L.PPError("pp_gemm_gn_next_ok() = 0 for this launch (PP_ERR_UNSUPPORTED)")
+    _attach_combine(a, x.device, fuse_combine)
     L.check(lib.pp_gemm_bf16(C.byref(a), _s()), "pp_gemm_bf16(conv)")
     return (out, ynext) if gn_next is not None else out
 

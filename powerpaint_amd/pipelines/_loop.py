@@ -342,7 +342,15 @@ class DenoiseLoop:
                 self.program.run(stream)
             if callback is not None:
                 callback(i, timesteps[i] if timesteps is not None else None, self.latents)
+        self._check_faults()
         return self.latents
+
+    def _check_faults(self):
+        """One synchronisation per pipeline call: the networks' in-kernel split-K combines prove their XCD co-location per
+        tile and count violations (NetRuntime.check_faults)."""
+        for r in (getattr(self, "rt", None), getattr(self, "side_rt", None)):
+            if r is not None:
+                r.check_faults()
 
     def _run_foreign(self, latents, num_steps, use_graph, callback, timesteps, scale_schedule):
         """Duck-typed scheduler: network part = the captured program (eps lands in the UNet runtime's fp32 output), then
@@ -392,4 +400,5 @@ class DenoiseLoop:
             if callback is not None:
                 callback(i, t, lat)
         self.latents.copy_(lat)
+        self._check_faults()
         return self.latents

@@ -44,6 +44,7 @@ class NetRuntime:
         # by the first launch of every step
         gn_cap = 96 * B * 32 * 2 * 8
         lay["gn_acc"] = arena.alloc(gn_cap)
+        lay["fault"] = arena.alloc(256)          # placement violations seen by the in-kernel split-K combines (check_faults)
         # network input, NHWC; the channels are zero-padded to one 64-deep K chunk (conv_in runs on the implicit-GEMM
         # kernel).  The arena is zero-filled and nothing else ever writes the pad channels.
         if cin_total != net.cin0:
@@ -67,6 +68,7 @@ class NetRuntime:
         pb = Builder(arena, dtype=net.dtype)
         pb.gemm_tile, pb.gemm_splitk = self.gemm_tile, self.gemm_splitk
         pb.gn_acc_base, pb.gn_acc_cap = lay["gn_acc"], gn_cap
+        pb.fault_ptr = lay["fault"]
         kw = {}
         if net.kind == "unet" and kind == "brushnet":
             ptrs = wiring[1]
@@ -132,6 +134,9 @@ class NetRuntime:
             return
         if H % (2 ** (len(self.net.boc) - 1)) or W % (2 ** (len(self.net.boc) - 1)):
             raise L.PPError(f"latent size {H}x{W} must be divisible by {2 ** (len(self.net.boc) - 1)}")
+        # (the one synchronising probe of the library runs here, at plan-build time and never under a stream capture: are
+        #  workgroups placed on the XCDs round-robin by linear id?  Plans combine split-K in-kernel only if so.)
+        self.xcd_placement_ok = bool(self.lib.pp_xcd_placement_ok())
         dry = Arena()
         self._build(dry, B, H, W, nctx, cin_total, wiring, cond_hw, scale, pad_uncond, twin)
         self.arena = Arena(_align(dry.peak, 4096), self.device)
@@ -240,6 +245,18 @@ class NetRuntime:
         with torch.cuda.graph(g):
             self.step_plan.run(_stream())
         self.graph = g
+
+    def check_faults(self):
+        """Synchronises.  The in-kernel split-K combine sums a tile's slabs through ONE XCD's L2; the workgroup that does it
+        proves, from the arrival counter, that every split of its tile ran on that XCD and counts a violation otherwise
+        (csrc/gemm_combine.h).  A non-zero count means results since the last check may hold stale partial sums: refuse."""
+        if self.arena is None or "fault" not in getattr(self, "lay", {}):
+            return
+        n = int(self.arena.view(self.lay["fault"], (1,), torch.int32).item())
+        if n:
+            self.arena.view(self.lay["fault"], (1,), torch.int32).zero_()
+            raise L.PPError(f"{n} split-K tiles were combined across XCDs (workgroup placement changed under the plan): "
+                            f"results are not trustworthy; rebuild the plan with PP_LAB=1 PP_FUSED_COMBINE=0")
 
     # ------------------------------------------------------------------ outputs
     def act_as_nchw(self, a: Act) -> torch.Tensor:
