@@ -252,7 +252,7 @@ class DenoiseLoop:
         ent = tabs[k]
         pver = getattr(r.net.params, "version", 0)
         if ent["plan"] is not r.step_plan or ent.get("pver") != pver:     # new plan / weights rewritten in place: stale rows
-            ent["plan"], ent["ts"], ent["pver"] = r.step_plan, None, pver
+            ent["plan"], ent["ts"], ent["pver"], ent["hkey"] = r.step_plan, None, pver, None
         return dict(idx=idx, out=out, total=total, table=ent["table"], ent=ent, rt=r)
 
     def _fill_temb_tables(self):
@@ -261,7 +261,12 @@ class DenoiseLoop:
         ts, step = self._keep[0], self._keep[1]
         for info in getattr(self, "_temb", {}).values():
             ent, r = info["ent"], info["rt"]
-            if ent["ts"] is not None and ent["ts"].shape == ts.shape and torch.equal(ent["ts"], ts):
+            # (this package's schedulers keep the timesteps on the host: compare there -- a device compare synchronises)
+            host = getattr(self.scheduler, "_ts_host", None) if not self.foreign else None
+            hkey = tuple(host.tolist()) if host is not None else None
+            if hkey is not None and ent.get("hkey") == hkey:
+                continue
+            if hkey is None and ent["ts"] is not None and ent["ts"].shape == ts.shape and torch.equal(ent["ts"], ts):
                 continue
             stream = torch.cuda.current_stream().cuda_stream
             saved = step.clone()
@@ -275,6 +280,7 @@ class DenoiseLoop:
                 info["table"][i].copy_(view)
             step.copy_(saved)
             ent["ts"] = ts.clone()
+            ent["hkey"] = hkey
 
     def _side_scale(self, v):
         """One entry of `run`'s scale schedule as the side runtime stores it (guess mode: the per-residual ramp)."""
@@ -346,10 +352,11 @@ class DenoiseLoop:
         return self.latents
 
     def _check_faults(self):
-        """One synchronisation per pipeline call: the networks' in-kernel split-K combines prove their XCD co-location per
-        tile and count violations (NetRuntime.check_faults)."""
+        """Only where a plan combines split-K in-kernel (none of the shipping plans does: pp_gemm_combine_ctr_bytes() advises it
+        nowhere): one synchronisation per pipeline call -- those combines prove their XCD co-location per tile and count
+        violations (NetRuntime.check_faults)."""
         for r in (getattr(self, "rt", None), getattr(self, "side_rt", None)):
-            if r is not None:
+            if r is not None and r.combines_in_kernel():
                 r.check_faults()
 
     def _run_foreign(self, latents, num_steps, use_graph, callback, timesteps, scale_schedule):

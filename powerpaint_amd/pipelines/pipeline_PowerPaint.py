@@ -123,10 +123,10 @@ class StableDiffusionInpaintPipeline(PipelineBase):
                                                               return_image_latents=four, return_all=True)
         # 5./7. mask + masked-image latents
         if not pixels:
+            # (latent-space inputs stay un-duplicated: the loop copies a tensor with the un-duplicated batch to both CFG halves
+            #  itself -- `torch.cat([m] * 2)` here would only make it compare the halves again, a device synchronisation)
             m = mask_latents.to(device=device, dtype=torch.float32)
             mil = masked_image_latents.to(device)
-            if do_cfg and m.shape[0] == nb:
-                m, mil = torch.cat([m] * 2), torch.cat([mil] * 2)
         else:
             m, mil = self.prepare_mask_latents(mk, masked_image, nb, height, width, prompt_embeds.dtype, device,
                                                generator, do_cfg, masked_image_latents)

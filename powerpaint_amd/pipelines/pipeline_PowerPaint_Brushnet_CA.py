@@ -169,8 +169,7 @@ class StableDiffusionPowerPaintBrushNetPipeline(PipelineBase):
             ml = hip_mask_prep(2, original_mask, None, (B0, 1, hl, wl), B0, 1, H0, W0, hl, wl)  # nearest  :1342-1344
             conditioning_latents = torch.cat([cl.float(), ml], 1)                            # :1345
         conditioning_latents = conditioning_latents.to(device)
-        if do_cfg and not guess_mode and conditioning_latents.shape[0] == nb:
-            conditioning_latents = torch.cat([conditioning_latents] * 2)
+        # (an un-duplicated tensor stays so: the loop copies it to both CFG halves itself, without comparing them)
         if do_cfg and guess_mode and conditioning_latents.shape[0] != nb:
             raise ValueError("guess_mode runs BrushNet on the conditional half only: conditioning_latents must have "
                              f"batch {nb}, got {conditioning_latents.shape[0]}")

@@ -101,8 +101,7 @@ class StableDiffusionControlNetInpaintPipeline(StableDiffusionInpaintPipeline):
         if not pixels:
             m = mask_latents.to(device=device, dtype=torch.float32)
             mil = masked_image_latents.to(device)
-            if do_cfg and m.shape[0] == nb:
-                m, mil = torch.cat([m] * 2), torch.cat([mil] * 2)
+            # (left un-duplicated: the loop copies an un-duplicated tensor to both CFG halves itself, without comparing them)
         else:
             m, mil = self.prepare_mask_latents(mk, masked_image, nb, height, width, prompt_embeds.dtype, device,
                                                generator, do_cfg, masked_image_latents)

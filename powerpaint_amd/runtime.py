@@ -246,6 +246,10 @@ class NetRuntime:
             self.step_plan.run(_stream())
         self.graph = g
 
+    def combines_in_kernel(self) -> bool:
+        """Does the step plan hand tile counters to any split-K launch (PPGemmArgs.tile_ctr)?"""
+        return any(getattr(a, "tile_ctr", None) for a in getattr(self.step_plan, "keep", []))
+
     def check_faults(self):
         """Synchronises.  The in-kernel split-K combine sums a tile's slabs through ONE XCD's L2; the workgroup that does it
         proves, from the arrival counter, that every split of its tile ran on that XCD and counts a violation otherwise

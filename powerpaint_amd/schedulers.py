@@ -230,6 +230,8 @@ class DDIMScheduler(_SchedulerBase):
         rewritten in place, so a captured step graph picks the new values up."""
         if not 0.0 <= float(eta) <= 1.0:
             raise ValueError(f"eta must be in [0, 1], got {eta}")
+        if float(eta) == self.eta and self.timesteps is not None:
+            return self               # (the table set_timesteps / set_begin_index filled already carries this eta)
         self.eta = float(eta)
         if self.timesteps is not None:
             self._fill_table()
