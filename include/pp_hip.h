@@ -409,7 +409,8 @@ int pp_ddim_variance_noise(float* latents, const float* noise, int n, const floa
  * pp_attention_fwd reads.  Arithmetic = pp_groupnorm_apply_acc -> pp_gemm_bf16(row_stats_out) -> pp_gemm_bf16(ln_stats)
  * up to the fp32 summation order.  pp_tfront_supported() = 1 for c = 320, 128-row tiles inside one batch item.
  * q_scale (ABI v20): the Q third is multiplied by it in fp32 before its one rounding to 16 bits -- 1.0 for
- * pp_attention_fwd, head_dim^-0.5 * log2(e) for PP_ATTN_PIPE_LOG2. */
+ * pp_attention_fwd, head_dim^-0.5 * log2(e) for PP_ATTN_PIPE_LOG2.  hs and qk: 16-byte aligned, ldhs % 8 == ldqk % 8 == 0
+ * (round 6: the rows leave as whole 128-byte lines). */
 int pp_tfront_supported(int M, int c, int rows_per_batch, int gn_groups);
 int pp_tfront(const void* x, int ldx, const void* gn_acc, const float* gn_gamma, const float* gn_beta, float gn_eps, int gn_groups,
               const void* w1, const float* b1, const void* w2p, const float* cs2, const float* b2, float ln_eps, void* hs,

@@ -26,6 +26,7 @@
 #include <utility>
 
 #include "pp_common.h"
+#include "rowtile_io.h"
 
 namespace {
 
@@ -33,7 +34,8 @@ constexpr int XA_C = 320, XA_HEADS = 8, XA_KP = 80, XA_S = XA_HEADS * XA_KP;   /
 constexpr int XA_BM = 128;
 constexpr int XA_SLAB = 320 * 128, XA_NS = 3, XA_NSLAB = 20;
 constexpr int XA_TAB = XA_NS * XA_SLAB;                   // (logit colsum | logit bias) of the batch item, fp32 [2][640]
-constexpr int XA_LDS = XA_TAB + 2 * XA_S * 4 + XA_C * 4;   // (+ the bias of the Linear in front, PRE)
+constexpr int XA_STG = XA_TAB + 2 * XA_S * 4 + XA_C * 4;   // (+ the bias of the Linear in front, PRE); then the eight waves'
+constexpr int XA_LDS = XA_STG + 8 * RT_TILE;               // private output / residual staging tiles (rowtile_io.h)
 constexpr int XA_QD = 8;                                  // fragment reads kept in flight ahead of their MFMA
 
 typedef __attribute__((address_space(3))) void* xa_lds_ptr_t;
@@ -303,23 +305,34 @@ __global__ void __launch_bounds__(512, 2) xattn_block_kernel(const XAArgs a) {
 #pragma unroll
   for (int nb = 0; nb < 20; ++nb) acc[nb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   // PRE, after the five pre_w slabs: + bias + residual, rounded to 16 bits; row moments of the rounded values (LayerNorm)
-  u32x2_t rv[20];
+  // Residual rows arrive row-major, two 16-byte pieces per lane and 64-column chunk (whole 128-byte lines), and are turned
+  // into the accumulator layout through the wave's private LDS tile when they are used; output rows leave the same way
+  // (rowtile_io.h: as 8-byte pieces scattered over 16 rows the epilogue was 19 of this kernel's 56 us).
+  u32x4_t rv4[10];
   f32x4_t bo[20];
-  // (its residual and bias: fetched one slab early, under the MFMAs of pre_w's fourth slab)
-  auto prefetch_pre = [&]() __attribute__((always_inline)) {
-    const uint16_t* rp = a.res ? a.res + (size_t)ms * a.ldres : nullptr;
+  char* const stg = smem + XA_STG + wave * RT_TILE;
+  const int m_w0 = m_blk + wave * 16;                    // first row of the wave's tile
+  auto load_rows = [&](const uint16_t* base, int ld, bool wrap) __attribute__((always_inline)) {
 #pragma unroll
-    for (int nb = 0; nb < 20; ++nb) {
-      const int n = nb * 16 + 4 * g;
-      rv[nb] = rp ? *reinterpret_cast<const u32x2_t*>(rp + n) : u32x2_t{0u, 0u};
-    }
+    for (int c = 0; c < 5; ++c)
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const int q = lane + 64 * jj;
+        int mr = m_w0 + (q >> 3);
+        if (wrap && a.src_wrap > 0 && mr >= a.src_wrap) mr -= a.src_wrap;
+        rv4[c * 2 + jj] = base ? *reinterpret_cast<const u32x4_t*>(base + (size_t)mr * ld + c * 64 + (q & 7) * 8) : u32x4_t{0u, 0u, 0u, 0u};
+      }
   };
+  // (its residual and bias: fetched one slab early, under the MFMAs of pre_w's fourth slab)
+  auto prefetch_pre = [&]() __attribute__((always_inline)) { load_rows(a.res, a.ldres, true); };
   auto finish_pre = [&]() __attribute__((always_inline)) {
     float sm = 0.f, sq = 0.f;
+    u32x2_t pk[4];
 #pragma unroll
     for (int nb = 0; nb < 20; ++nb) {
       const int n = nb * 16 + 4 * g;
-      const u32x2_t r = rv[nb];
+      if ((nb & 3) == 0) rt_fill(stg, lane, rv4[(nb >> 2) * 2], rv4[(nb >> 2) * 2 + 1]);
+      const u32x2_t r = rt_get(stg, r16, g, nb & 3);
       const f32x4_t bb = *reinterpret_cast<const f32x4_t*>(tabs + 2 * XA_S + n);
       const f32x4_t v = acc[nb] + bb + f32x4_t{E::lo(r[0]), E::hi(r[0]), E::lo(r[1]), E::hi(r[1])};
       const uint32_t o0 = E::pack2(v[0], v[1]), o1 = E::pack2(v[2], v[3]);
@@ -328,10 +341,15 @@ __global__ void __launch_bounds__(512, 2) xattn_block_kernel(const XAArgs a) {
       sq += (r0 * r0 + r1 * r1) + (r2 * r2 + r3 * r3);
       hq[nb >> 1][(nb & 1) * 2 + 0] = o0;
       hq[nb >> 1][(nb & 1) * 2 + 1] = o1;
-      // h is also the residual of the epilogue, fifteen slabs from here: parked in this lane's own piece of `out` (40 more
-      // live registers would spill) and read back by the same lane under the last slab
-      *reinterpret_cast<u32x2_t*>(a.out + (size_t)m * a.ldo + n) = u32x2_t{o0, o1};
+      // h is also the residual of the epilogue, fifteen slabs from here: parked in the wave's own rows of `out` (40 more
+      // live registers would spill) and read back by the same wave under the last slab
       acc[nb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      pk[nb & 3] = u32x2_t{o0, o1};
+      if ((nb & 3) == 3) {                                // (the chunk's four residual reads are done: the tile takes the outputs)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rt_put(stg, r16, g, j, pk[j][0], pk[j][1]);
+        rt_flush(stg, lane, a.out + (size_t)m_w0 * a.ldo, a.ldo, (nb >> 2) * 64);
+      }
     }
     if (a.ln_tiles > 0) {                                  // (LayerNorm folded into the logits: ln_tiles > 0 says so)
       sm += __shfl_xor(sm, 16, 64); sq += __shfl_xor(sq, 16, 64);
@@ -382,7 +400,8 @@ __global__ void __launch_bounds__(512, 2) xattn_block_kernel(const XAArgs a) {
   };
 
   // residual of the epilogue: fetched under the last slab's MFMAs (after stores nothing could be hoisted)
-  const uint16_t* rr = PRE ? a.out + (size_t)m * a.ldo : (a.res ? a.res + (size_t)ms * a.ldres : nullptr);
+  const uint16_t* const rr = PRE ? a.out : a.res;       // (PRE: h, parked in `out` by this wave; never wrapped)
+  const int rr_ld = PRE ? a.ldo : a.ldres;
   __syncthreads();                                        // the tables are in LDS
   issue(std::integral_constant<int, 0>{});
   issue(std::integral_constant<int, 1>{});
@@ -394,13 +413,7 @@ __global__ void __launch_bounds__(512, 2) xattn_block_kernel(const XAArgs a) {
     if constexpr (!(DBG & 32)) asm volatile("s_barrier" ::: "memory");
     if constexpr (tt + 2 < NSLAB) issue(std::integral_constant<int, tt + 2>{});   // (its stage was read at step tt - 1)
     if constexpr (PRE && tt == 3) prefetch_pre();
-    if constexpr (tt + 1 == NSLAB) {
-#pragma unroll
-      for (int nb = 0; nb < 20; ++nb) {
-        const int n = nb * 16 + 4 * g;
-        rv[nb] = rr ? *reinterpret_cast<const u32x2_t*>(rr + n) : u32x2_t{0u, 0u};
-      }
-    }
+    if constexpr (tt + 1 == NSLAB) load_rows(rr, rr_ld, !PRE);
     const char* st = smem + (tt % XA_NS) * XA_SLAB;
     // the slab's 40 weight fragments (ks 0 / 1 x 20 blocks) as a hand-made software pipeline: eight ds_read_b128 stay in
     // flight ahead of the MFMA that consumes the oldest (left to itself the compiler keeps ~5 reads ahead of an MFMA that
@@ -451,17 +464,23 @@ __global__ void __launch_bounds__(512, 2) xattn_block_kernel(const XAArgs a) {
     if (acc[0][0] == 12345.f) a.out[m] = 1;
     return;
   }
-  uint16_t* orow = a.out + (size_t)m * a.ldo;
 #pragma unroll
   for (int nb = 0; nb < 20; ++nb)                        // (L2-resident 1.25 KB; all twenty loads before the first store)
     bo[nb] = a.bias_o ? *reinterpret_cast<const f32x4_t*>(a.bias_o + nb * 16 + 4 * g) : f32x4_t{0.f, 0.f, 0.f, 0.f};
   float sm[2] = {0.f, 0.f}, sq[2] = {0.f, 0.f};
+  u32x2_t pk[4];
 #pragma unroll
   for (int nb = 0; nb < 20; ++nb) {
-    const int n = nb * 16 + 4 * g;
-    const f32x4_t v = acc[nb] + bo[nb] + f32x4_t{E::lo(rv[nb][0]), E::hi(rv[nb][0]), E::lo(rv[nb][1]), E::hi(rv[nb][1])};
+    if ((nb & 3) == 0) rt_fill(stg, lane, rv4[(nb >> 2) * 2], rv4[(nb >> 2) * 2 + 1]);
+    const u32x2_t r = rt_get(stg, r16, g, nb & 3);
+    const f32x4_t v = acc[nb] + bo[nb] + f32x4_t{E::lo(r[0]), E::hi(r[0]), E::lo(r[1]), E::hi(r[1])};
     const uint32_t o0 = E::pack2(v[0], v[1]), o1 = E::pack2(v[2], v[3]);
-    *reinterpret_cast<u32x2_t*>(orow + n) = u32x2_t{o0, o1};
+    pk[nb & 3] = u32x2_t{o0, o1};
+    if ((nb & 3) == 3) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) rt_put(stg, r16, g, j, pk[j][0], pk[j][1]);
+      rt_flush(stg, lane, a.out + (size_t)m_w0 * a.ldo, a.ldo, (nb >> 2) * 64);
+    }
     const float r0 = E::lo(o0), r1 = E::hi(o0), r2 = E::lo(o1), r3 = E::hi(o1);
     sm[nb / 10] += (r0 + r1) + (r2 + r3);
     sq[nb / 10] += (r0 * r0 + r1 * r1) + (r2 * r2 + r3 * r3);
@@ -656,8 +675,10 @@ __global__ void __launch_bounds__(256, 1) xattn_wide_kernel(const XAArgs a) {
 
   // ---- second GEMM: this column group's 320 outputs, K = 640 probabilities out of the registers
   const int n_out = cg * 320;
-  const uint16_t* rr = a.res ? a.res + (size_t)m * a.ldres + n_out : nullptr;
-  u32x2_t rv[20];
+  // (residual in / rows out as whole 128-byte lines through the wave's private LDS tile: rowtile_io.h)
+  const int m_w0 = m_blk + wave * 16;
+  char* const stg = smem + XA_STG + wave * RT_TILE;
+  u32x4_t rv4[10];
   f32x4_t bo[20];
   xa_static_for<10>([&](auto U) __attribute__((always_inline)) {
     constexpr int u = decltype(U)::value;
@@ -666,8 +687,13 @@ __global__ void __launch_bounds__(256, 1) xattn_wide_kernel(const XAArgs a) {
     else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     if constexpr (u + 1 == 10) {
 #pragma unroll
-      for (int nb = 0; nb < 20; ++nb)
-        rv[nb] = rr ? *reinterpret_cast<const u32x2_t*>(rr + nb * 16 + 4 * g) : u32x2_t{0u, 0u};
+      for (int c = 0; c < 5; ++c)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+          const int q = lane + 64 * jj;
+          rv4[c * 2 + jj] = a.res ? *reinterpret_cast<const u32x4_t*>(a.res + (size_t)(m_w0 + (q >> 3)) * a.ldres + n_out + c * 64 + (q & 7) * 8)
+                                  : u32x4_t{0u, 0u, 0u, 0u};
+        }
     }
     const v8_t b0 = __builtin_bit_cast(v8_t, u32x4_t{pf[2 * u][0], pf[2 * u][1], pf[2 * u][2], pf[2 * u][3]});
     const v8_t b1 = __builtin_bit_cast(v8_t, u32x4_t{pf[2 * u + 1][0], pf[2 * u + 1][1], pf[2 * u + 1][2], pf[2 * u + 1][3]});
@@ -675,17 +701,23 @@ __global__ void __launch_bounds__(256, 1) xattn_wide_kernel(const XAArgs a) {
   });
 
   // ---- epilogue: + bias + residual, 16-bit stores, row moments of the stored values per 160-column tile
-  uint16_t* orow = a.out + (size_t)m * a.ldo + n_out;
 #pragma unroll
   for (int nb = 0; nb < 20; ++nb)
     bo[nb] = a.bias_o ? *reinterpret_cast<const f32x4_t*>(a.bias_o + n_out + nb * 16 + 4 * g) : f32x4_t{0.f, 0.f, 0.f, 0.f};
   float sm[2] = {0.f, 0.f}, sq[2] = {0.f, 0.f};
+  u32x2_t pk[4];
 #pragma unroll
   for (int nb = 0; nb < 20; ++nb) {
-    const int n = nb * 16 + 4 * g;
-    const f32x4_t v = acc[nb] + bo[nb] + f32x4_t{E::lo(rv[nb][0]), E::hi(rv[nb][0]), E::lo(rv[nb][1]), E::hi(rv[nb][1])};
+    if ((nb & 3) == 0) rt_fill(stg, lane, rv4[(nb >> 2) * 2], rv4[(nb >> 2) * 2 + 1]);
+    const u32x2_t r = rt_get(stg, r16, g, nb & 3);
+    const f32x4_t v = acc[nb] + bo[nb] + f32x4_t{E::lo(r[0]), E::hi(r[0]), E::lo(r[1]), E::hi(r[1])};
     const uint32_t o0 = E::pack2(v[0], v[1]), o1 = E::pack2(v[2], v[3]);
-    *reinterpret_cast<u32x2_t*>(orow + n) = u32x2_t{o0, o1};
+    pk[nb & 3] = u32x2_t{o0, o1};
+    if ((nb & 3) == 3) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) rt_put(stg, r16, g, j, pk[j][0], pk[j][1]);
+      rt_flush(stg, lane, a.out + (size_t)m_w0 * a.ldo, a.ldo, n_out + (nb >> 2) * 64);
+    }
     const float r0 = E::lo(o0), r1 = E::hi(o0), r2 = E::lo(o1), r3 = E::hi(o1);
     sm[nb / 10] += (r0 + r1) + (r2 + r3);
     sq[nb / 10] += (r0 * r0 + r1 * r1) + (r2 * r2 + r3 * r3);
@@ -750,7 +782,8 @@ extern "C" int pp_xattn_block(const void* x, int ldx, const void* res, int ldres
   if (src_wrap_rows > 0 && c != XA_C) return PP_ERR_UNSUPPORTED;
   if (pre_w && c != XA_C) return PP_ERR_UNSUPPORTED;
   if (pre_b && !pre_w) return PP_ERR_BAD_ARG;
-  if (ldx < c || (ldx & 7) || ldo < c || (ldo & 3) || (res && (ldres < c || (ldres & 3)))) return PP_ERR_BAD_ARG;
+  if (ldx < c || (ldx & 7) || ldo < c || (ldo & 7) || (res && (ldres < c || (ldres & 7)))) return PP_ERR_BAD_ARG;   // (16-byte row pieces)
+  if ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(res)) & 15) return PP_ERR_BAD_ARG;
   if (ln_stats && ln_tiles <= 0) return PP_ERR_BAD_ARG;
   XAArgs a;
   a.x = (const uint16_t*)x; a.ldx = ldx;
