@@ -89,7 +89,7 @@ attn_pipe_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __rest
                  const uint16_t* __restrict__ vt, int ldvt, uint16_t* __restrict__ o, int ldo, int heads, int nq, int nk,
                  float scale_log2e) {
   // dbg (PP_ATTN_DBG, timing experiments only; results are garbage): 1 no MFMA, 2 no exp, 4 no tile DMA / barrier,
-  // 8 no LDS fragment reads
+  // 8 no LDS fragment reads, 16 no output store
   constexpr int SUBS = (OPT & 16) ? 2 : 1;
   constexpr int KT = KB * SUBS;
   constexpr bool BAKE = (OPT & 64) != 0;
@@ -488,7 +488,8 @@ attn_pipe_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __rest
             u32x2_t w;
             w[0] = E::pack2(oacc[qb][dt][4 * g + 0] * inv, oacc[qb][dt][4 * g + 1] * inv);
             w[1] = E::pack2(oacc[qb][dt][4 * g + 2] * inv, oacc[qb][dt][4 * g + 3] * inv);
-            *reinterpret_cast<u32x2_t*>(op + dc) = w;
+            if constexpr (!(dbg & 16)) *reinterpret_cast<u32x2_t*>(op + dc) = w;
+            else if (w[0] == 0x12345u) op[0] = 1;
           }
         }
     }
@@ -575,6 +576,9 @@ int pp_attention_pipe_launch(const void* q, int ldq, const void* k, int ldk, con
   const bool q64 = variant == PP_ATTN_PIPE_Q64 || ((variant == PP_ATTN_AUTO || log2q) && wg2 >= 512);
   if (log2q) {
     constexpr int O64 = PP_ATTN_OPT_DEFAULT | 64, O32 = (PP_ATTN_OPT_DEFAULT & ~16) | 64;
+#ifdef PP_LAB
+    if (q64 && dtype == PP_DT_BF16 && pp_lab_env("PP_ATTN_NOSTORE", 0)) return launch_pipe<32, 16, PP_DT_BF16, 4, 2, O64>(PP_ARGS);
+#endif
     if (q64) {
       if (dtype == PP_DT_F16) return launch_pipe<32, 0, PP_DT_F16, 4, 2, O64>(PP_ARGS);
       return launch_pipe<32, 0, PP_DT_BF16, 4, 2, O64>(PP_ARGS);
