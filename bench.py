@@ -150,8 +150,8 @@ def roofline_pass(pipe):
     return per, flops, counts, alg_bytes, hbm_bytes
 
 
-TRAFFIC_PROFILE = "profiles/r05_hbm_traffic.json"         # tools/hbm_traffic.sh (two rocprofv3 --pmc passes of this bench)
-KERNEL_STATS_PROFILE = "profiles/r05_kernel_stats.txt"     # rocprofv3 --kernel-trace --stats of this bench (tools/gpu_round.sh)
+TRAFFIC_PROFILE = "profiles/r06_hbm_traffic.json"         # tools/hbm_traffic.sh (two rocprofv3 --pmc passes of this bench)
+KERNEL_STATS_PROFILE = "profiles/r06_kernel_stats.txt"     # rocprofv3 --kernel-trace --stats of this bench (tools/gpu_round.sh)
 
 
 def lib_sha16() -> str:
