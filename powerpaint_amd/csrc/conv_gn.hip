@@ -173,7 +173,7 @@ __global__ void __launch_bounds__(CG_T, 2) pp_conv_gn_kernel(const PPGemmArgs a,
   if (ch_b < ch_e) {
     // (gamma, beta) of chunk c -> table buffer gbuf (every wave issues the same 1 KB piece: identical bytes)
     auto issue_gb = [&](int c, int gbuf, bool live) __attribute__((always_inline)) {
-      const __amdgpu_buffer_rsrc_t rs = make_rsrc(a.gn_in_gb, live ? (uint32_t)ctot * 8u : 0u);
+      const __amdgpu_buffer_rsrc_t rs = make_rsrc(a.gn_in_gb, (NORM && live) ? (uint32_t)ctot * 8u : 0u);   // (raw input: nothing is read)
       const int vo = lane < 32 ? lane * 16 : (int)PP_OOB;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (cg_lds_t)(smem + CG_T_GB + gbuf * 1024), 16, vo, c * 512, 0, 0);
     };
@@ -291,7 +291,7 @@ __global__ void __launch_bounds__(CG_T, 2) pp_conv_gn_kernel(const PPGemmArgs a,
       for (int j = 0; j < CG_HPW; ++j) issue_halo_piece(0, j);
       issue_gb(ch_b, 0, true);
     }
-    if (tid < a.gn_in_groups) {     // (the arithmetic of gn_fold_acc, norm.hip)
+    if (NORM && tid < a.gn_in_groups) {     // (the arithmetic of gn_fold_acc, norm.hip)
       const long long* ap = reinterpret_cast<const long long*>(a.gn_in_acc) + ((size_t)bimg * a.gn_in_groups + tid) * 2;
       const double s = (double)ap[0] * (1.0 / (double)PP_GN_SUM_SCALE);
       const double q = (double)ap[1] * (1.0 / (double)PP_GN_SQ_SCALE);
@@ -657,8 +657,7 @@ __global__ void __launch_bounds__(CG_T, 2) pp_conv_gn_kernel(const PPGemmArgs a,
   // (ABI v21) the split-K combine by the workgroup that arrives last at its tile (gemm_combine.h)
   if (splitk && a.tile_ctr) {
     static_assert(fc_lds_bytes(BM) <= CG_LDS, "fused combine staging must fit in the kernel's LDS");
-    if (splitk_arrive(a, blockIdx.x, splits, tid, reinterpret_cast<int*>(smem + fc_flag_off(BM))) == 0) return;
-    splitk_fused_combine<BM, T, EDT>(a, smem, m_blk, n_blk, splits, tid);
+    splitk_fused_combine<BM, T, EDT>(a, smem, m_blk, n_blk, blockIdx.x, blockIdx.y, splits, tid);
   }
 }
 
@@ -673,17 +672,17 @@ bool cg_shape_ok(const PPGemmArgs& a, int bm) {
   return bm % a.win == 0 && hw % bm == 0 && bm + 2 * a.win <= CG_HALO_PX;
 }
 
-bool cg_supported(const PPGemmArgs& a) {
-  if (a.x_mode != PP_X_CONV3X3 || !a.gn_in_acc || !a.gn_in_gb || !pp_dt_ok(a.dtype)) return false;
+// what the halo-tile kernel needs of a conv whatever stands in front of it
+bool cg_geometry_ok(const PPGemmArgs& a) {
+  if (a.x_mode != PP_X_CONV3X3 || !pp_dt_ok(a.dtype)) return false;
   if (a.stride != 1 || a.up || a.hin != a.hout || a.win != a.wout || a.win < 8 || (a.win & 7)) return false;
-  if (a.gn_in_silu != 1 || a.gn_in_groups <= 0 || a.gn_in_groups > 32) return false;
   const int ctot = a.c1 + a.c2;
-  if (a.c1 <= 0 || a.c1 % 64 || a.c2 % 64 || (a.c2 > 0 && !a.x2) || ctot % a.gn_in_groups) return false;
+  if (a.c1 <= 0 || a.c1 % 64 || a.c2 % 64 || (a.c2 > 0 && !a.x2)) return false;
   if (a.c3 < 0 || a.c4 < 0 || a.c3 % 64 || a.c4 % 64 || (a.c3 > 0 && !a.x3) || (a.c4 > 0 && (!a.x4 || a.c3 == 0))) return false;
   if (a.K != 9 * ctot + a.c3 + a.c4 || a.M != a.batch * a.hout * a.wout || a.M <= 0 || a.N <= 0) return false;
   if (a.N % 8 || a.ldo % 8 || a.out_f32 || a.out_vt || a.act != PP_ACT_NONE || a.ln_stats || a.row_stats_out) return false;
   if ((a.res1 && a.ldres1 % 8) || (a.res2 && a.ldres2 % 8)) return false;
-  if (a.rows_per_batch != a.hout * a.wout) return false;
+  if (a.rows_per_batch != a.hout * a.wout || a.out_dup_rows > 0 || a.w_batch_stride > 0 || a.vec_batch_stride > 0) return false;
   if ((uint64_t)a.batch * a.hin * a.win * (uint64_t)(a.c1 > a.c2 ? a.c1 : a.c2) * 2u >= 0x80000000ull) return false;
   if ((uint64_t)a.N * (uint64_t)a.K * 2u >= 0x80000000ull) return false;
   if ((uint64_t)a.M * (uint64_t)(a.c3 > a.c4 ? a.c3 : a.c4) * 2u >= 0x80000000ull) return false;
@@ -691,6 +690,26 @@ bool cg_supported(const PPGemmArgs& a) {
     if (a.gn_acc[k] && (a.gn_cg[k] < 8 || a.gn_groups[k] <= 0 || a.gn_c0[k] < 0)) return false;
   return cg_shape_ok(a, 256) || cg_shape_ok(a, 128) || cg_shape_ok(a, 64);
 }
+
+// norm -> SiLU -> conv3x3 in one launch (the request carries the producers' statistics of its input)
+bool cg_fused_ok(const PPGemmArgs& a) {
+  if (!a.gn_in_acc || !a.gn_in_gb || !cg_geometry_ok(a)) return false;
+  if (a.gn_in_silu != 1 || a.gn_in_groups <= 0 || a.gn_in_groups > 32) return false;
+  return (a.c1 + a.c2) % a.gn_in_groups == 0;
+}
+
+// A plain conv3x3 (input already normalised, or none: conv behind an apply launch) on the SAME halo-tile loop without the
+// normalisation (NMODE = 2): every input pixel crosses the 64 B/clk global -> LDS path once per tile (+ halo rows) instead
+// of once per tap, 52 against 58 us at 64x64 (K = 2880), 58 against 65 at 32x32 (K = 5760) beside the tap-major kernel
+// (tools/conv_gn_shapes.py, profiles/r06_conv_raw.txt).  Taken where the automatic choice is asked for (tile = AUTO) and
+// the image is at least 32 wide: below that the launches are split-K weight streams and the tap-major kernel's N-major
+// tile order wins.  (lab) PP_CONV_RAW = the smallest image width routed here (0 = never)
+bool cg_raw_ok(const PPGemmArgs& a) {
+  static const int min_w = pp_lab_env("PP_CONV_RAW", 32);
+  if (a.gn_in_acc || a.gn_in_gb || a.tile != PP_TILE_AUTO || min_w <= 0 || a.win < min_w) return false;
+  return cg_geometry_ok(a);
+}
+bool cg_supported(const PPGemmArgs& a) { return a.gn_in_acc ? cg_fused_ok(a) : cg_raw_ok(a); }
 
 CGChoice cg_choose(const PPGemmArgs& a) {
   const int tn = (a.N + 159) / 160;
@@ -755,7 +774,7 @@ int cg_launch(const PPGemmArgs& a, int splitk, hipStream_t st) {
   d.ntail3 = a.c3 / 64;
   d.ntail = (a.c3 + a.c4) / 64;
   d.hp = BM + 2 * a.win;
-  d.cg = (a.c1 + a.c2) / a.gn_in_groups;
+  d.cg = a.gn_in_groups > 0 ? (a.c1 + a.c2) / a.gn_in_groups : 1;
   d.inv_cg = 1.0f / (float)d.cg;
   hipLaunchKernelGGL(kern, dim3(d.tiles_m * d.tiles_n, splitk, 1), dim3(CG_T), CG_LDS, st, a, d);
   PP_CHECK_LAUNCH("pp_conv_gn_kernel");
@@ -802,6 +821,13 @@ int cg_dispatch(const PPGemmArgs& a, const CGChoice& c, hipStream_t st) {
 #undef CG_CASE
   }
 #endif
+  if (!a.gn_in_acc) {                 // plain conv: the loop without the normalisation (cg_raw_ok)
+    switch (c.bm) {
+      case 256: return cg_launch_hpw<256, true, 2, EDT>(a, c.splitk, st);
+      case 128: return cg_launch_hpw<128, true, 2, EDT>(a, c.splitk, st);
+      default: return cg_launch_hpw<64, true, 2, EDT>(a, c.splitk, st);
+    }
+  }
   switch (c.bm) {
     case 256: return cg_launch_hpw<256, true, 1, EDT>(a, c.splitk, st);
     case 128: return cg_launch_hpw<128, true, 1, EDT>(a, c.splitk, st);
@@ -812,7 +838,9 @@ int cg_dispatch(const PPGemmArgs& a, const CGChoice& c, hipStream_t st) {
 }  // namespace
 
 // entry points used by gemm.hip's pp_gemm_bf16 / pp_gemm_workspace_bytes (one C-ABI call per conv, whichever kernel runs)
-bool pp_conv_gn_wanted(const PPGemmArgs& a) { return a.x_mode == PP_X_CONV3X3 && a.gn_in_acc != nullptr; }
+// does this conv3x3 request run on the halo-tile kernel: the fused norm (asked for by gn_in_*; pp_gemm_bf16 refuses what the
+// kernel cannot do, never a silent fallback) or a plain conv the library routes there (cg_raw_ok)
+bool pp_conv_gn_wanted(const PPGemmArgs& a) { return a.x_mode == PP_X_CONV3X3 && (a.gn_in_acc != nullptr || cg_raw_ok(a)); }
 int pp_conv_gn_splitk(const PPGemmArgs& a) { return cg_supported(a) ? cg_choose(a).splitk : 0; }
 int pp_conv_gn_bm(const PPGemmArgs& a) { return cg_supported(a) ? cg_choose(a).bm : 0; }
 int pp_conv_gn_run(const PPGemmArgs& a, hipStream_t st) {
@@ -822,7 +850,12 @@ int pp_conv_gn_run(const PPGemmArgs& a, hipStream_t st) {
   return a.dtype == PP_DT_F16 ? cg_dispatch<PP_DT_F16>(a, c, st) : cg_dispatch<PP_DT_BF16>(a, c, st);
 }
 
-extern "C" int pp_conv_gn_supported(const PPGemmArgs* args) { return (args && cg_supported(*args)) ? 1 : 0; }
+// 1: the fused norm -> SiLU -> conv launch (gn_in_* set); 2: a plain conv3x3 that pp_gemm_bf16 routes to the same halo-tile
+// loop without the normalisation; 0: neither (the tap-major implicit GEMM runs it)
+extern "C" int pp_conv_gn_supported(const PPGemmArgs* args) {
+  if (!args) return 0;
+  return cg_fused_ok(*args) ? 1 : cg_raw_ok(*args) ? 2 : 0;
+}
 
 // Where the fused launch beats pp_groupnorm_apply_acc + plain conv inside the UNet step (same-box A/Bs of the headline
 // benchmark and per-launch timings, profiles/r04_conv_gn_variants.txt): the normalisation is ~600 wave cycles per strip
@@ -832,12 +865,19 @@ extern "C" int pp_conv_gn_supported(const PPGemmArgs* args) { return (args && cg
 //   class 4  W = 16 (N = 1280): draws per launch, wins the launch boundary
 //   class 8  W = 32 otherwise (concatenated inputs / long tails, 128-row tiles): +10 .. +40 us per launch back to back,
 //            a draw inside the step (9.61 against 9.62 ms) -- fused for the nine launches it removes
+//   Round 6: the plain conv behind an apply launch runs on this file's loop WITHOUT the normalisation (cg_raw_ok) instead of
+//   the tap-major kernel -- 52 against 58 us at 64x64 (K = 2880), 58 against 65 at 32x32 (K = 5760) -- and the apply kernel
+//   uses the hardware reciprocal in its SiLU (14.3 -> 11.4 us on the 21 MB tensors of the 64x64 level).  Classes 1, 2 and 8
+//   flip: back to back the 64x64 level costs 707 + 148 us per forward against 947 fused, the 32x32 level 769 + 114 against
+//   973; headline step, same box: everything fused 8.474 ms, classes 2 and 8 unfused 8.404, class 1 as well 8.380 (-1.1 %,
+//   twenty launches MORE; profiles/r06_conv_raw.txt).  Class 4 stays fused: at 16x16 the applies ride in the producers'
+//   split-K combines and the raw loop has no separate apply to hide behind.
 //   class 16 W <= 8: 64-row tiles, one workgroup per CU at 10 MFMAs per wave and K step: +10 .. +26 us, NOT fused
 //            (9.76 against 9.61 ms per step with it)
 // same-box step times, masks 0 / 1 / 5 / 7 / 15 / 31: 9.75 / 9.64 / 9.62 / 9.62 / 9.61 / 9.76 ms (251 .. 207 launches)
 // (lab build: PP_CONV_GN_ROUTE = bit mask of the classes to fuse)
 extern "C" int pp_conv_gn_preferred(const PPGemmArgs* args) {
-  if (!args || !cg_supported(*args)) return 0;
+  if (!args || !cg_fused_ok(*args)) return 0;
   const PPGemmArgs& a = *args;
   const int nch = (a.c1 + a.c2) / 64;
   int cls;
@@ -845,6 +885,6 @@ extern "C" int pp_conv_gn_preferred(const PPGemmArgs* args) {
   else if (a.win == 32) cls = (nch <= 5 && a.c2 == 0) ? 2 : 8;
   else if (a.win == 16) cls = 4;
   else cls = a.win < 16 ? 16 : 8;
-  static const int mask = pp_lab_env("PP_CONV_GN_ROUTE", 1 | 2 | 4 | 8);
+  static const int mask = pp_lab_env("PP_CONV_GN_ROUTE", 4);
   return (mask & cls) ? 1 : 0;
 }

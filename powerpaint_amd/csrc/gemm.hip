@@ -1217,8 +1217,7 @@ pp_gemm_kernel_v2(const PPGemmArgs a, const GemmDerived d) {   // 2nd bound = wa
     // the host only where every split of a tile runs on one XCD and the epilogue is the lean combine's
     if (splitk && a.tile_ctr) {
       static_assert(fc_lds_bytes(BM) <= NS * STAGE, "fused combine staging must fit in the pipeline stages");
-      if (splitk_arrive(a, blockIdx.x, gridDim.y, tid, reinterpret_cast<int*>(smem + fc_flag_off(BM))) == 0) return;
-      splitk_fused_combine<BM, T, EDT>(a, smem, m_blk, n_blk, gridDim.y, tid);
+      splitk_fused_combine<BM, T, EDT>(a, smem, m_blk, n_blk, blockIdx.x, blockIdx.y, gridDim.y, tid);
     }
   }
   }   // EPI != 2
@@ -1471,7 +1470,7 @@ __global__ void __launch_bounds__(640) pp_splitk_reduce_gn_apply_kernel(const PP
     r[6] = E::lo(v[3]) * a1[2] + b1[2]; r[7] = E::hi(v[3]) * a1[3] + b1[3];
     if (silu) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) r[j] = silu_f(r[j]);
+      for (int j = 0; j < 8; ++j) r[j] = silu_fast_f(r[j]);
     }
     u32x4_t o;
     o[0] = E::pack2(r[0], r[1]); o[1] = E::pack2(r[2], r[3]);
@@ -1581,20 +1580,23 @@ bool gn_next_shape_ok(const PPGemmArgs& a, int sub) {
 
 // (ABI v21) can the launch combine its split-K slabs in-kernel (gemm_combine.h)?  bm / tiles / pp_tile describe the form
 // pp_gemm_bf16 runs it in.  `with_consumers`: also honour what a consumer may have patched into the request (gn_next_*).
-bool fused_combine_shape_ok(const PPGemmArgs& a, int bm, int tiles, int splitk, bool pp_tile, bool with_consumers) {
-  if (splitk <= 1 || splitk > 8 || !pp_tile || !reduce_lean_ok(a)) return false;
+bool fused_combine_shape_ok(const PPGemmArgs& a, int bm, int tiles, int splitk, bool pp_tile, bool with_consumers, bool advice) {
+  if (!(splitk == 2 || splitk == 4 || splitk == 8) || !pp_tile || !reduce_lean_ok(a)) return false;
   if (tiles % 8) return false;                                   // every split of a tile on the XCD (tile id % 8)
-  // ONE workgroup pulls the tile's splitk x bm x 640 bytes (0.16 .. 1.3 MB) through one CU's 64 B/clk path while the rest
-  // of the chip idles: measured (tools/fc_time.py, tools/step_ab.sh; profiles/r06_fused_combine.txt) the tail costs 4-20 us
-  // MORE per launch than the separate combine (which spreads the same bytes over 256 CUs) from 128 rows x 8 splits up, and
-  // is a draw below (256 x 2, 128 x 2): headline step +3.0 % with every eligible launch combined in-kernel, +0.1 .. 0.25 %
-  // with only the small tiles.  So the library ADVISES it nowhere (pp_gemm_combine_ctr_bytes() = 0); a caller that hands
-  // counters over anyway gets it, bit-identical (tests/test_fused_combine_gpu.py).  (lab) PP_FUSED_COMBINE_ROWS = the
-  // largest splitk x rows product advised
-  static const int max_rows = pp_lab_env("PP_FUSED_COMBINE_ROWS", 0);
-  if (!with_consumers && splitk * bm > max_rows) return false;
+  if (bm % splitk || bm / splitk < 16) return false;             // a share = whole 16-row blocks
+  // ADVICE (what pp_gemm_combine_ctr_bytes() tells a planner; counters handed over anyway are honoured
+  // wherever the result is right).  Measured inside the headline step's hipGraph, kernel by kernel against the separate combine
+  // (rocprofv3, profiles/r06_fused_combine.txt): 2 and 4 splits win 0.5 .. 8 us per launch (shares of 32 .. 128 rows: the
+  // 16x16 and 32x32 levels, FF2 . proj_out at 16x16); 8 splits LOSE 2 .. 3 us (shares of 16 / 32 rows at the 8x8 level and the
+  // 32 -> 16 downsample: the tail is a chain of six ~1 us memory round trips -- drain, arrival, poll, slabs, statistics,
+  // second arrival -- against one 11 us kernel).  And only launches whose splits are all resident at once (one workgroup
+  // per CU): beyond that a split waits FC_SPIN_TICKS for a partner that cannot start.
+  // (lab) PP_FUSED_COMBINE_SPLITS = the largest split count advised
+  static const int max_splits = pp_lab_env("PP_FUSED_COMBINE_SPLITS", 4);
+  if (advice && (splitk > max_splits || tiles * splitk > pp_cu_count())) return false;
   if (a.M % bm || a.N % 8) return false;
   if ((uint64_t)splitk * (uint64_t)a.M * (uint64_t)a.N * 4u >= 0x80000000ull) return false;
+  if (a.rowvec && (a.rows_per_batch <= 0 || a.rows_per_batch % 64)) return false;   // a pass of <= 64 rows inside one batch item
   if (!with_consumers) return true;
   if ((a.gn_acc[0] || a.gn_acc[1]) && (a.rows_per_batch <= 0 || a.rows_per_batch % 64)) return false;
   if (a.gn_next_out) {
@@ -1880,29 +1882,29 @@ static PlannedForm planned_form(const PPGemmArgs& a) {
 extern "C" size_t pp_gemm_combine_ctr_bytes(const PPGemmArgs* args) {
   if (!args || validate(*args) != PP_OK) return 0;
   const PlannedForm f = planned_form(*args);
-  if (!fused_combine_shape_ok(*args, f.bm, f.tiles, f.splitk, f.pp_tile, false)) return 0;
+  if (!fused_combine_shape_ok(*args, f.bm, f.tiles, f.splitk, f.pp_tile, false, true)) return 0;
   if (!pp_xcd_placement_ok()) return 0;
-  return (size_t)f.tiles * sizeof(uint64_t);
+  return (size_t)f.tiles * FC_CTR_BYTES;
 }
 
 static bool combine_fused(const PPGemmArgs& a) {
   if (!a.tile_ctr) return false;
   const PlannedForm f = planned_form(a);
-  return fused_combine_shape_ok(a, f.bm, f.tiles, f.splitk, f.pp_tile, true);
+  return fused_combine_shape_ok(a, f.bm, f.tiles, f.splitk, f.pp_tile, true, false);
 }
 
 extern "C" int pp_gemm_combine_fused(const PPGemmArgs* args) {
   return (args && validate(*args) == PP_OK && combine_fused(*args)) ? 1 : 0;
 }
 
+// the fp32 slabs of a split-K launch + (behind them) the per-tile scratch of the in-kernel combine (gemm_combine.h)
 extern "C" size_t pp_gemm_workspace_bytes(const PPGemmArgs* args) {
   if (!args || validate(*args) != PP_OK) return 0;
-  if (pp_conv_gn_wanted(*args)) {
-    const int sk = pp_conv_gn_splitk(*args);
-    return sk > 1 ? (size_t)sk * args->M * args->N * sizeof(float) : 0;
-  }
-  const Choice c = choose(*args);
-  return c.splitk > 1 ? (size_t)c.splitk * args->M * args->N * sizeof(float) : 0;
+  const PlannedForm f = planned_form(*args);
+  const int sk = pp_conv_gn_wanted(*args) ? f.splitk : choose(*args).splitk;
+  if (sk <= 1) return 0;
+  const size_t scratch = fused_combine_shape_ok(*args, f.bm, f.tiles, f.splitk, f.pp_tile, false, false) ? (size_t)f.tiles * FC_SCR_BYTES : 0;
+  return (size_t)sk * args->M * args->N * sizeof(float) + scratch;
 }
 
 

@@ -186,7 +186,7 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const uint16_t* __restric
     r[6] = E16<EDT>::lo(v[3]) * a1[2] + b1[2]; r[7] = E16<EDT>::hi(v[3]) * a1[3] + b1[3];
     if (SILU) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) r[j] = silu_f(r[j]);
+      for (int j = 0; j < 8; ++j) r[j] = silu_fast_f(r[j]);
     }
     u32x4_t o;
     o[0] = E16<EDT>::pack2(r[0], r[1]); o[1] = E16<EDT>::pack2(r[2], r[3]);
@@ -312,7 +312,7 @@ __global__ void __launch_bounds__(256) gn_conv3x3_cout4_kernel(const uint16_t* _
         r[4] = E::lo(v[2]) * s1v[0] + h1v[0]; r[5] = E::hi(v[2]) * s1v[1] + h1v[1];
         r[6] = E::lo(v[3]) * s1v[2] + h1v[2]; r[7] = E::hi(v[3]) * s1v[3] + h1v[3];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) r[j] = silu_f(r[j]);
+        for (int j = 0; j < 8; ++j) r[j] = silu_fast_f(r[j]);
         u32x4_t o;
         o[0] = E::pack2(r[0], r[1]); o[1] = E::pack2(r[2], r[3]);
         o[2] = E::pack2(r[4], r[5]); o[3] = E::pack2(r[6], r[7]);

@@ -32,6 +32,21 @@ int pp_func_lds(const void* kern, int bytes, const char* what) {
   return PP_OK;
 }
 
+// compute units of the current device (cached per device; 256 if the query fails: the part this library is written for)
+int pp_cu_count() {
+  static std::mutex mu;
+  static std::map<int, int> cus;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 256;
+  std::lock_guard<std::mutex> g(mu);
+  auto it = cus.find(dev);
+  if (it != cus.end()) return it->second;
+  int n = 0;
+  if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+  cus[dev] = n;
+  return n;
+}
+
 // ---- workgroup -> XCD placement probe (ABI v21; what the in-kernel split-K combine's co-location rests on, gemm_combine.h)
 __global__ void __launch_bounds__(64) pp_xcc_probe_kernel(unsigned* out) {
   if (threadIdx.x == 0) {

@@ -56,7 +56,7 @@ def _attach_combine(a, device, enable):
     last_combine["fused"], last_combine["ctr"] = False, None
     if enable is None or enable is False:
         return
-    bound = ((a.M + 127) // 128) * ((a.N + 159) // 160) * 8       # 8 bytes per 128 x 160 tile always suffice
+    bound = ((a.M + 127) // 128) * ((a.N + 159) // 160) * 16      # 16 bytes per 128 x 160 tile always suffice
     if torch.is_tensor(enable):
         ctr = enable
         assert ctr.dtype == torch.int64 and ctr.numel() * 8 >= bound
@@ -149,6 +149,15 @@ def conv_gn_supported(x: torch.Tensor, cout: int, x2=None, x3=None, x4=None, gro
     a, _ = _conv_args(x, cout, 1, False, x2, x3, x4)
     a.gn_in_acc, a.gn_in_gb, a.gn_in_groups, a.gn_in_silu, a.gn_in_eps = 1, 1, groups, 1, 1e-5   # (non-null placeholders)
     return bool(L.lib().pp_conv_gn_supported(C.byref(a)))
+
+
+def conv_halo_routed(x: torch.Tensor, cout: int, x2=None, x3=None, x4=None, stride: int = 1, up: bool = False,
+                     tile: int = 0) -> bool:
+    """Does a PLAIN conv3x3 of these shapes run on the halo-tile loop (pp_conv_gn_supported() == 2) rather than the tap-major
+    implicit GEMM?"""
+    a, _ = _conv_args(x, cout, stride, up, x2, x3, x4)
+    a.tile = tile
+    return L.lib().pp_conv_gn_supported(C.byref(a)) == 2
 
 
 def _conv_args(x, cout, stride, up, x2, x3, x4):

@@ -220,3 +220,65 @@ def test_groupnorm_apply_in_combine_is_refused_where_it_cannot_run():
     with pytest.raises(L.PPError):
         ops.conv3x3(x, w, None, splitk=2, gn=[(acc, 10, 0, 32)],
                     gn_next=(torch.ones(320, device=DEV), torch.zeros(320, device=DEV), 1e-5, True, 0))
+
+
+# ---- round 6: a PLAIN conv3x3 on the halo-tile loop without the normalisation (pp_conv_gn_supported() == 2) ---------------
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,H,C1,C2,Cout,tail,splitk", [
+    (2, 64, 320, 0, 320, (0, 0), 0),          # 64x64 level
+    (2, 64, 640, 320, 320, (0, 0), 0),        # ... on a concatenated input (up block)
+    (2, 64, 320, 0, 320, (640, 320), 0),      # ... with conv_shortcut as a 1x1 K tail
+    (8, 32, 640, 0, 640, (0, 0), 0),          # 32x32 level, 128-row tiles
+    (8, 32, 1280, 640, 640, (0, 0), 0),       # long K: 256-row tiles x 2 splits
+    (2, 32, 640, 0, 640, (320, 0), 2),
+])
+def test_plain_conv_on_the_halo_tile_loop(B, H, C1, C2, Cout, tail, splitk, dtype):
+    """ResnetBlock2D's conv behind a separate GroupNorm apply (the 32x32 level since round 6; unet_2d_blocks.py:1274-1285):
+    the library runs it on conv_gn.hip's loop with the normalisation compiled out.  Same request, same contract: against the
+    tap-major implicit GEMM it replaces (an explicit tile code keeps that kernel) and against fp32 torch, with epilogue
+    operands and the statistics of the output."""
+    x1 = rnd(B, H, H, C1, seed=1).to(dtype)
+    x2 = rnd(B, H, H, C2, seed=2).to(dtype) if C2 else None
+    C3, C4 = tail
+    x3 = rnd(B, H, H, C3, seed=3).to(dtype) if C3 else None
+    x4 = rnd(B, H, H, C4, seed=4).to(dtype) if C4 else None
+    Ct = C1 + C2
+    K = 9 * Ct + C3 + C4
+    w = rnd(Cout, K, seed=5, scale=K ** -0.5).to(dtype).contiguous()
+    bias, rv = rnd(Cout, seed=6), rnd(B, Cout, seed=7)
+    res = rnd(B, H, H, Cout, seed=8).to(dtype)
+    assert ops.conv_halo_routed(x1, Cout, x2=x2, x3=x3, x4=x4)
+    assert not ops.conv_halo_routed(x1, Cout, x2=x2, x3=x3, x4=x4, tile=T128)          # an explicit tile keeps the tap-major kernel
+    A = [torch.zeros(B, 32, 2, dtype=torch.int64, device=DEV) for _ in range(2)]
+    out = ops.conv3x3(x1, w, bias, x2=x2, x3=x3, x4=x4, rowvec=rv, res1=res, splitk=splitk, gn=[(A[0], Cout // 32, 0, 32)])
+    again = ops.conv3x3(x1, w, bias, x2=x2, x3=x3, x4=x4, rowvec=rv, res1=res, splitk=splitk)
+    assert torch.equal(out, again), "not deterministic"
+    old = ops.conv3x3(x1, w, bias, x2=x2, x3=x3, x4=x4, rowvec=rv, res1=res, tile=54, gn=[(A[1], Cout // 32, 0, 32)])
+    ulp = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    close(out, old, 2 * ulp, 1.5 * ulp, "halo-tile loop vs tap-major implicit GEMM")
+    rel = ((A[0].double() - A[1].double()).abs() / (A[1].double().abs() + 2.0 ** 20)).max().item()
+    assert rel < 2e-3, f"output GroupNorm statistics differ from the tap-major path: {rel:.3g}"
+    xc = torch.cat([x1, x2], -1) if C2 else x1
+    ref = F.conv2d(xc.float().permute(0, 3, 1, 2), w[:, :9 * Ct].float().reshape(Cout, 3, 3, Ct).permute(0, 3, 1, 2), bias,
+                   padding=1).permute(0, 2, 3, 1)
+    if C3:
+        xt = torch.cat([x3, x4], -1) if C4 else x3
+        ref = ref + xt.float() @ w[:, 9 * Ct:].float().t()
+    ref = ref + rv.view(B, 1, 1, Cout) + res.float()
+    tol = 1.0 if dtype == torch.bfloat16 else 0.25
+    close(out, ref, 3e-2 * tol, 1e-2 * tol, "halo-tile loop vs fp32 torch")
+
+
+def test_plain_convs_that_stay_on_the_tap_major_kernel():
+    """Below 32 pixels of width (split-K weight streams: the tap-major kernel's N-major order wins), strided / upsampling convs,
+    channel counts off the 64 grid, the CFG twin store: not the halo-tile loop's -- routed as before, results as before."""
+    x16 = rnd(2, 16, 16, 640, seed=1).to(torch.bfloat16)
+    assert not ops.conv_halo_routed(x16, 1280)
+    x64 = rnd(1, 64, 64, 320, seed=2).to(torch.bfloat16)
+    assert not ops.conv_halo_routed(x64, 320, stride=2) and not ops.conv_halo_routed(x64, 320, up=True)
+    assert not ops.conv_halo_routed(rnd(1, 64, 64, 96, seed=3).to(torch.bfloat16), 320)
+    w = rnd(320, 9 * 320, seed=4, scale=0.02).to(torch.bfloat16)
+    out = ops.conv3x3(x64, w, None, dup=True)                                           # out_dup_rows: single-pass v2 epilogue
+    ref = ops.conv3x3(x64, w, None, tile=54)
+    assert torch.equal(out[0], out[1])
+    close(out[:1], ref, 2 * 2.0 ** -8, 1.5 * 2.0 ** -8, "twin-store conv vs plain")

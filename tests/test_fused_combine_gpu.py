@@ -1,12 +1,13 @@
 """-m gpu: the split-K combine INSIDE the producing kernel (ABI v21, csrc/gemm_combine.h).
 
-The workgroup that arrives last at its output tile sums the tile's fp32 slabs in slab order and runs the combine's
-epilogue.  Contract checked here, launch by launch, on the launch shapes of the headline step (batch 8, so that
-tiles % 8 == 0 and every split of a tile shares an XCD): the raw output, the GroupNorm accumulators and the normalised
-tensor of `gn_next` are BIT-IDENTICAL to the separate combine kernels (`pp_splitk_reduce_kernel<true>`,
-`pp_splitk_reduce_gn_kernel`, `pp_splitk_reduce_gn_apply_kernel`) -- which are themselves checked against fp32 torch in
-tests/test_ops_gpu.py / test_conv_gn_gpu.py -- the tile counters are zero again after the launch, and no tile was combined
-across XCDs.  Reference ops: the ResnetBlock2D convs and FeedForward / proj_out Linears of the 16x16 / 8x8 levels,
+The S splits of an output tile wait for each other at the tile's counter (XCD-local, bounded) and each sums 1 / S of the
+tile's rows over the fp32 slabs, in slab order, and runs the combine's epilogue on them.  Contract checked here, launch by
+launch, on the launch shapes of the headline step (batch 8, so that tiles % 8 == 0 and every split of a tile shares an
+XCD): the raw output, the GroupNorm accumulators and the normalised tensor of `gn_next` are BIT-IDENTICAL to the separate
+combine kernels (`pp_splitk_reduce_kernel<true>`, `pp_splitk_reduce_gn_kernel`, `pp_splitk_reduce_gn_apply_kernel`) -- which
+are themselves checked against fp32 torch in tests/test_ops_gpu.py / test_conv_gn_gpu.py -- the round-local fields of the
+tile counters are zero again after the launch, no share was left abandoned, and a launch whose splits are NOT all resident
+at once (512 workgroups: a split gives up waiting, the last arriver combines its share) is still bit-identical.  Reference ops: the ResnetBlock2D convs and FeedForward / proj_out Linears of the 16x16 / 8x8 levels,
 /root/reference/powerpaint/models/unet_2d_blocks.py:1457-1500, 850-899, 2696-2770.
 """
 import ctypes as C
@@ -45,7 +46,9 @@ def _after(fused_expected=True):
     torch.cuda.synchronize()
     assert ops.last_combine["fused"] == fused_expected, ops.last_combine
     if ops.last_combine["ctr"] is not None:
-        assert int(ops.last_combine["ctr"].abs().sum()) == 0, "tile counters not re-armed"
+        # (a counter word: bits 40.. = arrivals so far, monotonic; bits 0..39 = the round's per-XCC arrivals and abandoned
+        # shares, taken out again by the last arriver)
+        assert int((ops.last_combine["ctr"] & ((1 << 40) - 1)).abs().sum()) == 0, "tile counters not re-armed"
     assert ops.combine_faults(DEV) == 0
 
 
@@ -163,7 +166,8 @@ def test_counters_are_re_armed_and_results_reproducible_under_load():
         assert ops.last_combine["fused"]
         assert torch.equal(out, ref), f"launch {i} differs"
     torch.cuda.synchronize()
-    assert int(ctr.abs().sum()) == 0 and ops.combine_faults(DEV) == 0
+    assert int((ctr & ((1 << 40) - 1)).abs().sum()) == 0 and ops.combine_faults(DEV) == 0
+    assert int((ctr[0::2] >> 40).min()) == int((ctr[0::2] >> 40).max()) == 51 * 8      # 51 launches x 8 splits at every tile
 
 
 def test_launches_that_cannot_combine_in_kernel_keep_the_separate_combine():
@@ -187,16 +191,21 @@ def test_launches_that_cannot_combine_in_kernel_keep_the_separate_combine():
     assert torch.equal(out, ref)
 
 
-def test_the_library_advises_the_in_kernel_combine_nowhere():
-    """Measured slower than (or equal to) the separate combine on every launch shape of the step (profiles/
-    r06_fused_combine.txt): pp_gemm_combine_ctr_bytes() = 0, the plans keep the separate combine; counters handed over anyway
-    are honoured (every test above)."""
+def test_where_the_library_advises_the_in_kernel_combine():
+    """pp_gemm_combine_ctr_bytes() = what a planner is told.  Measured kernel by kernel inside the headline step's graph
+    (profiles/r06_fused_combine.txt): launches of 2 and 4 splits win 0.5 .. 8 us against the separate combine, launches of 8
+    splits (the 8x8 level, the 32 -> 16 downsample) lose 2 .. 3 us: advised for the former only, and only where every split
+    of the launch is resident at once.  Counters handed over anyway are honoured (every test above)."""
     x = rnd(8, 8, 8, 1280, seed=1).to(torch.bfloat16)
     w = rnd(1280, 9 * 1280, seed=2, scale=0.01).to(torch.bfloat16)
-    ops.conv3x3(x, w, None, fuse_combine=True)
+    ops.conv3x3(x, w, None, fuse_combine=True)                             # 128 rows x 8 splits
     _after(fused_expected=False)
     xs, ws = rnd(2048, 6400, seed=3).to(torch.bfloat16), rnd(1280, 6400, seed=4, scale=0.01).to(torch.bfloat16)
-    ops.gemm(xs, ws, fuse_combine=True)
+    ref = ops.gemm(xs, ws)
+    out = ops.gemm(xs, ws, fuse_combine=True)                              # 128 rows x 2 splits, 256 workgroups
+    _after(fused_expected=True)
+    assert torch.equal(out, ref)
+    ops.gemm(xs, ws, tile=54, splitk=4, fuse_combine=True)                 # 512 workgroups: the splits are not co-resident
     _after(fused_expected=False)
 
 
@@ -208,10 +217,15 @@ def test_host_predicates_agree():
     a.x1 = a.w = a.out = 4096
     a.ldo = a.ldres1 = a.ldres2 = 1280
     a.scale, a.dtype = 1.0, L.PP_DT_BF16
-    assert lib.pp_gemm_workspace_bytes(C.byref(a)) == 2 * 2048 * 1280 * 4      # the automatic choice: 128 rows x 2 splits
-    assert lib.pp_gemm_combine_ctr_bytes(C.byref(a)) == 0                      # advised nowhere (see above)
+    # the automatic choice: 128 rows x 2 splits = 128 tiles; two fp32 slabs + 6 KB of statistics scratch per tile
+    assert lib.pp_gemm_workspace_bytes(C.byref(a)) == 2 * 2048 * 1280 * 4 + 128 * 6144
+    assert lib.pp_gemm_combine_ctr_bytes(C.byref(a)) == 128 * 16               # advised: two counter words per tile
     assert lib.pp_gemm_combine_fused(C.byref(a)) == 0                          # no counters given
     a.tile_ctr = 4096
+    assert lib.pp_gemm_combine_fused(C.byref(a)) == 1
+    a.splitk, a.tile = 8, 54
+    assert lib.pp_gemm_combine_ctr_bytes(C.byref(a)) == 0                      # 8 splits: not advised ...
     assert lib.pp_gemm_combine_fused(C.byref(a)) == 1                          # ... but honoured where handed over
+    a.splitk, a.tile = 0, 0
     a.act = L.PP_ACT_SILU
     assert lib.pp_gemm_combine_fused(C.byref(a)) == 0                          # not the lean epilogue

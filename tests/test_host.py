@@ -54,10 +54,11 @@ def test_full_size_plans_and_flop_accounting():
         from powerpaint_amd.engine import GN_STATS_IN_EPILOGUE
         fused_out = 1 if (kind == "unet" and SDNet.fuse_conv_out and GN_STATS_IN_EPILOGUE) else 0
         # ... and the two norms of every ResnetBlock2D (22 / 22 / 10 blocks) run in the loader of the conv that consumes them
-        # (csrc/conv_gn.hip, PPGemmArgs.gn_in_*) wherever pp_conv_gn_preferred says the fused launch is the faster one: every
-        # level but the 8x8 one (7 / 7 / 4 blocks there; round 4, profiles/r04_conv_gn_variants.txt)
+        # (csrc/conv_gn.hip, PPGemmArgs.gn_in_*) wherever pp_conv_gn_preferred says the fused launch is the faster one: the
+        # 16x16 level (round 6: at 64x64 and 32x32 the apply launch + the plain conv on the same loop without the normalisation
+        # wins, profiles/r06_conv_raw.txt; at 8x8 the tap-major weight stream, round 4)
         from powerpaint_amd.engine import FUSE_GN_CONV, GN_NEXT_IN_COMBINE
-        n_cg = {"unet": 30, "brushnet": 30, "controlnet": 12}[kind] if (FUSE_GN_CONV and GN_STATS_IN_EPILOGUE) else 0
+        n_cg = {"unet": 10, "brushnet": 10, "controlnet": 4}[kind] if (FUSE_GN_CONV and GN_STATS_IN_EPILOGUE) else 0
         assert sum(1 for a in rt.step_plan.keep if getattr(a, "gn_in_acc", None)) == n_cg
         # ... and a single-tensor norm right behind a split-K launch at the 16x16 / 8x8 levels is applied by that launch's
         # combine (PPGemmArgs.gn_next_*): the non-concatenated resnet norms of the 8x8 level and the transformer norms of

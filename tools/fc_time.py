@@ -55,16 +55,18 @@ def conv_args(B, H, C1, C2, Cout, stride=1, up=False, tail=0, gn_in=False, form=
             y.data_ptr(), g2.data_ptr(), b2.data_ptr(), 1e-5, 1, 0
         keep += [y, g2, b2]
     ws = lib.pp_gemm_workspace_bytes(C.byref(a))
-    wsb = torch.empty(max(ws, 4) // 4, dtype=torch.float32, device=DEV)
+    wsb = torch.empty((max(ws, 8) + 7) // 8 * 2, dtype=torch.float32, device=DEV)
     a.workspace = wsb.data_ptr()
+    a._wsb = wsb
     keep.append(wsb)
     return a, keep
 
 
 def timeit(a, fused, cold, iters=30):
     n = ((a.M + 127) // 128) * ((a.N + 159) // 160) * 8       # (also where the library advises the separate combine)
-    ctr = torch.zeros(n // 8, dtype=torch.int64, device=DEV)
+    ctr = torch.zeros(n // 4, dtype=torch.int64, device=DEV)       # 16 bytes per tile
     a.tile_ctr = ctr.data_ptr() if fused else None
+    a.dbg = int(os.environ.get("PP_FC_DBG", "0"), 0) if fused else 0          # (lab build: phase ablations, gemm_combine.h)
     is_fused = bool(lib.pp_gemm_combine_fused(C.byref(a)))
     s = torch.cuda.current_stream().cuda_stream
     junk = torch.empty(64 << 20, dtype=torch.float32, device=DEV) if cold else None
@@ -82,7 +84,39 @@ def timeit(a, fused, cold, iters=30):
         evs.append((e0, e1))
     torch.cuda.synchronize()
     ts = sorted(e0.elapsed_time(e1) * 1e3 for e0, e1 in evs)
+    if fused and is_fused and os.environ.get("PP_FC_STAMPS") == "1":
+        stamps(a, cold, junk)
     return ts[len(ts) // 2], is_fused
+
+
+def stamps(a, cold, junk):
+    """(lab build) s_memrealtime stamps of every split's thread 0 in the tail of ONE launch (gemm_combine.h, FC_STAMP):
+    where the tail's time goes.  10 ns ticks -> us."""
+    ws = lib.pp_gemm_workspace_bytes(C.byref(a))
+    tiles = lib.pp_gemm_combine_ctr_bytes(C.byref(a)) // 16
+    scr = 16 * 24 * 16 + 512
+    slab_bytes = ws - tiles * scr
+    splits = slab_bytes // (a.M * a.N * 4)
+    a.dbg |= 0x2000
+    s = torch.cuda.current_stream().cuda_stream
+    if cold:
+        junk.zero_()
+    L.check(lib.pp_gemm_bf16(C.byref(a), s), "gemm")
+    torch.cuda.synchronize()
+    a.dbg &= ~0x2000
+    raw = a._wsb.view(torch.int64).cpu()
+    st = []
+    for t in range(tiles):
+        base = (slab_bytes + t * scr + 16 * 24 * 16) // 8
+        for sh in range(splits):
+            st.append(raw[base + sh * 8: base + sh * 8 + 8].tolist())
+    st = torch.tensor(st, dtype=torch.float64) * 0.01
+    t0min = st[:, 0].min()
+    d = lambda i, j: float((st[:, i] - st[:, j]).mean())
+    reach = lambda i: float(st[:, i].max() - t0min)
+    print(f"    stamps ({'cold' if cold else 'hot'}, {tiles} tiles x {splits}): mean per split  drain {d(1, 0):5.2f}  atomic {d(2, 1):5.2f}  "
+          f"wait {d(3, 2):5.2f}  inputs {d(7, 3):5.2f}  slabs {d(4, 7):5.2f}  rest {d(5, 4):5.2f}  acks {d(6, 5):5.2f} us | last split reaches: entry {reach(0):5.2f}  "
+          f"drained {reach(1):5.2f}  arrived {reach(2):5.2f}  released {reach(3):5.2f}  combined {reach(5):5.2f}  acked {reach(6):5.2f} us")
 
 
 CASES = [
@@ -99,6 +133,8 @@ print(f"# tools/fc_time.py on {torch.cuda.get_device_name(0)}, lib {lib.pp_build
       f"(kernel + separate combine, or kernel with the combine inside), 30 launches")
 print(f"{'launch':52s} {'form':6s} {'hot sep':>8s} {'hot fused':>9s} {'cold sep':>9s} {'cold fused':>10s}  fused?")
 for name, kw in CASES:
+    if os.environ.get("PP_FC_CASES") and not any(t in name for t in os.environ["PP_FC_CASES"].split(",")):
+        continue
     for form in ("lean", "gn", "apply"):
         ho = (2 * kw["H"] if kw.get("up") else kw["H"]) // kw.get("stride", 1)
         if form == "apply" and ho * ho > 256:
