@@ -702,10 +702,11 @@ bool cg_fused_ok(const PPGemmArgs& a) {
 // normalisation (NMODE = 2): every input pixel crosses the 64 B/clk global -> LDS path once per tile (+ halo rows) instead
 // of once per tap, 52 against 58 us at 64x64 (K = 2880), 58 against 65 at 32x32 (K = 5760) beside the tap-major kernel
 // (tools/conv_gn_shapes.py, profiles/r06_conv_raw.txt).  Taken where the automatic choice is asked for (tile = AUTO) and
-// the image is at least 32 wide: below that the launches are split-K weight streams and the tap-major kernel's N-major
-// tile order wins.  (lab) PP_CONV_RAW = the smallest image width routed here (0 = never)
+// the image is at least 16 wide: at 8x8 the launches are split-K weight streams on 64-row tiles and the tap-major kernel's
+// 128-row tiles in N-major order win (+1.7 % on the step with this loop there).
+// (lab) PP_CONV_RAW = the smallest image width routed here (0 = never)
 bool cg_raw_ok(const PPGemmArgs& a) {
-  static const int min_w = pp_lab_env("PP_CONV_RAW", 32);
+  static const int min_w = pp_lab_env("PP_CONV_RAW", 16);
   if (a.gn_in_acc || a.gn_in_gb || a.tile != PP_TILE_AUTO || min_w <= 0 || a.win < min_w) return false;
   return cg_geometry_ok(a);
 }
@@ -870,8 +871,10 @@ extern "C" int pp_conv_gn_supported(const PPGemmArgs* args) {
 //   uses the hardware reciprocal in its SiLU (14.3 -> 11.4 us on the 21 MB tensors of the 64x64 level).  Classes 1, 2 and 8
 //   flip: back to back the 64x64 level costs 707 + 148 us per forward against 947 fused, the 32x32 level 769 + 114 against
 //   973; headline step, same box: everything fused 8.474 ms, classes 2 and 8 unfused 8.404, class 1 as well 8.380 (-1.1 %,
-//   twenty launches MORE; profiles/r06_conv_raw.txt).  Class 4 stays fused: at 16x16 the applies ride in the producers'
-//   split-K combines and the raw loop has no separate apply to hide behind.
+//   twenty launches MORE), class 4 too -- at 16x16 most applies ride in the producers' split-K combines -- 8.854 against
+//   8.921 (-0.75 %; the tap-major kernel there: -0.32 %); the raw loop at 8x8: +1.7 % (profiles/r06_conv_raw.txt).
+//   So NO class is fused in the plans any more: the fused launch stays an operator for a caller that asks for it
+//   (gn_in_*), checked by tests/test_conv_gn_gpu.py as before.
 //   class 16 W <= 8: 64-row tiles, one workgroup per CU at 10 MFMAs per wave and K step: +10 .. +26 us, NOT fused
 //            (9.76 against 9.61 ms per step with it)
 // same-box step times, masks 0 / 1 / 5 / 7 / 15 / 31: 9.75 / 9.64 / 9.62 / 9.62 / 9.61 / 9.76 ms (251 .. 207 launches)
@@ -885,6 +888,6 @@ extern "C" int pp_conv_gn_preferred(const PPGemmArgs* args) {
   else if (a.win == 32) cls = (nch <= 5 && a.c2 == 0) ? 2 : 8;
   else if (a.win == 16) cls = 4;
   else cls = a.win < 16 ? 16 : 8;
-  static const int mask = pp_lab_env("PP_CONV_GN_ROUTE", 4);
+  static const int mask = pp_lab_env("PP_CONV_GN_ROUTE", 0);
   return (mask & cls) ? 1 : 0;
 }

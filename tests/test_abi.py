@@ -126,11 +126,12 @@ def test_fused_conv_routing_and_combine_apply_queries_on_the_host():
     lib = L.lib()
     sup = lambda a: lib.pp_conv_gn_supported(C.byref(a))       # noqa: E731
     pref = lambda a: lib.pp_conv_gn_preferred(C.byref(a))      # noqa: E731
-    # every level has a tile of whole image rows; fused at 16x16 -- at 64x64 and 32x32 (round 6) the apply launch + the plain
-    # conv on the halo-tile loop without the normalisation is faster, at 8x8 the tap-major weight stream
+    # every level has a tile of whole image rows; preferred NOWHERE since round 6: the apply launch (or the apply in the
+    # producer's combine) + the plain conv on the halo-tile loop without the normalisation is faster down to 16x16, at 8x8
+    # the tap-major weight stream
     for (H, c1, c2, cout, tail, want) in [(64, 320, 0, 320, (0, 0), 0), (64, 640, 320, 320, (0, 0), 0), (64, 320, 0, 320, (640, 320), 0),
                                           (32, 320, 0, 640, (0, 0), 0), (32, 1280, 640, 640, (0, 0), 0), (32, 640, 0, 640, (640, 320), 0),
-                                          (16, 1280, 1280, 1280, (0, 0), 1), (16, 640, 0, 1280, (0, 0), 1),
+                                          (16, 1280, 1280, 1280, (0, 0), 0), (16, 640, 0, 1280, (0, 0), 0),
                                           (8, 1280, 0, 1280, (0, 0), 0), (8, 1280, 1280, 1280, (0, 0), 0)]:
         a = _conv_args(8, H, H, c1, c2, cout, *tail)
         assert sup(a) == 1, (H, c1, c2)
@@ -143,7 +144,7 @@ def test_fused_conv_routing_and_combine_apply_queries_on_the_host():
     # a PLAIN conv (no statistics of its input): 2 = routed to the halo-tile loop without the normalisation, from 32 pixels of
     # width up and only where the automatic tile choice is asked for
     assert sup(_conv_args(8, 64, 64, 320, 0, 320, gn_in=False)) == 2 and sup(_conv_args(8, 32, 32, 640, 0, 640, gn_in=False)) == 2
-    assert sup(_conv_args(8, 16, 16, 1280, 0, 1280, gn_in=False)) == 0
+    assert sup(_conv_args(8, 16, 16, 1280, 0, 1280, gn_in=False)) == 2 and sup(_conv_args(8, 8, 8, 1280, 0, 1280, gn_in=False)) == 0
     a = _conv_args(8, 64, 64, 320, 0, 320, gn_in=False)
     a.tile = L.PP_TILE_128x160
     assert sup(a) == 0

@@ -231,6 +231,8 @@ def test_groupnorm_apply_in_combine_is_refused_where_it_cannot_run():
     (8, 32, 640, 0, 640, (0, 0), 0),          # 32x32 level, 128-row tiles
     (8, 32, 1280, 640, 640, (0, 0), 0),       # long K: 256-row tiles x 2 splits
     (2, 32, 640, 0, 640, (320, 0), 2),
+    (8, 16, 1280, 0, 1280, (0, 0), 0),        # 16x16 level: 256-row tiles x 4 splits
+    (8, 16, 1280, 640, 1280, (1280, 640), 0),
 ])
 def test_plain_conv_on_the_halo_tile_loop(B, H, C1, C2, Cout, tail, splitk, dtype):
     """ResnetBlock2D's conv behind a separate GroupNorm apply (the 32x32 level since round 6; unet_2d_blocks.py:1274-1285):
@@ -270,10 +272,10 @@ def test_plain_conv_on_the_halo_tile_loop(B, H, C1, C2, Cout, tail, splitk, dtyp
 
 
 def test_plain_convs_that_stay_on_the_tap_major_kernel():
-    """Below 32 pixels of width (split-K weight streams: the tap-major kernel's N-major order wins), strided / upsampling convs,
-    channel counts off the 64 grid, the CFG twin store: not the halo-tile loop's -- routed as before, results as before."""
-    x16 = rnd(2, 16, 16, 640, seed=1).to(torch.bfloat16)
-    assert not ops.conv_halo_routed(x16, 1280)
+    """The 8x8 level (split-K weight streams: the tap-major kernel's 128-row tiles in N-major order win), strided / upsampling
+    convs, channel counts off the 64 grid, the CFG twin store: not the halo-tile loop's -- routed as before, results as before."""
+    x8 = rnd(8, 8, 8, 1280, seed=1).to(torch.bfloat16)
+    assert not ops.conv_halo_routed(x8, 1280)
     x64 = rnd(1, 64, 64, 320, seed=2).to(torch.bfloat16)
     assert not ops.conv_halo_routed(x64, 320, stride=2) and not ops.conv_halo_routed(x64, 320, up=True)
     assert not ops.conv_halo_routed(rnd(1, 64, 64, 96, seed=3).to(torch.bfloat16), 320)

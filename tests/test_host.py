@@ -54,16 +54,17 @@ def test_full_size_plans_and_flop_accounting():
         from powerpaint_amd.engine import GN_STATS_IN_EPILOGUE
         fused_out = 1 if (kind == "unet" and SDNet.fuse_conv_out and GN_STATS_IN_EPILOGUE) else 0
         # ... and the two norms of every ResnetBlock2D (22 / 22 / 10 blocks) run in the loader of the conv that consumes them
-        # (csrc/conv_gn.hip, PPGemmArgs.gn_in_*) wherever pp_conv_gn_preferred says the fused launch is the faster one: the
-        # 16x16 level (round 6: at 64x64 and 32x32 the apply launch + the plain conv on the same loop without the normalisation
-        # wins, profiles/r06_conv_raw.txt; at 8x8 the tap-major weight stream, round 4)
+        # (csrc/conv_gn.hip, PPGemmArgs.gn_in_*) wherever pp_conv_gn_preferred says the fused launch is the faster one: NOWHERE
+        # since round 6 -- the apply (a launch, or inside the producer's split-K combine) + the plain conv on the same loop
+        # without the normalisation wins at every level down to 16x16 (profiles/r06_conv_raw.txt), at 8x8 the tap-major weight
+        # stream (round 4)
         from powerpaint_amd.engine import FUSE_GN_CONV, GN_NEXT_IN_COMBINE
-        n_cg = {"unet": 10, "brushnet": 10, "controlnet": 4}[kind] if (FUSE_GN_CONV and GN_STATS_IN_EPILOGUE) else 0
+        n_cg = 0
         assert sum(1 for a in rt.step_plan.keep if getattr(a, "gn_in_acc", None)) == n_cg
         # ... and a single-tensor norm right behind a split-K launch at the 16x16 / 8x8 levels is applied by that launch's
-        # combine (PPGemmArgs.gn_next_*): the non-concatenated resnet norms of the 8x8 level and the transformer norms of
-        # the 16x16 level and of the mid block
-        n_next = ({"unet": 17, "brushnet": 17, "controlnet": 11}[kind]
+        # combine (PPGemmArgs.gn_next_*): the non-concatenated resnet norms of the 8x8 level and (round 6: no fused-norm conv
+        # any more) of the 16x16 level, the transformer norms of the 16x16 level and of the mid block
+        n_next = ({"unet": 24, "brushnet": 24, "controlnet": 15}[kind]
                   if (GN_NEXT_IN_COMBINE and FUSE_GN_CONV and GN_STATS_IN_EPILOGUE) else 0)
         assert sum(1 for a in rt.step_plan.keep if getattr(a, "gn_next_out", None)) == n_next
         # ... and the front end of every C = 320 transformer (norm -> proj_in -> LayerNorm1-folded QKV) is one pp_tfront launch
@@ -600,7 +601,7 @@ def test_apply_inside_the_combine_never_aliases_what_the_producer_still_reads():
                 assert not overlap(out, sp), (kind, i, name, out, sp)
             # ... and somebody reads it: the next launches' x1
             assert any(b.x1 == a.gn_next_out for b in keep[i + 1:i + 4]), (kind, i, "normalised tensor is never consumed")
-        assert n == {"unet": 17, "brushnet": 17, "controlnet": 11}[kind]
+        assert n == {"unet": 24, "brushnet": 24, "controlnet": 15}[kind]
 
 
 def test_twin_prefix_plans_at_the_headline_shapes():

@@ -43,9 +43,20 @@ def test_conv_stores_its_rows_twice_and_feeds_both_halves_statistics(B, H, cin, 
     r_full = torch.zeros(B, 32, 2, dtype=torch.int64, device=DEV)
     ref = ops.conv3x3(x, w, bias, res2=res, tile=tile, gn=[(r_half, 10, 0, 32), (r_full, 20, 320, 32)])
     assert out.shape[0] == 2 * B
-    assert torch.equal(out[:B], ref) and torch.equal(out[B:], ref)
+    assert torch.equal(out[:B], out[B:]) and torch.equal(a_full[:B], a_full[B:])
+    if tile == 0 and ops.conv_halo_routed(x, cout):
+        # (round 6) the plain reference runs on the halo-tile loop (other tiles, maybe split-K: another summation order), the
+        # twin store on the tap-major kernel's single-pass epilogue: equal to rounding, not bit for bit
+        ulp = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+        err = (out[:B].float() - ref.float()).abs()
+        assert not (err > 2 * ulp + 1.5 * ulp * ref.float().abs()).any(), float(err.max())
+        for got, want in ((a_half, r_half), (a_full[:B], r_full)):
+            rel = ((got.double() - want.double()).abs() / (want.double().abs() + 2.0 ** 20)).max().item()
+            assert rel < 2e-3, rel
+        return
+    assert torch.equal(out[:B], ref)
     assert torch.equal(a_half, r_half)
-    assert torch.equal(a_full[:B], r_full) and torch.equal(a_full[B:], r_full)
+    assert torch.equal(a_full[:B], r_full)
 
 
 def test_dup_is_refused_where_the_single_pass_epilogue_does_not_run():
