@@ -455,6 +455,7 @@ def main():
     ppdist.barrier()
     dt = ppdist.max_over_ranks(time.perf_counter() - t0, device)
     assert torch.isfinite(out).all()
+    pipe._loop.flush_faults()          # (in-kernel split-K combines: no share left uncombined in any of the timed calls)
 
     if rank == 0:
         images = args.per_gpu * world * args.steps

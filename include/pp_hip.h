@@ -29,7 +29,7 @@ extern "C" {
 #define PP_ERR_LAUNCH (-3)       /* hipLaunchKernel / hipFuncSetAttribute failed                  */
 #define PP_ERR_WORKSPACE (-4)    /* workspace pointer null or too small                           */
 
-#define PP_ABI_VERSION 21
+#define PP_ABI_VERSION 22
 /* 16-bit storage format of activations and matrix weights ("dtype" arguments; the same codes pp_nchw_to_nhwc uses for
  * its source): bf16 or fp16 -- the reference's default is fp16 (/root/reference/app.py:548,559).  MFMA accumulation,
  * norm statistics, softmax, biases and latents are fp32 with either. */
@@ -195,16 +195,22 @@ typedef struct PPGemmArgs {
   int32_t gn_dup_mask;   /* see gn_dup_batch */
   /* (ABI v20) with w_batch_stride and act = PP_ACT_SOFTMAX80: bias and ln_colsum advance by this many floats per batch item */
   int32_t vec_batch_stride;
-  /* (ABI v21) The split-K combine INSIDE the producing kernel.  tile_ctr != NULL permits it: pp_gemm_combine_ctr_bytes()
-   * bytes of device memory, zero before the first launch that uses them (every launch leaves them zero again), private to
-   * this launch within a step.  Where pp_gemm_bf16 then finds the launch eligible -- lean epilogue, an 8-wave ping-pong or
-   * fused-norm tile, tiles % 8 == 0 so that the splits of a tile share an XCD (csrc/gemm_combine.h) -- the workgroup that
-   * arrives LAST at its tile sums the tile's fp32 slabs in slab order and runs the combine's epilogue (incl. gn_acc and
-   * gn_next_*): same bits as the separate combine launch, which then does not happen.  Not eligible => the separate
-   * combine as before; tile_ctr is a permission, never a request that can fail.  combine_fault (optional): a device
-   * counter the last arriver increments if it finds that the splits of its tile did NOT run on one XCD (the slab sums
-   * may then be stale): the caller checks it at its synchronisation points and refuses the results (pp_*  never
-   * synchronises).  Replaces the combine behind the split-K convs / Linears of the 16x16 and 8x8 levels
+  /* (ABI v21; v22: every split combines its own share) The split-K combine INSIDE the producing kernel.  tile_ctr != NULL
+   * permits it: pp_gemm_combine_ctr_bytes() bytes of device memory (two 64-bit words per tile), ZERO before the first launch
+   * that uses them, private to this launch within a step.  The words are monotonic arrival counts: a launch adds its split
+   * count to bits 40.. of each and leaves bits 0..39 (the round's bookkeeping) zero; they may be re-zeroed between launches
+   * (a step's accumulator-pool zeroing does) but never while one runs.  Where pp_gemm_bf16 finds the launch eligible -- lean
+   * epilogue, an 8-wave ping-pong or halo-tile kernel, 2 / 4 / 8 splits of a tile of >= 16 x splits rows, tiles % 8 == 0 so
+   * that the splits of a tile share an XCD (csrc/gemm_combine.h) -- the splits of a tile wait for each other at the tile's
+   * counter (XCD-local atomics; BOUNDED: a split that gives up marks its share abandoned and the last arriver combines it)
+   * and each sums ITS 1 / S of the tile's rows over the fp32 slabs, in slab order, and runs the combine's epilogue on them
+   * (incl. gn_acc; gn_next_* behind a second arrival, the shares' integer sums exchanged through per-tile scratch that
+   * pp_gemm_workspace_bytes() already counts behind the slabs): same bits as the separate combine launch, which then does
+   * not happen.  Not eligible => the separate combine as before; tile_ctr is a permission, never a request that can fail.
+   * combine_fault (optional): a device counter that stays non-zero if an abandoned share was never taken back (splits of a
+   * tile on different XCDs count in different L2s and never reach S) or a second-arrival wait hit its bound: the caller
+   * checks it at its synchronisation points and refuses the results (pp_* never synchronises).  Replaces the combine
+   * behind the split-K convs / Linears of the 32x32 and 16x16 levels
    * (/root/reference/powerpaint/models/unet_2d_blocks.py:1457-1500, 850-899, 2696-2770). */
   uint64_t* tile_ctr;
   uint32_t* combine_fault;
@@ -218,6 +224,8 @@ typedef struct PPGemmArgs {
 #define PP_TILE_256x160 3
 
 int pp_gemm_bf16(const PPGemmArgs* args, void* stream);   /* (historic name: bf16 or fp16 per args->dtype) */
+/* bytes of PPGemmArgs.workspace this request needs: the fp32 slabs of a split-K launch + (ABI v22) behind them 6 KB per tile
+ * of statistics scratch where the launch could combine in-kernel (tile_ctr); 0 = single pass */
 size_t pp_gemm_workspace_bytes(const PPGemmArgs* args);
 /* 1 if this launch (as pp_gemm_bf16 would configure it) can accumulate GroupNorm statistics (gn_acc), else 0 */
 int pp_gemm_gn_stats_ok(const PPGemmArgs* args);
@@ -231,19 +239,24 @@ int pp_conv_gn_supported(const PPGemmArgs* args);
 /* (ABI v16) 1 if the fused launch is supported AND, by the per-shape measurements on MI355X (profiles/
  * r04_conv_gn_variants.txt), at least as fast as pp_groupnorm_apply_acc + the plain conv it replaces; the engine asks this
  * one when it lays out a ResnetBlock2D.  The normalisation costs ~600 wave cycles per 8-pixel x 64-channel strip and is
- * repeated per 160-column tile and per halo row: it pays at the 64 x 64 level (and where K is short), not at 8 x 8. */
+ * repeated per 160-column tile and per halo row.  Round 6 (ABI v22): since plain convs run on the same loop WITHOUT the
+ * normalisation (pp_conv_gn_supported() == 2) and the apply kernels' SiLU uses the hardware reciprocal, apply + plain conv
+ * wins at every level (step -2.0 % same-box, profiles/r06_conv_raw.txt): this returns 0 for every shape of the SD-1.5 plans;
+ * the fused launch remains an operator for a caller that sets gn_in_* . */
 int pp_conv_gn_preferred(const PPGemmArgs* args);
 /* (ABI v17) 1 if this launch, as pp_gemm_bf16 would configure it, ends in the split-K combine that can apply the consumer
  * GroupNorm of subscription `sub` (PPGemmArgs.gn_next_*), else 0. */
 int pp_gemm_gn_next_ok(const PPGemmArgs* args, int sub);
-/* (ABI v21) Bytes of PPGemmArgs.tile_ctr the library ADVISES for this launch: 0 = the launch does not run split-K, can never
- * combine in-kernel (tile form, tiles % 8 != 0, epilogue not lean, placement check failed), or is one where the separate
- * combine launch measured at least as fast on MI355X -- which, as of round 6, is EVERY launch (one workgroup pulls the tile's
- * 0.16 .. 1.3 MB of slabs through one CU while the chip idles: +3 % on the headline step; profiles/r06_fused_combine.txt), so
- * the shipping library returns 0 throughout and the launch plans keep the separate combine.  The mechanism stays available: a
- * caller that sets tile_ctr anyway (8 bytes per 128-row x 160-column tile always suffice) gets the in-kernel combine, bit for
- * bit the separate one.  Asked at plan-build time, never inside a stream capture: the first call per process may run
- * pp_xcd_placement_ok(). */
+/* (ABI v21 / v22) Bytes of PPGemmArgs.tile_ctr the library ADVISES for this launch (16 per tile): 0 = the launch does not run
+ * split-K, can never combine in-kernel (tile form, tiles % 8 != 0, epilogue not lean, placement check failed), or is one where
+ * the separate combine launch measured faster on MI355X.  Measured inside the headline step's hipGraph (profiles/
+ * r06_fused_combine.txt): launches of 2 and 4 splits whose workgroups are all resident at once (tiles x splits <= CUs) are a
+ * draw to 8 us better per launch and a draw on the step with 18 kernels fewer -- advised; 8 splits (shares of 16 / 32 rows at
+ * the 8x8 level and the 32 -> 16 downsample: the tail is a chain of ~1 us memory round trips against one 11 us kernel) lose
+ * 2 .. 3 us per launch, 0.4 % on the step -- not advised.  (The first form, ONE workgroup combining the whole tile, lost
+ * everywhere: +3 %.)  A caller that sets tile_ctr anyway (16 bytes per 128-row x 160-column tile always suffice) gets the
+ * in-kernel combine wherever it is correct, bit for bit the separate one.  Asked at plan-build time, never inside a stream
+ * capture: the first call per process may run pp_xcd_placement_ok(). */
 size_t pp_gemm_combine_ctr_bytes(const PPGemmArgs* args);
 /* (ABI v21) 1 if pp_gemm_bf16 will combine this launch in-kernel (tile_ctr set and every condition met, incl. the
  * gn_next_* apply where requested), else 0: how many kernels the launch is. */

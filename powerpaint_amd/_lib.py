@@ -16,7 +16,7 @@ PP_ACT_NONE, PP_ACT_GEGLU, PP_ACT_SILU, PP_ACT_SOFTMAX80 = 0, 1, 2, 3
 PP_TILE_AUTO, PP_TILE_128x160, PP_TILE_64x160, PP_TILE_256x160 = 0, 1, 2, 3
 PP_DT_F32, PP_DT_BF16, PP_DT_F16 = 0, 1, 2      # dtype codes of the C ABI (include/pp_hip.h)
 PP_ATTN_AUTO, PP_ATTN_PHASED, PP_ATTN_PIPE_Q32, PP_ATTN_PIPE_Q64, PP_ATTN_PIPE_LOG2 = 0, 1, 2, 3, 4   # pp_attention_fwd_variant
-ABI_VERSION = 21                                  # PP_ABI_VERSION of include/pp_hip.h this binding was written against
+ABI_VERSION = 22                                  # PP_ABI_VERSION of include/pp_hip.h this binding was written against
 PP_ERR = {0: "PP_OK", -1: "PP_ERR_BAD_ARG", -2: "PP_ERR_UNSUPPORTED", -3: "PP_ERR_LAUNCH", -4: "PP_ERR_WORKSPACE"}
 
 vp, i32, f32, sz = C.c_void_p, C.c_int32, C.c_float, C.c_size_t

@@ -322,6 +322,9 @@ class PipelineBase(PipelinePretrainedMixin):
             ip = getattr(self, "image_processor", None)
             if ip is not None:
                 image = ip.postprocess(image, output_type=output_type, do_denormalize=[True] * image.shape[0])
+                loop = getattr(self, "_loop", None)
+                if loop is not None and output_type in ("pil", "np"):     # (the images are on the host: the device is idle anyway)
+                    loop.flush_faults()
         else:
             image = latents
         if not return_dict:

@@ -351,13 +351,17 @@ class DenoiseLoop:
         self._check_faults()
         return self.latents
 
-    def _check_faults(self):
-        """Only where a plan combines split-K in-kernel (none of the shipping plans does: pp_gemm_combine_ctr_bytes() advises it
-        nowhere): one synchronisation per pipeline call -- those combines prove their XCD co-location per tile and count
-        violations (NetRuntime.check_faults)."""
+    def _check_faults(self, blocking: bool = False):
+        """Where a plan combines split-K in-kernel (launches of 2 / 4 co-resident splits: pp_gemm_combine_ctr_bytes()): the
+        plan's fault word is examined WITHOUT a synchronisation -- copied to pinned memory behind this call's work, read by a
+        later call (NetRuntime.check_faults).  `flush_faults()` is the blocking form for a caller that synchronises anyway."""
         for r in (getattr(self, "rt", None), getattr(self, "side_rt", None)):
             if r is not None and r.combines_in_kernel():
-                r.check_faults()
+                r.check_faults(blocking=blocking)
+
+    def flush_faults(self):
+        """Synchronise and raise if any in-kernel split-K combine since the last check reported a fault."""
+        self._check_faults(blocking=True)
 
     def _run_foreign(self, latents, num_steps, use_graph, callback, timesteps, scale_schedule):
         """Duck-typed scheduler: network part = the captured program (eps lands in the UNet runtime's fp32 output), then

@@ -229,3 +229,30 @@ def test_host_predicates_agree():
     a.splitk, a.tile = 0, 0
     a.act = L.PP_ACT_SILU
     assert lib.pp_gemm_combine_fused(C.byref(a)) == 0                          # not the lean epilogue
+
+
+def test_a_plan_reports_combine_faults_without_synchronising_its_caller():
+    """NetRuntime.check_faults(blocking=False): the fault word travels to pinned host memory behind the queued work and is
+    examined by a LATER check -- a pipeline call never ends in a device synchronisation -- while blocking=True (what
+    DenoiseLoop.flush_faults and bench.py use where the host waits anyway) reads it on the spot."""
+    from powerpaint_amd.engine import SDNet
+    from powerpaint_amd.runtime import NetRuntime
+    SMALL = dict(block_out_channels=(320, 640), layers_per_block=1,
+                 down_block_types=("CrossAttnDownBlock2D", "DownBlock2D"), up_block_types=("UpBlock2D", "CrossAttnUpBlock2D"))
+    net = SDNet("unet", 9, **SMALL)
+    net.load_state_dict(net.synthetic_state_dict(seed=3), DEV)
+    rt = NetRuntime(net, DEV)
+    rt.ensure(2, 16, 16, 77, 9, ("plain",))
+    rt.check_faults(blocking=False)
+    rt.check_faults(blocking=True)                                   # clean
+    word = rt.arena.view(rt.lay["fault"], (1,), torch.int32)
+    word.fill_(3)                                                    # what three abandoned, never recovered shares leave
+    rt.check_faults(blocking=False)                                  # queued, not examined: must not raise, must not wait
+    torch.cuda.synchronize()
+    with pytest.raises(L.PPError, match="split-K"):
+        rt.check_faults(blocking=False)                              # the copy has landed: the next check sees it
+    assert int(word.item()) == 0                                     # ... and re-arms the word
+    word.fill_(1)
+    with pytest.raises(L.PPError):
+        rt.check_faults(blocking=True)
+    rt.check_faults(blocking=True)
