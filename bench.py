@@ -209,8 +209,8 @@ def measured_traffic():
 
 
 def profiled_conv_launch_us():
-    """Average duration of the 3x3 convolution kernels -- pp_conv_gn_kernel (round 4: halo-tile implicit GEMM with the
-    GroupNorm + SiLU of its input in the loader) and pp_gemm_kernel_v2 with template argument XMODE = 1 (tap-major implicit
+    """Average duration of the 3x3 convolution kernels -- pp_conv_gn_kernel (halo-tile implicit GEMM; round 6: on input that
+    is normalised already, NMODE = 2) and pp_gemm_kernel_v2 with template argument XMODE = 1 (tap-major implicit
     GEMM: 8x8 level, strided / upsampling convs) -- in the committed rocprofv3 --stats summary of this benchmark, and the
     build that summary was taken from (`# lib_sha16:` header line).  -> (us per conv launch, lib sha) or (None, None)."""
     import re
@@ -329,9 +329,9 @@ HBM_SPEC_GBS = 8000.0            # the part's HBM3E specification (fractions are
 
 
 def roofline_report(pipe, dump_launches=None, peak=MFMA_PEAK_TFLOPS, profile_matches=True) -> dict:
-    """`roofline` of the dominant kernel family (the 3x3 convolution launches: pp_conv_gn_kernel -- halo-tile implicit GEMM
-    with GroupNorm + SiLU in its loader -- and pp_gemm_kernel_v2<XMODE = 1>, with their split-K combines; the FLOPs counted
-    are the convolution's MACs only, the fused normalisation is extra work of the same launches).  `achieved` / `frac` are a LIVE measurement of this run: the family's launches replayed as
+    """`roofline` of the dominant kernel family (the 3x3 convolution launches: pp_conv_gn_kernel -- halo-tile implicit GEMM,
+    since round 6 on input normalised by a separate apply -- and pp_gemm_kernel_v2<XMODE = 1>, with their split-K combines;
+    the FLOPs counted are the convolution's MACs only).  `achieved` / `frac` are a LIVE measurement of this run: the family's launches replayed as
     their own hipGraph between one HIP event pair (`family_replay_us`).  Next to it: `frac_event` (an event pair around
     every launch of an eager step: includes the eager launch gap) and `frac_profile` (kernel-only average of the
     committed rocprofv3 --stats summary, valid only for the build named in that file).  `hbm_roofline`: the plain
@@ -346,11 +346,13 @@ def roofline_report(pipe, dump_launches=None, peak=MFMA_PEAK_TFLOPS, profile_mat
     ach_prof = (flops[k] / counts[k]) / (prof_us * 1e-6) / 1e12 if prof_us else None
     traffic, traffic_src = measured_traffic() if profile_matches else (None, None)
     sha = lib_sha16()
-    out = {"roofline": {"bound": "mfma", "kernel": "pp_conv_gn_kernel<...> (halo-tile implicit-GEMM 3x3 conv, GroupNorm + SiLU in the loader) / "
+    out = {"roofline": {"bound": "mfma", "kernel": "pp_conv_gn_kernel<...,NMODE=2,...> (halo-tile implicit-GEMM 3x3 conv on normalised input) / "
                                                             "pp_gemm_kernel_v2<...,XMODE=1,...> (tap-major implicit GEMM) + split-K combines",
                         "achieved": ach_live, "peak": peak, "unit": "TFLOP/s", "frac": ach_live / peak,
-                        "note": "FLOPs = the convolutions' MACs only; since round 4 the launches of this family also carry the "
-                                "GroupNorm + SiLU of their inputs (30 of 44 resnet norms per UNet forward: separate launches before)",
+                        "note": "FLOPs = the convolutions' MACs only.  Round 6: the GroupNorm + SiLU of the resnet convs' inputs is "
+                                "NOT in these launches any more (rounds 4-5 fused 30 of 44 into the conv loaders): it is the "
+                                "`groupnorm_apply` family of hbm_roofline (or rides in the producers' split-K combines); "
+                                "the combines of launches with <= 4 splits run inside the conv kernels",
                         "time_base": "live: the family's launches replayed as their own hipGraph between one HIP event "
                                      "pair in this run (launch boundaries and split-K combines included)",
                         "avg_launch_us": live_us / n_live,

@@ -4,7 +4,7 @@
 # configs 3 / 4 / 5 and fp16.  -> gpurun_out/$ROUND/ (default r04); the profiles the judge reads are copied to profiles/ by hand.
 set -u
 cd "$(dirname "$0")/.."
-R=${ROUND:-r05}
+R=${ROUND:-r06}
 O=gpurun_out/$R
 mkdir -p $O
 export TMPDIR=/tmp
