@@ -232,7 +232,7 @@ int pp_gemm_gn_stats_ok(const PPGemmArgs* args);
 /* 1 if pp_gemm_bf16 runs this PP_X_CONV3X3 request with the GroupNorm + SiLU of its input fused into the loader
  * (gn_in_acc / gn_in_gb set), else 0 -- the caller then keeps pp_groupnorm_apply_acc + a plain conv.
  * 2 (round 6) for a PLAIN request (no gn_in_*) that pp_gemm_bf16 routes to the same halo-tile loop WITHOUT the
- * normalisation instead of the tap-major implicit GEMM: stride 1, no upsample, tile = PP_TILE_AUTO, images at least 16 wide
+ * normalisation instead of the tap-major implicit GEMM: stride 1 (Upsample2D's nearest-2x conv included), tile = PP_TILE_AUTO, output images at least 16 wide
  * (every input pixel crosses the global -> LDS path once per tile instead of once per tap: 52 against 58 us at 64x64,
  * K = 2880; profiles/r06_conv_raw.txt).  Same request, same result contract; a routing fact for tests and planners. */
 int pp_conv_gn_supported(const PPGemmArgs* args);

@@ -109,7 +109,10 @@ __global__ void __launch_bounds__(CG_T, 2) pp_conv_gn_kernel(const PPGemmArgs a,
   const int ch_b = split * d.nch / splits, ch_e = (split + 1) * d.nch / splits;
   const int tk_b = split * d.ntail / splits, tk_e = (split + 1) * d.ntail / splits;
 
-  const int Wd = a.win, Hd = a.hin, HW = Hd * Wd;
+  // tile / halo geometry in OUTPUT pixels; (round 6) a.up: the input is the nearest-2x upsampling of a [hin][win] source
+  // (Upsample2D: F.interpolate(scale_factor=2, mode="nearest") -> conv), i.e. halo pixel (iy, hx) is source pixel (iy / 2, hx / 2)
+  const int Wd = a.wout, Hd = a.hout, HW = Hd * Wd;
+  const int HWs = a.hin * a.win;                      // source pixels per image
   const int bimg = m_blk / HW;                        // the tile lies inside ONE image (host-checked: HW % BM == 0)
   const int y0 = (m_blk - bimg * HW) / Wd;            // its first image row (BM % W == 0)
   const int ctot = a.c1 + a.c2;
@@ -136,7 +139,7 @@ __global__ void __launch_bounds__(CG_T, 2) pp_conv_gn_kernel(const PPGemmArgs a,
     const int hp = (wave + 8 * j) * 8 + lrow;
     const int hr = hp / Wd, hx = hp - hr * Wd;
     const int iy = y0 + hr - 1;
-    hpix[j] = (hp < d.hp && iy >= 0 && iy < Hd) ? bimg * HW + iy * Wd + hx : -1;
+    hpix[j] = (hp < d.hp && iy >= 0 && iy < Hd) ? (a.up ? bimg * HWs + (iy >> 1) * a.win + (hx >> 1) : bimg * HW + iy * Wd + hx) : -1;
   }
   // ---- fragments: lane (r16, g) reads row (.. + r16), k-slot (ks * 4 + g) of a 16 x 32 fragment
   const int r16 = lane & 15, g = lane >> 4;
@@ -260,11 +263,11 @@ __global__ void __launch_bounds__(CG_T, 2) pp_conv_gn_kernel(const PPGemmArgs a,
       int csrc;
       if (first) {
         csrc = a.c1;
-        rs_h = make_rsrc(a.x1, live ? (uint32_t)a.batch * (uint32_t)HW * (uint32_t)a.c1 * 2u : 0u);
+        rs_h = make_rsrc(a.x1, live ? (uint32_t)a.batch * (uint32_t)HWs * (uint32_t)a.c1 * 2u : 0u);
         hsoff = c * 128;
       } else {
         csrc = a.c2;
-        rs_h = make_rsrc(a.x2 ? a.x2 : a.x1, (live && a.x2) ? (uint32_t)a.batch * (uint32_t)HW * (uint32_t)a.c2 * 2u : 0u);
+        rs_h = make_rsrc(a.x2 ? a.x2 : a.x1, (live && a.x2) ? (uint32_t)a.batch * (uint32_t)HWs * (uint32_t)a.c2 * 2u : 0u);
         hsoff = (c - d.nch1) * 128;
       }
       hcsrc = csrc;
@@ -668,14 +671,15 @@ struct CGChoice {
 
 // the loader's geometry: stride 1, no upsample, tiles of whole image rows inside one image, halo tile <= 384 pixels
 bool cg_shape_ok(const PPGemmArgs& a, int bm) {
-  const int hw = a.hin * a.win;
-  return bm % a.win == 0 && hw % bm == 0 && bm + 2 * a.win <= CG_HALO_PX;
+  const int hw = a.hout * a.wout;
+  return bm % a.wout == 0 && hw % bm == 0 && bm + 2 * a.wout <= CG_HALO_PX;
 }
 
 // what the halo-tile kernel needs of a conv whatever stands in front of it
 bool cg_geometry_ok(const PPGemmArgs& a) {
   if (a.x_mode != PP_X_CONV3X3 || !pp_dt_ok(a.dtype)) return false;
-  if (a.stride != 1 || a.up || a.hin != a.hout || a.win != a.wout || a.win < 8 || (a.win & 7)) return false;
+  if (a.stride != 1 || a.wout < 8 || (a.wout & 7)) return false;
+  if (a.up ? (a.hout != 2 * a.hin || a.wout != 2 * a.win) : (a.hin != a.hout || a.win != a.wout)) return false;
   const int ctot = a.c1 + a.c2;
   if (a.c1 <= 0 || a.c1 % 64 || a.c2 % 64 || (a.c2 > 0 && !a.x2)) return false;
   if (a.c3 < 0 || a.c4 < 0 || a.c3 % 64 || a.c4 % 64 || (a.c3 > 0 && !a.x3) || (a.c4 > 0 && (!a.x4 || a.c3 == 0))) return false;
@@ -693,7 +697,7 @@ bool cg_geometry_ok(const PPGemmArgs& a) {
 
 // norm -> SiLU -> conv3x3 in one launch (the request carries the producers' statistics of its input)
 bool cg_fused_ok(const PPGemmArgs& a) {
-  if (!a.gn_in_acc || !a.gn_in_gb || !cg_geometry_ok(a)) return false;
+  if (!a.gn_in_acc || !a.gn_in_gb || a.up || !cg_geometry_ok(a)) return false;
   if (a.gn_in_silu != 1 || a.gn_in_groups <= 0 || a.gn_in_groups > 32) return false;
   return (a.c1 + a.c2) % a.gn_in_groups == 0;
 }
@@ -701,13 +705,14 @@ bool cg_fused_ok(const PPGemmArgs& a) {
 // A plain conv3x3 (input already normalised, or none: conv behind an apply launch) on the SAME halo-tile loop without the
 // normalisation (NMODE = 2): every input pixel crosses the 64 B/clk global -> LDS path once per tile (+ halo rows) instead
 // of once per tap, 52 against 58 us at 64x64 (K = 2880), 58 against 65 at 32x32 (K = 5760) beside the tap-major kernel
-// (tools/conv_gn_shapes.py, profiles/r06_conv_raw.txt).  Taken where the automatic choice is asked for (tile = AUTO) and
+// (tools/conv_gn_shapes.py, profiles/r06_conv_raw.txt).  Upsample2D's conv (a.up: nearest 2x in front of the conv) as well:
+// the halo tile is gathered from the half-resolution source.  Taken where the automatic choice is asked for (tile = AUTO) and
 // the image is at least 16 wide: at 8x8 the launches are split-K weight streams on 64-row tiles and the tap-major kernel's
 // 128-row tiles in N-major order win (+1.7 % on the step with this loop there).
 // (lab) PP_CONV_RAW = the smallest image width routed here (0 = never)
 bool cg_raw_ok(const PPGemmArgs& a) {
   static const int min_w = pp_lab_env("PP_CONV_RAW", 16);
-  if (a.gn_in_acc || a.gn_in_gb || a.tile != PP_TILE_AUTO || min_w <= 0 || a.win < min_w) return false;
+  if (a.gn_in_acc || a.gn_in_gb || a.tile != PP_TILE_AUTO || min_w <= 0 || a.wout < min_w) return false;
   return cg_geometry_ok(a);
 }
 bool cg_supported(const PPGemmArgs& a) { return a.gn_in_acc ? cg_fused_ok(a) : cg_raw_ok(a); }
@@ -728,7 +733,7 @@ CGChoice cg_choose(const PPGemmArgs& a) {
 #ifdef PP_LAB
   // (lab) PP_CONV_GN_W16 = 10 * BM + splits: the tile / split-K form of the 16x16-level launches (ships: 256 rows x 4 splits)
   static const int w16 = pp_lab_env("PP_CONV_GN_W16", 0);
-  if (w16 > 0 && a.win == 16 && !want && a.splitk <= 0 && cg_shape_ok(a, w16 / 10)) {
+  if (w16 > 0 && a.wout == 16 && !want && a.splitk <= 0 && cg_shape_ok(a, w16 / 10)) {
     c.bm = w16 / 10;
     c.splitk = w16 % 10;
     if (c.splitk > nch0) c.splitk = nch0;
@@ -774,7 +779,7 @@ int cg_launch(const PPGemmArgs& a, int splitk, hipStream_t st) {
   d.nch = (a.c1 + a.c2) / 64;
   d.ntail3 = a.c3 / 64;
   d.ntail = (a.c3 + a.c4) / 64;
-  d.hp = BM + 2 * a.win;
+  d.hp = BM + 2 * a.wout;
   d.cg = a.gn_in_groups > 0 ? (a.c1 + a.c2) / a.gn_in_groups : 1;
   d.inv_cg = 1.0f / (float)d.cg;
   hipLaunchKernelGGL(kern, dim3(d.tiles_m * d.tiles_n, splitk, 1), dim3(CG_T), CG_LDS, st, a, d);
@@ -786,7 +791,7 @@ int cg_launch(const PPGemmArgs& a, int splitk, hipStream_t st) {
 //   BM = 256: W = 64 -> 6, W = 32 / 16 -> 5;  BM = 128: W = 128 -> 6, 64 -> 4, <= 32 -> 3;  BM = 64: W = 64 -> 3, <= 32 -> 2
 template <int BM, bool PP, int NMODE, int EDT>
 int cg_launch_hpw(const PPGemmArgs& a, int splitk, hipStream_t st) {
-  const int need = (BM + 2 * a.win + 63) / 64;
+  const int need = (BM + 2 * a.wout + 63) / 64;
   if constexpr (BM == 256) {
     if (need <= 5) return cg_launch<256, 5, PP, NMODE, EDT>(a, splitk, st);
     return cg_launch<256, 6, PP, NMODE, EDT>(a, splitk, st);

@@ -272,15 +272,36 @@ def test_plain_conv_on_the_halo_tile_loop(B, H, C1, C2, Cout, tail, splitk, dtyp
 
 
 def test_plain_convs_that_stay_on_the_tap_major_kernel():
-    """The 8x8 level (split-K weight streams: the tap-major kernel's 128-row tiles in N-major order win), strided / upsampling
-    convs, channel counts off the 64 grid, the CFG twin store: not the halo-tile loop's -- routed as before, results as before."""
+    """The 8x8 level (split-K weight streams: the tap-major kernel's 128-row tiles in N-major order win), strided convs,
+    channel counts off the 64 grid, the CFG twin store: not the halo-tile loop's -- routed as before, results as before."""
     x8 = rnd(8, 8, 8, 1280, seed=1).to(torch.bfloat16)
     assert not ops.conv_halo_routed(x8, 1280)
     x64 = rnd(1, 64, 64, 320, seed=2).to(torch.bfloat16)
-    assert not ops.conv_halo_routed(x64, 320, stride=2) and not ops.conv_halo_routed(x64, 320, up=True)
+    assert not ops.conv_halo_routed(x64, 320, stride=2)
     assert not ops.conv_halo_routed(rnd(1, 64, 64, 96, seed=3).to(torch.bfloat16), 320)
     w = rnd(320, 9 * 320, seed=4, scale=0.02).to(torch.bfloat16)
     out = ops.conv3x3(x64, w, None, dup=True)                                           # out_dup_rows: single-pass v2 epilogue
     ref = ops.conv3x3(x64, w, None, tile=54)
     assert torch.equal(out[0], out[1])
     close(out[:1], ref, 2 * 2.0 ** -8, 1.5 * 2.0 ** -8, "twin-store conv vs plain")
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,H,C,Cout", [(2, 32, 320, 320), (8, 16, 640, 640), (8, 8, 1280, 1280), (1, 16, 64, 160)])
+def test_upsampling_conv_on_the_halo_tile_loop(B, H, C, Cout, dtype):
+    """Upsample2D: `F.interpolate(x, scale_factor=2.0, mode="nearest")` then `Conv2d(3x3)` (diffusers 0.27; ctor sites
+    /root/reference/powerpaint/models/unet_2d_blocks.py:2406, 2542).  The halo tile of the 2H x 2W image is gathered from
+    the H x W source (halo pixel (y, x) = source pixel (y / 2, x / 2)); zero padding applies to the upsampled image."""
+    x = rnd(B, H, H, C, seed=1).to(dtype)
+    w = rnd(Cout, 9 * C, seed=2, scale=(9 * C) ** -0.5).to(dtype).contiguous()
+    bias = rnd(Cout, seed=3)
+    assert ops.conv_halo_routed(x, Cout, up=True)
+    out = ops.conv3x3(x, w, bias, up=True)
+    assert out.shape == (B, 2 * H, 2 * H, Cout) and torch.equal(out, ops.conv3x3(x, w, bias, up=True))
+    old = ops.conv3x3(x, w, bias, up=True, tile=54)
+    ulp = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    close(out, old, 2 * ulp, 1.5 * ulp, "halo-tile loop vs tap-major implicit GEMM (upsampling)")
+    xu = F.interpolate(x.float().permute(0, 3, 1, 2), scale_factor=2.0, mode="nearest")
+    ref = F.conv2d(xu, w.float().reshape(Cout, 3, 3, C).permute(0, 3, 1, 2), bias, padding=1).permute(0, 2, 3, 1)
+    tol = 1.0 if dtype == torch.bfloat16 else 0.25
+    close(out, ref, 3e-2 * tol, 1e-2 * tol, "halo-tile loop (upsampling) vs fp32 torch")
