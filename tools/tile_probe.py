@@ -19,8 +19,11 @@ SHAPES = [("ff2_16", 2048, 1280, 5120, 1280, L.PP_ACT_NONE, True, False),
           ("qkv_16", 2048, 3840, 1280, 0, L.PP_ACT_NONE, False, False),
           ("qkv_32", 8192, 1920, 640, 0, L.PP_ACT_NONE, False, False),
           ("out_16", 2048, 1280, 1280, 0, L.PP_ACT_NONE, True, True),
-          ("out_32", 8192, 640, 640, 0, L.PP_ACT_NONE, True, True)]
-TILES = (0, 32, 42, 31, 54, 21, 24, 33, 53)
+          ("out_32", 8192, 640, 640, 0, L.PP_ACT_NONE, True, True),
+          ("out_8", 512, 1280, 1280, 0, L.PP_ACT_NONE, True, True),
+          ("qkv_8", 512, 3840, 1280, 0, L.PP_ACT_NONE, False, False),
+          ("q_16", 2048, 1280, 1280, 0, L.PP_ACT_NONE, False, False)]
+TILES = tuple(int(t) for t in os.environ.get("PP_TILE_PROBE_TILES", "0,32,42,31,54,21,24,33,53").split(","))
 BIG = None
 
 
