@@ -19,9 +19,10 @@ def run(M, N, K, tile, sk, dbg, res=True, iters=20):
     b = torch.randn(N, device=dev)
     r = torch.randn(M, N, device=dev).to(torch.bfloat16)
     out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
-    ws = torch.empty(max(1, sk) * M * N, dtype=torch.float32, device=dev)
+    ws = torch.empty(max(1, sk) * M * N + (1 << 20), dtype=torch.float32, device=dev)      # slabs + combine scratch
     a = L.PPGemmArgs()
     a.M, a.N, a.K, a.x_mode = M, N, K, 0
+    a.dtype = L.PP_DT_BF16
     a.x1, a.c1, a.ldx1 = x.data_ptr(), K, K
     a.w, a.bias = w.data_ptr(), b.data_ptr()
     if res:
