@@ -22,8 +22,11 @@ SHAPES = [("ff2_16", 2048, 1280, 5120, 1280, L.PP_ACT_NONE, True, False),
           ("out_32", 8192, 640, 640, 0, L.PP_ACT_NONE, True, True),
           ("out_8", 512, 1280, 1280, 0, L.PP_ACT_NONE, True, True),
           ("qkv_8", 512, 3840, 1280, 0, L.PP_ACT_NONE, False, False),
-          ("q_16", 2048, 1280, 1280, 0, L.PP_ACT_NONE, False, False)]
+          ("q_16", 2048, 1280, 1280, 0, L.PP_ACT_NONE, False, False),
+          ("w8_11520", 512, 1280, 11520, 0, L.PP_ACT_NONE, True, False),      # the 8x8-level convs as plain GEMMs
+          ("w8_23040", 512, 1280, 23040, 0, L.PP_ACT_NONE, True, False)]
 TILES = tuple(int(t) for t in os.environ.get("PP_TILE_PROBE_TILES", "0,32,42,31,54,21,24,33,53").split(","))
+SPLITS = tuple(int(t) for t in os.environ.get("PP_TILE_PROBE_SPLITS", "1,2,4").split(","))
 BIG = None
 
 
@@ -63,7 +66,7 @@ def main():
         print(f"{name}: M={M} N={N} K={K + K2}", flush=True)
         for tile in TILES:
             line = f"   tile {tile:2d}:"
-            for sk in ((0,) if tile == 0 else (1, 2, 4)):
+            for sk in ((0,) if tile == 0 else SPLITS):
                 if rs and sk > 1:
                     continue
                 try:
