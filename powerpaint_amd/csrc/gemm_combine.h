@@ -221,8 +221,10 @@ struct FcGeom {
 };
 
 // What a share needs that does NOT depend on the other splits: the bias strip, the time-embedding row of its first pass and the
-// residual rows of its first group.  Loaded BEFORE the arrival (these are cold HBM lines, ~2 us; loads return in order, so
-// behind them the slab loads would wait as well): their latency hides behind the slab stores draining and the wait.
+// residual rows of its first group -- cold HBM lines, ~1.9 us, and loads return in order, so slab loads issued behind them wait
+// for them as well.  They are issued right BEHIND the arrival atomic (fc_arrive's `between`) and pass while thread 0 waits for
+// the last split.  (In FRONT of the arrival they queue behind the 80 KB of slab stores and the arrival's own
+// `s_waitcnt vmcnt(0)` waits for them too: +2 us per launch, measured.)
 template <int G>
 struct FcPre {
   f32x4_t bs, rv0;
